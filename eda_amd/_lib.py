@@ -1,0 +1,62 @@
+"""ctypes binding of libeda_hip.so (C ABI declared in include/eda_hip.h).
+
+There is no fallback: if the HIP library is missing or an entry point fails,
+this raises.  (The CPU oracle under oracle/ is test infrastructure and is never
+imported from here.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libeda_hip.so")
+
+_i, _f, _p, _sz = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/eda_hip.h one to one
+SIGNATURES = {
+    "eda_version": (_i, []),
+    "eda_last_error_string": (ctypes.c_char_p, []),
+    "eda_set_fma_mode": (_i, [_i]),
+    "eda_get_fma_mode": (_i, []),
+    "eda_fps_workspace_bytes": (_sz, [_i, _i, _i]),
+    "eda_furthest_point_sampling_f32": (_i, [_p, _i, _i, _i, _p, _p, _sz, _p]),
+    "eda_gather_points_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
+    "eda_gather_points_grad_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
+    "eda_ball_query_f32": (_i, [_p, _p, _i, _i, _i, _f, _i, _p, _p]),
+    "eda_group_points_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "eda_group_points_grad_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "eda_three_nn_f32": (_i, [_p, _p, _i, _i, _i, _p, _p, _p]),
+    "eda_three_interpolate_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "eda_three_interpolate_grad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
+}
+
+_lib = None
+
+
+class EdaHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle of libeda_hip.so."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EdaHipError(
+                f"{LIB_PATH} is missing: build it with `python -m eda_amd.build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if L.eda_version() != 1:
+            raise EdaHipError(f"libeda_hip.so ABI version {L.eda_version()} != 1")
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().eda_last_error_string()
+        raise EdaHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

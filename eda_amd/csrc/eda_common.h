@@ -1,0 +1,104 @@
+// eda_common.h -- shared host/device helpers for libeda_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/eda_hip.h"
+
+#define EDA_WAVE 64
+
+// ---- host-side error plumbing ------------------------------------------
+void eda_set_error(const char *fmt, ...);
+extern int g_eda_fma_mode;
+
+#define EDA_CHECK_ARG(cond, msg)                         \
+  do {                                                   \
+    if (!(cond)) {                                       \
+      eda_set_error("%s: %s", __func__, msg);            \
+      return EDA_ERR_INVALID_ARG;                        \
+    }                                                    \
+  } while (0)
+
+#define EDA_CHECK_LAUNCH()                                              \
+  do {                                                                  \
+    hipError_t e__ = hipGetLastError();                                 \
+    if (e__ != hipSuccess) {                                            \
+      eda_set_error("%s: launch failed: %s", __func__,                  \
+                    hipGetErrorString(e__));                            \
+      return (int)e__;                                                  \
+    }                                                                   \
+  } while (0)
+
+#define EDA_CHECK_HIP(expr)                                             \
+  do {                                                                  \
+    hipError_t e__ = (expr);                                            \
+    if (e__ != hipSuccess) {                                            \
+      eda_set_error("%s: %s failed: %s", __func__, #expr,               \
+                    hipGetErrorString(e__));                            \
+      return (int)e__;                                                  \
+    }                                                                   \
+  } while (0)
+
+// ---- canonical fp32 arithmetic (DESIGN.md "Canonical arithmetic") -------
+// The library is built with -ffp-contract=off: every fused op is explicit.
+// MODE 0: a*a + b*b + c*c as nvcc -fmad=true / LLVM's DAG combiner contract
+//         it: t = b*b; t = fma(a,a,t); t = fma(c,c,t).
+// MODE 1: strict IEEE, ((a*a + b*b) + c*c).
+template <int MODE>
+__device__ __forceinline__ float eda_sumsq3(float a, float b, float c) {
+  if (MODE == 0) {
+    float t = b * b;
+    t = __builtin_fmaf(a, a, t);
+    t = __builtin_fmaf(c, c, t);
+    return t;
+  } else {
+    return (a * a + b * b) + c * c;
+  }
+}
+
+// ---- DPP cross-lane helpers (wave64, gfx9-family DPP controls) -----------
+// dpp_ctrl encodings: quad_perm = 0x00..0xFF, row_shr:n = 0x110+n,
+// row_ror:n = 0x120+n.
+#define EDA_DPP_QUAD_XOR1 0xB1  // quad_perm [1,0,3,2]
+#define EDA_DPP_QUAD_XOR2 0x4E  // quad_perm [2,3,0,1]
+#define EDA_DPP_ROW_ROR(n) (0x120 + (n))
+
+template <int CTRL>
+__device__ __forceinline__ int eda_dpp(int v) {
+  // all rows / all banks enabled, bound_ctrl irrelevant for permutations
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
+
+// All-reduce within each 16-lane row (result uniform per row).
+__device__ __forceinline__ int eda_row_max_i32(int v) {
+  v = max(v, eda_dpp<EDA_DPP_QUAD_XOR1>(v));
+  v = max(v, eda_dpp<EDA_DPP_QUAD_XOR2>(v));
+  v = max(v, eda_dpp<EDA_DPP_ROW_ROR(4)>(v));
+  v = max(v, eda_dpp<EDA_DPP_ROW_ROR(8)>(v));
+  return v;
+}
+__device__ __forceinline__ unsigned eda_row_min_u32(unsigned v) {
+  v = min(v, (unsigned)eda_dpp<EDA_DPP_QUAD_XOR1>((int)v));
+  v = min(v, (unsigned)eda_dpp<EDA_DPP_QUAD_XOR2>((int)v));
+  v = min(v, (unsigned)eda_dpp<EDA_DPP_ROW_ROR(4)>((int)v));
+  v = min(v, (unsigned)eda_dpp<EDA_DPP_ROW_ROR(8)>((int)v));
+  return v;
+}
+// Wave-wide all-reduce; the result is wave-uniform (SGPR).
+__device__ __forceinline__ int eda_wave_max_i32(int v) {
+  v = eda_row_max_i32(v);
+  int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+  int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  return max(max(a, b), max(c, d));
+}
+__device__ __forceinline__ unsigned eda_wave_min_u32(unsigned v) {
+  v = eda_row_min_u32(v);
+  unsigned a = __builtin_amdgcn_readlane((int)v, 0), b = __builtin_amdgcn_readlane((int)v, 16);
+  unsigned c = __builtin_amdgcn_readlane((int)v, 32), d = __builtin_amdgcn_readlane((int)v, 48);
+  return min(min(a, b), min(c, d));
+}
+
+__device__ __forceinline__ int eda_lane_id() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}

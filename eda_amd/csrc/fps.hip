@@ -1,0 +1,364 @@
+// fps.hip -- furthest point sampling for gfx950.
+//
+// Replaces furthest_point_sampling_kernel<bs> (reference
+// pointnet2/_ext_src/src/sampling_gpu.cu:74-178) and its host wrapper
+// (sampling.cpp:70-91).  Same results bit for bit (including the origin-ball
+// skip and the shared-memory-tree tie rule), different machine mapping:
+//
+//  * the reference runs ONE 512-thread block per scene and re-reads xyz and the
+//    global `temp` array every round.  Here a scene is owned by a CLUSTER of G
+//    workgroups (T = 512/1024 threads each); every thread keeps its P points
+//    (x, y, z, running min distance) in registers for the whole kernel, so a
+//    round touches no global memory except one 40-byte mailbox record per
+//    workgroup.
+//  * per round: register update -> DPP wave arg-max -> LDS arg-max over the
+//    workgroup's waves -> (cluster only) all-gather of the G workgroup
+//    candidates through tagged 8-byte granules (agent-scope relaxed atomics,
+//    double-buffered by round parity; cdna_hip_programming.md G16 recipe R2)
+//    -> every workgroup picks the same winner and broadcasts it through LDS.
+//  * a scene with n <= 8192 points is handled by a single workgroup (G = 1) and
+//    skips the mailbox step entirely.
+//
+// Tie rule.  The reference's winner among equal maxima is the minimum over
+// (bitreverse_p(k mod bs), k) with bs = 2^p = opt_n_threads(n) (its thread
+// tid = k mod bs keeps its lowest k on strict '>', and the LDS tree with strides
+// bs/2..1 keeps slot idx1 on ties).  Because k mod bs are the low p bits of k,
+// that order equals the order of   tiekey(k) = rev_p(k & (bs-1)) << (31-p) | k >> p,
+// which is what the arg-max below minimises among equal distances.
+// A point inside the origin ball (mag <= 1e-3) is never updated nor selectable
+// in the reference; here it carries the constant candidate (-1.0f, k = 0), which
+// is exactly what a reference thread without a valid point contributes.
+#include "eda_common.h"
+
+#include <limits.h>
+
+namespace {
+
+constexpr int kRecWords = 8;          // u64 words per mailbox record (5 used, 64-byte record)
+constexpr int kMaxG = 64;             // workgroups per scene (one poll lane each)
+constexpr size_t kStatusBytes = 256;  // status words in front of the mailboxes
+constexpr unsigned kSpinLimit = 1u << 20;   // ~1 s of polling, then give up
+
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) u64 gu64;
+
+__device__ __forceinline__ unsigned fps_tiekey(unsigned k, int p) {
+  const unsigned lowmask = (1u << p) - 1u;
+  const unsigned hi = p ? (__brev(k & lowmask) >> (32 - p)) : 0u;
+  return (hi << (31 - p)) | (k >> p);
+}
+
+__device__ __forceinline__ void granule_store(u64 *p, unsigned tag, unsigned value) {
+  __hip_atomic_store(p, ((u64)tag << 32) | (u64)value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 granule_load(const u64 *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// LDS layout (dynamic): float lx[T*P], ly[T*P], lz[T*P]; then scratch.
+struct FpsShared {
+  int wave_bits[16];
+  int wave_k[16];
+  float next_xyz[4];   // x, y, z of the point chosen this round (+ pad)
+  int fail;
+};
+
+template <int MODE, int T, int P, bool CLUSTER>
+__global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz_all, int n, int m,
+                                                int *__restrict__ idx_all, int S, int G, int p_log2,
+                                                u64 *mail_all, int *status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *lx = reinterpret_cast<float *>(smem);
+  float *ly = lx + T * P;
+  float *lz = ly + T * P;
+  FpsShared *sh = reinterpret_cast<FpsShared *>(lz + T * P);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  constexpr int NW = T / 64;
+  const int scene = blockIdx.x % S;   // consecutive blocks -> different scenes, so a
+  const int w = blockIdx.x / S;       // scene's workgroups share an XCD when S % 8 == 0 (speed only)
+
+  const float *xyz = xyz_all + (size_t)scene * n * 3;
+  int *idx = idx_all + (size_t)scene * m;
+  u64 *mail = mail_all + (size_t)scene * 2 * kMaxG * kRecWords;
+
+  if (m <= 0) return;
+
+  // ---- load this thread's P points into registers -------------------------
+  float px[P], py[P], pz[P], pt[P];
+  int pk[P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    const long long k = ((long long)(j * G + w)) * T + tid;
+    float x = 0.f, y = 0.f, z = 0.f;
+    bool valid = k < n;
+    if (valid) {
+      x = xyz[k * 3 + 0];
+      y = xyz[k * 3 + 1];
+      z = xyz[k * 3 + 2];
+      const float mag = eda_sumsq3<MODE>(x, y, z);
+      valid = !((double)mag <= 1e-3);          // sampling_gpu.cu:106-107 (double compare)
+    }
+    px[j] = x; py[j] = y; pz[j] = z;
+    pt[j] = valid ? 1e10f : -1.0f;             // sampling.cpp:78-80 / thread init best=-1
+    pk[j] = valid ? (int)k : 0;
+    lx[j * T + tid] = x; ly[j * T + tid] = y; lz[j * T + tid] = z;
+  }
+  if (tid == 0) sh->fail = 0;
+
+  // first sample is index 0 (sampling_gpu.cu:90-92)
+  float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
+  if (w == 0 && tid == 0) idx[0] = 0;
+  __syncthreads();
+
+  for (int r = 1; r < m; ++r) {
+    // ---- per-thread update + running best (strict '>' keeps the lowest k) --
+    int best_bits = __float_as_int(-1.0f);
+    int best_k = 0;
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const float d = eda_sumsq3<MODE>(px[j] - x1, py[j] - y1, pz[j] - z1);  // point minus centre
+      const float t = fminf(d, pt[j]);   // invalid points stay at -1
+      pt[j] = t;
+      const int tb = __float_as_int(t);  // t >= 0 or == -1: signed int order == float order
+      const bool gt = tb > best_bits;
+      best_bits = gt ? tb : best_bits;
+      best_k = gt ? pk[j] : best_k;
+    }
+    // ---- wave arg-max: max distance, then min tie key among the maxima -----
+    {
+      const int wm = eda_wave_max_i32(best_bits);
+      const unsigned tk = (best_bits == wm) ? fps_tiekey((unsigned)best_k, p_log2) : 0xFFFFFFFFu;
+      const unsigned wt = eda_wave_min_u32(tk);
+      if (tk == wt) {        // several lanes only when they all carry (-1, k=0)
+        sh->wave_bits[wave] = wm;
+        sh->wave_k[wave] = best_k;
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      int b = lane < NW ? sh->wave_bits[lane] : INT_MIN;
+      int kk = lane < NW ? sh->wave_k[lane] : 0;
+      int wm = __builtin_amdgcn_readlane(eda_row_max_i32(b), 0);
+      unsigned tk = (lane < NW && b == wm) ? fps_tiekey((unsigned)kk, p_log2) : 0xFFFFFFFFu;
+      unsigned wt = (unsigned)__builtin_amdgcn_readlane((int)eda_row_min_u32(tk), 0);
+      u64 hit = __ballot(tk == wt);
+      int wl = __ffsll((long long)hit) - 1;
+      int kw = __builtin_amdgcn_readlane(kk, wl);
+      // coordinates of this workgroup's candidate from the LDS copy
+      const int li = ((kw / T) / G) * T + (kw % T);
+      float cx = lx[li], cy = ly[li], cz = lz[li];
+      int fk = kw;
+      float fx = cx, fy = cy, fz = cz;
+      if (CLUSTER) {
+        u64 *box = mail + (size_t)(r & 1) * kMaxG * kRecWords;
+        if (lane == 0) {
+          u64 *rec = box + (size_t)w * kRecWords;
+          granule_store(rec + 0, (unsigned)r, (unsigned)wm);
+          granule_store(rec + 1, (unsigned)r, (unsigned)kw);
+          granule_store(rec + 2, (unsigned)r, __float_as_uint(cx));
+          granule_store(rec + 3, (unsigned)r, __float_as_uint(cy));
+          granule_store(rec + 4, (unsigned)r, __float_as_uint(cz));
+        }
+        // all-gather: lane l < G polls workgroup l's record until its 5 tags match
+        unsigned v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+        bool ok = lane >= G;
+        unsigned spins = 0;
+        bool failed = false;
+        for (;;) {
+          if (!ok) {
+            const u64 *rec = box + (size_t)lane * kRecWords;
+            const u64 g0 = granule_load(rec + 0), g1 = granule_load(rec + 1);
+            const u64 g2 = granule_load(rec + 2), g3 = granule_load(rec + 3);
+            const u64 g4 = granule_load(rec + 4);
+            v0 = (unsigned)g0; v1 = (unsigned)g1; v2 = (unsigned)g2; v3 = (unsigned)g3; v4 = (unsigned)g4;
+            ok = ((unsigned)(g0 >> 32) == (unsigned)r) & ((unsigned)(g1 >> 32) == (unsigned)r) &
+                 ((unsigned)(g2 >> 32) == (unsigned)r) & ((unsigned)(g3 >> 32) == (unsigned)r) &
+                 ((unsigned)(g4 >> 32) == (unsigned)r);
+          }
+          if (__all(ok)) break;
+          if (++spins > kSpinLimit) { failed = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (failed) {
+          if (lane == 0) { sh->fail = 1; atomicExch(status, 1); }
+        } else {
+          const int gb = lane < G ? (int)v0 : INT_MIN;
+          const int gm = eda_wave_max_i32(gb);
+          const unsigned gtk = (lane < G && gb == gm) ? fps_tiekey(v1, p_log2) : 0xFFFFFFFFu;
+          const unsigned gt = eda_wave_min_u32(gtk);
+          const int gl = __ffsll((long long)__ballot(gtk == gt)) - 1;
+          fk = __builtin_amdgcn_readlane((int)v1, gl);
+          fx = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)v2, gl));
+          fy = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)v3, gl));
+          fz = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)v4, gl));
+          if (gm < 0) {  // every point of the scene is invalid: reference emits index 0
+            fk = 0;
+          }
+        }
+      }
+      if (lane == 0) {
+        sh->next_xyz[0] = fx; sh->next_xyz[1] = fy; sh->next_xyz[2] = fz;
+        if (w == 0) idx[r] = fk;
+      }
+    }
+    __syncthreads();
+    if (sh->fail) return;
+    // If the winner is the all-invalid candidate (-1, k = 0) these coordinates are
+    // meaningless, but then no point of the scene is ever updated, so they are unused.
+    x1 = sh->next_xyz[0]; y1 = sh->next_xyz[1]; z1 = sh->next_xyz[2];
+    // No third barrier: wave slots are rewritten only after every wave has passed
+    // the barrier above, next_xyz only after the NEXT round's first barrier.
+  }
+}
+
+template <int MODE, int T, int P, bool CLUSTER>
+int launch_fps(const float *xyz, int n, int m, int *idx, int S, int G, int p_log2, u64 *mail,
+               int *status, hipStream_t stream) {
+  const size_t lds = (size_t)T * P * 3 * sizeof(float) + sizeof(FpsShared);
+  auto kern = fps_kernel<MODE, T, P, CLUSTER>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      eda_set_error("fps: cannot raise dynamic LDS to %zu bytes: %s", lds, hipGetErrorString(e));
+      return (int)e;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(S * G), dim3(T), lds, stream, xyz, n, m, idx, S, G, p_log2, mail,
+                     status);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    eda_set_error("fps: launch failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+template <int MODE, int T, bool CLUSTER>
+int dispatch_p(int P, const float *xyz, int n, int m, int *idx, int S, int G, int p_log2,
+               u64 *mail, int *status, hipStream_t stream) {
+  switch (P) {
+    case 1: return launch_fps<MODE, T, 1, CLUSTER>(xyz, n, m, idx, S, G, p_log2, mail, status, stream);
+    case 2: return launch_fps<MODE, T, 2, CLUSTER>(xyz, n, m, idx, S, G, p_log2, mail, status, stream);
+    case 4: return launch_fps<MODE, T, 4, CLUSTER>(xyz, n, m, idx, S, G, p_log2, mail, status, stream);
+    case 8: return launch_fps<MODE, T, 8, CLUSTER>(xyz, n, m, idx, S, G, p_log2, mail, status, stream);
+    case 16:
+      if (T == 512)
+        return launch_fps<MODE, 512, 16, CLUSTER>(xyz, n, m, idx, S, G, p_log2, mail, status, stream);
+      break;
+  }
+  eda_set_error("fps: unsupported points-per-thread %d for T=%d", P, T);
+  return EDA_ERR_UNSUPPORTED;
+}
+
+int round_up_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+int env_int(const char *name, int dflt) {
+  const char *s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+
+}  // namespace
+
+extern "C" size_t eda_fps_workspace_bytes(int b, int n, int m) {
+  (void)n; (void)m;
+  if (b < 0) b = 0;
+  return kStatusBytes + (size_t)b * 2 * kMaxG * kRecWords * sizeof(u64);
+}
+
+// cuda_utils.h:20-24: 2^floor(log2 n) clamped to [1, 512]; only its log2 is needed.
+static int fps_block_log2(int n) {
+  if (n <= 0) return 0;
+  int p = 0;
+  while ((2 << p) <= n) ++p;   // floor(log2 n), exact in integers
+  if (p > 9) p = 9;
+  return p;
+}
+
+extern "C" int eda_furthest_point_sampling_f32(const float *xyz, int b, int n, int m, int *idx,
+                                               void *ws, size_t ws_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(b >= 0 && n >= 0 && m >= 0, "negative dimension");
+  if (b == 0 || m == 0) return 0;
+  EDA_CHECK_ARG(n > 0, "n must be positive when m > 0 (the reference reads point 0)");
+  EDA_CHECK_ARG(xyz && idx, "null pointer");
+  EDA_CHECK_ARG(ws != nullptr, "workspace required");
+  if (ws_bytes < eda_fps_workspace_bytes(b, n, m)) {
+    eda_set_error("fps: workspace too small (%zu < %zu)", ws_bytes, eda_fps_workspace_bytes(b, n, m));
+    return EDA_ERR_WORKSPACE;
+  }
+  const int p_log2 = fps_block_log2(n);
+
+  // ---- geometry: T threads, P points per thread, G workgroups per scene ----
+  int T, P, G;
+  const int single_max = 8192;   // 512 threads x 16 points, 96 KiB of LDS coordinates
+  if (n <= single_max) {
+    T = 512;
+    P = round_up_pow2((n + T - 1) / T);
+    G = 1;
+    if (n > 2048 && env_int("EDA_FPS_SMALL_T", 512) == 1024) { T = 1024; P = round_up_pow2((n + T - 1) / T); }
+  } else {
+    T = env_int("EDA_FPS_T", 1024);
+    P = env_int("EDA_FPS_P", 8);
+    if (T != 512 && T != 1024) T = 1024;
+    if (!(P == 1 || P == 2 || P == 4 || P == 8 || (P == 16 && T == 512))) P = 8;
+    const int chunks = (n + T - 1) / T;
+    G = (chunks + P - 1) / P;
+    if (G > kMaxG) {
+      T = 1024; P = 8;
+      G = ((n + T - 1) / T + P - 1) / P;
+    }
+    if (G > kMaxG) {
+      eda_set_error("fps: n=%d exceeds the supported %d points per scene", n, kMaxG * 8 * 1024);
+      return EDA_ERR_UNSUPPORTED;
+    }
+  }
+
+  int dev = 0, num_cu = 256;
+  EDA_CHECK_HIP(hipGetDevice(&dev));
+  EDA_CHECK_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  // Every workgroup of a launch must be co-resident (they spin on each other):
+  // at most one workgroup per CU is assumed.
+  int scenes_per_launch = G == 1 ? b : num_cu / G;
+  if (scenes_per_launch < 1) {
+    eda_set_error("fps: a cluster of %d workgroups does not fit %d CUs", G, num_cu);
+    return EDA_ERR_UNSUPPORTED;
+  }
+
+  EDA_CHECK_HIP(hipMemsetAsync(ws, 0, eda_fps_workspace_bytes(b, n, m), stream));
+  int *status = reinterpret_cast<int *>(ws);
+  u64 *mail = reinterpret_cast<u64 *>(reinterpret_cast<unsigned char *>(ws) + kStatusBytes);
+
+  const int mode = g_eda_fma_mode;
+  for (int s0 = 0; s0 < b; s0 += scenes_per_launch) {
+    const int S = (b - s0) < scenes_per_launch ? (b - s0) : scenes_per_launch;
+    const float *x = xyz + (size_t)s0 * n * 3;
+    int *o = idx + (size_t)s0 * m;
+    u64 *mb = mail + (size_t)s0 * 2 * kMaxG * kRecWords;
+    int rc;
+    if (G == 1) {
+      if (T == 512)
+        rc = mode == 0 ? dispatch_p<0, 512, false>(P, x, n, m, o, S, G, p_log2, mb, status, stream)
+                       : dispatch_p<1, 512, false>(P, x, n, m, o, S, G, p_log2, mb, status, stream);
+      else
+        rc = mode == 0 ? dispatch_p<0, 1024, false>(P, x, n, m, o, S, G, p_log2, mb, status, stream)
+                       : dispatch_p<1, 1024, false>(P, x, n, m, o, S, G, p_log2, mb, status, stream);
+    } else {
+      if (T == 512)
+        rc = mode == 0 ? dispatch_p<0, 512, true>(P, x, n, m, o, S, G, p_log2, mb, status, stream)
+                       : dispatch_p<1, 512, true>(P, x, n, m, o, S, G, p_log2, mb, status, stream);
+      else
+        rc = mode == 0 ? dispatch_p<0, 1024, true>(P, x, n, m, o, S, G, p_log2, mb, status, stream)
+                       : dispatch_p<1, 1024, true>(P, x, n, m, o, S, G, p_log2, mb, status, stream);
+    }
+    if (rc) return rc;
+  }
+  return 0;
+}

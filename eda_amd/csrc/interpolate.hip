@@ -1,0 +1,173 @@
+// interpolate.hip -- 3-nearest-neighbour search and inverse-distance
+// interpolation for gfx950.
+//
+// Replaces (reference pointnet2/_ext_src/src/):
+//   three_nn_kernel               interpolate_gpu.cu:14-64    (host interpolate.cpp:19-45)
+//   three_interpolate_kernel      interpolate_gpu.cu:77-106   (host interpolate.cpp:47-75)
+//   three_interpolate_grad_kernel interpolate_gpu.cu:121-148  (host interpolate.cpp:76-104)
+//
+// three_nn: one thread per unknown point, the scene's known points staged in LDS
+// in 1024-point chunks; grid = b * ceil(n/256) instead of the reference's b.
+// The reference compares the fp32 distance against DOUBLE running bests
+// initialised to 1e40 and stores them back as fp32; comparing against fp32
+// bests initialised to +inf gives the same decisions (an fp32 value converts to
+// double exactly, 1e40 > FLT_MAX, and (float)1e40 == +inf), so no fp64 is used.
+#include "eda_common.h"
+
+#include <math.h>
+
+namespace {
+
+constexpr int NN_THREADS = 256;
+constexpr int NN_CHUNK = 1024;
+
+template <int MODE>
+__global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(
+    const float *__restrict__ unknown_all, const float *__restrict__ known_all, int n, int m,
+    float *__restrict__ dist2_all, int *__restrict__ idx_all, int blocks_per_scene) {
+  __shared__ float pts[NN_CHUNK * 3];
+  const int scene = blockIdx.x / blocks_per_scene;
+  const int j = (blockIdx.x % blocks_per_scene) * NN_THREADS + threadIdx.x;
+  const float *unknown = unknown_all + (size_t)scene * n * 3;
+  const float *known = known_all + (size_t)scene * m * 3;
+  const bool live = j < n;
+  const float ux = live ? unknown[j * 3 + 0] : 0.f;
+  const float uy = live ? unknown[j * 3 + 1] : 0.f;
+  const float uz = live ? unknown[j * 3 + 2] : 0.f;
+
+  float best1 = INFINITY, best2 = INFINITY, best3 = INFINITY;
+  int besti1 = 0, besti2 = 0, besti3 = 0;
+  for (int base = 0; base < m; base += NN_CHUNK) {
+    const int npts = min(NN_CHUNK, m - base);
+    __syncthreads();
+    for (int f = threadIdx.x; f < npts * 3; f += NN_THREADS) pts[f] = known[(size_t)base * 3 + f];
+    __syncthreads();
+    for (int p = 0; p < npts; ++p) {           // LDS broadcast reads
+      const float x = pts[p * 3 + 0], y = pts[p * 3 + 1], z = pts[p * 3 + 2];
+      const float d = eda_sumsq3<MODE>(ux - x, uy - y, uz - z);
+      const int k = base + p;
+      if (d < best1) {                          // interpolate_gpu.cu:40-56
+        best3 = best2; besti3 = besti2;
+        best2 = best1; besti2 = besti1;
+        best1 = d; besti1 = k;
+      } else if (d < best2) {
+        best3 = best2; besti3 = besti2;
+        best2 = d; besti2 = k;
+      } else if (d < best3) {
+        best3 = d; besti3 = k;
+      }
+    }
+  }
+  if (live) {
+    float *d2 = dist2_all + ((size_t)scene * n + j) * 3;
+    int *ix = idx_all + ((size_t)scene * n + j) * 3;
+    d2[0] = best1; d2[1] = best2; d2[2] = best3;
+    ix[0] = besti1; ix[1] = besti2; ix[2] = besti3;
+  }
+}
+
+// out[b,l,j] = sum_t points[b,l,idx[b,j,t]] * weight[b,j,t]
+// MODE 0 contraction of p1*w1 + p2*w2 + p3*w3: t = p2*w2; fma(p1,w1,t); fma(p3,w3,t).
+template <int MODE>
+__global__ __launch_bounds__(256) void three_interpolate_kernel(
+    const float *__restrict__ points, const int *__restrict__ idx, const float *__restrict__ weight,
+    int c, int m, int n, float *__restrict__ out) {
+  const int scene = blockIdx.z;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const float *w = weight + ((size_t)scene * n + j) * 3;
+  const int *ix = idx + ((size_t)scene * n + j) * 3;
+  const float w1 = w[0], w2 = w[1], w3 = w[2];
+  const int i1 = ix[0], i2 = ix[1], i3 = ix[2];
+  const int l0 = blockIdx.y * 8;
+  const int lend = min(l0 + 8, c);
+  for (int l = l0; l < lend; ++l) {
+    const float *p = points + ((size_t)scene * c + l) * m;
+    float r;
+    if (MODE == 0) {
+      r = p[i2] * w2;
+      r = __builtin_fmaf(p[i1], w1, r);
+      r = __builtin_fmaf(p[i3], w3, r);
+    } else {
+      r = (p[i1] * w1 + p[i2] * w2) + p[i3] * w3;
+    }
+    out[((size_t)scene * c + l) * n + j] = r;
+  }
+}
+
+__global__ __launch_bounds__(256) void three_interpolate_grad_kernel(
+    const float *__restrict__ grad_out, const int *__restrict__ idx,
+    const float *__restrict__ weight, int c, int n, int m, float *__restrict__ grad_points) {
+  const int scene = blockIdx.z;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const float *w = weight + ((size_t)scene * n + j) * 3;
+  const int *ix = idx + ((size_t)scene * n + j) * 3;
+  const float w1 = w[0], w2 = w[1], w3 = w[2];
+  const int i1 = ix[0], i2 = ix[1], i3 = ix[2];
+  const int l0 = blockIdx.y * 8;
+  const int lend = min(l0 + 8, c);
+  for (int l = l0; l < lend; ++l) {
+    const float g = grad_out[((size_t)scene * c + l) * n + j];
+    float *gp = grad_points + ((size_t)scene * c + l) * m;
+    atomicAdd(gp + i1, g * w1);
+    atomicAdd(gp + i2, g * w2);
+    atomicAdd(gp + i3, g * w3);
+  }
+}
+
+}  // namespace
+
+extern "C" int eda_three_nn_f32(const float *unknown, const float *known, int b, int n, int m,
+                                float *dist2, int *idx, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(b >= 0 && n >= 0 && m >= 0, "negative dimension");
+  if (b == 0 || n == 0) return 0;
+  EDA_CHECK_ARG(unknown && dist2 && idx && (known || m == 0), "null pointer");
+  const int bps = (n + NN_THREADS - 1) / NN_THREADS;
+  const dim3 grid((unsigned)((size_t)b * bps));
+  if (g_eda_fma_mode == 0)
+    hipLaunchKernelGGL(three_nn_kernel<0>, grid, dim3(NN_THREADS), 0, stream, unknown, known, n, m,
+                       dist2, idx, bps);
+  else
+    hipLaunchKernelGGL(three_nn_kernel<1>, grid, dim3(NN_THREADS), 0, stream, unknown, known, n, m,
+                       dist2, idx, bps);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int eda_three_interpolate_f32(const float *points, const int *idx, const float *weight,
+                                         int b, int c, int m, int n, float *out, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(b >= 0 && c >= 0 && n >= 0 && m >= 0, "negative dimension");
+  if (b == 0 || c == 0 || n == 0) return 0;
+  EDA_CHECK_ARG(points && idx && weight && out, "null pointer");
+  EDA_CHECK_ARG(b <= 65535 && (c + 7) / 8 <= 65535, "shape too large");
+  const dim3 grid((unsigned)((n + 255) / 256), (unsigned)((c + 7) / 8), (unsigned)b);
+  if (g_eda_fma_mode == 0)
+    hipLaunchKernelGGL(three_interpolate_kernel<0>, grid, dim3(256), 0, stream, points, idx, weight,
+                       c, m, n, out);
+  else
+    hipLaunchKernelGGL(three_interpolate_kernel<1>, grid, dim3(256), 0, stream, points, idx, weight,
+                       c, m, n, out);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int eda_three_interpolate_grad_f32(const float *grad_out, const int *idx,
+                                              const float *weight, int b, int c, int n, int m,
+                                              float *grad_points, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(b >= 0 && c >= 0 && n >= 0 && m >= 0, "negative dimension");
+  if (b == 0 || c == 0 || m == 0) return 0;
+  EDA_CHECK_ARG(grad_points, "null pointer");
+  EDA_CHECK_HIP(hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * c * m, stream));
+  if (n == 0) return 0;
+  EDA_CHECK_ARG(grad_out && idx && weight, "null pointer");
+  EDA_CHECK_ARG(b <= 65535 && (c + 7) / 8 <= 65535, "shape too large");
+  const dim3 grid((unsigned)((n + 255) / 256), (unsigned)((c + 7) / 8), (unsigned)b);
+  hipLaunchKernelGGL(three_interpolate_grad_kernel, grid, dim3(256), 0, stream, grad_out, idx,
+                     weight, c, n, m, grad_points);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,234 @@
+"""Drop-in for the reference's ``pointnet2._ext`` pybind11 module.
+
+The reference binds nine functions (pointnet2/_ext_src/src/bindings.cpp:11-24);
+this module exposes the same nine callables -- same positional signatures, same
+argument checks and messages (include/utils.h:10-30), same allocation behaviour
+(fresh, callee-owned outputs on the input's device) -- on top of the C ABI of
+``libeda_hip.so`` (include/eda_hip.h).  Work is enqueued on torch's current HIP
+stream and never synchronises, like the reference.
+
+``install_as_pointnet2_ext()`` registers it as ``sys.modules['pointnet2._ext']``
+so the reference's own ``pointnet2_utils.py`` (which does ``import
+pointnet2._ext as _ext``, pointnet2_utils.py:25-33) runs unmodified on MI355X.
+
+CPU tensors raise "CPU not supported" exactly like the reference
+(sampling.cpp:39,65,87 ...): there is no CPU path in the product.
+"""
+import sys
+import types
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check_contiguous(t, name):
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be a contiguous tensor")
+
+
+def _check_float(t, name):
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be a float tensor")
+
+
+def _check_int(t, name):
+    if t.dtype != torch.int32:
+        raise RuntimeError(f"{name} must be an int tensor")
+
+
+def _check_cuda(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+
+
+def _require_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError("CPU not supported")
+
+
+def furthest_point_sampling(points, nsamples):
+    """sampling.cpp:70-91 -- points (B,N,3) f32 -> (B,nsamples) i32."""
+    _check_contiguous(points, "points")
+    _check_float(points, "points")
+    _require_gpu(points)
+    L = _lib.lib()
+    b, n = points.shape[0], points.shape[1]
+    nsamples = int(nsamples)
+    out = torch.empty((b, nsamples), dtype=torch.int32, device=points.device)
+    if b == 0 or nsamples == 0:
+        return out
+    ws_bytes = L.eda_fps_workspace_bytes(b, n, nsamples)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=points.device)
+    with torch.cuda.device(points.device):
+        rc = L.eda_furthest_point_sampling_f32(points.data_ptr(), b, n, nsamples, out.data_ptr(),
+                                               ws.data_ptr(), ws_bytes, _stream())
+    _lib.check(rc, "eda_furthest_point_sampling_f32")
+    return out
+
+
+def gather_points(points, idx):
+    """sampling.cpp:20-43 -- points (B,C,N), idx (B,m) -> (B,C,m)."""
+    _check_contiguous(points, "points"); _check_contiguous(idx, "idx")
+    _check_float(points, "points"); _check_int(idx, "idx")
+    if points.is_cuda:
+        _check_cuda(idx, "idx")
+    _require_gpu(points)
+    b, c, n = points.shape
+    m = idx.shape[1]
+    out = torch.empty((b, c, m), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        rc = _lib.lib().eda_gather_points_f32(points.data_ptr(), idx.data_ptr(), b, c, n, m,
+                                              out.data_ptr(), _stream())
+    _lib.check(rc, "eda_gather_points_f32")
+    return out
+
+
+def gather_points_grad(grad_out, idx, n):
+    """sampling.cpp:45-69 -- grad_out (B,C,m), idx (B,m) -> (B,C,n)."""
+    _check_contiguous(grad_out, "grad_out"); _check_contiguous(idx, "idx")
+    _check_float(grad_out, "grad_out"); _check_int(idx, "idx")
+    if grad_out.is_cuda:
+        _check_cuda(idx, "idx")
+    _require_gpu(grad_out)
+    b, c, m = grad_out.shape
+    n = int(n)
+    out = torch.empty((b, c, n), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        rc = _lib.lib().eda_gather_points_grad_f32(grad_out.data_ptr(), idx.data_ptr(), b, c, n, m,
+                                                   out.data_ptr(), _stream())
+    _lib.check(rc, "eda_gather_points_grad_f32")
+    return out
+
+
+def ball_query(new_xyz, xyz, radius, nsample):
+    """ball_query.cpp:13-37 -- new_xyz (B,m,3), xyz (B,N,3) -> (B,m,nsample) i32.
+    NB: argument order differs from pointnet2_utils.ball_query(radius, nsample, xyz, new_xyz)."""
+    _check_contiguous(new_xyz, "new_xyz"); _check_contiguous(xyz, "xyz")
+    _check_float(new_xyz, "new_xyz"); _check_float(xyz, "xyz")
+    if new_xyz.is_cuda:
+        _check_cuda(xyz, "xyz")
+    _require_gpu(new_xyz)
+    b, n = xyz.shape[0], xyz.shape[1]
+    m = new_xyz.shape[1]
+    nsample = int(nsample)
+    idx = torch.empty((new_xyz.shape[0], m, nsample), dtype=torch.int32, device=new_xyz.device)
+    with torch.cuda.device(new_xyz.device):
+        rc = _lib.lib().eda_ball_query_f32(new_xyz.data_ptr(), xyz.data_ptr(), b, n, m,
+                                           float(radius), nsample, idx.data_ptr(), _stream())
+    _lib.check(rc, "eda_ball_query_f32")
+    return idx
+
+
+def group_points(points, idx):
+    """group_points.cpp:17-40 -- points (B,C,N), idx (B,m,ns) -> fresh (B,C,m,ns)."""
+    _check_contiguous(points, "points"); _check_contiguous(idx, "idx")
+    _check_float(points, "points"); _check_int(idx, "idx")
+    if points.is_cuda:
+        _check_cuda(idx, "idx")
+    _require_gpu(points)
+    b, c, n = points.shape
+    npoints, nsample = idx.shape[1], idx.shape[2]
+    out = torch.empty((b, c, npoints, nsample), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        rc = _lib.lib().eda_group_points_f32(points.data_ptr(), idx.data_ptr(), b, c, n, npoints,
+                                             nsample, out.data_ptr(), _stream())
+    _lib.check(rc, "eda_group_points_f32")
+    return out
+
+
+def group_points_grad(grad_out, idx, n):
+    """group_points.cpp:42-65 -- grad_out (B,C,m,ns), idx (B,m,ns) -> (B,C,n)."""
+    _check_contiguous(grad_out, "grad_out"); _check_contiguous(idx, "idx")
+    _check_float(grad_out, "grad_out"); _check_int(idx, "idx")
+    if grad_out.is_cuda:
+        _check_cuda(idx, "idx")
+    _require_gpu(grad_out)
+    b, c = grad_out.shape[0], grad_out.shape[1]
+    npoints, nsample = idx.shape[1], idx.shape[2]
+    n = int(n)
+    out = torch.empty((b, c, n), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        rc = _lib.lib().eda_group_points_grad_f32(grad_out.data_ptr(), idx.data_ptr(), b, c, n,
+                                                  npoints, nsample, out.data_ptr(), _stream())
+    _lib.check(rc, "eda_group_points_grad_f32")
+    return out
+
+
+def three_nn(unknowns, knows):
+    """interpolate.cpp:19-45 -- unknowns (B,n,3), knows (B,m,3) -> [dist2 (B,n,3) f32, idx (B,n,3) i32]."""
+    _check_contiguous(unknowns, "unknowns"); _check_contiguous(knows, "knows")
+    _check_float(unknowns, "unknowns"); _check_float(knows, "knows")
+    if unknowns.is_cuda:
+        _check_cuda(knows, "knows")
+    _require_gpu(unknowns)
+    b, n = unknowns.shape[0], unknowns.shape[1]
+    m = knows.shape[1]
+    idx = torch.empty((b, n, 3), dtype=torch.int32, device=unknowns.device)
+    dist2 = torch.empty((b, n, 3), dtype=torch.float32, device=unknowns.device)
+    with torch.cuda.device(unknowns.device):
+        rc = _lib.lib().eda_three_nn_f32(unknowns.data_ptr(), knows.data_ptr(), b, n, m,
+                                         dist2.data_ptr(), idx.data_ptr(), _stream())
+    _lib.check(rc, "eda_three_nn_f32")
+    return [dist2, idx]
+
+
+def three_interpolate(points, idx, weight):
+    """interpolate.cpp:47-75 -- points (B,C,m), idx (B,n,3), weight (B,n,3) -> (B,C,n)."""
+    _check_contiguous(points, "points"); _check_contiguous(idx, "idx"); _check_contiguous(weight, "weight")
+    _check_float(points, "points"); _check_int(idx, "idx"); _check_float(weight, "weight")
+    if points.is_cuda:
+        _check_cuda(idx, "idx"); _check_cuda(weight, "weight")
+    _require_gpu(points)
+    b, c, m = points.shape
+    n = idx.shape[1]
+    out = torch.empty((b, c, n), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        rc = _lib.lib().eda_three_interpolate_f32(points.data_ptr(), idx.data_ptr(), weight.data_ptr(),
+                                                  b, c, m, n, out.data_ptr(), _stream())
+    _lib.check(rc, "eda_three_interpolate_f32")
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    """interpolate.cpp:76-104 -- grad_out (B,C,n), idx/weight (B,n,3) -> (B,C,m)."""
+    _check_contiguous(grad_out, "grad_out"); _check_contiguous(idx, "idx"); _check_contiguous(weight, "weight")
+    _check_float(grad_out, "grad_out"); _check_int(idx, "idx"); _check_float(weight, "weight")
+    if grad_out.is_cuda:
+        _check_cuda(idx, "idx"); _check_cuda(weight, "weight")
+    _require_gpu(grad_out)
+    b, c, n = grad_out.shape
+    m = int(m)
+    out = torch.empty((b, c, m), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        rc = _lib.lib().eda_three_interpolate_grad_f32(grad_out.data_ptr(), idx.data_ptr(),
+                                                       weight.data_ptr(), b, c, n, m,
+                                                       out.data_ptr(), _stream())
+    _lib.check(rc, "eda_three_interpolate_grad_f32")
+    return out
+
+
+def set_fma_mode(mode):
+    """0 = nvcc-style contracted distance arithmetic (default), 1 = strict IEEE."""
+    _lib.check(_lib.lib().eda_set_fma_mode(int(mode)), "eda_set_fma_mode")
+
+
+_NAMES = ("gather_points", "gather_points_grad", "furthest_point_sampling", "three_nn",
+          "three_interpolate", "three_interpolate_grad", "ball_query", "group_points",
+          "group_points_grad")
+
+
+def install_as_pointnet2_ext():
+    """Make ``import pointnet2._ext`` resolve to this module's nine functions."""
+    mod = types.ModuleType("pointnet2._ext")
+    for name in _NAMES:
+        setattr(mod, name, globals()[name])
+    sys.modules["pointnet2._ext"] = mod
+    pkg = sys.modules.get("pointnet2")
+    if pkg is not None:
+        setattr(pkg, "_ext", mod)
+    return mod

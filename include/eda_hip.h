@@ -1,0 +1,117 @@
+/*
+ * eda_hip.h -- C ABI of libeda_hip.so, the MI355X (gfx950) implementation of
+ * the hot path of yanmin-wu/EDA: the nine ops of pointnet2/_ext_src plus the
+ * fused kernels built on them.
+ *
+ * This is the drop-in boundary.  Each entry point replaces one function the
+ * reference binds through pybind11 (pointnet2/_ext_src/src/bindings.cpp:11-24);
+ * the citation on each declaration names the reference host dispatcher and
+ * CUDA kernel it replaces (paths relative to /root/reference/pointnet2/_ext_src).
+ *
+ * Conventions
+ *  - plain pointers + int32 dims; all pointers are DEVICE pointers (HBM);
+ *    fp32 / int32 only, dense row-major ("contiguous") exactly as the
+ *    reference requires (include/utils.h:15-30).
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  Every
+ *    call only ENQUEUES work on that stream: no allocation, no host sync,
+ *    graph-capturable.  Scratch memory comes from the caller (`ws`).
+ *  - return value: 0 on success, otherwise a hipError_t (or EDA_ERR_*) value;
+ *    never exit()s (the reference does, include/cuda_utils.h:35-44).
+ *    eda_last_error_string() describes the last failure on this thread.
+ *  - outputs are written completely by the kernels (the reference relies on
+ *    torch::zeros + partial writes; results are identical).  The *_grad entry
+ *    points zero their output themselves before accumulating.
+ *  - re-entrant; the only process-global state is the arithmetic mode below.
+ */
+#ifndef EDA_HIP_H
+#define EDA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EDA_HIP_ABI_VERSION 1
+
+#define EDA_ERR_INVALID_ARG   10001
+#define EDA_ERR_WORKSPACE     10002
+#define EDA_ERR_UNSUPPORTED   10003
+
+int         eda_version(void);
+const char *eda_last_error_string(void);
+
+/* Arithmetic of the fp32 squared-distance expression (see DESIGN.md
+ * "Canonical arithmetic").  0 = nvcc -fmad=true contraction
+ * [t=dy*dy; t=fma(dx,dx,t); t=fma(dz,dz,t)] (default), 1 = no contraction. */
+int eda_set_fma_mode(int mode);
+int eda_get_fma_mode(void);
+
+/* ---- furthest point sampling ------------------------------------------
+ * replaces furthest_point_sampling()            src/sampling.cpp:70-91
+ *          furthest_point_sampling_kernel<bs>   src/sampling_gpu.cu:74-234
+ * xyz (b,n,3) f32 -> idx (b,m) i32.  The running min-distance array the
+ * reference keeps in a (b,n) global `temp` tensor lives in registers here.
+ * ws: eda_fps_workspace_bytes(b,n,m) bytes of device scratch (inter-workgroup
+ * mailboxes + status word); it is zeroed on `stream` by the call itself.
+ * After the stream has drained, ws[0] (int32) != 0 reports a give-up of the
+ * bounded inter-workgroup spin (never observed).            */
+size_t eda_fps_workspace_bytes(int b, int n, int m);
+int eda_furthest_point_sampling_f32(const float *xyz, int b, int n, int m,
+                                    int *idx, void *ws, size_t ws_bytes,
+                                    void *stream);
+
+/* ---- gather -----------------------------------------------------------
+ * replaces gather_points()        src/sampling.cpp:20-43, sampling_gpu.cu:13-35
+ * points (b,c,n), idx (b,m) -> out (b,c,m)                                 */
+int eda_gather_points_f32(const float *points, const int *idx, int b, int c,
+                          int n, int m, float *out, void *stream);
+/* replaces gather_points_grad()   src/sampling.cpp:45-69, sampling_gpu.cu:39-62
+ * grad_out (b,c,m), idx (b,m) -> grad_points (b,c,n) (zeroed here)          */
+int eda_gather_points_grad_f32(const float *grad_out, const int *idx, int b,
+                               int c, int n, int m, float *grad_points,
+                               void *stream);
+
+/* ---- ball query -------------------------------------------------------
+ * replaces ball_query()               src/ball_query.cpp:13-37
+ *          query_ball_point_kernel    src/ball_query_gpu.cu:14-59
+ * new_xyz (b,m,3), xyz (b,n,3) -> idx (b,m,nsample): the first `nsample`
+ * points with d2 < radius^2 in ascending index order, padded with the first
+ * hit; an empty ball yields an all-zero row.                               */
+int eda_ball_query_f32(const float *new_xyz, const float *xyz, int b, int n,
+                       int m, float radius, int nsample, int *idx,
+                       void *stream);
+
+/* ---- grouping ---------------------------------------------------------
+ * replaces group_points()        src/group_points.cpp:17-40, group_points_gpu.cu:13-45
+ * points (b,c,n), idx (b,npoints,nsample) -> out (b,c,npoints,nsample)      */
+int eda_group_points_f32(const float *points, const int *idx, int b, int c,
+                         int n, int npoints, int nsample, float *out,
+                         void *stream);
+/* replaces group_points_grad()   src/group_points.cpp:42-65, group_points_gpu.cu:48-80
+ * grad_out (b,c,npoints,nsample) -> grad_points (b,c,n) (zeroed here)       */
+int eda_group_points_grad_f32(const float *grad_out, const int *idx, int b,
+                              int c, int n, int npoints, int nsample,
+                              float *grad_points, void *stream);
+
+/* ---- 3-NN interpolation -----------------------------------------------
+ * replaces three_nn()            src/interpolate.cpp:19-45, interpolate_gpu.cu:14-74
+ * unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) f32 (squared), idx (b,n,3) */
+int eda_three_nn_f32(const float *unknown, const float *known, int b, int n,
+                     int m, float *dist2, int *idx, void *stream);
+/* replaces three_interpolate()   src/interpolate.cpp:47-75, interpolate_gpu.cu:77-116
+ * points (b,c,m), idx (b,n,3), weight (b,n,3) -> out (b,c,n)                */
+int eda_three_interpolate_f32(const float *points, const int *idx,
+                              const float *weight, int b, int c, int m, int n,
+                              float *out, void *stream);
+/* replaces three_interpolate_grad() src/interpolate.cpp:76-104, interpolate_gpu.cu:121-159
+ * grad_out (b,c,n) -> grad_points (b,c,m) (zeroed here)                     */
+int eda_three_interpolate_grad_f32(const float *grad_out, const int *idx,
+                                   const float *weight, int b, int c, int n,
+                                   int m, float *grad_points, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EDA_HIP_H */

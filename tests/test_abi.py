@@ -1,0 +1,63 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol that
+include/eda_hip.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "eda_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(eda_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_nine_ops():
+    names = _declared()
+    for op in ["furthest_point_sampling", "gather_points", "gather_points_grad", "ball_query",
+               "group_points", "group_points_grad", "three_nn", "three_interpolate",
+               "three_interpolate_grad"]:
+        assert f"eda_{op}_f32" in names
+
+
+def test_library_exports_every_declared_symbol():
+    from eda_amd import build, _lib
+    build.build()
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in _declared() if not hasattr(L, n)]
+    assert not missing, missing
+    # ctypes table covers the header one to one
+    assert sorted(_lib.SIGNATURES) == _declared()
+    lib = _lib.lib()
+    assert lib.eda_version() == 1
+    assert lib.eda_get_fma_mode() == 0
+    assert lib.eda_set_fma_mode(7) != 0 and b"mode" in lib.eda_last_error_string()
+    assert lib.eda_fps_workspace_bytes(8, 50000, 2048) > 0
+
+
+def test_ext_refuses_cpu_tensors():
+    """The product has no CPU path: same error as the reference (sampling.cpp:39)."""
+    import torch
+    from eda_amd import ext
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        ext.furthest_point_sampling(torch.zeros(1, 8, 3), 2)
+    with pytest.raises(RuntimeError, match="must be a contiguous tensor"):
+        ext.furthest_point_sampling(torch.zeros(1, 3, 8).transpose(1, 2), 2)
+    with pytest.raises(RuntimeError, match="must be an int tensor"):
+        ext.gather_points(torch.zeros(1, 3, 8), torch.zeros(1, 2, dtype=torch.int64))
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        ext.ball_query(torch.zeros(1, 2, 3), torch.zeros(1, 8, 3), 0.2, 4)
+
+
+def test_product_never_imports_oracle():
+    """Nothing under eda_amd/ or bench product paths may reference oracle/."""
+    import glob
+    bad = []
+    for path in glob.glob(os.path.join(ROOT, "eda_amd", "**", "*.py"), recursive=True):
+        src = open(path).read()
+        if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "libeda_oracle" in src:
+            bad.append(path)
+    assert not bad, bad
