@@ -1,0 +1,208 @@
+"""BeaUTyDETR -- the 3D visual-grounding model, module API of models/bdetr.py.
+
+Same constructor keywords (bdetr.py:46-52), same ``forward(inputs) -> end_points``
+contract (:208-339: input keys point_clouds / text / det_boxes /
+det_bbox_label_mask / det_class_ids; 60 output entries incl. the 7 prediction
+prefixes) and the same sub-module names, so reference checkpoints load and the
+reference's three-group optimiser filter ("backbone_net" / "text_encoder" in the
+parameter name, main_utils.py:279-301) keeps working.
+
+Differences that are deliberate and documented in DESIGN.md:
+ * no network / no weights offline: when ``{data_path}roberta-base/`` is absent the
+   text encoder is a random-init RoBERTa-base (frozen either way) and the class
+   embedding table is seeded random of the reference's shape (485 x 768);
+ * ``inputs['tokenized'] = {'input_ids', 'attention_mask'}`` may replace
+   ``inputs['text']`` (device-side tokenised input, no host work inside forward).
+"""
+import os
+
+import numpy as np
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from .backbone_module import Pointnet2Backbone
+from .encoder_decoder_layers import BiDecoderLayer, BiEncoder, BiEncoderLayer, PositionEmbeddingLearned
+from .modules import ClsAgnosticPredictHead, GeneralSamplingModule, PointsObjClsModule
+
+
+def _mlp3(d_in, d_out):
+    return nn.Sequential(nn.Linear(d_in, d_in), nn.ReLU(), nn.Linear(d_in, d_in), nn.ReLU(),
+                         nn.Linear(d_in, d_out))
+
+
+def _load_text_stack(data_path):
+    from transformers import RobertaConfig, RobertaModel
+    t_type = f"{data_path}roberta-base/"
+    if data_path is not None and os.path.isdir(t_type):
+        from transformers import RobertaTokenizerFast
+        return (RobertaTokenizerFast.from_pretrained(t_type, local_files_only=True),
+                RobertaModel.from_pretrained(t_type, local_files_only=True))
+    cfg = RobertaConfig(vocab_size=50265, max_position_embeddings=514, type_vocab_size=1,
+                        pad_token_id=1)       # roberta-base geometry, random init
+    return None, RobertaModel(cfg)
+
+
+class BeaUTyDETR(nn.Module):
+    def __init__(self, num_class=256, num_obj_class=485, input_feature_dim=3, num_queries=256,
+                 num_decoder_layers=6, self_position_embedding="loc_learned",
+                 contrastive_align_loss=True, d_model=288, butd=True, pointnet_ckpt=None,
+                 data_path=None, self_attend=True):
+        super().__init__()
+        self.num_queries = num_queries
+        self.num_decoder_layers = num_decoder_layers
+        self.self_position_embedding = self_position_embedding
+        self.contrastive_align_loss = contrastive_align_loss
+        self.butd = butd
+
+        self.backbone_net = Pointnet2Backbone(input_feature_dim=input_feature_dim, width=1)
+        if input_feature_dim == 3 and pointnet_ckpt is not None:
+            self.backbone_net.load_state_dict(torch.load(pointnet_ckpt), strict=False)
+
+        self.tokenizer, self.text_encoder = _load_text_stack(data_path)
+        for p in self.text_encoder.parameters():
+            p.requires_grad = False
+        self.text_projector = nn.Sequential(
+            nn.Linear(self.text_encoder.config.hidden_size, d_model),
+            nn.LayerNorm(d_model, eps=1e-12), nn.Dropout(0.1))
+
+        if self.butd:
+            self.butd_class_embeddings = nn.Embedding(num_obj_class, 768)
+            emb_path = os.path.join("data", "class_embeddings3d.npy")
+            if os.path.exists(emb_path):
+                self.butd_class_embeddings.weight.data.copy_(
+                    torch.from_numpy(np.load(emb_path, allow_pickle=True)))
+            # the reference sets requires_grad on the MODULE (bdetr.py:95), so the table
+            # stays trainable and takes part in the gradient all-reduce; kept on purpose.
+            self.butd_class_embeddings.requires_grad = False
+            self.class_embeddings = nn.Linear(768, d_model - 128)
+            self.box_embeddings = PositionEmbeddingLearned(6, 128)
+
+        self.pos_embed = PositionEmbeddingLearned(3, d_model)
+        bi_layer = BiEncoderLayer(d_model, dropout=0.1, activation="relu", n_heads=8,
+                                  dim_feedforward=256, self_attend_lang=self_attend,
+                                  self_attend_vis=self_attend, use_butd_enc_attn=butd)
+        self.cross_encoder = BiEncoder(bi_layer, 3)
+
+        self.points_obj_cls = PointsObjClsModule(d_model)
+        self.gsample_module = GeneralSamplingModule()
+        self.decoder_query_proj = nn.Conv1d(d_model, d_model, kernel_size=1)
+        self.proposal_head = ClsAgnosticPredictHead(num_class, 1, num_queries, d_model,
+                                                    objectness=False, heading=False,
+                                                    compute_sem_scores=True)
+        self.decoder = nn.ModuleList(
+            BiDecoderLayer(d_model, n_heads=8, dim_feedforward=256, dropout=0.1, activation="relu",
+                           self_position_embedding=self_position_embedding, butd=self.butd)
+            for _ in range(num_decoder_layers))
+        self.prediction_heads = nn.ModuleList(
+            ClsAgnosticPredictHead(num_class, 1, num_queries, d_model, objectness=False,
+                                   heading=False, compute_sem_scores=True)
+            for _ in range(num_decoder_layers))
+        if contrastive_align_loss:
+            self.contrastive_align_projection_image = _mlp3(d_model, 64)
+            self.contrastive_align_projection_text = _mlp3(d_model, 64)
+        self.init_bn_momentum()
+
+    # ------------------------------------------------------------------ pieces
+    def _encode_text(self, inputs, device):
+        if "tokenized" in inputs:
+            tok = inputs["tokenized"]
+            ids, am = tok["input_ids"].to(device), tok["attention_mask"].to(device)
+        else:
+            if self.tokenizer is None:
+                raise RuntimeError("no RoBERTa tokenizer files offline: pass inputs['tokenized'] = "
+                                   "{'input_ids', 'attention_mask'} instead of inputs['text']")
+            tok = self.tokenizer.batch_encode_plus(inputs["text"], padding="longest",
+                                                   return_tensors="pt").to(device)
+            ids, am = tok["input_ids"], tok["attention_mask"]
+        with torch.no_grad():
+            hidden = self.text_encoder(input_ids=ids, attention_mask=am).last_hidden_state
+        return hidden, am.ne(1).bool(), {"input_ids": ids, "attention_mask": am}
+
+    def _run_backbones(self, inputs):
+        end_points = self.backbone_net(inputs["point_clouds"], end_points={})
+        end_points["seed_inds"] = end_points["fp2_inds"]
+        end_points["seed_xyz"] = end_points["fp2_xyz"]
+        end_points["seed_features"] = end_points["fp2_features"]
+        hidden, text_mask, tok = self._encode_text(inputs, inputs["point_clouds"].device)
+        end_points["text_feats"] = self.text_projector(hidden)
+        end_points["text_attention_mask"] = text_mask
+        end_points["tokenized"] = tok
+        return end_points
+
+    def _generate_queries(self, xyz, features, end_points):
+        logits = self.points_obj_cls(features)
+        end_points["seeds_obj_cls_logits"] = logits
+        sample_inds = torch.topk(torch.sigmoid(logits).squeeze(1), self.num_queries)[1].int()
+        xyz, features, sample_inds = self.gsample_module(xyz, features, sample_inds)
+        end_points["query_points_xyz"] = xyz
+        end_points["query_points_feature"] = features
+        end_points["query_points_sample_inds"] = sample_inds
+        return end_points
+
+    # ----------------------------------------------------------------- forward
+    def forward(self, inputs):
+        end_points = self._run_backbones(inputs)
+        points_xyz = end_points["fp2_xyz"]                       # (B, 1024, 3)
+        points_features = end_points["fp2_features"]             # (B, 288, 1024)
+        text_feats = end_points["text_feats"]
+        text_padding_mask = end_points["text_attention_mask"]
+
+        if self.butd:
+            detected_mask = ~inputs["det_bbox_label_mask"]
+            box_emb = self.box_embeddings(inputs["det_boxes"])                          # (B,128,D)
+            cls_emb = self.class_embeddings(self.butd_class_embeddings(inputs["det_class_ids"]))
+            detected_feats = torch.cat([box_emb, cls_emb.transpose(1, 2)], 1).transpose(1, 2).contiguous()
+        else:
+            detected_mask, detected_feats = None, None
+
+        vis, text_feats = self.cross_encoder(
+            vis_feats=points_features.transpose(1, 2).contiguous(),
+            pos_feats=self.pos_embed(points_xyz).transpose(1, 2).contiguous(),
+            padding_mask=torch.zeros(points_xyz.shape[:2], dtype=torch.bool, device=points_xyz.device),
+            text_feats=text_feats, text_padding_mask=text_padding_mask, end_points=end_points,
+            detected_feats=detected_feats, detected_mask=detected_mask)
+        points_features = vis.transpose(1, 2).contiguous()       # (B, 288, 1024)
+        end_points["text_memory"] = text_feats
+        end_points["seed_features"] = points_features
+        if self.contrastive_align_loss:
+            end_points["proj_tokens"] = F.normalize(
+                self.contrastive_align_projection_text(text_feats), p=2, dim=-1)
+
+        end_points = self._generate_queries(points_xyz, points_features, end_points)
+        cluster_feature = end_points["query_points_feature"]     # (B, 288, Q)
+        cluster_xyz = end_points["query_points_xyz"]             # (B, Q, 3)
+        query = self.decoder_query_proj(cluster_feature).transpose(1, 2).contiguous()
+        if self.contrastive_align_loss:
+            end_points["proposal_proj_queries"] = F.normalize(
+                self.contrastive_align_projection_image(query), p=2, dim=-1)
+        center, size = self.proposal_head(cluster_feature, base_xyz=cluster_xyz,
+                                          end_points=end_points, prefix="proposal_")
+        base_xyz, base_size = center.detach().clone(), size.detach().clone()
+
+        for i in range(self.num_decoder_layers):
+            prefix = "last_" if i == self.num_decoder_layers - 1 else f"{i}head_"
+            if self.self_position_embedding == "none":
+                query_pos = None
+            elif self.self_position_embedding == "xyz_learned":
+                query_pos = base_xyz
+            elif self.self_position_embedding == "loc_learned":
+                query_pos = torch.cat([base_xyz, base_size], -1)
+            else:
+                raise NotImplementedError
+            query = self.decoder[i](query, vis, text_feats, query_pos, None, text_padding_mask,
+                                    detected_feats=detected_feats if self.butd else None,
+                                    detected_mask=detected_mask if self.butd else None)
+            if self.contrastive_align_loss:
+                end_points[f"{prefix}proj_queries"] = F.normalize(
+                    self.contrastive_align_projection_image(query), p=2, dim=-1)
+            center, size = self.prediction_heads[i](query.transpose(1, 2).contiguous(),
+                                                    base_xyz=cluster_xyz, end_points=end_points,
+                                                    prefix=prefix)
+            base_xyz, base_size = center.detach().clone(), size.detach().clone()
+        return end_points
+
+    def init_bn_momentum(self):
+        for m in self.modules():
+            if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
+                m.momentum = 0.1

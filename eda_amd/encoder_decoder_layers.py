@@ -1,0 +1,195 @@
+"""Cross-modal encoder / decoder layers (text tokens <-> points / queries / boxes).
+
+Mirrors models/encoder_decoder_layers.py: PositionEmbeddingLearned (:15-30),
+CrossAttentionLayer (:33-124), TransformerEncoderLayerNoFFN (:127-156),
+PosTransformerEncoderLayerNoFFN (:159-186), BiEncoderLayer (:189-255), BiEncoder
+(:258-285), BiDecoderLayer (:288-407) -- same constructor arguments, forward
+signatures, sub-module names (state_dict contract) and post-norm residual order.
+Internally everything stays batch-first (B, N, F).
+"""
+from copy import deepcopy
+
+import torch
+from torch import nn
+
+from .attention import MultiheadAttention
+
+
+def _get_clones(module, n):
+    return nn.ModuleList([deepcopy(module) for _ in range(n)])
+
+
+def _ffn(d_model, dim_feedforward, dropout):
+    return nn.Sequential(nn.Linear(d_model, dim_feedforward), nn.ReLU(), nn.Dropout(dropout),
+                         nn.Linear(dim_feedforward, d_model), nn.Dropout(dropout))
+
+
+class PositionEmbeddingLearned(nn.Module):
+    """(B, N, 3 or 6) -> (B, F, N): conv1d - BN - ReLU - conv1d."""
+
+    def __init__(self, input_channel, num_pos_feats=288):
+        super().__init__()
+        self.position_embedding_head = nn.Sequential(
+            nn.Conv1d(input_channel, num_pos_feats, kernel_size=1),
+            nn.BatchNorm1d(num_pos_feats),
+            nn.ReLU(inplace=True),
+            nn.Conv1d(num_pos_feats, num_pos_feats, kernel_size=1))
+
+    def forward(self, xyz):
+        return self.position_embedding_head(xyz.transpose(1, 2).contiguous())
+
+
+class CrossAttentionLayer(nn.Module):
+    """text <- points, points <- text, (points <- detected boxes), FFNs."""
+
+    def __init__(self, d_model=256, dropout=0.1, n_heads=8, dim_feedforward=256,
+                 use_butd_enc_attn=False):
+        super().__init__()
+        self.use_butd_enc_attn = use_butd_enc_attn
+        self.cross_lv = MultiheadAttention(d_model, n_heads, dropout=dropout)
+        self.dropout_lv = nn.Dropout(dropout)
+        self.norm_lv = nn.LayerNorm(d_model)
+        self.ffn_lv = _ffn(d_model, dim_feedforward, dropout)
+        self.norm_lv2 = nn.LayerNorm(d_model)
+        self.cross_vl = deepcopy(self.cross_lv)       # same initial weights, as the reference (:62)
+        self.dropout_vl = nn.Dropout(dropout)
+        self.norm_vl = nn.LayerNorm(d_model)
+        self.ffn_vl = deepcopy(self.ffn_lv)
+        self.norm_vl2 = nn.LayerNorm(d_model)
+        if use_butd_enc_attn:
+            self.cross_d = MultiheadAttention(d_model, n_heads, dropout=dropout)
+            self.dropout_d = nn.Dropout(dropout)
+            self.norm_d = nn.LayerNorm(d_model)
+
+    def forward(self, vis_feats, vis_key_padding_mask, text_feats, text_key_padding_mask,
+                pos_feats, detected_feats=None, detected_mask=None):
+        # text attends to points: no positional term on the keys (:80-93)
+        t2 = self.cross_lv(text_feats, vis_feats, vis_feats,
+                           key_padding_mask=vis_key_padding_mask, batch_first=True)[0]
+        text_out = self.norm_lv(text_feats + self.dropout_lv(t2))
+        text_out = self.norm_lv2(text_out + self.ffn_lv(text_out))
+        # points attend to the ORIGINAL text (:99-105), position added to the query only
+        v2 = self.cross_vl(vis_feats + pos_feats, text_feats, text_feats,
+                           key_padding_mask=text_key_padding_mask, batch_first=True)[0]
+        vis = self.norm_vl(vis_feats + self.dropout_vl(v2))
+        if detected_feats is not None and self.use_butd_enc_attn:
+            v2 = self.cross_d(vis, detected_feats, detected_feats,
+                              key_padding_mask=detected_mask, batch_first=True)[0]
+            vis = self.norm_d(vis + self.dropout_d(v2))
+        vis = self.norm_vl2(vis + self.ffn_vl(vis))
+        return vis, text_out
+
+
+class TransformerEncoderLayerNoFFN(nn.Module):
+    """Self-attention + residual + LayerNorm.  (S,B,F) like the reference unless batch_first."""
+
+    def __init__(self, d_model, nhead, dropout):
+        super().__init__()
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+
+    def forward(self, src, src_mask=None, src_key_padding_mask=None, batch_first=False):
+        src2 = self.self_attn(src, src, src, attn_mask=src_mask,
+                              key_padding_mask=src_key_padding_mask, batch_first=batch_first)[0]
+        return self.norm1(src + self.dropout1(src2))
+
+
+class PosTransformerEncoderLayerNoFFN(TransformerEncoderLayerNoFFN):
+    """Same, with the positional embedding added to query and key (not value)."""
+
+    def forward(self, src, pos, src_mask=None, src_key_padding_mask=None, batch_first=False):
+        qk = src + pos
+        src2 = self.self_attn(qk, qk, src, attn_mask=src_mask,
+                              key_padding_mask=src_key_padding_mask, batch_first=batch_first)[0]
+        return self.norm1(src + self.dropout1(src2))
+
+
+class BiEncoderLayer(nn.Module):
+    def __init__(self, d_model=256, dropout=0.1, activation="relu", n_heads=8, dim_feedforward=256,
+                 self_attend_lang=True, self_attend_vis=True, use_butd_enc_attn=False):
+        super().__init__()
+        self.self_attention_lang = (TransformerEncoderLayerNoFFN(d_model, n_heads, dropout)
+                                    if self_attend_lang else None)
+        self.self_attention_visual = (PosTransformerEncoderLayerNoFFN(d_model, n_heads, dropout)
+                                      if self_attend_vis else None)
+        self.cross_layer = CrossAttentionLayer(d_model, dropout, n_heads, dim_feedforward,
+                                               use_butd_enc_attn)
+
+    def forward(self, vis_feats, pos_feats, padding_mask, text_feats, text_padding_mask,
+                end_points={}, detected_feats=None, detected_mask=None):
+        if self.self_attention_visual is not None:
+            vis_feats = self.self_attention_visual(vis_feats, pos_feats,
+                                                   src_key_padding_mask=padding_mask, batch_first=True)
+        if self.self_attention_lang is not None:
+            text_feats = self.self_attention_lang(text_feats, src_key_padding_mask=text_padding_mask,
+                                                  batch_first=True)
+        return self.cross_layer(vis_feats=vis_feats, vis_key_padding_mask=padding_mask,
+                                text_feats=text_feats, text_key_padding_mask=text_padding_mask,
+                                pos_feats=pos_feats, detected_feats=detected_feats,
+                                detected_mask=detected_mask)
+
+
+class BiEncoder(nn.Module):
+    def __init__(self, bi_layer, num_layers):
+        super().__init__()
+        self.layers = _get_clones(bi_layer, num_layers)
+        self.num_layers = num_layers
+
+    def forward(self, vis_feats, pos_feats, padding_mask, text_feats, text_padding_mask,
+                end_points={}, detected_feats=None, detected_mask=None):
+        for layer in self.layers:
+            vis_feats, text_feats = layer(vis_feats, pos_feats, padding_mask, text_feats,
+                                          text_padding_mask, end_points,
+                                          detected_feats=detected_feats, detected_mask=detected_mask)
+        return vis_feats, text_feats
+
+
+class BiDecoderLayer(nn.Module):
+    """queries: self -> text -> (boxes) -> points -> FFN, all post-norm."""
+
+    def __init__(self, d_model, n_heads, dim_feedforward=2048, dropout=0.1, activation="relu",
+                 self_position_embedding="loc_learned", butd=False):
+        super().__init__()
+        self.self_attn = MultiheadAttention(d_model, n_heads, dropout=dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.cross_l = MultiheadAttention(d_model, n_heads, dropout=dropout)
+        self.dropout_l = nn.Dropout(dropout)
+        self.norm_l = nn.LayerNorm(d_model)
+        if butd:
+            self.cross_d = deepcopy(self.cross_l)
+            self.dropout_d = nn.Dropout(dropout)
+            self.norm_d = nn.LayerNorm(d_model)
+        self.cross_v = deepcopy(self.cross_l)
+        self.dropout_v = nn.Dropout(dropout)
+        self.norm_v = nn.LayerNorm(d_model)
+        self.ffn = _ffn(d_model, dim_feedforward, dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+        if self_position_embedding == "xyz_learned":
+            self.self_posembed = PositionEmbeddingLearned(3, d_model)
+        elif self_position_embedding == "loc_learned":
+            self.self_posembed = PositionEmbeddingLearned(6, d_model)
+        else:
+            self.self_posembed = None
+
+    def forward(self, query, vis_feats, lang_feats, query_pos, padding_mask, text_key_padding_mask,
+                detected_feats=None, detected_mask=None):
+        if self.self_posembed is not None:
+            pos = self.self_posembed(query_pos).transpose(1, 2)
+        else:
+            pos = torch.zeros_like(query)
+        qp = query + pos
+        q2 = self.self_attn(qp, qp, query, key_padding_mask=padding_mask, batch_first=True)[0]
+        query = self.norm1(query + self.dropout1(q2))
+        q2 = self.cross_l(query + pos, lang_feats, lang_feats,
+                          key_padding_mask=text_key_padding_mask, batch_first=True)[0]
+        query = self.norm_l(query + self.dropout_l(q2))
+        if detected_feats is not None:
+            q2 = self.cross_d(query + pos, detected_feats, detected_feats,
+                              key_padding_mask=detected_mask, batch_first=True)[0]
+            query = self.norm_d(query + self.dropout_d(q2))
+        q2 = self.cross_v(query + pos, vis_feats, vis_feats, key_padding_mask=None, batch_first=True)[0]
+        query = self.norm_v(query + self.dropout_v(q2))
+        query = self.norm2(query + self.ffn(query))
+        return query.contiguous()

@@ -1,0 +1,85 @@
+"""Set-abstraction and feature-propagation modules of the PointNet++ backbone.
+
+Mirrors the two classes EDA uses from pointnet2/pointnet2_modules.py:
+PointnetSAModuleVotes (:164-272) and PointnetFPModule (:356-416), with the same
+constructor keywords, return values and sub-module names (``mlp_module``,
+``grouper``, ``mlp``).  The MSG / LFP variants of the reference are unused by EDA
+and are not part of this path.
+"""
+from typing import List
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from . import pointnet2_utils
+from .pytorch_utils import SharedMLP
+
+
+class PointnetSAModuleVotes(nn.Module):
+    """FPS -> gather centres -> ball query + group -> shared MLP -> pool."""
+
+    def __init__(self, *, mlp: List[int], npoint: int = None, radius: float = None,
+                 nsample: int = None, bn: bool = True, use_xyz: bool = True, pooling: str = "max",
+                 sigma: float = None, normalize_xyz: bool = False, sample_uniformly: bool = False,
+                 ret_unique_cnt: bool = False):
+        super().__init__()
+        self.npoint, self.radius, self.nsample = npoint, radius, nsample
+        self.pooling = pooling
+        self.use_xyz = use_xyz
+        self.sigma = sigma if sigma is not None else (radius / 2 if radius is not None else None)
+        self.normalize_xyz = normalize_xyz
+        if ret_unique_cnt:
+            raise NotImplementedError("ret_unique_cnt is unused by EDA")
+        if npoint is not None:
+            self.grouper = pointnet2_utils.QueryAndGroup(
+                radius, nsample, use_xyz=use_xyz, ret_grouped_xyz=True,
+                normalize_xyz=normalize_xyz, sample_uniformly=sample_uniformly)
+        else:
+            self.grouper = pointnet2_utils.GroupAll(use_xyz, ret_grouped_xyz=True)
+        spec = list(mlp)          # (the reference mutates the caller's list, :204-206)
+        if use_xyz and len(spec) > 0:
+            spec[0] += 3
+        self.mlp_module = SharedMLP(spec, bn=bn)
+
+    def forward(self, xyz, features=None, inds=None):
+        if inds is None:
+            inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+        else:
+            assert inds.shape[1] == self.npoint
+        new_xyz = None
+        if self.npoint is not None:
+            new_xyz = pointnet2_utils.gather_operation(
+                xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+        out = self.grouper(xyz, new_xyz, features)
+        grouped, grouped_xyz = out if isinstance(out, tuple) else (out, None)
+        x = self.mlp_module(grouped)                       # (B, C, npoint, nsample)
+        if self.pooling == "max":
+            x = x.max(dim=3)[0]
+        elif self.pooling == "avg":
+            x = x.mean(dim=3)
+        elif self.pooling == "rbf":
+            rbf = torch.exp(-1 * grouped_xyz.pow(2).sum(1) / (self.sigma ** 2) / 2)
+            x = torch.sum(x * rbf.unsqueeze(1), -1) / float(self.nsample)
+        else:
+            raise ValueError(self.pooling)
+        return new_xyz, x, inds
+
+
+class PointnetFPModule(nn.Module):
+    """3-NN inverse-distance interpolation -> concat skip -> shared MLP."""
+
+    def __init__(self, *, mlp: List[int], bn: bool = True):
+        super().__init__()
+        self.mlp = SharedMLP(list(mlp), bn=bn)
+
+    def forward(self, unknown, known, unknow_feats, known_feats):
+        if known is not None:
+            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            dist_recip = 1.0 / (dist + 1e-8)
+            weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+            interpolated = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+        else:
+            interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
+        x = torch.cat([interpolated, unknow_feats], dim=1) if unknow_feats is not None else interpolated
+        return self.mlp(x.unsqueeze(-1)).squeeze(-1)

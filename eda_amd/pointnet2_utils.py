@@ -1,0 +1,161 @@
+"""Operator API of the hot path -- mirrors the reference's
+``pointnet2/pointnet2_utils.py`` (same names, argument order and autograd
+behaviour) on top of the HIP library.
+
+    furthest_point_sample(xyz, npoint)            pointnet2_utils.py:51-80
+    gather_operation(features, idx)               :83-117
+    three_nn(unknown, known) -> (dist, idx)       :120-149   (dist = sqrt(dist2))
+    three_interpolate(features, idx, weight)      :152-206
+    grouping_operation(features, idx)             :209-257
+    ball_query(radius, nsample, xyz, new_xyz)     :260-291
+    QueryAndGroup / GroupAll                      :294-426
+
+``_ext`` is the module that provides the nine native ops.  In the product it is
+``eda_amd.ext`` (HIP, GPU only, no fallback).
+"""
+import torch
+from torch import nn
+from torch.autograd import Function
+
+from . import ext as _ext
+
+
+class FurthestPointSampling(Function):
+    @staticmethod
+    def forward(ctx, xyz, npoint):
+        inds = _ext.furthest_point_sampling(xyz, npoint)
+        ctx.mark_non_differentiable(inds)
+        return inds
+
+    @staticmethod
+    def backward(ctx, grad=None):
+        return None, None
+
+
+furthest_point_sample = FurthestPointSampling.apply
+
+
+class GatherOperation(Function):
+    @staticmethod
+    def forward(ctx, features, idx):
+        ctx.n = features.size(2)
+        ctx.save_for_backward(idx)
+        return _ext.gather_points(features, idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        return _ext.gather_points_grad(grad_out.contiguous(), idx, ctx.n), None
+
+
+gather_operation = GatherOperation.apply
+
+
+class ThreeNN(Function):
+    @staticmethod
+    def forward(ctx, unknown, known):
+        dist2, idx = _ext.three_nn(unknown, known)
+        ctx.mark_non_differentiable(idx)
+        return torch.sqrt(dist2), idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None
+
+
+three_nn = ThreeNN.apply
+
+
+class ThreeInterpolate(Function):
+    @staticmethod
+    def forward(ctx, features, idx, weight):
+        ctx.m = features.size(2)
+        ctx.save_for_backward(idx, weight)
+        return _ext.three_interpolate(features, idx, weight)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight = ctx.saved_tensors
+        return _ext.three_interpolate_grad(grad_out.contiguous(), idx, weight, ctx.m), None, None
+
+
+three_interpolate = ThreeInterpolate.apply
+
+
+class GroupingOperation(Function):
+    @staticmethod
+    def forward(ctx, features, idx):
+        ctx.n = features.size(2)
+        ctx.save_for_backward(idx)
+        return _ext.group_points(features, idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        return _ext.group_points_grad(grad_out.contiguous(), idx, ctx.n), None
+
+
+grouping_operation = GroupingOperation.apply
+
+
+class BallQuery(Function):
+    @staticmethod
+    def forward(ctx, radius, nsample, xyz, new_xyz):
+        inds = _ext.ball_query(new_xyz, xyz, radius, nsample)   # NB: native arg order
+        ctx.mark_non_differentiable(inds)
+        return inds
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None, None
+
+
+ball_query = BallQuery.apply
+
+
+class QueryAndGroup(nn.Module):
+    """Ball query + grouping of xyz (centred, optionally / radius) and features.
+
+    Reference: pointnet2_utils.py:294-376.  ``sample_uniformly`` (a per-row CPU
+    loop in the reference, off in EDA) is not supported on this path.
+    """
+
+    def __init__(self, radius, nsample, use_xyz=True, ret_grouped_xyz=False, normalize_xyz=False,
+                 sample_uniformly=False, ret_unique_cnt=False):
+        super().__init__()
+        if sample_uniformly or ret_unique_cnt:
+            raise NotImplementedError("sample_uniformly / ret_unique_cnt are unused by EDA "
+                                      "(backbone_module.py:44-78) and not built on this path")
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+        self.ret_grouped_xyz = ret_grouped_xyz
+        self.normalize_xyz = normalize_xyz
+
+    def forward(self, xyz, new_xyz, features=None):
+        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        grouped_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)   # (B,3,m,ns), fresh
+        grouped_xyz = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
+        if self.normalize_xyz:
+            grouped_xyz = grouped_xyz / self.radius      # true division, as the reference
+        if features is not None:
+            grouped = grouping_operation(features, idx)
+            new_features = torch.cat([grouped_xyz, grouped], dim=1) if self.use_xyz else grouped
+        else:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+            new_features = grouped_xyz
+        return (new_features, grouped_xyz) if self.ret_grouped_xyz else new_features
+
+
+class GroupAll(nn.Module):
+    """pointnet2_utils.py:379-426 (note: the reference forces ret_grouped_xyz False)."""
+
+    def __init__(self, use_xyz=True, ret_grouped_xyz=False):
+        super().__init__()
+        self.use_xyz = use_xyz
+        self.ret_grouped_xyz = False
+
+    def forward(self, xyz, new_xyz, features=None):
+        grouped_xyz = xyz.transpose(1, 2).unsqueeze(2)
+        if features is not None:
+            gf = features.unsqueeze(2)
+            return torch.cat([grouped_xyz, gf], dim=1) if self.use_xyz else gf
+        return grouped_xyz

@@ -1,0 +1,148 @@
+"""Shared bodies of the model-layer parity tests.  `dev` is 'cpu' (host-logic
+tests, native ops supplied by the oracle façade which the TEST injects) or 'cuda'
+(the product path: HIP kernels through the C ABI).  Goldens come from the
+reference's own Python layers (tools/gen_golden_model.py)."""
+import os
+
+import numpy as np
+import torch
+
+import model_fixtures as MF
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, f"model_{name}.npz"))
+
+
+def run_query_and_group(dev):
+    from eda_amd import pointnet2_utils as PU
+    g = gold("query_and_group")
+    pc = MF.make_cloud(1, 2, 4096).to(dev)
+    xyz = pc[..., :3].contiguous()
+    feats = pc[..., 3:].transpose(1, 2).contiguous()
+    inds = PU.furthest_point_sample(xyz, 256)
+    MF.assert_matches(g, "inds", inds)
+    new_xyz = PU.gather_operation(xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+    qg = PU.QueryAndGroup(0.3, 16, use_xyz=True, ret_grouped_xyz=True, normalize_xyz=True)
+    nf, gx = qg(xyz, new_xyz, feats)
+    MF.assert_matches(g, "new_features", nf, rtol=0, atol=0)       # pure copies + one sub/div: exact
+    MF.assert_matches(g, "grouped_xyz", gx, rtol=0, atol=0)
+
+
+def run_sa_module(dev):
+    from eda_amd.pointnet2_modules import PointnetSAModuleVotes
+    g = gold("sa_module")
+    pc = MF.make_cloud(1, 2, 4096).to(dev)
+    xyz = pc[..., :3].contiguous()
+    feats = pc[..., 3:].transpose(1, 2).contiguous().requires_grad_(True)
+    spec = [3, 16, 16, 32]
+    sa = PointnetSAModuleVotes(npoint=256, radius=0.3, nsample=16, mlp=spec, use_xyz=True, normalize_xyz=True)
+    assert spec == [3, 16, 16, 32]            # this build does not mutate the caller's list
+    MF.fill_det_state(sa, seed=2); sa.eval().to(dev)
+    sx, sf, si = sa(xyz, feats)
+    sf.sum().backward()
+    MF.assert_matches(g, "inds", si)
+    MF.assert_matches(g, "new_xyz", sx, rtol=0, atol=0)
+    MF.assert_matches(g, "features", sf)
+    MF.assert_matches(g, "grad_features", feats.grad, rtol=1e-4, atol=1e-5)
+    return sx, sf
+
+
+def run_fp_module(dev):
+    from eda_amd.pointnet2_modules import PointnetFPModule
+    g = gold("fp_module")
+    sx, sf = run_sa_module(dev)
+    pc = MF.make_cloud(1, 2, 4096).to(dev)
+    xyz = pc[..., :3].contiguous()
+    fp = PointnetFPModule(mlp=[32 + 8, 24, 16])
+    MF.fill_det_state(fp, seed=3); fp.eval().to(dev)
+    unk_f = MF.make_feats(4, 2, 8, 4096).to(dev).requires_grad_(True)
+    kn_f = sf.detach().clone().requires_grad_(True)
+    fo = fp(xyz, sx, unk_f, kn_f)
+    (fo * MF.make_feats(5, *fo.shape).to(dev)).sum().backward()
+    MF.assert_matches(g, "out", fo)
+    MF.assert_matches(g, "grad_unknown", unk_f.grad, rtol=1e-4, atol=1e-5)
+    MF.assert_matches(g, "grad_known", kn_f.grad, rtol=1e-4, atol=1e-4)
+
+
+def run_backbone(dev):
+    from eda_amd.backbone_module import Pointnet2Backbone
+    g = gold("backbone")
+    bb = Pointnet2Backbone(input_feature_dim=3, width=1)
+    MF.fill_det_state(bb, seed=4); bb.eval().to(dev)
+    with torch.no_grad():
+        ep = bb(MF.make_cloud(1, 2, 4096).to(dev), {})
+    assert sorted(ep) == MF.names(g)
+    for k in MF.names(g):
+        MF.assert_matches(g, k, ep[k], rtol=2e-4, atol=2e-5)
+
+
+def run_encoder_decoder(dev, butd):
+    from eda_amd import encoder_decoder_layers as EDL
+    tag = "butd" if butd else "nobutd"
+    d = 288
+    B, V, L, D, Q = 2, 96, 12, 20, 40
+    g = gold(f"biencoder_{tag}")
+    vis = MF.make_feats(10, B, V, d).to(dev).requires_grad_(True)
+    pos = MF.make_feats(11, B, V, d, scale=0.5).to(dev)
+    text = MF.make_feats(12, B, L, d).to(dev).requires_grad_(True)
+    det = MF.make_feats(13, B, D, d).to(dev).requires_grad_(True) if butd else None
+    vmask = torch.zeros(B, V, dtype=torch.bool, device=dev)
+    tmask = MF.make_mask(1, B, L, min_valid=3).to(dev)
+    dmask = MF.make_mask(2, B, D, min_valid=2).to(dev) if butd else None
+    layer = EDL.BiEncoderLayer(d, dropout=0.1, activation="relu", n_heads=8, dim_feedforward=256,
+                               self_attend_lang=True, self_attend_vis=True, use_butd_enc_attn=butd)
+    enc = EDL.BiEncoder(layer, 3)
+    MF.fill_det_state(enc, seed=20); enc.eval().to(dev)
+    vo, to = enc(vis, pos, vmask, text, tmask, {}, detected_feats=det, detected_mask=dmask)
+    loss = (vo * MF.make_feats(14, *vo.shape).to(dev)).sum() + (to * MF.make_feats(15, *to.shape).to(dev)).sum()
+    loss.backward()
+    MF.assert_matches(g, "vis_out", vo, rtol=1e-4, atol=2e-5)
+    MF.assert_matches(g, "text_out", to, rtol=1e-4, atol=2e-5)
+    MF.assert_matches(g, "grad_vis", vis.grad, rtol=1e-3, atol=1e-4)
+    MF.assert_matches(g, "grad_text", text.grad, rtol=1e-3, atol=1e-4)
+    MF.assert_matches(g, "grad_w", enc.layers[1].cross_layer.cross_lv.in_proj_weight.grad, rtol=1e-3, atol=1e-4)
+    if butd:
+        MF.assert_matches(g, "grad_det", det.grad, rtol=1e-3, atol=1e-4)
+
+    g = gold(f"bidecoder_{tag}")
+    dec = EDL.BiDecoderLayer(d, n_heads=8, dim_feedforward=256, dropout=0.1, activation="relu",
+                             self_position_embedding="loc_learned", butd=butd)
+    MF.fill_det_state(dec, seed=21); dec.eval().to(dev)
+    query = MF.make_feats(16, B, Q, d).to(dev).requires_grad_(True)
+    qpos = MF.make_feats(17, B, Q, 6).to(dev)
+    vis2 = MF.make_feats(18, B, V, d).to(dev).requires_grad_(True)
+    lang = MF.make_feats(19, B, L, d).to(dev).requires_grad_(True)
+    det2 = MF.make_feats(20, B, D, d).to(dev) if butd else None
+    qo = dec(query, vis2, lang, qpos, None, tmask, detected_feats=det2, detected_mask=dmask)
+    (qo * MF.make_feats(21, *qo.shape).to(dev)).sum().backward()
+    MF.assert_matches(g, "out", qo, rtol=1e-4, atol=2e-5)
+    MF.assert_matches(g, "grad_query", query.grad, rtol=1e-3, atol=1e-4)
+    MF.assert_matches(g, "grad_vis", vis2.grad, rtol=1e-3, atol=1e-4)
+    MF.assert_matches(g, "grad_lang", lang.grad, rtol=1e-3, atol=1e-4)
+    MF.assert_matches(g, "grad_w", dec.cross_v.in_proj_weight.grad, rtol=1e-3, atol=1e-4)
+
+
+def run_full_model(dev, butd):
+    from eda_amd.bdetr import BeaUTyDETR
+    tag = "butd" if butd else "nobutd"
+    g = gold(f"full_{tag}")
+    model = BeaUTyDETR(num_queries=64, butd=butd)
+    model.text_encoder = MF.small_roberta(1)
+    MF.fill_det_state(model, seed=30)
+    with torch.no_grad():
+        model.points_obj_cls.conv3.bias.fill_(float(g["fixture_obj_cls_bias"]))
+    model.eval().to(dev)
+    inputs = MF.full_model_inputs(int(g["fixture_input_seed"]))
+    inputs = {k: ({kk: vv.to(dev) for kk, vv in v.items()} if isinstance(v, dict) else v.to(dev))
+              for k, v in inputs.items()}
+    with torch.no_grad():
+        ep = model(inputs)
+    out = {k: v for k, v in ep.items() if torch.is_tensor(v)}
+    gnames = [k for k in MF.names(g) if not k.startswith("fixture_")]
+    assert sorted(out) == gnames, (sorted(set(out) ^ set(gnames)))
+    # Index outputs first: queries are a top-k over learned logits, exact equality expected
+    for k in gnames:
+        MF.assert_matches(g, k, out[k], rtol=5e-4, atol=5e-5)

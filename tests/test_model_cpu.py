@@ -1,0 +1,51 @@
+"""Host-logic parity on CPU: this repo's Python layers against goldens produced
+by the reference's Python layers.  The nine native ops have no CPU path in the
+product, so for these CPU-only tests the TEST injects the oracle façade as the op
+backend of eda_amd.pointnet2_utils (the product never does)."""
+import pytest
+
+import model_cases as MC
+
+
+@pytest.fixture(autouse=True)
+def oracle_backend(oracle, monkeypatch):
+    from eda_amd import pointnet2_utils
+    monkeypatch.setattr(pointnet2_utils, "_ext", oracle)
+    yield
+
+
+def test_state_dict_contract():
+    """805 non-RoBERTa tensors with the reference's names and shapes; 21 433 931
+    trainable parameters."""
+    import json
+    import os
+    from eda_amd.bdetr import BeaUTyDETR
+    m = BeaUTyDETR()
+    mine = {k: tuple(v.shape) for k, v in m.state_dict().items() if not k.startswith("text_encoder.")}
+    ref = {k: tuple(s) for k, s in json.load(open(os.path.join(MC.GOLD, "state_dict_manifest.json")))}
+    assert mine == ref
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 21433931
+    names = [n for n, p in m.named_parameters() if p.requires_grad]
+    assert any("backbone_net" in n for n in names) and not any("text_encoder" in n for n in names)
+
+
+def test_query_and_group():
+    MC.run_query_and_group("cpu")
+
+
+def test_sa_and_fp_modules():
+    MC.run_fp_module("cpu")
+
+
+def test_backbone():
+    MC.run_backbone("cpu")
+
+
+@pytest.mark.parametrize("butd", [True, False])
+def test_encoder_decoder(butd):
+    MC.run_encoder_decoder("cpu", butd)
+
+
+@pytest.mark.parametrize("butd", [True, False])
+def test_full_model(butd):
+    MC.run_full_model("cpu", butd)
