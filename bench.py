@@ -1,0 +1,292 @@
+#!/usr/bin/env python
+"""Headline benchmark: scenes/s of one training step (forward + backward +
+optimizer) of BeaUTyDETR on synthetic ScanRefer-shaped batches.
+
+Workload (BASELINE.json metric "scenes/sec fwd+bwd (50k pts, 256 queries, 80 tok)"):
+8 scenes per GPU, 50 000 points x (xyz+rgb), 256 queries, 80 text tokens, 132
+detected boxes (butd on), fp32, random-init weights (no checkpoints offline),
+frozen random-init RoBERTa-base; synthetic scalar loss touching every trainable
+parameter.  Inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One JSON line on rank 0 (contract in the task statement) carrying `roofline` and
+`cpu_baseline` objects.  N > 1: scenes shard data-parallel (8 per rank, weak
+scaling); gradients are summed with ONE RCCL all-reduce of a flat fp32 buffer.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+SA_LEVELS = [  # (N, npoint, radius, nsample, C_feat) -- models/backbone_module.py:44-78
+    (50000, 2048, 0.2, 64, 3), (2048, 1024, 0.4, 32, 128), (1024, 512, 0.8, 16, 256), (512, 256, 1.2, 16, 256)]
+
+
+def algorithmic_bytes(name):
+    """Algorithmic HBM bytes of one launch of a native op, keyed like
+    eda_amd.ext._timed: (op, dims...).  Formulas of SURVEY.md §8d."""
+    op, d = name[0], name[1:]
+    if op == "ball_query":
+        b, n, m, ns = d
+        return b * (12 * n + 12 * m + 4 * m * ns)
+    if op == "group_points":
+        b, c, n, m, ns = d
+        return b * (4 * c * n + 4 * m * ns + 4 * c * m * ns)
+    if op == "group_points_grad":
+        b, c, n, m, ns = d
+        return b * (4 * c * n + 4 * m * ns + 4 * c * m * ns)
+    if op == "furthest_point_sampling":
+        b, n, m = d
+        return b * (12 * n + 4 * m)
+    if op in ("gather_points", "gather_points_grad"):
+        b, c, n, m = d
+        return b * (4 * c * m * 2 + 4 * m)
+    if op == "three_nn":
+        b, n, m = d
+        return b * (12 * n + 12 * m + 24 * n)
+    if op in ("three_interpolate", "three_interpolate_grad"):
+        b, c, m, n = d if op == "three_interpolate" else (d[0], d[1], d[3], d[2])
+        return b * (4 * c * m + 24 * n + 4 * c * n)
+    return 0
+
+
+def synthetic_loss(end_points):
+    """Scalar that reaches every trainable parameter the real loss reaches, with
+    no host sync (SURVEY.md §8d 'Loss for bwd')."""
+    loss = end_points["seeds_obj_cls_logits"].pow(2).mean()
+    proj_tokens = end_points["proj_tokens"]
+    for p in ["proposal_", "0head_", "1head_", "2head_", "3head_", "4head_", "last_"]:
+        loss = loss + end_points[f"{p}center"].pow(2).sum(-1).mean()
+        loss = loss + end_points[f"{p}pred_size"].pow(2).sum(-1).mean()
+        loss = loss + end_points[f"{p}sem_cls_scores"].pow(2).mean()
+        loss = loss + torch.matmul(end_points[f"{p}proj_queries"], proj_tokens.transpose(1, 2)).mean()
+    return loss
+
+
+def make_inputs(rank, per_gpu, device, n_points, max_len):
+    from eda_amd import synthetic
+    seeds = [rank * per_gpu + i for i in range(per_gpu)]
+    pc = torch.from_numpy(synthetic.batch(seeds, n_points)).to(device)
+    ids, am = synthetic.utterance_tokens(rank, per_gpu, max_len=max_len)
+    boxes, bmask, cls = synthetic.detected_boxes(rank, per_gpu)
+    return {
+        "point_clouds": pc,
+        "tokenized": {"input_ids": torch.from_numpy(ids).to(device),
+                      "attention_mask": torch.from_numpy(am).to(device)},
+        "det_boxes": torch.from_numpy(boxes).to(device),
+        "det_bbox_label_mask": torch.from_numpy(bmask).to(device),
+        "det_class_ids": torch.from_numpy(cls).to(device),
+    }
+
+
+class FlatGrads:
+    """All trainable gradients live in one contiguous fp32 buffer so data-parallel
+    training needs a single RCCL all-reduce per step (85.7 MB at the headline
+    config; SURVEY.md §5: direct RS+AG over 7 xGMI links beats 4 DDP buckets)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self, world):
+        if world > 1:
+            dist.all_reduce(self.flat)
+            self.flat.mul_(1.0 / world)
+
+
+def cpu_baseline(args):
+    """The same training step on the host cores: this repo's model on torch CPU with
+    the C oracle (oracle/, the CPU restatement of the reference's CUDA ops -- the
+    reference has no CPU op path) as op backend.  Bounded sample: 1 step of 2 scenes."""
+    from oracle import oracle_ext
+    from eda_amd import pointnet2_utils
+    from eda_amd.bdetr import BeaUTyDETR
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    oracle_ext.set_threads(cores)
+
+    class MT:   # multi-threaded oracle entry points for the three SA-stack ops
+        def __getattr__(self, k):
+            return getattr(oracle_ext, k)
+
+        def furthest_point_sampling(self, p, m):
+            return oracle_ext.furthest_point_sampling(p, m, mt=True)
+
+        def ball_query(self, a, b, r, ns):
+            return oracle_ext.ball_query(a, b, r, ns, mt=True)
+
+        def group_points(self, p, i):
+            return oracle_ext.group_points(p, i, mt=True)
+
+    saved = pointnet2_utils._ext
+    pointnet2_utils._ext = MT()
+    try:
+        scenes = args.cpu_scenes
+        torch.manual_seed(0)
+        model = BeaUTyDETR(num_queries=args.queries, butd=True).train()
+        inputs = make_inputs(0, scenes, "cpu", args.points, args.tokens)
+        t0 = time.time()
+        loss = synthetic_loss(model(inputs))
+        loss.backward()
+        dt = time.time() - t0
+    finally:
+        pointnet2_utils._ext = saved
+        torch.set_num_threads(max(1, cores // 2))
+    model_name = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model_name = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(scenes / dt, 4), "unit": "scenes/s", "cores": cores, "kind": "port",
+            "sample": f"1 fwd+bwd step of {scenes} scenes ({args.points} pts, {args.queries} queries, "
+                      f"{args.tokens} tok) on torch-CPU + oracle ops, {dt:.1f} s, no optimizer step",
+            "cpu": model_name}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--per-gpu", type=int, default=8, help="scenes per GPU")
+    ap.add_argument("--points", type=int, default=50000)
+    ap.add_argument("--queries", type=int, default=256)
+    ap.add_argument("--tokens", type=int, default=80)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-scenes", type=int, default=2)
+    ap.add_argument("--no-butd", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path is HIP-only (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from eda_amd import ext
+    from eda_amd.bdetr import BeaUTyDETR
+
+    torch.manual_seed(0)                       # same init on every rank (DDP broadcast equivalent)
+    model = BeaUTyDETR(num_queries=args.queries, butd=not args.no_butd).to(device).train()
+    model.text_encoder.eval()                  # frozen (bdetr.py:78-80)
+    grads = FlatGrads(model.parameters())
+    opt = torch.optim.AdamW(grads.params, lr=1e-4, weight_decay=5e-4, fused=True)
+    inputs = make_inputs(rank, args.per_gpu, device, args.points, args.tokens)
+
+    def step():
+        grads.zero()
+        loss = synthetic_loss(model(inputs))
+        loss.backward()
+        grads.all_reduce_mean(world)
+        torch.nn.utils.clip_grad_norm_(grads.params, 0.1, foreach=True)   # main_utils.py:483-486
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    timer = ext.OpTimer()
+    barrier()
+    ext.op_timer = timer
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        loss = step()
+    ev1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    ext.op_timer = None
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        scenes = args.per_gpu * world * args.steps
+        # ---- per-kernel numbers measured live with HIP events on the launch stream ----
+        summ = timer.summary()
+        kernels = []
+        for name, (calls, ms) in summ.items():
+            byts = algorithmic_bytes(name)
+            kernels.append({"op": name[0], "dims": list(name[1:]), "calls_per_step": calls / args.steps,
+                            "ms": round(ms, 4), "alg_bytes": byts,
+                            "gbs": round(byts / (ms * 1e-3) / 1e9, 1) if ms > 0 else None})
+        kernels.sort(key=lambda k: -k["ms"] * k["calls_per_step"])
+        native_ms = sum(k["ms"] * k["calls_per_step"] for k in kernels)
+        # dominant HBM-priced kernel (FPS is latency-bound: reported as us/round below)
+        hbm = [k for k in kernels if k["op"] != "furthest_point_sampling"]
+        dom = hbm[0] if hbm else None
+        roofline = None
+        if dom:
+            roofline = {"kernel": f"{dom['op']}{tuple(dom['dims'])}", "bound": "hbm",
+                        "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(dom["gbs"] / HBM_PEAK_GBS, 5), "traffic": None,
+                        "ms_per_launch": dom["ms"], "alg_bytes_per_launch": dom["alg_bytes"]}
+        fps = [k for k in kernels if k["op"] == "furthest_point_sampling"]
+        fps_info = [{"n": k["dims"][1], "m": k["dims"][2], "ms": k["ms"],
+                     "us_per_round": round(k["ms"] * 1e3 / max(1, k["dims"][2] - 1), 3)} for k in fps]
+        out = {
+            "metric": "scenes/sec fwd+bwd (50k pts, 256 queries, 80 tok)",
+            "value": round(scenes / dt, 3), "unit": "scenes/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BeaUTyDETR train step (fwd+bwd+clip+AdamW), butd=%s" % (not args.no_butd),
+                       "scenes_per_gpu": args.per_gpu, "global_batch": args.per_gpu * world,
+                       "points": args.points, "queries": args.queries, "tokens": args.tokens,
+                       "parallelism": f"dp{world}", "batchnorm": "per-GPU statistics",
+                       "text_encoder": "RoBERTa-base random-init frozen"},
+            "roofline": roofline,
+            "native_ms_per_step": round(native_ms, 3),
+            "fps": fps_info,
+            "kernels": kernels[:12],
+            "loss": float(loss),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

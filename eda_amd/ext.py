@@ -26,6 +26,44 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional per-op timing (bench.py): when `op_timer` is set, every native call is
+# bracketed with events on the stream it is launched on (torch's current stream).
+op_timer = None
+
+
+class OpTimer:
+    """Collects (start, end) HIP event pairs per native entry point."""
+
+    def __init__(self):
+        self.events = {}
+
+    def record(self, name):
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        self.events.setdefault(name, []).append((s, e))
+        return s, e
+
+    def summary(self):
+        """name -> (calls, mean ms per call); call after torch.cuda.synchronize()."""
+        return {k: (len(v), sum(s.elapsed_time(e) for s, e in v) / len(v)) for k, v in self.events.items()}
+
+
+class _timed:
+    def __init__(self, name, dims=()):
+        self.name = (name,) + tuple(int(d) for d in dims)   # op name + its shape
+        self.pair = None
+
+    def __enter__(self):
+        if op_timer is not None:
+            self.pair = op_timer.record(self.name)
+            self.pair[0].record()
+
+    def __exit__(self, *a):
+        if self.pair is not None:
+            self.pair[1].record()
+        return False
+
+
 def _check_contiguous(t, name):
     if not t.is_contiguous():
         raise RuntimeError(f"{name} must be a contiguous tensor")
@@ -64,7 +102,7 @@ def furthest_point_sampling(points, nsamples):
         return out
     ws_bytes = L.eda_fps_workspace_bytes(b, n, nsamples)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=points.device)
-    with torch.cuda.device(points.device):
+    with torch.cuda.device(points.device), _timed('furthest_point_sampling', (b, n, nsamples)):
         rc = L.eda_furthest_point_sampling_f32(points.data_ptr(), b, n, nsamples, out.data_ptr(),
                                                ws.data_ptr(), ws_bytes, _stream())
     _lib.check(rc, "eda_furthest_point_sampling_f32")
@@ -81,7 +119,7 @@ def gather_points(points, idx):
     b, c, n = points.shape
     m = idx.shape[1]
     out = torch.empty((b, c, m), dtype=torch.float32, device=points.device)
-    with torch.cuda.device(points.device):
+    with torch.cuda.device(points.device), _timed('gather_points', (b, c, n, m)):
         rc = _lib.lib().eda_gather_points_f32(points.data_ptr(), idx.data_ptr(), b, c, n, m,
                                               out.data_ptr(), _stream())
     _lib.check(rc, "eda_gather_points_f32")
@@ -98,7 +136,7 @@ def gather_points_grad(grad_out, idx, n):
     b, c, m = grad_out.shape
     n = int(n)
     out = torch.empty((b, c, n), dtype=torch.float32, device=grad_out.device)
-    with torch.cuda.device(grad_out.device):
+    with torch.cuda.device(grad_out.device), _timed('gather_points_grad', (b, c, n, m)):
         rc = _lib.lib().eda_gather_points_grad_f32(grad_out.data_ptr(), idx.data_ptr(), b, c, n, m,
                                                    out.data_ptr(), _stream())
     _lib.check(rc, "eda_gather_points_grad_f32")
@@ -117,7 +155,7 @@ def ball_query(new_xyz, xyz, radius, nsample):
     m = new_xyz.shape[1]
     nsample = int(nsample)
     idx = torch.empty((new_xyz.shape[0], m, nsample), dtype=torch.int32, device=new_xyz.device)
-    with torch.cuda.device(new_xyz.device):
+    with torch.cuda.device(new_xyz.device), _timed('ball_query', (b, n, m, nsample)):
         rc = _lib.lib().eda_ball_query_f32(new_xyz.data_ptr(), xyz.data_ptr(), b, n, m,
                                            float(radius), nsample, idx.data_ptr(), _stream())
     _lib.check(rc, "eda_ball_query_f32")
@@ -134,7 +172,7 @@ def group_points(points, idx):
     b, c, n = points.shape
     npoints, nsample = idx.shape[1], idx.shape[2]
     out = torch.empty((b, c, npoints, nsample), dtype=torch.float32, device=points.device)
-    with torch.cuda.device(points.device):
+    with torch.cuda.device(points.device), _timed('group_points', (b, c, n, npoints, nsample)):
         rc = _lib.lib().eda_group_points_f32(points.data_ptr(), idx.data_ptr(), b, c, n, npoints,
                                              nsample, out.data_ptr(), _stream())
     _lib.check(rc, "eda_group_points_f32")
@@ -152,7 +190,7 @@ def group_points_grad(grad_out, idx, n):
     npoints, nsample = idx.shape[1], idx.shape[2]
     n = int(n)
     out = torch.empty((b, c, n), dtype=torch.float32, device=grad_out.device)
-    with torch.cuda.device(grad_out.device):
+    with torch.cuda.device(grad_out.device), _timed('group_points_grad', (b, c, n, npoints, nsample)):
         rc = _lib.lib().eda_group_points_grad_f32(grad_out.data_ptr(), idx.data_ptr(), b, c, n,
                                                   npoints, nsample, out.data_ptr(), _stream())
     _lib.check(rc, "eda_group_points_grad_f32")
@@ -170,7 +208,7 @@ def three_nn(unknowns, knows):
     m = knows.shape[1]
     idx = torch.empty((b, n, 3), dtype=torch.int32, device=unknowns.device)
     dist2 = torch.empty((b, n, 3), dtype=torch.float32, device=unknowns.device)
-    with torch.cuda.device(unknowns.device):
+    with torch.cuda.device(unknowns.device), _timed('three_nn', (b, n, m)):
         rc = _lib.lib().eda_three_nn_f32(unknowns.data_ptr(), knows.data_ptr(), b, n, m,
                                          dist2.data_ptr(), idx.data_ptr(), _stream())
     _lib.check(rc, "eda_three_nn_f32")
@@ -187,7 +225,7 @@ def three_interpolate(points, idx, weight):
     b, c, m = points.shape
     n = idx.shape[1]
     out = torch.empty((b, c, n), dtype=torch.float32, device=points.device)
-    with torch.cuda.device(points.device):
+    with torch.cuda.device(points.device), _timed('three_interpolate', (b, c, m, n)):
         rc = _lib.lib().eda_three_interpolate_f32(points.data_ptr(), idx.data_ptr(), weight.data_ptr(),
                                                   b, c, m, n, out.data_ptr(), _stream())
     _lib.check(rc, "eda_three_interpolate_f32")
@@ -204,7 +242,7 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     b, c, n = grad_out.shape
     m = int(m)
     out = torch.empty((b, c, m), dtype=torch.float32, device=grad_out.device)
-    with torch.cuda.device(grad_out.device):
+    with torch.cuda.device(grad_out.device), _timed('three_interpolate_grad', (b, c, n, m)):
         rc = _lib.lib().eda_three_interpolate_grad_f32(grad_out.data_ptr(), idx.data_ptr(),
                                                        weight.data_ptr(), b, c, n, m,
                                                        out.data_ptr(), _stream())
