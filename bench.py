@@ -122,7 +122,7 @@ def cpu_baseline(args):
     from oracle import oracle_ext
     from eda_amd import pointnet2_utils
     from eda_amd.bdetr import BeaUTyDETR
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, args.cpu_threads)
     torch.set_num_threads(cores)
     oracle_ext.set_threads(cores)
 
@@ -167,6 +167,27 @@ def cpu_baseline(args):
             "cpu": model_name}
 
 
+def run_cpu_baseline(args):
+    """Host-CPU leg in a child process (own thread pools, hard time limit)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only",
+           "--cpu-scenes", str(args.cpu_scenes), "--cpu-threads", str(args.cpu_threads),
+           "--points", str(args.points), "--queries", str(args.queries), "--tokens", str(args.tokens)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_timeout, env=env)
+        for line in r.stdout.splitlines():
+            if line.startswith("CPU_BASELINE "):
+                return json.loads(line[len("CPU_BASELINE "):])
+        return {"value": None, "unit": "scenes/s", "cores": None, "kind": "port",
+                "sample": "cpu leg failed: " + (r.stderr or "")[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "scenes/s", "cores": None, "kind": "port",
+                "sample": f"cpu leg exceeded {args.cpu_timeout} s and was stopped"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,9 +199,18 @@ def main():
     ap.add_argument("--tokens", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scenes", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=64, help="cap on host threads of the CPU leg")
+    ap.add_argument("--cpu-baseline-only", action="store_true",
+                    help="internal: run only the host-CPU leg and print its JSON object")
+    ap.add_argument("--cpu-timeout", type=int, default=150)
     ap.add_argument("--no-butd", action="store_true")
     args = ap.parse_args()
 
+    if args.cpu_baseline_only:
+        print("CPU_BASELINE " + json.dumps(cpu_baseline(args)))
+        return
+
+    t_start = time.perf_counter()
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -213,8 +243,15 @@ def main():
         opt.step()
         return loss
 
+    def log(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    log("model + inputs ready")
     for _ in range(args.warmup):
         step()
+    torch.cuda.synchronize()
+    log("warmup done")
 
     def barrier():
         if world > 1:
@@ -238,6 +275,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
 
+    log(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step")
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         scenes = args.per_gpu * world * args.steps
@@ -278,10 +316,10 @@ def main():
             "native_ms_per_step": round(native_ms, 3),
             "fps": fps_info,
             "kernels": kernels[:12],
-            "loss": float(loss),
+            "loss": float(loss.detach()),
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = run_cpu_baseline(args)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -27,8 +27,12 @@ def run_query_and_group(dev):
     new_xyz = PU.gather_operation(xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
     qg = PU.QueryAndGroup(0.3, 16, use_xyz=True, ret_grouped_xyz=True, normalize_xyz=True)
     nf, gx = qg(xyz, new_xyz, feats)
-    MF.assert_matches(g, "new_features", nf, rtol=0, atol=0)       # pure copies + one sub/div: exact
-    MF.assert_matches(g, "grouped_xyz", gx, rtol=0, atol=0)
+    # CPU: exact (pure copies + one sub + one true division).  GPU: torch divides a tensor by a
+    # host scalar as x * (1/r) (BinaryDivTrueKernel on CUDA and ROCm alike), 1 ulp off the CPU
+    # golden -- which is also what the reference itself does on its CUDA device.
+    tol = dict(rtol=0, atol=0) if dev == "cpu" else dict(rtol=3e-7, atol=1e-7)
+    MF.assert_matches(g, "new_features", nf, **tol)
+    MF.assert_matches(g, "grouped_xyz", gx, **tol)
 
 
 def run_sa_module(dev):
@@ -143,6 +147,22 @@ def run_full_model(dev, butd):
     out = {k: v for k, v in ep.items() if torch.is_tensor(v)}
     gnames = [k for k in MF.names(g) if not k.startswith("fixture_")]
     assert sorted(out) == gnames, (sorted(set(out) ^ set(gnames)))
-    # Index outputs first: queries are a top-k over learned logits, exact equality expected
+    # The 64 queries are a top-k over learned logits.  Near-ties may legitimately come out
+    # in a different ORDER on another device (the fixture guarantees a clear gap only at the
+    # 64/65 boundary), and the decoder is permutation-equivariant over queries: align this
+    # run's query order with the golden's before comparing per-query tensors.
+    mine = out["query_points_sample_inds"].cpu().long()
+    ref = torch.from_numpy(g["query_points_sample_inds"]).long()
+    assert (mine.sort(1)[0] == ref.sort(1)[0]).all(), "different query SET selected"
+    perm = torch.stack([torch.tensor([(mine[b] == r).nonzero()[0, 0] for r in ref[b]]) for b in range(len(ref))])
+    prefixes = ("proposal_", "0head_", "1head_", "2head_", "3head_", "4head_", "last_")
+
+    def aligned(k, v):
+        v = v.cpu()
+        if k.startswith(prefixes) or k in ("query_points_xyz", "query_points_sample_inds"):
+            return torch.stack([v[b][perm[b]] for b in range(len(v))])
+        if k == "query_points_feature":
+            return torch.stack([v[b][:, perm[b]] for b in range(len(v))])
+        return v
     for k in gnames:
-        MF.assert_matches(g, k, out[k], rtol=5e-4, atol=5e-5)
+        MF.assert_matches(g, k, aligned(k, out[k]), rtol=5e-4, atol=5e-5)

@@ -133,8 +133,9 @@ def main():
             out = {k: v for k, v in ep.items() if torch.is_tensor(v)}
             sc = torch.sigmoid(out["seeds_obj_cls_logits"][:, 0]).sort(dim=1, descending=True)[0][:, :65]
             gap = (sc[:, :-1] - sc[:, 1:]).min().item()
-            print("input seed", input_seed, "min top-k gap", gap)
-            if gap > 2e-6:      # query top-k far enough from a tie for a stable fixture
+            edge = (sc[:, 63] - sc[:, 64]).min().item()
+            print("input seed", input_seed, "min top-k gap", gap, "gap at the 64/65 boundary", edge)
+            if gap > 2e-6 and edge > 2e-4:   # a stable query SET (tests align the order)
                 break
         else:
             raise SystemExit("no stable fixture seed found")
