@@ -92,29 +92,6 @@ def make_inputs(rank, per_gpu, device, n_points, max_len):
     }
 
 
-class FlatGrads:
-    """All trainable gradients live in one contiguous fp32 buffer so data-parallel
-    training needs a single RCCL all-reduce per step (85.7 MB at the headline
-    config; SURVEY.md §5: direct RS+AG over 7 xGMI links beats 4 DDP buckets)."""
-
-    def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
-        off = 0
-        for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
-
-    def zero(self):
-        self.flat.zero_()
-
-    def all_reduce_mean(self, world):
-        if world > 1:
-            dist.all_reduce(self.flat)
-            self.flat.mul_(1.0 / world)
-
-
 def cpu_baseline(args):
     """The same training step on the host cores: this repo's model on torch CPU with
     the C oracle (oracle/, the CPU restatement of the reference's CUDA ops -- the
@@ -226,6 +203,7 @@ def main():
 
     from eda_amd import ext
     from eda_amd.bdetr import BeaUTyDETR
+    from eda_amd.parallel import FlatGrads
 
     torch.manual_seed(0)                       # same init on every rank (DDP broadcast equivalent)
     model = BeaUTyDETR(num_queries=args.queries, butd=not args.no_butd).to(device).train()
