@@ -23,6 +23,7 @@ import torch.nn.functional as F
 
 from .backbone_module import Pointnet2Backbone
 from .encoder_decoder_layers import BiDecoderLayer, BiEncoder, BiEncoderLayer, PositionEmbeddingLearned
+from .nn_utils import Conv1dK1
 from .modules import ClsAgnosticPredictHead, GeneralSamplingModule, PointsObjClsModule
 
 
@@ -86,7 +87,7 @@ class BeaUTyDETR(nn.Module):
 
         self.points_obj_cls = PointsObjClsModule(d_model)
         self.gsample_module = GeneralSamplingModule()
-        self.decoder_query_proj = nn.Conv1d(d_model, d_model, kernel_size=1)
+        self.decoder_query_proj = Conv1dK1(d_model, d_model, kernel_size=1)
         self.proposal_head = ClsAgnosticPredictHead(num_class, 1, num_queries, d_model,
                                                     objectness=False, heading=False,
                                                     compute_sem_scores=True)

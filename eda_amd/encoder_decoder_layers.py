@@ -13,6 +13,7 @@ import torch
 from torch import nn
 
 from .attention import MultiheadAttention
+from .nn_utils import Conv1dK1
 
 
 def _get_clones(module, n):
@@ -30,10 +31,10 @@ class PositionEmbeddingLearned(nn.Module):
     def __init__(self, input_channel, num_pos_feats=288):
         super().__init__()
         self.position_embedding_head = nn.Sequential(
-            nn.Conv1d(input_channel, num_pos_feats, kernel_size=1),
+            Conv1dK1(input_channel, num_pos_feats, kernel_size=1),
             nn.BatchNorm1d(num_pos_feats),
             nn.ReLU(inplace=True),
-            nn.Conv1d(num_pos_feats, num_pos_feats, kernel_size=1))
+            Conv1dK1(num_pos_feats, num_pos_feats, kernel_size=1))
 
     def forward(self, xyz):
         return self.position_embedding_head(xyz.transpose(1, 2).contiguous())

@@ -5,6 +5,7 @@ import numpy as np
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .nn_utils import Conv1dK1
 from .pointnet2_utils import gather_operation
 from .encoder_decoder_layers import PositionEmbeddingLearned  # noqa: F401  (re-exported like the reference)
 
@@ -15,11 +16,11 @@ class PointsObjClsModule(nn.Module):
     def __init__(self, seed_feature_dim):
         super().__init__()
         self.in_dim = seed_feature_dim
-        self.conv1 = nn.Conv1d(self.in_dim, self.in_dim, 1)
+        self.conv1 = Conv1dK1(self.in_dim, self.in_dim, 1)
         self.bn1 = nn.BatchNorm1d(self.in_dim)
-        self.conv2 = nn.Conv1d(self.in_dim, self.in_dim, 1)
+        self.conv2 = Conv1dK1(self.in_dim, self.in_dim, 1)
         self.bn2 = nn.BatchNorm1d(self.in_dim)
-        self.conv3 = nn.Conv1d(self.in_dim, 1, 1)
+        self.conv3 = Conv1dK1(self.in_dim, 1, 1)
 
     def forward(self, seed_features):
         net = F.relu(self.bn1(self.conv1(seed_features)))
@@ -40,9 +41,9 @@ class ThreeLayerMLP(nn.Module):
     def __init__(self, dim, out_dim):
         super().__init__()
         self.net = nn.Sequential(
-            nn.Conv1d(dim, dim, 1, bias=False), nn.BatchNorm1d(dim), nn.ReLU(), nn.Dropout(0.3),
-            nn.Conv1d(dim, dim, 1, bias=False), nn.BatchNorm1d(dim), nn.ReLU(), nn.Dropout(0.3),
-            nn.Conv1d(dim, out_dim, 1))
+            Conv1dK1(dim, dim, 1, bias=False), nn.BatchNorm1d(dim), nn.ReLU(), nn.Dropout(0.3),
+            Conv1dK1(dim, dim, 1, bias=False), nn.BatchNorm1d(dim), nn.ReLU(), nn.Dropout(0.3),
+            Conv1dK1(dim, out_dim, 1))
 
     def forward(self, x):
         return self.net(x)
@@ -61,8 +62,8 @@ class ClsAgnosticPredictHead(nn.Module):
             self.objectness_scores_head = ThreeLayerMLP(seed_feat_dim, 1)
         self.center_residual_head = ThreeLayerMLP(seed_feat_dim, 3)
         if heading:
-            self.heading_class_head = nn.Conv1d(seed_feat_dim, num_heading_bin, 1)
-            self.heading_residual_head = nn.Conv1d(seed_feat_dim, num_heading_bin, 1)
+            self.heading_class_head = Conv1dK1(seed_feat_dim, num_heading_bin, 1)
+            self.heading_residual_head = Conv1dK1(seed_feat_dim, num_heading_bin, 1)
         self.size_pred_head = ThreeLayerMLP(seed_feat_dim, 3)
         if compute_sem_scores:
             self.sem_cls_scores_head = ThreeLayerMLP(seed_feat_dim, self.num_class)

@@ -9,6 +9,8 @@ import torch
 from torch import nn
 import torch.nn.functional as F
 
+from .nn_utils import Conv2dK1
+
 
 class _BNHolder(nn.Module):
     """Gives BatchNorm2d the reference's ``bn.bn`` key prefix (pytorch_utils.py:39-45)."""
@@ -25,7 +27,7 @@ class PointwiseConvBNReLU(nn.Module):
     def __init__(self, cin, cout, bn=True):
         super().__init__()
         # bias is dropped when followed by BN (pytorch_utils.py:87)
-        self.conv = nn.Conv2d(cin, cout, kernel_size=(1, 1), bias=not bn)
+        self.conv = Conv2dK1(cin, cout, kernel_size=(1, 1), bias=not bn)
         nn.init.kaiming_normal_(self.conv.weight)
         if not bn:
             nn.init.constant_(self.conv.bias, 0)

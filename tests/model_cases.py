@@ -165,4 +165,7 @@ def run_full_model(dev, butd):
             return torch.stack([v[b][:, perm[b]] for b in range(len(v))])
         return v
     for k in gnames:
-        MF.assert_matches(g, k, aligned(k, out[k]), rtol=5e-4, atol=5e-5)
+        # the fixture scales the objectness head's last layer x40 (clear top-k gaps), which
+        # scales its rounding noise too: logits of O(1) with ~5e-5 absolute noise
+        atol = 3e-4 if k == "seeds_obj_cls_logits" else 5e-5
+        MF.assert_matches(g, k, aligned(k, out[k]), rtol=5e-4, atol=atol)

@@ -1,0 +1,52 @@
+"""Steady-state per-kernel breakdown of the bench step with torch.profiler
+(only the profiled steps are counted, unlike a whole-process rocprofv3 run)."""
+import os
+import sys
+
+import torch
+from torch.profiler import ProfilerActivity, profile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from eda_amd.bdetr import BeaUTyDETR  # noqa: E402
+from eda_amd.parallel import FlatGrads  # noqa: E402
+
+
+def main():
+    steps = int(os.environ.get("STEPS", 3))
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    model = BeaUTyDETR().to(dev).train()
+    model.text_encoder.eval()
+    grads = FlatGrads(model.parameters())
+    opt = torch.optim.AdamW(grads.params, lr=1e-4, weight_decay=5e-4, fused=True)
+    inputs = bench.make_inputs(0, 8, dev, 50000, 80)
+
+    def step():
+        grads.zero()
+        loss = bench.synthetic_loss(model(inputs))
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(grads.params, 0.1, foreach=True)
+        opt.step()
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+    ka = prof.key_averages()
+    rows = [(e.key, e.count, e.device_time_total) for e in ka if e.device_time_total > 0 and e.device_type.name != "CPU"]
+    if not rows:
+        rows = [(e.key, e.count, e.device_time_total) for e in ka if e.device_time_total > 0]
+    rows.sort(key=lambda r: -r[2])
+    tot = sum(r[2] for r in rows)
+    print(f"device time per step: {tot / steps / 1e3:.2f} ms over {sum(r[1] for r in rows) / steps:.0f} kernels/step")
+    for k, c, t in rows[:45]:
+        print(f"{t / steps / 1e3:8.3f} ms/step {100 * t / tot:5.1f}%  x{c / steps:6.1f}  {k[:120]}")
+
+
+if __name__ == "__main__":
+    main()
