@@ -116,8 +116,12 @@ def cpu_baseline(args):
         def group_points(self, p, i):
             return oracle_ext.group_points(p, i, mt=True)
 
+    from eda_amd import attention
+    from oracle import attention_ref
     saved = pointnet2_utils._ext
+    saved_core = attention._core
     pointnet2_utils._ext = MT()
+    attention._core = attention_ref.attention_core
     try:
         scenes = args.cpu_scenes
         torch.manual_seed(0)
@@ -129,6 +133,7 @@ def cpu_baseline(args):
         dt = time.time() - t0
     finally:
         pointnet2_utils._ext = saved
+        attention._core = saved_core
         torch.set_num_threads(max(1, cores // 2))
     model_name = "unknown"
     try:
@@ -216,8 +221,11 @@ def main():
                             capturable=bool(args.graph))
     inputs = make_inputs(rank, args.per_gpu, device, args.points, args.tokens)
 
+    from eda_amd import attention
+
     def step():
         grads.zero()
+        attention.advance_dropout_state(device)      # new attention-dropout masks every step
         loss = synthetic_loss(model(inputs))
         loss.backward()
         grads.all_reduce_mean(world)

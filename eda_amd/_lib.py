@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libeda_hip.so")
 
 _i, _f, _p, _sz = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+_l, _u = ctypes.c_long, ctypes.c_uint
 
 # name -> (restype, argtypes); mirrors include/eda_hip.h one to one
 SIGNATURES = {
@@ -28,6 +29,10 @@ SIGNATURES = {
     "eda_three_nn_f32": (_i, [_p, _p, _i, _i, _i, _p, _p, _p]),
     "eda_three_interpolate_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "eda_three_interpolate_grad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "eda_mha_fwd_f32": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _l, _p, _i, _i, _i, _i, _i, _f, _f,
+                            _p, _u, _p, _p, _p]),
+    "eda_mha_bwd_f32": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _l, _p, _i, _i, _i, _i, _i, _f, _f,
+                            _p, _u, _p, _p, _p, _l, _l, _p, _p, _p, _p, _p]),
 }
 
 _lib = None

@@ -6,26 +6,115 @@ masks, attention-probability dropout 0.1).
 -- the reference builds 39 of those (models/encoder_decoder_layers.py:47,62,69,133,
 298,306,314,319) and checkpoints must load -- but works batch-first: no
 (B,N,F)<->(N,B,F) transposes, one packed projection GEMM when q/k/v share their
-input, and the QK^T-softmax-PV core goes to ``attention_core``.
+input, and the QK^T-softmax-dropout-PV core is ONE fused HIP kernel
+(csrc/mha.hip, fp32 MFMA) that reads the heads in place from the (B,L,288)
+projection outputs and never materialises the (B*8,Lq,Lk) probabilities; its
+backward is two more kernels (dQ; dK+dV) that recompute the probabilities.
+
+``attention_core`` has no CPU path (the HIP library is the product); the torch
+restatement used by CPU-side tests lives in oracle/attention_ref.py.
 """
-import math
+import itertools
 
 import torch
 from torch import nn
 import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import _lib
+
+_dropout_state = {}      # device -> int64 counter tensor read by the kernels
+_salt_counter = itertools.count(1)
 
 
-def attention_core(q, k, v, key_padding_mask=None, dropout_p=0.0):
-    """softmax(q k^T / sqrt(hd) + mask) v for q (B,H,Lq,hd), k/v (B,H,Lk,hd).
+def dropout_state(device):
+    device = torch.device(device)
+    if device not in _dropout_state:
+        _dropout_state[device] = torch.zeros(1, dtype=torch.int64, device=device)
+    return _dropout_state[device]
 
-    key_padding_mask: (B,Lk) bool, True = ignore.  A fully masked row gives NaN,
-    as in the reference.
-    """
-    mask = None
-    if key_padding_mask is not None:
-        mask = torch.zeros(key_padding_mask.shape, dtype=q.dtype, device=q.device)
-        mask = mask.masked_fill(key_padding_mask, float("-inf"))[:, None, None, :]
-    return F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=dropout_p)
+
+def advance_dropout_state(device):
+    """Bump the device-side dropout counter (once per training step; capturable in a
+    HIP graph, so every replay draws new masks)."""
+    dropout_state(device).add_(1)
+
+
+def _rows(t):
+    """(B,L,D) view with unit last stride and 16-byte aligned rows, else a copy."""
+    if t.stride(-1) != 1 or t.stride(0) % 4 or t.stride(1) % 4 or t.data_ptr() % 16:
+        t = t.contiguous()
+    return t
+
+
+class _FusedMHA(Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask, num_heads, p_drop, salt):
+        if not q.is_cuda:
+            raise RuntimeError("CPU not supported: attention_core runs on the HIP library only")
+        q, k, v = _rows(q), _rows(k), _rows(v)
+        B, Lq, D = q.shape
+        Lk = k.shape[1]
+        hd = D // num_heads
+        out = torch.empty((B, Lq, D), dtype=torch.float32, device=q.device)
+        lse = torch.empty((B, num_heads, Lq), dtype=torch.float32, device=q.device)
+        m8 = None
+        if mask is not None:
+            m8 = mask.contiguous().view(torch.uint8)
+        seed = dropout_state(q.device) if p_drop > 0 else None
+        with torch.cuda.device(q.device):
+            rc = _lib.lib().eda_mha_fwd_f32(
+                q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
+                k.stride(1), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else None,
+                B, num_heads, Lq, Lk, hd, hd ** -0.5, float(p_drop),
+                seed.data_ptr() if seed is not None else None, int(salt), out.data_ptr(),
+                lse.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "eda_mha_fwd_f32")
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.mask8 = m8
+        ctx.cfg = (num_heads, float(p_drop), int(salt))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        num_heads, p_drop, salt = ctx.cfg
+        dout = _rows(dout)
+        B, Lq, D = q.shape
+        Lk = k.shape[1]
+        hd = D // num_heads
+        dq = torch.empty((B, Lq, D), dtype=torch.float32, device=q.device)
+        dk = torch.empty((B, Lk, D), dtype=torch.float32, device=q.device)
+        dv = torch.empty((B, Lk, D), dtype=torch.float32, device=q.device)
+        delta = torch.empty((B, num_heads, Lq), dtype=torch.float32, device=q.device)
+        m8 = ctx.mask8
+        seed = dropout_state(q.device) if p_drop > 0 else None
+        with torch.cuda.device(q.device):
+            rc = _lib.lib().eda_mha_bwd_f32(
+                q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
+                k.stride(1), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else None,
+                B, num_heads, Lq, Lk, hd, hd ** -0.5, p_drop,
+                seed.data_ptr() if seed is not None else None, salt, out.data_ptr(), lse.data_ptr(),
+                dout.data_ptr(), dout.stride(0), dout.stride(1), delta.data_ptr(), dq.data_ptr(),
+                dk.data_ptr(), dv.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "eda_mha_bwd_f32")
+        return dq, dk, dv, None, None, None, None
+
+
+def _hip_core(q, k, v, key_padding_mask, num_heads, dropout_p, salt):
+    return _FusedMHA.apply(q, k, v, key_padding_mask, num_heads, dropout_p, salt)
+
+
+# The implementation behind attention_core.  Product: the HIP kernels.  (CPU-side
+# tests and bench.py's cpu_baseline leg swap in oracle/attention_ref.py themselves.)
+_core = _hip_core
+
+
+def attention_core(q, k, v, key_padding_mask=None, num_heads=8, dropout_p=0.0, salt=0):
+    """softmax(q k^T / sqrt(hd) + mask) v per head, for PROJECTED q (B,Lq,D), k/v (B,Lk,D)
+    with head h in columns [h*hd, (h+1)*hd).  key_padding_mask: (B,Lk) bool, True = ignore
+    (a fully masked row gives NaN, as in the reference).  Returns (B,Lq,D)."""
+    return _core(q, k, v, key_padding_mask, num_heads, dropout_p, salt)
 
 
 class _OutProj(nn.Linear):
@@ -45,10 +134,14 @@ class MultiheadAttention(nn.Module):
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.constant_(self.in_proj_bias, 0.0)
         nn.init.constant_(self.out_proj.bias, 0.0)
+        self._salt = next(_salt_counter)       # distinguishes this call site's dropout stream
 
-    def _split_heads(self, x):
-        B, L, _ = x.shape
-        return x.view(B, L, self.num_heads, self.head_dim).transpose(1, 2)
+    def __deepcopy__(self, memo):
+        new = MultiheadAttention(self.embed_dim, self.num_heads, self.dropout)
+        new.load_state_dict(self.state_dict())
+        new.train(self.training)
+        memo[id(self)] = new
+        return new
 
     def forward(self, query, key, value, key_padding_mask=None, need_weights=False,
                 attn_mask=None, batch_first=False):
@@ -71,10 +164,9 @@ class MultiheadAttention(nn.Module):
             q = F.linear(query, W[:d], b[:d])
             k = F.linear(key, W[d:2 * d], b[d:2 * d])
             v = F.linear(value, W[2 * d:], b[2 * d:])
-        o = attention_core(self._split_heads(q), self._split_heads(k), self._split_heads(v),
-                           key_padding_mask, self.dropout if self.training else 0.0)
-        B, H, L, hd = o.shape
-        o = self.out_proj(o.transpose(1, 2).reshape(B, L, H * hd))
+        o = attention_core(q, k, v, key_padding_mask, self.num_heads,
+                           self.dropout if self.training else 0.0, self._salt)
+        o = self.out_proj(o)
         if not batch_first:
             o = o.transpose(0, 1)
         return o, None

@@ -1,0 +1,482 @@
+// mha.hip -- fused multi-head attention (forward + backward) on the fp32 MFMA
+// pipe of gfx950, for the shapes EDA uses: d_model 288 = 8 heads x 36, sequence
+// lengths 80..1024, boolean key-padding masks, attention-probability dropout.
+//
+// Replaces the unfused path inside torch.nn.MultiheadAttention that the reference
+// runs 39 times per forward (models/encoder_decoder_layers.py:47,62,69,133,298,
+// 306,314,319 -> F.multi_head_attention_forward: q*scale, bmm QK^T, -inf key
+// padding fill, softmax, dropout(0.1), bmm PV) -- the (B*8, Lq, Lk) probability
+// tensor (268 MB for the 1024x1024 self-attention at B=8) is never written.
+//
+// Arithmetic: v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate; bit-for-bit an fmaf
+// chain), so results match an fp32 reference to rounding; head_dim 36 = 9 x 4 means
+// the QK^T contraction needs no padding, only PV pads 36 -> 48 output columns.
+//
+// Formulation.  Everything is computed TRANSPOSED so that one index stays
+// lane-local: in the forward and dQ kernels lane l owns query (l & 15) of its
+// wave's 16-query tile, in the dK/dV kernel it owns key (l & 15):
+//     S^T = K Q^T      A = K[key = l&15][dim = 4s + (l>>4)],  B = Q[query = l&15][dim = 4s + (l>>4)]
+//     D   = S^T[key = 4(l>>4) + r][query = l&15]               r = 0..3 (accumulator regs)
+// so the softmax max/sum of a query are 16 lane-local values plus a reduction over
+// the 4 lane groups, and P^T sits in exactly the B-operand layout of the second
+// product  O^T += V^T P^T  (keys taken in the permuted order 4(l>>4)+t, which a sum
+// does not care about).  O^T[dim = 4(l>>4)+r][query = l&15] makes the 1/l rescale
+// lane-local and the epilogue a 16-byte store of 4 consecutive head dims.
+//
+// Dropout: keep(b,h,q,k) = hash32(seed, linear index) -- counter-based, identical
+// in forward and backward; seed = *seed_ptr (device counter, so a replayed HIP graph
+// sees a new mask every step) mixed with a per-call-site salt.
+#include "eda_common.h"
+
+namespace {
+
+constexpr int HD = 36;            // head dim
+constexpr int KSTEPS = HD / 4;    // 9 MFMA k-steps for a 36-deep contraction
+constexpr int TILE = 64;          // rows of the streamed operand staged in LDS per iteration
+constexpr int WAVES = 4;
+constexpr int THREADS = WAVES * 64;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MhaArgs {
+  const float *q, *k, *v;   // head h at column h*36; rows strided
+  long q_sb, q_sl, k_sb, k_sl, v_sb, v_sl;   // element strides (batch, row)
+  float *o; long o_sb, o_sl;                  // forward output (B,Lq,288)
+  float *lse;                                 // (B,H,Lq) log-sum-exp of the scaled masked scores
+  const unsigned char *mask;                  // (B,Lk) 1 = ignore, or null
+  int B, H, Lq, Lk;
+  float scale, p_drop;
+  const unsigned long long *seed_ptr; unsigned salt;
+  // backward
+  const float *dout; long do_sb, do_sl;       // (B,Lq,288)
+  const float *delta;                         // (B,H,Lq) rowsum(dO * O)
+  float *dq, *dk, *dv;                        // contiguous (B,L,288)
+};
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+
+__device__ __forceinline__ float xor_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16));
+  v = fmaxf(v, __shfl_xor(v, 32));
+  return v;
+}
+__device__ __forceinline__ float xor_sum(float v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+// Stage TILE rows x 36 floats of one head into LDS (row stride 36), zero-filling
+// rows >= nrows.  16-byte global loads, 16-byte LDS stores.
+__device__ __forceinline__ void stage_rows(float *lds, const float *base, long row_stride,
+                                           int row0, int nrows) {
+  for (int i = threadIdx.x; i < TILE * 9; i += THREADS) {
+    const int row = i / 9, c4 = i - row * 9;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + row < nrows)
+      v = *reinterpret_cast<const float4 *>(base + (long)(row0 + row) * row_stride + 4 * c4);
+    *reinterpret_cast<float4 *>(lds + row * HD + 4 * c4) = v;
+  }
+}
+
+// ============================================================== forward ======
+__global__ __launch_bounds__(THREADS) void mha_fwd_kernel(MhaArgs a) {
+  __shared__ __attribute__((aligned(16))) float Kl[TILE * HD];
+  __shared__ __attribute__((aligned(16))) float Vl[TILE * HD];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int qi = blockIdx.x * (WAVES * 16) + wave * 16 + c;
+  const bool qvalid = qi < a.Lq;
+
+  const float *qrow = a.q + (long)b * a.q_sb + (long)(qvalid ? qi : 0) * a.q_sl + h * HD;
+  float qreg[KSTEPS];
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) qreg[s] = qvalid ? qrow[4 * s + g] * a.scale : 0.f;
+
+  const float *kbase = a.k + (long)b * a.k_sb + h * HD;
+  const float *vbase = a.v + (long)b * a.v_sb + h * HD;
+  const unsigned char *mrow = a.mask ? a.mask + (long)b * a.Lk : nullptr;
+
+  const bool drop = a.p_drop > 0.f;
+  unsigned seed = 0, thresh = 0;
+  float inv_keep = 1.f;
+  if (drop) {
+    seed = hash32((unsigned)(*a.seed_ptr) * 0x9E3779B1u + a.salt);
+    thresh = (unsigned)((double)a.p_drop * 4294967296.0);
+    inv_keep = 1.f / (1.f - a.p_drop);
+  }
+  const unsigned rowbase = ((unsigned)bh * (unsigned)a.Lq + (unsigned)qi) * (unsigned)a.Lk;
+
+  float m = -INFINITY, lsum = 0.f;
+  f32x4 o[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+
+  for (int k0 = 0; k0 < a.Lk; k0 += TILE) {
+    __syncthreads();
+    stage_rows(Kl, kbase, a.k_sl, k0, a.Lk);
+    stage_rows(Vl, vbase, a.v_sl, k0, a.Lk);
+    __syncthreads();
+
+    f32x4 st[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) acc = mfma4(Kl[(16 * j + c) * HD + 4 * s + g], qreg[s], acc);
+      st[j] = acc;
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = k0 + 16 * j + 4 * g + r;
+        const bool dead = key >= a.Lk || (mrow && mrow[key]);
+        st[j][r] = dead ? -INFINITY : st[j][r];
+        tmax = fmaxf(tmax, st[j][r]);
+      }
+    tmax = xor_max(tmax);
+    const float m_new = fmaxf(m, tmax);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __expf(m - m_safe);       // m = -inf -> 0
+    float psum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf(st[j][r] - m_safe);
+        st[j][r] = p;
+        psum += p;
+      }
+    psum = xor_sum(psum);
+    lsum = lsum * alpha + psum;
+    m = m_new;
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) o[nt] *= alpha;
+    if (drop) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const unsigned key = (unsigned)(k0 + 16 * j + 4 * g + r);
+          const bool keep = hash32(seed ^ (rowbase + key)) >= thresh;
+          st[j][r] = keep ? st[j][r] * inv_keep : 0.f;
+        }
+    }
+    // O^T[dim][query] += V^T P^T
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float *vr = Vl + (16 * j + 4 * g + t) * HD;
+        const float pb = st[j][t];
+        o[0] = mfma4(vr[c], pb, o[0]);
+        o[1] = mfma4(vr[16 + c], pb, o[1]);
+        o[2] = mfma4(c < 4 ? vr[32 + c] : 0.f, pb, o[2]);
+      }
+  }
+
+  if (qvalid) {
+    const float inv = 1.f / lsum;                  // all keys masked -> NaN, like the reference
+    float *orow = a.o + (long)b * a.o_sb + (long)qi * a.o_sl + h * HD;
+    *reinterpret_cast<float4 *>(orow + 4 * g) = make_float4(o[0][0] * inv, o[0][1] * inv, o[0][2] * inv, o[0][3] * inv);
+    *reinterpret_cast<float4 *>(orow + 16 + 4 * g) = make_float4(o[1][0] * inv, o[1][1] * inv, o[1][2] * inv, o[1][3] * inv);
+    if (g == 0) {
+      *reinterpret_cast<float4 *>(orow + 32) = make_float4(o[2][0] * inv, o[2][1] * inv, o[2][2] * inv, o[2][3] * inv);
+      a.lse[(long)bh * a.Lq + qi] = m + __logf(lsum);
+    }
+  }
+}
+
+// ===================================================== backward: delta =======
+// delta[b,h,q] = sum_d dO[b,q,h*36+d] * O[b,q,h*36+d]
+__global__ __launch_bounds__(256) void mha_delta_kernel(const float *__restrict__ o,
+                                                        const float *__restrict__ dout, long o_sb,
+                                                        long o_sl, long do_sb, long do_sl, int B,
+                                                        int H, int Lq, float *__restrict__ delta) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;     // over B*H*Lq
+  if (i >= (long)B * H * Lq) return;
+  const int q = (int)(i % Lq);
+  const int bh = (int)(i / Lq);
+  const int b = bh / H, h = bh - b * H;
+  const float4 *po = reinterpret_cast<const float4 *>(o + (long)b * o_sb + (long)q * o_sl + h * HD);
+  const float4 *pd = reinterpret_cast<const float4 *>(dout + (long)b * do_sb + (long)q * do_sl + h * HD);
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float4 x = po[t], y = pd[t];
+    s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+  }
+  delta[i] = s;
+}
+
+// ======================================================== backward: dQ =======
+// lane owns query (l&15); streams K/V tiles.
+//   S^T = K Q^T, P^T = exp(S^T - lse);  dP^T = V dO^T;  dS^T = P^T o (dP^T_eff - delta)
+//   dQ^T[dim][query] += K^T dS^T    (then * scale)
+__global__ __launch_bounds__(THREADS) void mha_bwd_dq_kernel(MhaArgs a) {
+  __shared__ __attribute__((aligned(16))) float Kl[TILE * HD];
+  __shared__ __attribute__((aligned(16))) float Vl[TILE * HD];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int qi = blockIdx.x * (WAVES * 16) + wave * 16 + c;
+  const bool qvalid = qi < a.Lq;
+
+  const float *qrow = a.q + (long)b * a.q_sb + (long)(qvalid ? qi : 0) * a.q_sl + h * HD;
+  const float *drow = a.dout + (long)b * a.do_sb + (long)(qvalid ? qi : 0) * a.do_sl + h * HD;
+  float qreg[KSTEPS], dreg[KSTEPS];
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) {
+    qreg[s] = qvalid ? qrow[4 * s + g] * a.scale : 0.f;
+    dreg[s] = qvalid ? drow[4 * s + g] : 0.f;
+  }
+  const float lse = qvalid ? a.lse[(long)bh * a.Lq + qi] : 0.f;
+  const float delta = qvalid ? a.delta[(long)bh * a.Lq + qi] : 0.f;
+
+  const float *kbase = a.k + (long)b * a.k_sb + h * HD;
+  const float *vbase = a.v + (long)b * a.v_sb + h * HD;
+  const unsigned char *mrow = a.mask ? a.mask + (long)b * a.Lk : nullptr;
+  const bool drop = a.p_drop > 0.f;
+  unsigned seed = 0, thresh = 0;
+  float inv_keep = 1.f;
+  if (drop) {
+    seed = hash32((unsigned)(*a.seed_ptr) * 0x9E3779B1u + a.salt);
+    thresh = (unsigned)((double)a.p_drop * 4294967296.0);
+    inv_keep = 1.f / (1.f - a.p_drop);
+  }
+  const unsigned rowbase = ((unsigned)bh * (unsigned)a.Lq + (unsigned)qi) * (unsigned)a.Lk;
+
+  f32x4 dq[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  for (int k0 = 0; k0 < a.Lk; k0 += TILE) {
+    __syncthreads();
+    stage_rows(Kl, kbase, a.k_sl, k0, a.Lk);
+    stage_rows(Vl, vbase, a.v_sl, k0, a.Lk);
+    __syncthreads();
+    f32x4 ds[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 sacc = {0, 0, 0, 0}, pacc = {0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        sacc = mfma4(Kl[(16 * j + c) * HD + 4 * s + g], qreg[s], sacc);
+        pacc = mfma4(Vl[(16 * j + c) * HD + 4 * s + g], dreg[s], pacc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = k0 + 16 * j + 4 * g + r;
+        const bool dead = key >= a.Lk || (mrow && mrow[key]) || !qvalid;
+        const float p = dead ? 0.f : __expf(sacc[r] - lse);
+        float dp = pacc[r];
+        if (drop) {
+          const bool keep = hash32(seed ^ (rowbase + (unsigned)key)) >= thresh;
+          dp = keep ? dp * inv_keep : 0.f;
+        }
+        ds[j][r] = p * (dp - delta);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float *kr = Kl + (16 * j + 4 * g + t) * HD;
+        const float sb = ds[j][t];
+        dq[0] = mfma4(kr[c], sb, dq[0]);
+        dq[1] = mfma4(kr[16 + c], sb, dq[1]);
+        dq[2] = mfma4(c < 4 ? kr[32 + c] : 0.f, sb, dq[2]);
+      }
+  }
+  if (qvalid) {
+    float *out = a.dq + ((long)b * a.Lq + qi) * (a.H * HD) + h * HD;
+    const float sc = a.scale;
+    *reinterpret_cast<float4 *>(out + 4 * g) = make_float4(dq[0][0] * sc, dq[0][1] * sc, dq[0][2] * sc, dq[0][3] * sc);
+    *reinterpret_cast<float4 *>(out + 16 + 4 * g) = make_float4(dq[1][0] * sc, dq[1][1] * sc, dq[1][2] * sc, dq[1][3] * sc);
+    if (g == 0)
+      *reinterpret_cast<float4 *>(out + 32) = make_float4(dq[2][0] * sc, dq[2][1] * sc, dq[2][2] * sc, dq[2][3] * sc);
+  }
+}
+
+// ===================================================== backward: dK, dV ======
+// lane owns key (l&15); streams Q/dO tiles (plus their lse/delta).
+//   S = Q K^T [query 4g+r][key l&15], P = exp(S - lse[query]);  dP = dO V^T
+//   dV^T[dim][key] += dO^T P_drop;  dS = P o (dP_eff - delta[query]);  dK^T[dim][key] += Q^T dS
+__global__ __launch_bounds__(THREADS) void mha_bwd_dkv_kernel(MhaArgs a) {
+  __shared__ __attribute__((aligned(16))) float Ql[TILE * HD];
+  __shared__ __attribute__((aligned(16))) float Dl[TILE * HD];
+  __shared__ float lse_l[TILE], delta_l[TILE];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int ki = blockIdx.x * (WAVES * 16) + wave * 16 + c;
+  const bool kvalid = ki < a.Lk;
+  const bool kdead = !kvalid || (a.mask && a.mask[(long)b * a.Lk + (kvalid ? ki : 0)]);
+
+  const float *krow = a.k + (long)b * a.k_sb + (long)(kvalid ? ki : 0) * a.k_sl + h * HD;
+  const float *vrow = a.v + (long)b * a.v_sb + (long)(kvalid ? ki : 0) * a.v_sl + h * HD;
+  float kreg[KSTEPS], vreg[KSTEPS];
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) {
+    kreg[s] = kvalid ? krow[4 * s + g] : 0.f;
+    vreg[s] = kvalid ? vrow[4 * s + g] : 0.f;
+  }
+  const float *qbase = a.q + (long)b * a.q_sb + h * HD;
+  const float *dbase = a.dout + (long)b * a.do_sb + h * HD;
+  const bool drop = a.p_drop > 0.f;
+  unsigned seed = 0, thresh = 0;
+  float inv_keep = 1.f;
+  if (drop) {
+    seed = hash32((unsigned)(*a.seed_ptr) * 0x9E3779B1u + a.salt);
+    thresh = (unsigned)((double)a.p_drop * 4294967296.0);
+    inv_keep = 1.f / (1.f - a.p_drop);
+  }
+
+  f32x4 dk[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  f32x4 dv[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  for (int q0 = 0; q0 < a.Lq; q0 += TILE) {
+    __syncthreads();
+    stage_rows(Ql, qbase, a.q_sl, q0, a.Lq);
+    stage_rows(Dl, dbase, a.do_sl, q0, a.Lq);
+    if (threadIdx.x < TILE) {
+      const int qq = q0 + threadIdx.x;
+      lse_l[threadIdx.x] = qq < a.Lq ? a.lse[(long)bh * a.Lq + qq] : 0.f;
+      delta_l[threadIdx.x] = qq < a.Lq ? a.delta[(long)bh * a.Lq + qq] : 0.f;
+    }
+    __syncthreads();
+    f32x4 pd[4], ds[4];     // dropped P (for dV) and dS (for dK), B-operand layout
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 sacc = {0, 0, 0, 0}, pacc = {0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        sacc = mfma4(Ql[(16 * j + c) * HD + 4 * s + g], kreg[s], sacc);
+        pacc = mfma4(Dl[(16 * j + c) * HD + 4 * s + g], vreg[s], pacc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = 16 * j + 4 * g + r;
+        const int qq = q0 + ql;
+        const bool dead = kdead || qq >= a.Lq;
+        const float p = dead ? 0.f : __expf(sacc[r] * a.scale - lse_l[ql]);
+        float dp = pacc[r];
+        float pdrop = p;
+        if (drop) {
+          const unsigned idx = ((unsigned)bh * (unsigned)a.Lq + (unsigned)qq) * (unsigned)a.Lk + (unsigned)ki;
+          const bool keep = hash32(seed ^ idx) >= thresh;
+          dp = keep ? dp * inv_keep : 0.f;
+          pdrop = keep ? p * inv_keep : 0.f;
+        }
+        pd[j][r] = pdrop;
+        ds[j][r] = p * (dp - delta_l[ql]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float *qr = Ql + (16 * j + 4 * g + t) * HD;
+        const float *dr = Dl + (16 * j + 4 * g + t) * HD;
+        const float pb = pd[j][t], sb = ds[j][t];
+        dv[0] = mfma4(dr[c], pb, dv[0]);
+        dv[1] = mfma4(dr[16 + c], pb, dv[1]);
+        dv[2] = mfma4(c < 4 ? dr[32 + c] : 0.f, pb, dv[2]);
+        dk[0] = mfma4(qr[c], sb, dk[0]);
+        dk[1] = mfma4(qr[16 + c], sb, dk[1]);
+        dk[2] = mfma4(c < 4 ? qr[32 + c] : 0.f, sb, dk[2]);
+      }
+  }
+  if (kvalid) {
+    const long off = ((long)b * a.Lk + ki) * (a.H * HD) + h * HD;
+    const float sc = a.scale;
+    float *ok = a.dk + off, *ov = a.dv + off;
+    *reinterpret_cast<float4 *>(ok + 4 * g) = make_float4(dk[0][0] * sc, dk[0][1] * sc, dk[0][2] * sc, dk[0][3] * sc);
+    *reinterpret_cast<float4 *>(ok + 16 + 4 * g) = make_float4(dk[1][0] * sc, dk[1][1] * sc, dk[1][2] * sc, dk[1][3] * sc);
+    *reinterpret_cast<float4 *>(ov + 4 * g) = make_float4(dv[0][0], dv[0][1], dv[0][2], dv[0][3]);
+    *reinterpret_cast<float4 *>(ov + 16 + 4 * g) = make_float4(dv[1][0], dv[1][1], dv[1][2], dv[1][3]);
+    if (g == 0) {
+      *reinterpret_cast<float4 *>(ok + 32) = make_float4(dk[2][0] * sc, dk[2][1] * sc, dk[2][2] * sc, dk[2][3] * sc);
+      *reinterpret_cast<float4 *>(ov + 32) = make_float4(dv[2][0], dv[2][1], dv[2][2], dv[2][3]);
+    }
+  }
+}
+
+bool mult4(long v) { return (v & 3) == 0; }
+bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" int eda_mha_fwd_f32(const float *q, const float *k, const float *v, long q_sb, long q_sl,
+                               long k_sb, long k_sl, long v_sb, long v_sl,
+                               const unsigned char *key_padding_mask, int B, int H, int Lq, int Lk,
+                               int head_dim, float scale, float p_drop,
+                               const unsigned long long *seed_ptr, unsigned salt, float *out,
+                               float *lse, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(head_dim == HD, "only head_dim 36 (d_model 288 / 8 heads) is built");
+  EDA_CHECK_ARG(B >= 0 && H > 0 && Lq >= 0 && Lk >= 0, "bad dimension");
+  if (B == 0 || Lq == 0) return 0;
+  EDA_CHECK_ARG(q && k && v && out && lse, "null pointer");
+  EDA_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed_ptr), "bad dropout arguments");
+  EDA_CHECK_ARG(mult4(q_sb) && mult4(q_sl) && mult4(k_sb) && mult4(k_sl) && mult4(v_sb) && mult4(v_sl) &&
+                    al16(q) && al16(k) && al16(v) && al16(out),
+                "rows must be 16-byte aligned");
+  EDA_CHECK_ARG((long)B * H <= 65535, "B*H too large");
+  MhaArgs a = {};
+  a.q = q; a.k = k; a.v = v; a.q_sb = q_sb; a.q_sl = q_sl; a.k_sb = k_sb; a.k_sl = k_sl;
+  a.v_sb = v_sb; a.v_sl = v_sl; a.o = out; a.o_sb = (long)Lq * H * HD; a.o_sl = (long)H * HD;
+  a.lse = lse; a.mask = key_padding_mask; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale;
+  a.p_drop = p_drop; a.seed_ptr = seed_ptr; a.salt = salt;
+  const dim3 grid((unsigned)((Lq + WAVES * 16 - 1) / (WAVES * 16)), (unsigned)(B * H));
+  hipLaunchKernelGGL(mha_fwd_kernel, grid, dim3(THREADS), 0, stream, a);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int eda_mha_bwd_f32(const float *q, const float *k, const float *v, long q_sb, long q_sl,
+                               long k_sb, long k_sl, long v_sb, long v_sl,
+                               const unsigned char *key_padding_mask, int B, int H, int Lq, int Lk,
+                               int head_dim, float scale, float p_drop,
+                               const unsigned long long *seed_ptr, unsigned salt, const float *out,
+                               const float *lse, const float *dout, long do_sb, long do_sl,
+                               float *delta_ws, float *dq, float *dk, float *dv, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(head_dim == HD, "only head_dim 36 (d_model 288 / 8 heads) is built");
+  EDA_CHECK_ARG(B >= 0 && H > 0 && Lq >= 0 && Lk >= 0, "bad dimension");
+  if (B == 0) return 0;
+  EDA_CHECK_ARG(q && k && v && out && lse && dout && delta_ws && dq && dk && dv, "null pointer");
+  EDA_CHECK_ARG(mult4(q_sb) && mult4(q_sl) && mult4(k_sb) && mult4(k_sl) && mult4(v_sb) && mult4(v_sl) &&
+                    mult4(do_sb) && mult4(do_sl) && al16(q) && al16(k) && al16(v) && al16(out) &&
+                    al16(dout) && al16(dq) && al16(dk) && al16(dv),
+                "rows must be 16-byte aligned");
+  EDA_CHECK_ARG((long)B * H <= 65535, "B*H too large");
+  MhaArgs a = {};
+  a.q = q; a.k = k; a.v = v; a.q_sb = q_sb; a.q_sl = q_sl; a.k_sb = k_sb; a.k_sl = k_sl;
+  a.v_sb = v_sb; a.v_sl = v_sl; a.lse = const_cast<float *>(lse); a.mask = key_padding_mask;
+  a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.p_drop = p_drop; a.seed_ptr = seed_ptr;
+  a.salt = salt; a.dout = dout; a.do_sb = do_sb; a.do_sl = do_sl; a.delta = delta_ws; a.dq = dq;
+  a.dk = dk; a.dv = dv;
+  if (Lq > 0) {
+    const long n = (long)B * H * Lq;
+    hipLaunchKernelGGL(mha_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, out,
+                       dout, (long)Lq * H * HD, (long)H * HD, do_sb, do_sl, B, H, Lq, delta_ws);
+    EDA_CHECK_LAUNCH();
+    const dim3 gq((unsigned)((Lq + WAVES * 16 - 1) / (WAVES * 16)), (unsigned)(B * H));
+    hipLaunchKernelGGL(mha_bwd_dq_kernel, gq, dim3(THREADS), 0, stream, a);
+    EDA_CHECK_LAUNCH();
+  }
+  if (Lk > 0) {
+    const dim3 gk((unsigned)((Lk + WAVES * 16 - 1) / (WAVES * 16)), (unsigned)(B * H));
+    hipLaunchKernelGGL(mha_bwd_dkv_kernel, gk, dim3(THREADS), 0, stream, a);
+    EDA_CHECK_LAUNCH();
+  }
+  return 0;
+}

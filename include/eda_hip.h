@@ -111,6 +111,35 @@ int eda_three_interpolate_grad_f32(const float *grad_out, const int *idx,
                                    const float *weight, int b, int c, int n,
                                    int m, float *grad_points, void *stream);
 
+/* ---- fused multi-head attention ---------------------------------------
+ * replaces the QK^T -> key-padding mask -> softmax -> dropout -> PV core of
+ * torch.nn.MultiheadAttention as the reference calls it
+ * (models/encoder_decoder_layers.py:87-93,99-105,111-117,149-153,179-183,366-401;
+ * 8 heads x 36, attn_mask=None, boolean key_padding_mask, dropout 0.1).
+ * q/k/v: PROJECTED activations, head h in columns [h*36, h*36+36) of each row;
+ * element strides (batch, row) given explicitly so slices of a packed QKV GEMM
+ * output are consumed in place.  out (B,Lq,H*36) dense; lse (B,H,Lq) scratch kept
+ * for the backward.  key_padding_mask (B,Lk) bytes, 1 = ignore, or NULL.
+ * Dropout (p_drop > 0): keep mask = hash(*seed_ptr, salt, b,h,q,k), regenerated
+ * identically by the backward; seed_ptr is a DEVICE counter so that a replayed
+ * HIP graph draws a fresh mask whenever the host bumps the counter.
+ * fp32 in / fp32 accumulate on v_mfma_f32_16x16x4_f32.                      */
+int eda_mha_fwd_f32(const float *q, const float *k, const float *v, long q_sb, long q_sl,
+                    long k_sb, long k_sl, long v_sb, long v_sl,
+                    const unsigned char *key_padding_mask, int B, int H, int Lq, int Lk,
+                    int head_dim, float scale, float p_drop,
+                    const unsigned long long *seed_ptr, unsigned salt, float *out,
+                    float *lse, void *stream);
+/* Backward of the above: dq (B,Lq,H*36), dk, dv (B,Lk,H*36) dense outputs;
+ * delta_ws: (B,H,Lq) floats of scratch.                                      */
+int eda_mha_bwd_f32(const float *q, const float *k, const float *v, long q_sb, long q_sl,
+                    long k_sb, long k_sl, long v_sb, long v_sl,
+                    const unsigned char *key_padding_mask, int B, int H, int Lq, int Lk,
+                    int head_dim, float scale, float p_drop,
+                    const unsigned long long *seed_ptr, unsigned salt, const float *out,
+                    const float *lse, const float *dout, long do_sb, long do_sl,
+                    float *delta_ws, float *dq, float *dk, float *dv, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

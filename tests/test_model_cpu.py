@@ -9,8 +9,10 @@ import model_cases as MC
 
 @pytest.fixture(autouse=True)
 def oracle_backend(oracle, monkeypatch):
-    from eda_amd import pointnet2_utils
+    from eda_amd import pointnet2_utils, attention
+    from oracle import attention_ref
     monkeypatch.setattr(pointnet2_utils, "_ext", oracle)
+    monkeypatch.setattr(attention, "_core", attention_ref.attention_core)
     yield
 
 

@@ -21,7 +21,10 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle_ext
     from eda_amd import pointnet2_utils
-    pointnet2_utils._ext = oracle_ext          # CPU test double for the HIP ops
+    pointnet2_utils._ext = oracle_ext          # CPU test doubles for the HIP ops
+    from eda_amd import attention
+    from oracle import attention_ref
+    attention._core = attention_ref.attention_core
     from eda_amd.parallel import FlatGrads, broadcast_parameters, shard_scene_seeds
     from eda_amd.pointnet2_modules import PointnetSAModuleVotes
     from eda_amd.encoder_decoder_layers import BiDecoderLayer
