@@ -29,6 +29,8 @@ _salt_counter = itertools.count(1)
 
 def dropout_state(device):
     device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
     if device not in _dropout_state:
         _dropout_state[device] = torch.zeros(1, dtype=torch.int64, device=device)
     return _dropout_state[device]

@@ -86,10 +86,28 @@ __device__ __forceinline__ void stage_rows(float *lds, const float *base, long r
   }
 }
 
+// Dead-key flags of one 64-key tile, packed 4 per word: byte r of word w is 1 when
+// key k0 + 4w + r is padding (>= Lk) or masked.  Staged through LDS so that the
+// masking in the hot loop is branch-free (no predicated byte loads).
+__device__ __forceinline__ void stage_dead(unsigned *flags, const unsigned char *mrow, int k0, int Lk) {
+  if (threadIdx.x < TILE / 4) {
+    unsigned w = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = k0 + 4 * (int)threadIdx.x + r;
+      unsigned dead = key >= Lk ? 1u : 0u;
+      if (key < Lk && mrow) dead = mrow[key] ? 1u : 0u;
+      w |= dead << (8 * r);
+    }
+    flags[threadIdx.x] = w;
+  }
+}
+
 // ============================================================== forward ======
 __global__ __launch_bounds__(THREADS) void mha_fwd_kernel(MhaArgs a) {
   __shared__ __attribute__((aligned(16))) float Kl[TILE * HD];
   __shared__ __attribute__((aligned(16))) float Vl[TILE * HD];
+  __shared__ unsigned deadl[TILE / 4];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;
@@ -123,6 +141,7 @@ __global__ __launch_bounds__(THREADS) void mha_fwd_kernel(MhaArgs a) {
     __syncthreads();
     stage_rows(Kl, kbase, a.k_sl, k0, a.Lk);
     stage_rows(Vl, vbase, a.v_sl, k0, a.Lk);
+    stage_dead(deadl, mrow, k0, a.Lk);
     __syncthreads();
 
     f32x4 st[4];
@@ -135,14 +154,15 @@ __global__ __launch_bounds__(THREADS) void mha_fwd_kernel(MhaArgs a) {
     }
     float tmax = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) {
+      const unsigned dw = deadl[4 * j + g];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int key = k0 + 16 * j + 4 * g + r;
-        const bool dead = key >= a.Lk || (mrow && mrow[key]);
+        const bool dead = ((dw >> (8 * r)) & 0xffu) != 0u;
         st[j][r] = dead ? -INFINITY : st[j][r];
         tmax = fmaxf(tmax, st[j][r]);
       }
+    }
     tmax = xor_max(tmax);
     const float m_new = fmaxf(m, tmax);
     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
@@ -225,6 +245,7 @@ __global__ __launch_bounds__(256) void mha_delta_kernel(const float *__restrict_
 __global__ __launch_bounds__(THREADS) void mha_bwd_dq_kernel(MhaArgs a) {
   __shared__ __attribute__((aligned(16))) float Kl[TILE * HD];
   __shared__ __attribute__((aligned(16))) float Vl[TILE * HD];
+  __shared__ unsigned deadl[TILE / 4];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;
@@ -261,6 +282,7 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_dq_kernel(MhaArgs a) {
     __syncthreads();
     stage_rows(Kl, kbase, a.k_sl, k0, a.Lk);
     stage_rows(Vl, vbase, a.v_sl, k0, a.Lk);
+    stage_dead(deadl, mrow, k0, a.Lk);
     __syncthreads();
     f32x4 ds[4];
 #pragma unroll
@@ -271,10 +293,11 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_dq_kernel(MhaArgs a) {
         sacc = mfma4(Kl[(16 * j + c) * HD + 4 * s + g], qreg[s], sacc);
         pacc = mfma4(Vl[(16 * j + c) * HD + 4 * s + g], dreg[s], pacc);
       }
+      const unsigned dw = deadl[4 * j + g];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = k0 + 16 * j + 4 * g + r;
-        const bool dead = key >= a.Lk || (mrow && mrow[key]) || !qvalid;
+        const bool dead = (((dw >> (8 * r)) & 0xffu) != 0u) || !qvalid;
         const float p = dead ? 0.f : __expf(sacc[r] - lse);
         float dp = pacc[r];
         if (drop) {

@@ -82,7 +82,7 @@ def test_fused_forward_backward_vs_restatement(B, Lq, Lk, masked):
     for name, g, e in zip(["out", "dq", "dk", "dv"], got, exp):
         err = (g.double() - e).abs().max().item()
         scale = e.abs().max().item() + 1e-12
-        assert err <= 1e-4 * scale + 1e-6, (name, err, scale)
+        assert err <= 1e-4 * scale + 5e-6, (name, err, scale)
 
 
 @pytest.mark.gpu
