@@ -1,0 +1,438 @@
+// sa_cl.hip -- the set-abstraction "grouped MLP" pipeline in channels-last layout.
+//
+// Reference path (pointnet2/pointnet2_utils.py:317-376 QueryAndGroup, then
+// pointnet2/pytorch_utils.py SharedMLP = 3 x [conv1x1 -> BatchNorm2d -> ReLU], then
+// F.max_pool2d over the nsample axis, pointnet2_modules.py:243-257): every step
+// round-trips a (B, C, npoint, nsample) tensor through HBM -- group xyz, subtract
+// centre, divide, group features, concat, conv out, BN out, ReLU, pool.
+//
+// Here a position (scene, centre j, neighbour k) is a ROW of a (B*m*ns, C) matrix:
+//  * group_concat: one pass writes [ (xyz[idx]-centre)*(1/r) | feats[idx] ] rows,
+//    reading features as contiguous C-float rows of a (B,N,C) channels-last tensor
+//    (coalesced gather instead of a stride-N scatter);
+//  * the three 1x1 convolutions are plain row-major GEMMs Z = A W^T (library GEMM);
+//  * batch-norm statistics: column sums in fp32 per slab, merged in fp64 atomics;
+//  * BN + ReLU (+ max-pool over the ns consecutive rows of a centre, with arg-max
+//    kept for the backward) in one pass over Z;
+//  * backward: one pass for the two BN reductions (sum dY, sum dY*xhat), one pass
+//    that writes dZ; dW / dA are library GEMMs again.
+// Results equal the reference's to fp32 rounding (tested against goldens generated
+// by the reference's own modules, tests/golden/model_sa_*).
+#include "eda_common.h"
+
+namespace {
+
+constexpr int CL_THREADS = 256;
+
+// ---------------------------------------------------------------- group + concat
+// X[b, j*ns+k, :] = [ (xyz[b, idx, :] - new_xyz[b, j, :]) * inv_radius , feats[b, idx, :] ]
+__global__ __launch_bounds__(CL_THREADS) void group_concat_cl_kernel(
+    const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    const float *__restrict__ feats, const int *__restrict__ idx, int n, int m, int ns, int c,
+    float inv_radius, float *__restrict__ out) {
+  const int cw = 3 + c;
+  const long rows_per_scene = (long)m * ns;
+  const int b = blockIdx.y;
+  const long total = rows_per_scene * cw;
+  const float *xyz_b = xyz + (long)b * n * 3;
+  const float *ctr_b = new_xyz + (long)b * m * 3;
+  const float *f_b = feats ? feats + (long)b * n * c : nullptr;
+  const int *idx_b = idx + (long)b * rows_per_scene;
+  float *out_b = out + (long)b * total;
+  for (long e = (long)blockIdx.x * CL_THREADS + threadIdx.x; e < total;
+       e += (long)gridDim.x * CL_THREADS) {
+    const long row = e / cw;
+    const int ch = (int)(e - row * cw);
+    const int src = idx_b[row];
+    float v;
+    if (ch < 3) {
+      const int j = (int)(row / ns);
+      v = (xyz_b[(long)src * 3 + ch] - ctr_b[(long)j * 3 + ch]) * inv_radius;
+    } else {
+      v = f_b[(long)src * c + (ch - 3)];
+    }
+    out_b[e] = v;
+  }
+}
+
+// dfeats[b, idx, :] += dX[b, row, 3:]
+__global__ __launch_bounds__(CL_THREADS) void group_concat_cl_grad_kernel(
+    const float *__restrict__ dx, const int *__restrict__ idx, int n, int m, int ns, int c,
+    float *__restrict__ dfeats) {
+  const int cw = 3 + c;
+  const long rows_per_scene = (long)m * ns;
+  const int b = blockIdx.y;
+  const long total = rows_per_scene * c;
+  const int *idx_b = idx + (long)b * rows_per_scene;
+  const float *dx_b = dx + (long)b * rows_per_scene * cw;
+  float *df_b = dfeats + (long)b * n * c;
+  for (long e = (long)blockIdx.x * CL_THREADS + threadIdx.x; e < total;
+       e += (long)gridDim.x * CL_THREADS) {
+    const long row = e / c;
+    const int ch = (int)(e - row * c);
+    atomicAdd(df_b + (long)idx_b[row] * c + ch, dx_b[row * cw + 3 + ch]);
+  }
+}
+
+// ---------------------------------------------------------------- BN statistics
+// Column sums of Z (R, C): every block owns a slab of rows, sums it in fp32
+// (<= a few hundred terms per partial), then merges into fp64 accumulators.
+// Thread t handles column (t % C4)*4.. +3 of rows (t / C4) + k * rows_per_pass.
+template <int VEC>
+__global__ __launch_bounds__(CL_THREADS) void bn_stats_kernel(const float *__restrict__ z, long R,
+                                                              int C, long rows_per_block,
+                                                              double *__restrict__ sum,
+                                                              double *__restrict__ sumsq) {
+  __shared__ float red[2][CL_THREADS * VEC];
+  const int cgroups = C / VEC;                       // threads per row
+  const int rpp = CL_THREADS / cgroups;              // rows per pass (threads beyond rpp*cgroups idle)
+  const int tcol = threadIdx.x % cgroups, trow = threadIdx.x / cgroups;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+  float s[VEC], q[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { s[v] = 0.f; q[v] = 0.f; }
+  if (trow < rpp) {
+    for (long r = r0 + trow; r < r1; r += rpp) {
+      const float *p = z + r * C + tcol * VEC;
+      if (VEC == 4) {
+        const float4 x = *reinterpret_cast<const float4 *>(p);
+        s[0] += x.x; s[1] += x.y; s[2] += x.z; s[3] += x.w;
+        q[0] += x.x * x.x; q[1] += x.y * x.y; q[2] += x.z * x.z; q[3] += x.w * x.w;
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { const float x = p[v]; s[v] += x; q[v] += x * x; }
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    red[0][threadIdx.x * VEC + v] = s[v];
+    red[1][threadIdx.x * VEC + v] = q[v];
+  }
+  __syncthreads();
+  // column c = tcol*VEC+v lives at threads with the same tcol: reduce over trow
+  for (int col = threadIdx.x; col < C; col += CL_THREADS) {
+    const int tc = col / VEC, v = col - tc * VEC;
+    double a = 0.0, bq = 0.0;
+    for (int tr = 0; tr < rpp; ++tr) {
+      const int t = tr * cgroups + tc;
+      a += (double)red[0][t * VEC + v];
+      bq += (double)red[1][t * VEC + v];
+    }
+    atomicAdd(sum + col, a);
+    atomicAdd(sumsq + col, bq);
+  }
+}
+
+// mean / rstd / fused scale-shift and the running-statistics update
+// (torch.nn.BatchNorm: biased variance normalises, unbiased variance is tracked).
+__global__ void bn_finalize_kernel(const double *__restrict__ sum, const double *__restrict__ sumsq,
+                                   long R, int C, const float *__restrict__ gamma,
+                                   const float *__restrict__ beta, float eps, float momentum,
+                                   float *__restrict__ running_mean, float *__restrict__ running_var,
+                                   float *__restrict__ mean_out, float *__restrict__ rstd_out,
+                                   float *__restrict__ scale, float *__restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = sum[c] / (double)R;
+  double var = sumsq[c] / (double)R - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float meanf = (float)mean;
+  mean_out[c] = meanf;
+  rstd_out[c] = rstd;
+  const float sc = gamma[c] * rstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - meanf * sc;
+  if (running_mean) {
+    const double unbiased = R > 1 ? var * (double)R / (double)(R - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// eval mode: scale/shift from the running statistics
+__global__ void bn_eval_affine_kernel(const float *__restrict__ running_mean,
+                                      const float *__restrict__ running_var,
+                                      const float *__restrict__ gamma, const float *__restrict__ beta,
+                                      float eps, int C, float *__restrict__ mean_out,
+                                      float *__restrict__ rstd_out, float *__restrict__ scale,
+                                      float *__restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float rstd = 1.f / sqrtf(running_var[c] + eps);
+  mean_out[c] = running_mean[c];
+  rstd_out[c] = rstd;
+  const float sc = gamma[c] * rstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - running_mean[c] * sc;
+}
+
+// ---------------------------------------------------------------- BN + ReLU apply
+// A = relu(Z*scale + shift), elementwise over (R, C); C % 4 == 0.
+__global__ __launch_bounds__(CL_THREADS) void bn_relu_apply_kernel(const float *__restrict__ z,
+                                                                   long total4, int C,
+                                                                   const float *__restrict__ scale,
+                                                                   const float *__restrict__ shift,
+                                                                   float *__restrict__ a) {
+  for (long i = (long)blockIdx.x * CL_THREADS + threadIdx.x; i < total4;
+       i += (long)gridDim.x * CL_THREADS) {
+    const int col = (int)((i * 4) % C);
+    const float4 x = reinterpret_cast<const float4 *>(z)[i];
+    const float4 sc = *reinterpret_cast<const float4 *>(scale + col);
+    const float4 sh = *reinterpret_cast<const float4 *>(shift + col);
+    float4 y;
+    y.x = fmaxf(x.x * sc.x + sh.x, 0.f);
+    y.y = fmaxf(x.y * sc.y + sh.y, 0.f);
+    y.z = fmaxf(x.z * sc.z + sh.z, 0.f);
+    y.w = fmaxf(x.w * sc.w + sh.w, 0.f);
+    reinterpret_cast<float4 *>(a)[i] = y;
+  }
+}
+
+// pooled[g, c] = max_k relu(Z[g*ns+k, c]*scale+shift); argmax[g, c] = first k attaining it
+__global__ __launch_bounds__(CL_THREADS) void bn_relu_pool_kernel(const float *__restrict__ z,
+                                                                  long G, int ns, int C,
+                                                                  const float *__restrict__ scale,
+                                                                  const float *__restrict__ shift,
+                                                                  float *__restrict__ pooled,
+                                                                  unsigned char *__restrict__ argmax) {
+  const long total = G * C;
+  for (long i = (long)blockIdx.x * CL_THREADS + threadIdx.x; i < total;
+       i += (long)gridDim.x * CL_THREADS) {
+    const long g = i / C;
+    const int c = (int)(i - g * C);
+    const float sc = scale[c], sh = shift[c];
+    const float *p = z + (g * ns) * C + c;
+    float best = -INFINITY;
+    int bi = 0;
+    for (int k = 0; k < ns; ++k) {
+      const float y = fmaxf(p[(long)k * C] * sc + sh, 0.f);
+      if (y > best) { best = y; bi = k; }
+    }
+    pooled[i] = best;
+    argmax[i] = (unsigned char)bi;
+  }
+}
+
+// ---------------------------------------------------------------- backward
+// dY = dA * (Y > 0);  s1 = sum dY, s2 = sum dY * xhat  (per channel, fp64 merge)
+// POOL: dA is given per (group, channel) and lands on row argmax only.
+template <bool POOL>
+__global__ __launch_bounds__(CL_THREADS) void bn_relu_bwd_stats_kernel(
+    const float *__restrict__ da, const unsigned char *__restrict__ argmax,
+    const float *__restrict__ z, long R, int C, int ns, long rows_per_block,
+    const float *__restrict__ mean, const float *__restrict__ rstd,
+    const float *__restrict__ scale, const float *__restrict__ shift, double *__restrict__ s1,
+    double *__restrict__ s2) {
+  __shared__ float red[2][CL_THREADS];
+  // one thread per column, CL_THREADS / C row lanes (C <= 256 assumed by the launcher, else loops)
+  const int lanes = CL_THREADS / C > 0 ? CL_THREADS / C : 1;
+  for (int cbase = 0; cbase < C; cbase += CL_THREADS) {
+    const int col = cbase + (int)(threadIdx.x % (C < CL_THREADS ? C : CL_THREADS));
+    const int rl = threadIdx.x / (C < CL_THREADS ? C : CL_THREADS);
+    float a1 = 0.f, a2 = 0.f;
+    if (col < C && rl < lanes) {
+      const float mu = mean[col], rs = rstd[col], sc = scale[col], sh = shift[col];
+      const long r0 = (long)blockIdx.x * rows_per_block;
+      const long r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+      if (POOL) {
+        // rows_per_block is a multiple of ns: iterate groups
+        for (long g = r0 / ns + rl; g < r1 / ns; g += lanes) {
+          const int k = argmax[g * C + col];
+          const float x = z[(g * ns + k) * C + col];
+          const float y = x * sc + sh;
+          const float dy = y > 0.f ? da[g * C + col] : 0.f;
+          a1 += dy;
+          a2 += dy * (x - mu) * rs;
+        }
+      } else {
+        for (long r = r0 + rl; r < r1; r += lanes) {
+          const float x = z[r * C + col];
+          const float y = x * sc + sh;
+          const float dy = y > 0.f ? da[r * C + col] : 0.f;
+          a1 += dy;
+          a2 += dy * (x - mu) * rs;
+        }
+      }
+    }
+    red[0][threadIdx.x] = a1;
+    red[1][threadIdx.x] = a2;
+    __syncthreads();
+    if (rl == 0 && col < C) {
+      double t1 = 0.0, t2 = 0.0;
+      const int stride = C < CL_THREADS ? C : CL_THREADS;
+      for (int l = 0; l < lanes; ++l) {
+        t1 += (double)red[0][l * stride + (col - cbase)];
+        t2 += (double)red[1][l * stride + (col - cbase)];
+      }
+      atomicAdd(s1 + col, t1);
+      atomicAdd(s2 + col, t2);
+    }
+    __syncthreads();
+  }
+}
+
+// dZ = gamma*rstd * (dY - s1/R - xhat * s2/R)
+template <bool POOL>
+__global__ __launch_bounds__(CL_THREADS) void bn_relu_bwd_apply_kernel(
+    const float *__restrict__ da, const unsigned char *__restrict__ argmax,
+    const float *__restrict__ z, long R, int C, int ns, const float *__restrict__ mean,
+    const float *__restrict__ rstd, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ gamma,
+    const double *__restrict__ s1, const double *__restrict__ s2, int train,
+    float *__restrict__ dz) {
+  const long total = R * C;
+  const float invR = 1.f / (float)R;
+  for (long i = (long)blockIdx.x * CL_THREADS + threadIdx.x; i < total;
+       i += (long)gridDim.x * CL_THREADS) {
+    const long r = i / C;
+    const int c = (int)(i - r * C);
+    const float x = z[i];
+    const float y = x * scale[c] + shift[c];
+    float dy;
+    if (POOL) {
+      const long g = r / ns;
+      const int k = (int)(r - g * ns);
+      dy = (y > 0.f && argmax[g * C + c] == k) ? da[g * C + c] : 0.f;
+    } else {
+      dy = y > 0.f ? da[i] : 0.f;
+    }
+    const float gr = gamma[c] * rstd[c];
+    float out;
+    if (train) {
+      const float xhat = (x - mean[c]) * rstd[c];
+      out = gr * (dy - (float)s1[c] * invR - xhat * (float)s2[c] * invR);
+    } else {
+      out = gr * dy;           // eval: statistics are constants
+    }
+    dz[i] = out;
+  }
+}
+
+int grid_for(long work_items) {
+  long g = (work_items + CL_THREADS - 1) / CL_THREADS;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int eda_group_concat_cl_f32(const float *xyz, const float *new_xyz, const float *feats_cl,
+                                       const int *idx, int b, int n, int m, int ns, int c,
+                                       float radius, int normalize_xyz, float *out, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(b >= 0 && n >= 0 && m >= 0 && ns >= 0 && c >= 0, "negative dimension");
+  if (b == 0 || m == 0 || ns == 0) return 0;
+  EDA_CHECK_ARG(xyz && new_xyz && idx && out && (feats_cl || c == 0), "null pointer");
+  EDA_CHECK_ARG(b <= 65535, "batch too large");
+  // torch divides a tensor by a host scalar as x * (1/r) on the GPU; mirror that.
+  const float inv = normalize_xyz ? 1.0f / radius : 1.0f;
+  const long total = (long)m * ns * (3 + c);
+  hipLaunchKernelGGL(group_concat_cl_kernel, dim3(grid_for(total), b), dim3(CL_THREADS), 0, stream,
+                     xyz, new_xyz, feats_cl, idx, n, m, ns, c, inv, out);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int eda_group_concat_cl_grad_f32(const float *dx, const int *idx, int b, int n, int m,
+                                            int ns, int c, float *dfeats_cl, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(b >= 0 && n >= 0 && m >= 0 && ns >= 0 && c >= 0, "negative dimension");
+  if (b == 0 || n == 0 || c == 0) return 0;
+  EDA_CHECK_ARG(dfeats_cl, "null pointer");
+  EDA_CHECK_HIP(hipMemsetAsync(dfeats_cl, 0, sizeof(float) * (size_t)b * n * c, stream));
+  if (m == 0 || ns == 0) return 0;
+  EDA_CHECK_ARG(dx && idx && b <= 65535, "bad arguments");
+  const long total = (long)m * ns * c;
+  hipLaunchKernelGGL(group_concat_cl_grad_kernel, dim3(grid_for(total), b), dim3(CL_THREADS), 0,
+                     stream, dx, idx, n, m, ns, c, dfeats_cl);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}
+
+// Forward of BatchNorm (batch or running statistics) + ReLU (+ max-pool over `pool`
+// consecutive rows when pool > 1).  ws: 2*C doubles (zeroed here).  Outputs: mean,
+// rstd, scale, shift (C floats each, kept for the backward), and either a (R,C) or
+// pooled (R/pool,C) + argmax (R/pool,C bytes).
+extern "C" int eda_bn_relu_fwd_f32(const float *z, long R, int C, const float *gamma,
+                                   const float *beta, float eps, float momentum, int training,
+                                   float *running_mean, float *running_var, int pool,
+                                   double *ws, float *mean, float *rstd, float *scale, float *shift,
+                                   float *out, unsigned char *argmax, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(R >= 0 && C > 0 && pool >= 1, "bad dimension");
+  EDA_CHECK_ARG(C % 4 == 0 && C <= 1024, "channel count must be a multiple of 4 (<= 1024)");
+  EDA_CHECK_ARG(pool <= 255 && R % pool == 0, "rows must be a multiple of the pooling width");
+  if (R == 0) return 0;
+  EDA_CHECK_ARG(z && gamma && beta && mean && rstd && scale && shift && out, "null pointer");
+  if (training) {
+    EDA_CHECK_ARG(ws, "workspace required");
+    EDA_CHECK_HIP(hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, stream));
+    const int cgroups = C / 4;
+    int nblocks = 2048;
+    long rpb = (R + nblocks - 1) / nblocks;
+    if (rpb < 64) rpb = 64;
+    nblocks = (int)((R + rpb - 1) / rpb);
+    (void)cgroups;   // C/4 <= 256 threads per row pass (C <= 1024 checked above); idle threads allowed
+    hipLaunchKernelGGL(bn_stats_kernel<4>, dim3(nblocks), dim3(CL_THREADS), 0, stream, z, R, C, rpb, ws,
+                       ws + C);
+    EDA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, ws, ws + C, R,
+                       C, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale,
+                       shift);
+  } else {
+    EDA_CHECK_ARG(running_mean && running_var, "eval mode needs running statistics");
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, stream,
+                       running_mean, running_var, gamma, beta, eps, C, mean, rstd, scale, shift);
+  }
+  EDA_CHECK_LAUNCH();
+  if (pool > 1) {
+    EDA_CHECK_ARG(argmax, "argmax buffer required when pooling");
+    hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(grid_for(R / pool * C)), dim3(CL_THREADS), 0, stream,
+                       z, R / pool, pool, C, scale, shift, out, argmax);
+  } else {
+    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(grid_for(R * C / 4)), dim3(CL_THREADS), 0, stream, z,
+                       R * C / 4, C, scale, shift, out);
+  }
+  EDA_CHECK_LAUNCH();
+  return 0;
+}
+
+// Backward of the above.  dout: (R,C), or (R/pool,C) when pool > 1.  Outputs dz (R,C),
+// dgamma, dbeta (C).  ws: 2*C doubles (zeroed here).
+extern "C" int eda_bn_relu_bwd_f32(const float *dout, const unsigned char *argmax, const float *z,
+                                   long R, int C, int pool, const float *gamma, const float *mean,
+                                   const float *rstd, const float *scale, const float *shift,
+                                   int training, double *ws, float *dz, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(R >= 0 && C > 0 && pool >= 1 && C % 4 == 0, "bad dimension");
+  if (R == 0) return 0;
+  EDA_CHECK_ARG(dout && z && gamma && mean && rstd && scale && shift && ws && dz, "null pointer");
+  EDA_CHECK_ARG(pool == 1 || argmax, "argmax required when pooling");
+  EDA_CHECK_HIP(hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, stream));
+  int nblocks = 1024;
+  long rpb = (R + nblocks - 1) / nblocks;
+  if (rpb < 64) rpb = 64;
+  rpb = (rpb + pool - 1) / pool * pool;           // whole groups per block
+  nblocks = (int)((R + rpb - 1) / rpb);
+  if (pool > 1)
+    hipLaunchKernelGGL(bn_relu_bwd_stats_kernel<true>, dim3(nblocks), dim3(CL_THREADS), 0, stream, dout,
+                       argmax, z, R, C, pool, rpb, mean, rstd, scale, shift, ws, ws + C);
+  else
+    hipLaunchKernelGGL(bn_relu_bwd_stats_kernel<false>, dim3(nblocks), dim3(CL_THREADS), 0, stream, dout,
+                       argmax, z, R, C, pool, rpb, mean, rstd, scale, shift, ws, ws + C);
+  EDA_CHECK_LAUNCH();
+  if (pool > 1)
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<true>, dim3(grid_for(R * C)), dim3(CL_THREADS), 0,
+                       stream, dout, argmax, z, R, C, pool, mean, rstd, scale, shift, gamma, ws, ws + C,
+                       training, dz);
+  else
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<false>, dim3(grid_for(R * C)), dim3(CL_THREADS), 0,
+                       stream, dout, argmax, z, R, C, pool, mean, rstd, scale, shift, gamma, ws, ws + C,
+                       training, dz);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}

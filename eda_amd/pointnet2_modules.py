@@ -12,7 +12,7 @@ import torch
 from torch import nn
 import torch.nn.functional as F
 
-from . import pointnet2_utils
+from . import pointnet2_utils, sa_ops
 from .pytorch_utils import SharedMLP
 
 
@@ -51,6 +51,8 @@ class PointnetSAModuleVotes(nn.Module):
         if self.npoint is not None:
             new_xyz = pointnet2_utils.gather_operation(
                 xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+        if self._fast_path(xyz):
+            return new_xyz, self._forward_rows(xyz, new_xyz, features), inds
         out = self.grouper(xyz, new_xyz, features)
         grouped, grouped_xyz = out if isinstance(out, tuple) else (out, None)
         x = self.mlp_module(grouped)                       # (B, C, npoint, nsample)
@@ -64,6 +66,24 @@ class PointnetSAModuleVotes(nn.Module):
         else:
             raise ValueError(self.pooling)
         return new_xyz, x, inds
+
+
+    # ---- channels-last fast path (csrc/sa_cl.hip) ------------------------------
+    def _fast_path(self, xyz):
+        layers = self.mlp_module.layers()
+        return (xyz.is_cuda and self.npoint is not None and self.pooling == "max" and self.use_xyz
+                and self.nsample <= 255 and all(l.bn is not None for l in layers)
+                and all(l.conv.out_channels % 4 == 0 for l in layers))
+
+    def _forward_rows(self, xyz, new_xyz, features):
+        """ball query -> [centred xyz | gathered features] rows -> 3 x (GEMM, fused BN+ReLU)
+        -> max over the nsample rows of each centre.  Same math as the generic path."""
+        B, m = new_xyz.shape[0], new_xyz.shape[1]
+        idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
+        feats_cl = features.transpose(1, 2).contiguous() if features is not None else None
+        rows = sa_ops.GroupConcatCL.apply(xyz, new_xyz, feats_cl, idx, self.radius, self.normalize_xyz)
+        pooled = sa_ops.shared_mlp_rows(self.mlp_module, rows.view(B * m * self.nsample, -1), self.nsample)
+        return pooled.view(B, m, -1).transpose(1, 2).contiguous()
 
 
 class PointnetFPModule(nn.Module):
@@ -82,4 +102,10 @@ class PointnetFPModule(nn.Module):
         else:
             interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
         x = torch.cat([interpolated, unknow_feats], dim=1) if unknow_feats is not None else interpolated
+        layers = self.mlp.layers()
+        if (x.is_cuda and all(l.bn is not None for l in layers)
+                and all(l.conv.out_channels % 4 == 0 for l in layers)):
+            B, C, n = x.shape                                   # channels-last rows, fused BN+ReLU
+            rows = sa_ops.shared_mlp_rows(self.mlp, x.transpose(1, 2).reshape(B * n, C), 1)
+            return rows.view(B, n, -1).transpose(1, 2).contiguous()
         return self.mlp(x.unsqueeze(-1)).squeeze(-1)

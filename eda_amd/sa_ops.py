@@ -1,0 +1,158 @@
+"""Autograd wrappers of the channels-last set-abstraction kernels (csrc/sa_cl.hip).
+
+Rows are positions; see the kernel file for the mapping to the reference's
+QueryAndGroup / SharedMLP / max_pool2d chain.  GPU only (HIP library).
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError("CPU not supported: the channels-last SA kernels run on the HIP library only")
+
+
+class GroupConcatCL(Function):
+    """[ (xyz[idx]-centre)*(1/r) | feats_cl[idx] ] rows: (B, m*ns, 3+C)."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, feats_cl, idx, radius, normalize_xyz):
+        _need_gpu(xyz)
+        B, N, _ = xyz.shape
+        m, ns = idx.shape[1], idx.shape[2]
+        C = 0 if feats_cl is None else feats_cl.shape[2]
+        xyz, new_xyz, idx = xyz.contiguous(), new_xyz.contiguous(), idx.contiguous()
+        if feats_cl is not None:
+            feats_cl = feats_cl.contiguous()
+        out = torch.empty((B, m * ns, 3 + C), dtype=torch.float32, device=xyz.device)
+        with torch.cuda.device(xyz.device):
+            rc = _lib.lib().eda_group_concat_cl_f32(
+                xyz.data_ptr(), new_xyz.data_ptr(), feats_cl.data_ptr() if C else None, idx.data_ptr(),
+                B, N, m, ns, C, float(radius), int(bool(normalize_xyz)), out.data_ptr(), _stream())
+        _lib.check(rc, "eda_group_concat_cl_f32")
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, N, m, ns, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        B, N, m, ns, C = ctx.dims
+        dfeats = None
+        if C and ctx.needs_input_grad[2]:
+            dout = dout.contiguous()
+            dfeats = torch.empty((B, N, C), dtype=torch.float32, device=dout.device)
+            with torch.cuda.device(dout.device):
+                rc = _lib.lib().eda_group_concat_cl_grad_f32(dout.data_ptr(), idx.data_ptr(), B, N, m, ns,
+                                                             C, dfeats.data_ptr(), _stream())
+            _lib.check(rc, "eda_group_concat_cl_grad_f32")
+        return None, None, dfeats, None, None, None
+
+
+def _split_k(rows):
+    """Number of K-slices for the weight-gradient GEMM (contraction over `rows` positions)."""
+    for s in (256, 128, 64, 32, 16, 8, 4, 2):
+        if rows % s == 0 and rows // s >= 512:
+            return s
+    return 1
+
+
+class PointwiseLinearCL(Function):
+    """Z = A W^T for rows A (R,Cin) and a 1x1-conv weight W (Cout,Cin,...).  The weight
+    gradient contracts over up to 10^6 rows; it is computed split-K as a batched GEMM
+    of partial (Cout,Cin) products (a single GEMM would run on a handful of CUs)."""
+
+    @staticmethod
+    def forward(ctx, a, weight):
+        w2 = weight.reshape(weight.shape[0], -1)
+        ctx.save_for_backward(a, weight)
+        return a @ w2.t()
+
+    @staticmethod
+    def backward(ctx, dz):
+        a, weight = ctx.saved_tensors
+        w2 = weight.reshape(weight.shape[0], -1)
+        da = dw = None
+        dz = dz.contiguous()
+        if ctx.needs_input_grad[0]:
+            da = dz @ w2
+        if ctx.needs_input_grad[1]:
+            R = a.shape[0]
+            s = _split_k(R)
+            if s > 1:
+                dw = torch.bmm(dz.view(s, R // s, -1).transpose(1, 2), a.view(s, R // s, -1)).sum(0)
+            else:
+                dw = dz.t() @ a
+            dw = dw.view_as(weight)
+        return da, dw
+
+
+class BNReLUCL(Function):
+    """relu(batch_norm(z)) on rows z (R,C), optionally max-pooled over `pool` consecutive rows."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, eps, momentum, training, pool):
+        _need_gpu(z)
+        z = z.contiguous()
+        R, C = z.shape
+        dev = z.device
+        stats = torch.empty((4, C), dtype=torch.float32, device=dev)     # mean, rstd, scale, shift
+        ws = torch.empty((2 * C,), dtype=torch.float64, device=dev)
+        if pool > 1:
+            out = torch.empty((R // pool, C), dtype=torch.float32, device=dev)
+            argmax = torch.empty((R // pool, C), dtype=torch.uint8, device=dev)
+        else:
+            out = torch.empty((R, C), dtype=torch.float32, device=dev)
+            argmax = None
+        with torch.cuda.device(dev):
+            rc = _lib.lib().eda_bn_relu_fwd_f32(
+                z.data_ptr(), R, C, gamma.data_ptr(), beta.data_ptr(), float(eps), float(momentum),
+                int(bool(training)), running_mean.data_ptr(), running_var.data_ptr(), int(pool),
+                ws.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
+                stats[3].data_ptr(), out.data_ptr(), argmax.data_ptr() if argmax is not None else None,
+                _stream())
+        _lib.check(rc, "eda_bn_relu_fwd_f32")
+        ctx.save_for_backward(z, gamma, stats, argmax)
+        ctx.cfg = (int(pool), bool(training))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, gamma, stats, argmax = ctx.saved_tensors
+        pool, training = ctx.cfg
+        R, C = z.shape
+        dout = dout.contiguous()
+        dz = torch.empty_like(z)
+        ws = torch.empty((2 * C,), dtype=torch.float64, device=z.device)
+        with torch.cuda.device(z.device):
+            rc = _lib.lib().eda_bn_relu_bwd_f32(
+                dout.data_ptr(), argmax.data_ptr() if argmax is not None else None, z.data_ptr(), R, C,
+                pool, gamma.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
+                stats[3].data_ptr(), int(training), ws.data_ptr(), dz.data_ptr(), _stream())
+        _lib.check(rc, "eda_bn_relu_bwd_f32")
+        dbeta = ws[:C].float()
+        dgamma = ws[C:].float()
+        return dz, dgamma, dbeta, None, None, None, None, None, None
+
+
+def shared_mlp_rows(mlp, rows, pool):
+    """Run a SharedMLP (conv1x1 -> BN -> ReLU stack) on rows (R,Cin); the LAST layer's
+    BN+ReLU is fused with a max over each `pool` consecutive rows.  Returns (R/pool, Cout)."""
+    layers = mlp.layers()
+    x = rows
+    for i, layer in enumerate(layers):
+        z = PointwiseLinearCL.apply(x, layer.conv.weight)
+        bn = layer.bn.bn
+        last = i == len(layers) - 1
+        training = bn.training
+        x = BNReLUCL.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                           bn.momentum, training, pool if last else 1)
+        if training and bn.track_running_stats:
+            bn.num_batches_tracked.add_(1)
+    return x

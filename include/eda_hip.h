@@ -140,6 +140,37 @@ int eda_mha_bwd_f32(const float *q, const float *k, const float *v, long q_sb, l
                     const float *lse, const float *dout, long do_sb, long do_sl,
                     float *delta_ws, float *dq, float *dk, float *dv, void *stream);
 
+/* ---- set-abstraction grouped MLP, channels-last pipeline -----------------
+ * Rows are positions (scene, centre j, neighbour k) of a (b*m*ns, C) matrix.
+ *
+ * eda_group_concat_cl_f32 replaces QueryAndGroup's grouping + centring + concat
+ * (pointnet2/pointnet2_utils.py:347-360: 2x group_points, `-= centre`, `/= radius`,
+ * torch.cat): out[b, j*ns+k, :] = [ (xyz[b,idx]-new_xyz[b,j]) * (1/radius) | feats_cl[b,idx,:] ]
+ * with feats_cl (b,n,c) channels-last (c may be 0).  *_grad scatter-adds the feature
+ * columns of d(out) back into dfeats_cl (b,n,c) (zeroed here).                 */
+int eda_group_concat_cl_f32(const float *xyz, const float *new_xyz, const float *feats_cl,
+                            const int *idx, int b, int n, int m, int ns, int c, float radius,
+                            int normalize_xyz, float *out, void *stream);
+int eda_group_concat_cl_grad_f32(const float *dx, const int *idx, int b, int n, int m, int ns,
+                                 int c, float *dfeats_cl, void *stream);
+/* eda_bn_relu_fwd_f32 replaces BatchNorm2d + ReLU (+ F.max_pool2d over nsample) of
+ * SharedMLP (pointnet2/pytorch_utils.py:67-120, pointnet2_modules.py:251-257) on a
+ * (R,C) pre-activation matrix z: batch statistics (training != 0; running stats are
+ * updated with `momentum`, unbiased variance) or running statistics (eval);
+ * out = relu(bn(z)) (R,C), or with pool > 1 its max over each `pool` consecutive rows
+ * (R/pool,C) plus the arg-max row (bytes).  mean/rstd/scale/shift (C each) are kept
+ * for the backward.  ws: 2*C doubles.
+ * eda_bn_relu_bwd_f32: dz (R,C); on return ws[0..C) = d(beta), ws[C..2C) = d(gamma).  */
+int eda_bn_relu_fwd_f32(const float *z, long R, int C, const float *gamma, const float *beta,
+                        float eps, float momentum, int training, float *running_mean,
+                        float *running_var, int pool, double *ws, float *mean, float *rstd,
+                        float *scale, float *shift, float *out, unsigned char *argmax,
+                        void *stream);
+int eda_bn_relu_bwd_f32(const float *dout, const unsigned char *argmax, const float *z, long R,
+                        int C, int pool, const float *gamma, const float *mean, const float *rstd,
+                        const float *scale, const float *shift, int training, double *ws,
+                        float *dz, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,10 @@ def test_sa_and_fp_modules():
     MC.run_fp_module("cpu")
 
 
+def test_sa_module_train_mode():
+    MC.run_sa_module_train("cpu")
+
+
 def test_backbone():
     MC.run_backbone("cpu")
 

@@ -15,6 +15,10 @@ def test_sa_and_fp_modules():
     MC.run_fp_module("cuda")
 
 
+def test_sa_module_train_mode():
+    MC.run_sa_module_train("cuda")
+
+
 def test_backbone():
     MC.run_backbone("cuda")
 

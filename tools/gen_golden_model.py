@@ -52,6 +52,22 @@ def main():
     sf.sum().backward()
     save("sa_module", new_xyz=sx, features=sf, inds=si, grad_features=f_in.grad)
 
+    # the same module in TRAIN mode: batch statistics, running-stat update, parameter grads
+    sa_t = mods.pointnet2_modules.PointnetSAModuleVotes(npoint=256, radius=0.3, nsample=16,
+                                                        mlp=[3, 16, 16, 32], use_xyz=True, normalize_xyz=True)
+    MF.fill_det_state(sa_t, seed=2); sa_t.train()
+    f_t = feats.clone().requires_grad_(True)
+    _, tf, _ = sa_t(xyz, f_t)
+    (tf * MF.make_feats(6, *tf.shape)).sum().backward()
+    l0, l2 = sa_t.mlp_module.layer0, sa_t.mlp_module.layer2
+    save("sa_module_train", features=tf, grad_features=f_t.grad,
+         grad_w0=l0.conv.weight.grad, grad_w2=l2.conv.weight.grad,
+         grad_gamma0=l0.bn.bn.weight.grad, grad_beta0=l0.bn.bn.bias.grad,
+         grad_gamma2=l2.bn.bn.weight.grad, grad_beta2=l2.bn.bn.bias.grad,
+         running_mean0=l0.bn.bn.running_mean, running_var0=l0.bn.bn.running_var,
+         running_mean2=l2.bn.bn.running_mean, running_var2=l2.bn.bn.running_var,
+         nbt=l2.bn.bn.num_batches_tracked)
+
     fp = mods.pointnet2_modules.PointnetFPModule(mlp=[32 + 8, 24, 16])
     MF.fill_det_state(fp, seed=3); fp.eval()
     unk_f = MF.make_feats(4, 2, 8, 4096).requires_grad_(True)
