@@ -22,6 +22,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from . import _lib
+from .ext import _timed
 
 _dropout_state = {}      # device -> int64 counter tensor read by the kernels
 _salt_counter = itertools.count(1)
@@ -64,7 +65,7 @@ class _FusedMHA(Function):
         if mask is not None:
             m8 = mask.contiguous().view(torch.uint8)
         seed = dropout_state(q.device) if p_drop > 0 else None
-        with torch.cuda.device(q.device):
+        with torch.cuda.device(q.device), _timed('mha_fwd', (B, num_heads, Lq, Lk)):
             rc = _lib.lib().eda_mha_fwd_f32(
                 q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
                 k.stride(1), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else None,
@@ -91,7 +92,7 @@ class _FusedMHA(Function):
         delta = torch.empty((B, num_heads, Lq), dtype=torch.float32, device=q.device)
         m8 = ctx.mask8
         seed = dropout_state(q.device) if p_drop > 0 else None
-        with torch.cuda.device(q.device):
+        with torch.cuda.device(q.device), _timed('mha_bwd', (B, num_heads, Lq, Lk)):
             rc = _lib.lib().eda_mha_bwd_f32(
                 q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
                 k.stride(1), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else None,

@@ -7,6 +7,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib
+from .ext import _timed
 
 
 def _stream():
@@ -31,7 +32,7 @@ class GroupConcatCL(Function):
         if feats_cl is not None:
             feats_cl = feats_cl.contiguous()
         out = torch.empty((B, m * ns, 3 + C), dtype=torch.float32, device=xyz.device)
-        with torch.cuda.device(xyz.device):
+        with torch.cuda.device(xyz.device), _timed('group_concat_cl', (B, N, m, ns, C)):
             rc = _lib.lib().eda_group_concat_cl_f32(
                 xyz.data_ptr(), new_xyz.data_ptr(), feats_cl.data_ptr() if C else None, idx.data_ptr(),
                 B, N, m, ns, C, float(radius), int(bool(normalize_xyz)), out.data_ptr(), _stream())
@@ -48,7 +49,7 @@ class GroupConcatCL(Function):
         if C and ctx.needs_input_grad[2]:
             dout = dout.contiguous()
             dfeats = torch.empty((B, N, C), dtype=torch.float32, device=dout.device)
-            with torch.cuda.device(dout.device):
+            with torch.cuda.device(dout.device), _timed('group_concat_cl_grad', (B, N, m, ns, C)):
                 rc = _lib.lib().eda_group_concat_cl_grad_f32(dout.data_ptr(), idx.data_ptr(), B, N, m, ns,
                                                              C, dfeats.data_ptr(), _stream())
             _lib.check(rc, "eda_group_concat_cl_grad_f32")
@@ -110,7 +111,7 @@ class BNReLUCL(Function):
         else:
             out = torch.empty((R, C), dtype=torch.float32, device=dev)
             argmax = None
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _timed('bn_relu_fwd', (R, C, pool, int(bool(training)))):
             rc = _lib.lib().eda_bn_relu_fwd_f32(
                 z.data_ptr(), R, C, gamma.data_ptr(), beta.data_ptr(), float(eps), float(momentum),
                 int(bool(training)), running_mean.data_ptr(), running_var.data_ptr(), int(pool),
@@ -130,7 +131,7 @@ class BNReLUCL(Function):
         dout = dout.contiguous()
         dz = torch.empty_like(z)
         ws = torch.empty((2 * C,), dtype=torch.float64, device=z.device)
-        with torch.cuda.device(z.device):
+        with torch.cuda.device(z.device), _timed('bn_relu_bwd', (R, C, pool, int(training))):
             rc = _lib.lib().eda_bn_relu_bwd_f32(
                 dout.data_ptr(), argmax.data_ptr() if argmax is not None else None, z.data_ptr(), R, C,
                 pool, gamma.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
