@@ -222,25 +222,26 @@ def main():
 
     from eda_amd import ext
     from eda_amd.bdetr import BeaUTyDETR
-    from eda_amd.parallel import FlatGrads
+    from eda_amd.parallel import FlatParams, reference_lr_groups
 
     torch.manual_seed(0)                       # same init on every rank (DDP broadcast equivalent)
     model = BeaUTyDETR(num_queries=args.queries, butd=not args.no_butd).to(device).train()
     model.text_encoder.eval()                  # frozen (bdetr.py:78-80)
-    grads = FlatGrads(model.parameters())
-    opt = torch.optim.AdamW(grads.params, lr=1e-4, weight_decay=5e-4, fused=True,
-                            capturable=bool(args.graph))
+    flat = FlatParams(model, reference_lr_groups)
+    lrs = {"base": 1e-4, "backbone_net": 1e-3, "text_encoder": 1e-5}     # scripts/train_scanrefer.sh
+    opt = torch.optim.AdamW([{"params": [gp], "lr": lrs[k]} for k, gp in flat.groups.items()],
+                            weight_decay=5e-4, fused=True, capturable=bool(args.graph))
     inputs = make_inputs(rank, args.per_gpu, device, args.points, args.tokens)
 
     from eda_amd import attention
 
     def step():
-        grads.zero()
         attention.advance_dropout_state(device)      # new attention-dropout masks every step
         loss = synthetic_loss(model(inputs))
         loss.backward()
-        grads.all_reduce_mean(world)
-        torch.nn.utils.clip_grad_norm_(grads.params, 0.1, foreach=True)   # main_utils.py:483-486
+        flat.collect_grads()
+        flat.all_reduce_mean(world)
+        flat.clip_grad_norm_(0.1)                    # main_utils.py:483-486
         opt.step()
         return loss
 

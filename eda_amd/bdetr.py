@@ -55,6 +55,8 @@ class BeaUTyDETR(nn.Module):
         self.self_position_embedding = self_position_embedding
         self.contrastive_align_loss = contrastive_align_loss
         self.butd = butd
+        self.overlap_text_encoder = True      # run RoBERTa on a side stream under the point backbone
+        self._side_stream = None
 
         self.backbone_net = Pointnet2Backbone(input_feature_dim=input_feature_dim, width=1)
         if input_feature_dim == 3 and pointnet_ckpt is not None:
@@ -120,13 +122,35 @@ class BeaUTyDETR(nn.Module):
             hidden = self.text_encoder(input_ids=ids, attention_mask=am).last_hidden_state
         return hidden, am.ne(1).bool(), {"input_ids": ids, "attention_mask": am}
 
+    def _text_branch(self, inputs, device):
+        hidden, text_mask, tok = self._encode_text(inputs, device)
+        return self.text_projector(hidden), text_mask, tok
+
     def _run_backbones(self, inputs):
-        end_points = self.backbone_net(inputs["point_clouds"], end_points={})
+        pc = inputs["point_clouds"]
+        if pc.is_cuda and self.overlap_text_encoder:
+            # The point backbone starts with furthest point sampling: 2047 dependent rounds
+            # on a cluster of ~60 workgroups, i.e. most of the chip idles for milliseconds.
+            # The text encoder does not depend on it, so it runs on a second HIP stream
+            # underneath (fork/join is captured as graph dependencies under HIP graphs).
+            cur = torch.cuda.current_stream(pc.device)
+            if self._side_stream is None or self._side_stream.device != pc.device:
+                self._side_stream = torch.cuda.Stream(device=pc.device)
+            side = self._side_stream
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                text_feats, text_mask, tok = self._text_branch(inputs, pc.device)
+            end_points = self.backbone_net(pc, end_points={})
+            cur.wait_stream(side)
+            for t in (text_feats, text_mask):
+                t.record_stream(cur)
+        else:
+            end_points = self.backbone_net(pc, end_points={})
+            text_feats, text_mask, tok = self._text_branch(inputs, pc.device)
         end_points["seed_inds"] = end_points["fp2_inds"]
         end_points["seed_xyz"] = end_points["fp2_xyz"]
         end_points["seed_features"] = end_points["fp2_features"]
-        hidden, text_mask, tok = self._encode_text(inputs, inputs["point_clouds"].device)
-        end_points["text_feats"] = self.text_projector(hidden)
+        end_points["text_feats"] = text_feats
         end_points["text_attention_mask"] = text_mask
         end_points["tokenized"] = tok
         return end_points

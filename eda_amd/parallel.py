@@ -6,43 +6,92 @@ The reference wraps the model in DistributedDataParallel (main_utils.py:343-346:
 (68 layers -> 136 latency-bound micro-collectives, main_utils.py:336-338).  On
 MI355X the 8 GPUs are fully connected by xGMI (7 links x ~153 GB/s per GPU): a
 single large all-reduce lets RCCL use every link at once (direct
-reduce-scatter + all-gather ~ 2 x 10.7 MB per link), so all trainable gradients
-live in one contiguous buffer that autograd accumulates into directly.
-Batch-norm statistics stay per-GPU (8 scenes x >= 4096 positions per channel);
-that deviation from SyncBN is stated in DESIGN.md.
+reduce-scatter + all-gather ~ 2 x 10.7 MB per link).  So all trainable parameters
+are views of ONE flat buffer and all gradients are gathered into ONE flat buffer
+(a multi-tensor copy; autograd itself only hands over freshly produced tensors, no
+per-parameter accumulate kernels), which is what RCCL reduces and what the
+optimizer updates -- one fused AdamW kernel per learning-rate group instead of one
+per ~50 parameter tensors.  Batch-norm statistics stay per-GPU (8 scenes x >= 4096
+positions per channel); that deviation from SyncBN is stated in DESIGN.md.
 """
 import torch
 import torch.distributed as dist
 
 
-class FlatGrads:
-    """Owns one contiguous fp32 gradient buffer; every parameter's .grad is a view."""
+class FlatParams:
+    """Flat parameter / gradient storage, split into learning-rate groups.
 
-    def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
-        if not self.params:
+    ``group_of(name) -> key`` assigns every trainable parameter to a group (the
+    reference uses three: backbone_net / text_encoder / rest, main_utils.py:277-305).
+    ``self.groups`` maps key -> nn.Parameter over that group's slice of the flat
+    buffer, whose ``.grad`` is the matching slice of the flat gradient buffer: hand
+    these to the optimizer.
+    """
+
+    def __init__(self, module, group_of=None):
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        if not named:
             raise ValueError("no trainable parameters")
-        n = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
+        group_of = group_of or (lambda name: "all")
+        keys = []
+        for n, _ in named:
+            k = group_of(n)
+            if k not in keys:
+                keys.append(k)
+        ordered = [(n, p) for k in keys for (n, p) in named if group_of(n) == k]
+        self.params = [p for _, p in ordered]
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._grad_views = []
         off = 0
-        for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+        bounds = {}
+        for n, p in ordered:
+            k = group_of(n)
+            sl = slice(off, off + p.numel())
+            self.flat_param[sl].copy_(p.data.reshape(-1))
+            p.data = self.flat_param[sl].view_as(p)          # the parameter now lives in the flat buffer
+            p.grad = None
+            self._grad_views.append(self.flat_grad[sl].view_as(p))
+            lo, hi = bounds.get(k, (off, off))
+            bounds[k] = (min(lo, off), off + p.numel())
             off += p.numel()
+        self.groups = {}
+        for k, (lo, hi) in bounds.items():
+            gp = torch.nn.Parameter(self.flat_param[lo:hi], requires_grad=True)
+            gp.grad = self.flat_grad[lo:hi]
+            self.groups[k] = gp
 
-    def zero(self):
-        self.flat.zero_()
+    def collect_grads(self):
+        """Gather the gradients autograd produced this step into the flat buffer
+        (multi-tensor copy) and release them, so the next backward again ASSIGNS
+        instead of accumulating."""
+        have = [(v, p.grad) for v, p in zip(self._grad_views, self.params) if p.grad is not None]
+        if len(have) != len(self.params):
+            self.flat_grad.zero_()
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for p in self.params:
+            p.grad = None
 
     def all_reduce_mean(self, world=None, async_op=False):
-        """Sum over ranks, divide by world size (DDP semantics)."""
+        """Sum the flat gradient over ranks, divide by the world size (DDP semantics)."""
         if world is None:
             world = dist.get_world_size() if dist.is_initialized() else 1
         if world <= 1:
             return None
-        work = dist.all_reduce(self.flat, async_op=async_op)
+        work = dist.all_reduce(self.flat_grad, async_op=async_op)
         if async_op:
             return work
-        self.flat.mul_(1.0 / world)
+        self.flat_grad.mul_(1.0 / world)
         return None
+
+    def clip_grad_norm_(self, max_norm):
+        """torch.nn.utils.clip_grad_norm_ over all parameters (main_utils.py:483-486) on the flat buffer."""
+        norm = torch.linalg.vector_norm(self.flat_grad)
+        self.flat_grad.mul_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
+        return norm
 
 
 def broadcast_parameters(module, src=0):
@@ -57,3 +106,12 @@ def shard_scene_seeds(global_batch, rank, world):
     """Scene indices of this rank (DistributedSampler-equivalent over the synthetic generator)."""
     per = global_batch // world
     return list(range(rank * per, (rank + 1) * per))
+
+
+def reference_lr_groups(name):
+    """The reference's optimiser groups (main_utils.py:277-305)."""
+    if "backbone_net" in name:
+        return "backbone_net"
+    if "text_encoder" in name:
+        return "text_encoder"
+    return "base"

@@ -25,7 +25,7 @@ def _worker(rank, world, port, out_dir):
     from eda_amd import attention
     from oracle import attention_ref
     attention._core = attention_ref.attention_core
-    from eda_amd.parallel import FlatGrads, broadcast_parameters, shard_scene_seeds
+    from eda_amd.parallel import FlatParams, broadcast_parameters, shard_scene_seeds
     from eda_amd.pointnet2_modules import PointnetSAModuleVotes
     from eda_amd.encoder_decoder_layers import BiDecoderLayer
     from eda_amd import synthetic
@@ -35,8 +35,9 @@ def _worker(rank, world, port, out_dir):
     dec = BiDecoderLayer(32, n_heads=4, dim_feedforward=64, dropout=0.0, self_position_embedding="xyz_learned", butd=False)
     model = torch.nn.ModuleList([sa, dec]).train()
     broadcast_parameters(model, 0)
-    grads = FlatGrads(model.parameters())
-    opt = torch.optim.AdamW(grads.params, lr=1e-2)
+    grads = FlatParams(model, lambda n: "sa" if n.startswith("0.") else "dec")
+    assert set(grads.groups) == {"sa", "dec"}
+    opt = torch.optim.AdamW([{"params": [gp], "lr": 1e-2} for gp in grads.groups.values()])
 
     seeds = shard_scene_seeds(4, rank, world)            # global batch 4 -> 2 scenes per rank
     pc = torch.from_numpy(synthetic.batch(seeds, 1500))
@@ -50,17 +51,22 @@ def _worker(rank, world, port, out_dir):
         return q.pow(2).mean()
 
     for it in range(2):
-        grads.zero()
         local_loss().backward()
-        local = grads.flat.clone()
+        grads.collect_grads()
+        assert all(p.grad is None for p in grads.params)
+        local = grads.flat_grad.clone()
         gathered = [torch.zeros_like(local) for _ in range(world)]
         dist.all_gather(gathered, local)
         grads.all_reduce_mean(world)
         expect = sum(gathered) / world
-        assert torch.allclose(grads.flat, expect, rtol=1e-6, atol=1e-7), "all-reduce != mean of rank grads"
+        assert torch.allclose(grads.flat_grad, expect, rtol=1e-6, atol=1e-7), "all-reduce != mean of rank grads"
         assert not torch.equal(gathered[0], gathered[1]), "ranks saw the same scenes"
+        grads.clip_grad_norm_(10.0)
+        before = grads.params[0].detach().clone()
         opt.step()
+        assert not torch.equal(before, grads.params[0].detach()), "flat update did not reach the module parameter"
     flat_params = torch.cat([p.detach().reshape(-1) for p in grads.params])
+    assert torch.equal(flat_params, grads.flat_param)
     torch.save(flat_params, os.path.join(out_dir, f"params_{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
