@@ -235,14 +235,21 @@ def main():
 
     from eda_amd import attention
 
-    def step():
+    def fwd_bwd():
         attention.advance_dropout_state(device)      # new attention-dropout masks every step
         loss = synthetic_loss(model(inputs))
         loss.backward()
         flat.collect_grads()
-        flat.all_reduce_mean(world)
+        return loss
+
+    def update():
         flat.clip_grad_norm_(0.1)                    # main_utils.py:483-486
         opt.step()
+
+    def step():
+        loss = fwd_bwd()
+        flat.all_reduce_mean(world)
+        update()
         return loss
 
     def log(msg):
@@ -252,11 +259,11 @@ def main():
     log("model + inputs ready")
     eager_step = step
     if args.graph:
-        # HIP graph of the WHOLE step (forward, backward, gradient all-reduce, clip,
-        # AdamW): ~3000 launches per step are replayed from one graph, removing the
-        # host launch cost.  Inputs live in static HBM buffers (a data loader would
-        # copy the next batch into them).  Warm up on a side stream first (allocator,
-        # lazy library init), as torch.cuda.graphs requires.
+        # HIP graphs of the step: ~4000 launches are replayed instead of issued by the host.
+        # Inputs live in static HBM buffers (a data loader would copy the next batch into
+        # them).  N = 1: one graph holds forward, backward, clip and AdamW.  N > 1: the RCCL
+        # all-reduce of the flat gradient buffer is launched eagerly between two graphs
+        # (forward+backward | clip+AdamW) rather than captured.
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -264,14 +271,28 @@ def main():
                 eager_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_loss = eager_step()
-        log("step captured in a HIP graph")
+        if world == 1:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_loss = eager_step()
 
-        def step():
-            graph.replay()
-            return static_loss
+            def step():
+                graph.replay()
+                return static_loss
+        else:
+            g_fb, g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            pool = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(g_fb, pool=pool):
+                static_loss = fwd_bwd()
+            with torch.cuda.graph(g_up, pool=pool):
+                update()
+
+            def step():
+                g_fb.replay()
+                flat.all_reduce_mean(world)
+                g_up.replay()
+                return static_loss
+        log("step captured in HIP graph(s)")
 
     for _ in range(args.warmup):
         step()

@@ -274,7 +274,8 @@ __global__ __launch_bounds__(CL_THREADS) void bn_relu_bwd_stats_kernel(
   }
 }
 
-// dZ = gamma*rstd * (dY - s1/R - xhat * s2/R)
+// dZ = gamma*rstd * (dY - s1/R - xhat * s2/R).  Thread = 4 consecutive channels of a row
+// (16-byte loads/stores); per-channel constants are folded into  dz = A*dy + B*x + D.
 template <bool POOL>
 __global__ __launch_bounds__(CL_THREADS) void bn_relu_bwd_apply_kernel(
     const float *__restrict__ da, const unsigned char *__restrict__ argmax,
@@ -283,31 +284,102 @@ __global__ __launch_bounds__(CL_THREADS) void bn_relu_bwd_apply_kernel(
     const float *__restrict__ shift, const float *__restrict__ gamma,
     const double *__restrict__ s1, const double *__restrict__ s2, int train,
     float *__restrict__ dz) {
-  const long total = R * C;
+  const int cgroups = C / 4;
+  const int rpp = CL_THREADS / cgroups;
+  const int tcol = threadIdx.x % cgroups, trow = threadIdx.x / cgroups;
+  if (trow >= rpp) return;
+  const int c0 = tcol * 4;
   const float invR = 1.f / (float)R;
-  for (long i = (long)blockIdx.x * CL_THREADS + threadIdx.x; i < total;
-       i += (long)gridDim.x * CL_THREADS) {
-    const long r = i / C;
-    const int c = (int)(i - r * C);
-    const float x = z[i];
-    const float y = x * scale[c] + shift[c];
-    float dy;
+  float sc[4], sh[4], ka[4], kb[4], kd[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int c = c0 + v;
+    sc[v] = scale[c]; sh[v] = shift[c];
+    const float gr = gamma[c] * rstd[c];
+    ka[v] = gr;
+    if (train) {
+      // gr*(dy - s1/R - (x-mu)*rs*s2/R) = gr*dy + x*(-gr*rs*s2/R) + gr*(mu*rs*s2/R - s1/R)
+      const float t2 = rstd[c] * (float)s2[c] * invR;
+      kb[v] = -gr * t2;
+      kd[v] = gr * (mean[c] * t2 - (float)s1[c] * invR);
+    } else {
+      kb[v] = 0.f; kd[v] = 0.f;
+    }
+  }
+  for (long r = (long)blockIdx.x * rpp + trow; r < R; r += (long)gridDim.x * rpp) {
+    const float4 x4 = *reinterpret_cast<const float4 *>(z + r * C + c0);
+    const float x[4] = {x4.x, x4.y, x4.z, x4.w};
+    float dy[4];
     if (POOL) {
       const long g = r / ns;
       const int k = (int)(r - g * ns);
-      dy = (y > 0.f && argmax[g * C + c] == k) ? da[g * C + c] : 0.f;
+      const uchar4 am = *reinterpret_cast<const uchar4 *>(argmax + g * C + c0);
+      const float4 d4 = *reinterpret_cast<const float4 *>(da + g * C + c0);
+      dy[0] = am.x == k ? d4.x : 0.f; dy[1] = am.y == k ? d4.y : 0.f;
+      dy[2] = am.z == k ? d4.z : 0.f; dy[3] = am.w == k ? d4.w : 0.f;
     } else {
-      dy = y > 0.f ? da[i] : 0.f;
+      const float4 d4 = *reinterpret_cast<const float4 *>(da + r * C + c0);
+      dy[0] = d4.x; dy[1] = d4.y; dy[2] = d4.z; dy[3] = d4.w;
     }
-    const float gr = gamma[c] * rstd[c];
-    float out;
-    if (train) {
-      const float xhat = (x - mean[c]) * rstd[c];
-      out = gr * (dy - (float)s1[c] * invR - xhat * (float)s2[c] * invR);
-    } else {
-      out = gr * dy;           // eval: statistics are constants
+    float o[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float y = x[v] * sc[v] + sh[v];
+      const float d = y > 0.f ? dy[v] : 0.f;
+      o[v] = ka[v] * d + kb[v] * x[v] + kd[v];
     }
-    dz[i] = out;
+    *reinterpret_cast<float4 *>(dz + r * C + c0) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// Non-pooled backward statistics with 16-byte loads (same mapping as bn_stats_kernel).
+__global__ __launch_bounds__(CL_THREADS) void bn_relu_bwd_stats_vec_kernel(
+    const float *__restrict__ da, const float *__restrict__ z, long R, int C, long rows_per_block,
+    const float *__restrict__ mean, const float *__restrict__ rstd,
+    const float *__restrict__ scale, const float *__restrict__ shift, double *__restrict__ s1,
+    double *__restrict__ s2) {
+  __shared__ float red[2][CL_THREADS * 4];
+  const int cgroups = C / 4;
+  const int rpp = CL_THREADS / cgroups;
+  const int tcol = threadIdx.x % cgroups, trow = threadIdx.x / cgroups;
+  const int c0 = tcol * 4;
+  float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+  if (trow < rpp) {
+    float sc[4], sh[4], mu[4], rs[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { sc[v] = scale[c0 + v]; sh[v] = shift[c0 + v]; mu[v] = mean[c0 + v]; rs[v] = rstd[c0 + v]; }
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+    for (long r = r0 + trow; r < r1; r += rpp) {
+      const float4 x4 = *reinterpret_cast<const float4 *>(z + r * C + c0);
+      const float4 d4 = *reinterpret_cast<const float4 *>(da + r * C + c0);
+      const float x[4] = {x4.x, x4.y, x4.z, x4.w};
+      const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float y = x[v] * sc[v] + sh[v];
+        const float dy = y > 0.f ? d[v] : 0.f;
+        a1[v] += dy;
+        a2[v] += dy * (x[v] - mu[v]) * rs[v];
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    red[0][threadIdx.x * 4 + v] = a1[v];
+    red[1][threadIdx.x * 4 + v] = a2[v];
+  }
+  __syncthreads();
+  for (int col = threadIdx.x; col < C; col += CL_THREADS) {
+    const int tc = col / 4, v = col - tc * 4;
+    double t1 = 0.0, t2 = 0.0;
+    for (int tr = 0; tr < rpp; ++tr) {
+      const int t = tr * cgroups + tc;
+      t1 += (double)red[0][t * 4 + v];
+      t2 += (double)red[1][t * 4 + v];
+    }
+    atomicAdd(s1 + col, t1);
+    atomicAdd(s2 + col, t2);
   }
 }
 
@@ -408,7 +480,7 @@ extern "C" int eda_bn_relu_bwd_f32(const float *dout, const unsigned char *argma
                                    const float *rstd, const float *scale, const float *shift,
                                    int training, double *ws, float *dz, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  EDA_CHECK_ARG(R >= 0 && C > 0 && pool >= 1 && C % 4 == 0, "bad dimension");
+  EDA_CHECK_ARG(R >= 0 && C > 0 && pool >= 1 && C % 4 == 0 && C <= 1024, "bad dimension");
   if (R == 0) return 0;
   EDA_CHECK_ARG(dout && z && gamma && mean && rstd && scale && shift && ws && dz, "null pointer");
   EDA_CHECK_ARG(pool == 1 || argmax, "argmax required when pooling");
@@ -422,17 +494,18 @@ extern "C" int eda_bn_relu_bwd_f32(const float *dout, const unsigned char *argma
     hipLaunchKernelGGL(bn_relu_bwd_stats_kernel<true>, dim3(nblocks), dim3(CL_THREADS), 0, stream, dout,
                        argmax, z, R, C, pool, rpb, mean, rstd, scale, shift, ws, ws + C);
   else
-    hipLaunchKernelGGL(bn_relu_bwd_stats_kernel<false>, dim3(nblocks), dim3(CL_THREADS), 0, stream, dout,
-                       argmax, z, R, C, pool, rpb, mean, rstd, scale, shift, ws, ws + C);
+    hipLaunchKernelGGL(bn_relu_bwd_stats_vec_kernel, dim3(nblocks), dim3(CL_THREADS), 0, stream, dout, z,
+                       R, C, rpb, mean, rstd, scale, shift, ws, ws + C);
   EDA_CHECK_LAUNCH();
+  const int apply_grid = grid_for(R * (C / 4));
   if (pool > 1)
-    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<true>, dim3(grid_for(R * C)), dim3(CL_THREADS), 0,
-                       stream, dout, argmax, z, R, C, pool, mean, rstd, scale, shift, gamma, ws, ws + C,
-                       training, dz);
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<true>, dim3(apply_grid), dim3(CL_THREADS), 0, stream,
+                       dout, argmax, z, R, C, pool, mean, rstd, scale, shift, gamma, ws, ws + C, training,
+                       dz);
   else
-    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<false>, dim3(grid_for(R * C)), dim3(CL_THREADS), 0,
-                       stream, dout, argmax, z, R, C, pool, mean, rstd, scale, shift, gamma, ws, ws + C,
-                       training, dz);
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<false>, dim3(apply_grid), dim3(CL_THREADS), 0, stream,
+                       dout, argmax, z, R, C, pool, mean, rstd, scale, shift, gamma, ws, ws + C, training,
+                       dz);
   EDA_CHECK_LAUNCH();
   return 0;
 }
