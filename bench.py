@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA (v_mfma_f32_16x16x4_f32) dense peak
 
 SA_LEVELS = [  # (N, npoint, radius, nsample, C_feat) -- models/backbone_module.py:44-78
     (50000, 2048, 0.2, 64, 3), (2048, 1024, 0.4, 32, 128), (1024, 512, 0.8, 16, 256), (512, 256, 1.2, 16, 256)]
@@ -70,6 +71,19 @@ def algorithmic_bytes(name):
         b, c, m, n = d if op == "three_interpolate" else (d[0], d[1], d[3], d[2])
         return b * (4 * c * m + 24 * n + 4 * c * n)
     return 0
+
+
+def algorithmic_flops(name):
+    """Useful QK^T + PV FLOPs of the fused attention ops (head_dim 36; padded columns not counted).
+    Backward: dV, dP, dQ, dK plus the recomputed scores = 5 contractions of 2*Lq*Lk*36 per head."""
+    op, d = name[0], name[1:]
+    if op == "mha_fwd":
+        b, h, lq, lk = d
+        return 4.0 * b * h * lq * lk * 36
+    if op == "mha_bwd":
+        b, h, lq, lk = d
+        return 10.0 * b * h * lq * lk * 36
+    return 0.0
 
 
 def synthetic_loss(end_points):
@@ -195,6 +209,8 @@ def main():
                     help="internal: run only the host-CPU leg and print its JSON object")
     ap.add_argument("--cpu-timeout", type=int, default=150)
     ap.add_argument("--no-butd", action="store_true")
+    ap.add_argument("--split-graphs", action="store_true",
+                    help="use the N>1 graph structure (two graphs, eager all-reduce slot) even at N=1")
     ap.add_argument("--kernel-steps", type=int, default=3,
                     help="eager steps (after the timed region) used for the per-kernel event timings in graph mode")
     ap.add_argument("--graph", type=int, default=1,
@@ -271,7 +287,7 @@ def main():
                 eager_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        if world == 1:
+        if world == 1 and not args.split_graphs:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 static_loss = eager_step()
@@ -342,9 +358,11 @@ def main():
         kernels = []
         for name, (calls, ms) in summ.items():
             byts = algorithmic_bytes(name)
+            flops = algorithmic_flops(name)
             kernels.append({"op": name[0], "dims": list(name[1:]), "calls_per_step": calls / ksteps,
                             "ms": round(ms, 4), "alg_bytes": byts,
-                            "gbs": round(byts / (ms * 1e-3) / 1e9, 1) if ms > 0 else None})
+                            "gbs": round(byts / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+                            "tflops": round(flops / (ms * 1e-3) / 1e12, 2) if flops and ms > 0 else None})
         kernels.sort(key=lambda k: -k["ms"] * k["calls_per_step"])
         native_ms = sum(k["ms"] * k["calls_per_step"] for k in kernels)
         # dominant HBM-priced kernel (FPS is latency-bound: reported as us/round below)
@@ -356,6 +374,15 @@ def main():
                         "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(dom["gbs"] / HBM_PEAK_GBS, 5), "traffic": None,
                         "ms_per_launch": dom["ms"], "alg_bytes_per_launch": dom["alg_bytes"]}
+        mf = [k for k in kernels if k["tflops"]]
+        roofline_mfma = None
+        if mf:
+            # dominant attention launch (the 1024x1024 point self-attention) against the fp32-MFMA peak
+            top = max(mf, key=lambda k: k["ms"] * k["calls_per_step"])
+            roofline_mfma = {"kernel": f"{top['op']}{tuple(top['dims'])}", "bound": "mfma",
+                             "achieved": top["tflops"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(top["tflops"] / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                             "ms_per_launch": top["ms"], "dtype": "f32 in / f32 accumulate MFMA"}
         fps = [k for k in kernels if k["op"] == "furthest_point_sampling"]
         fps_info = [{"n": k["dims"][1], "m": k["dims"][2], "ms": k["ms"],
                      "us_per_round": round(k["ms"] * 1e3 / max(1, k["dims"][2] - 1), 3)} for k in fps]
@@ -372,12 +399,13 @@ def main():
                        "launch": "hipGraph replay of the whole step" if args.graph else "eager",
                        "text_encoder": "RoBERTa-base random-init frozen"},
             "roofline": roofline,
+            "roofline_mfma": roofline_mfma,
             "native_ms_per_step": round(native_ms, 3),
             "fps": fps_info,
             "kernel_timing": ("HIP events on the launch stream, %d eager runs of the same step after the "
                               "graph-replayed timed region" % args.kernel_steps) if args.graph else
                              "HIP events on the launch stream inside the timed region",
-            "kernels": kernels[:16],
+            "kernels": kernels[:24],
             "loss": float(loss.detach()),
         }
         if not args.no_cpu_baseline and world == 1:
