@@ -11,8 +11,8 @@
 //    (x, y, z, running min distance) in registers for the whole kernel, so a
 //    round touches no global memory except one 40-byte mailbox record per
 //    workgroup.
-//  * per round: register update -> DPP wave arg-max -> LDS arg-max over the
-//    workgroup's waves -> (cluster only) all-gather of the G workgroup
+//  * per round: register update -> DPP wave max -> one 64-bit LDS atomic max per
+//    wave (distance bits | inverted tie key) -> ONE barrier -> (cluster only) all-gather of the G workgroup
 //    candidates through tagged 8-byte granules (agent-scope relaxed atomics,
 //    double-buffered by round parity; cdna_hip_programming.md G16 recipe R2)
 //    -> every workgroup picks the same winner and broadcasts it through LDS.
@@ -55,11 +55,22 @@ __device__ __forceinline__ u64 granule_load(const u64 *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Inverse of fps_tiekey.
+__device__ __forceinline__ unsigned fps_untie(unsigned tk, int p) {
+  const unsigned hi = p ? (tk >> (31 - p)) : 0u;
+  const unsigned low = p ? (__brev(hi) >> (32 - p)) : 0u;
+  const unsigned mask = (1u << (31 - p)) - 1u;
+  return ((tk & mask) << p) | low;
+}
+
 // LDS layout (dynamic): float lx[T*P], ly[T*P], lz[T*P]; then scratch.
 struct FpsShared {
-  int wave_bits[16];
-  int wave_k[16];
-  float next_xyz[4];   // x, y, z of the point chosen this round (+ pad)
+  // Workgroup arg-max of a round: 64-bit key = (order-preserving distance bits << 32) |
+  // ~tiekey, merged with ONE LDS atomic max per wave.  Three slots, used round-robin:
+  // slot[(r+1)%3] is cleared during round r, when its last readers (round r-2) are
+  // provably past (they are separated from this point by the barrier of round r-1).
+  u64 slot[3];
+  float next_xyz[4];   // cluster only: x, y, z of the point chosen this round (+ chosen index bits)
   int fail;
 };
 
@@ -76,7 +87,6 @@ __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz_al
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  constexpr int NW = T / 64;
   const int scene = blockIdx.x % S;   // consecutive blocks -> different scenes, so a
   const int w = blockIdx.x / S;       // scene's workgroups share an XCD when S % 8 == 0 (speed only)
 
@@ -106,7 +116,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz_al
     pk[j] = valid ? (int)k : 0;
     lx[j * T + tid] = x; ly[j * T + tid] = y; lz[j * T + tid] = z;
   }
-  if (tid == 0) sh->fail = 0;
+  if (tid == 0) { sh->fail = 0; sh->slot[0] = 0; sh->slot[1] = 0; sh->slot[2] = 0; }
 
   // first sample is index 0 (sampling_gpu.cu:90-92)
   float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
@@ -127,77 +137,74 @@ __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz_al
       best_bits = gt ? tb : best_bits;
       best_k = gt ? pk[j] : best_k;
     }
-    // ---- wave arg-max: max distance, then min tie key among the maxima -----
+    // ---- workgroup arg-max: DPP wave max, then one 64-bit LDS atomic per wave-max lane
+    u64 *slot = &sh->slot[r % 3];
     {
       const int wm = eda_wave_max_i32(best_bits);
-      const unsigned tk = (best_bits == wm) ? fps_tiekey((unsigned)best_k, p_log2) : 0xFFFFFFFFu;
-      const unsigned wt = eda_wave_min_u32(tk);
-      if (tk == wt) {        // several lanes only when they all carry (-1, k=0)
-        sh->wave_bits[wave] = wm;
-        sh->wave_k[wave] = best_k;
+      if (best_bits == wm) {       // several lanes only on exact distance ties
+        const u64 key = ((u64)((unsigned)wm ^ 0x80000000u) << 32) |
+                        (u64)(~fps_tiekey((unsigned)best_k, p_log2));
+        atomicMax(slot, key);
       }
+      if (tid == 0) sh->slot[(r + 1) % 3] = 0;
     }
     __syncthreads();
+    const u64 wkey = *slot;
+    const int wbits = (int)((unsigned)(wkey >> 32) ^ 0x80000000u);
+    const int kw = (int)fps_untie(~(unsigned)wkey, p_log2);
+    // coordinates of this workgroup's candidate from the LDS copy
+    const int li = ((kw / T) / G) * T + (kw % T);
+    const float cx = lx[li], cy = ly[li], cz = lz[li];
+    if (!CLUSTER) {
+      x1 = cx; y1 = cy; z1 = cz;
+      if (tid == 0) idx[r] = kw;
+      continue;
+    }
     if (wave == 0) {
-      int b = lane < NW ? sh->wave_bits[lane] : INT_MIN;
-      int kk = lane < NW ? sh->wave_k[lane] : 0;
-      int wm = __builtin_amdgcn_readlane(eda_row_max_i32(b), 0);
-      unsigned tk = (lane < NW && b == wm) ? fps_tiekey((unsigned)kk, p_log2) : 0xFFFFFFFFu;
-      unsigned wt = (unsigned)__builtin_amdgcn_readlane((int)eda_row_min_u32(tk), 0);
-      u64 hit = __ballot(tk == wt);
-      int wl = __ffsll((long long)hit) - 1;
-      int kw = __builtin_amdgcn_readlane(kk, wl);
-      // coordinates of this workgroup's candidate from the LDS copy
-      const int li = ((kw / T) / G) * T + (kw % T);
-      float cx = lx[li], cy = ly[li], cz = lz[li];
       int fk = kw;
       float fx = cx, fy = cy, fz = cz;
-      if (CLUSTER) {
-        u64 *box = mail + (size_t)(r & 1) * kMaxG * kRecWords;
-        if (lane == 0) {
-          u64 *rec = box + (size_t)w * kRecWords;
-          granule_store(rec + 0, (unsigned)r, (unsigned)wm);
-          granule_store(rec + 1, (unsigned)r, (unsigned)kw);
-          granule_store(rec + 2, (unsigned)r, __float_as_uint(cx));
-          granule_store(rec + 3, (unsigned)r, __float_as_uint(cy));
-          granule_store(rec + 4, (unsigned)r, __float_as_uint(cz));
+      u64 *box = mail + (size_t)(r & 1) * kMaxG * kRecWords;
+      if (lane == 0) {
+        u64 *rec = box + (size_t)w * kRecWords;
+        granule_store(rec + 0, (unsigned)r, (unsigned)wbits);
+        granule_store(rec + 1, (unsigned)r, (unsigned)kw);
+        granule_store(rec + 2, (unsigned)r, __float_as_uint(cx));
+        granule_store(rec + 3, (unsigned)r, __float_as_uint(cy));
+        granule_store(rec + 4, (unsigned)r, __float_as_uint(cz));
+      }
+      // all-gather: lane l < G polls workgroup l's record until its 5 tags match
+      unsigned v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+      bool ok = lane >= G;
+      unsigned spins = 0;
+      bool failed = false;
+      for (;;) {
+        if (!ok) {
+          const u64 *rec = box + (size_t)lane * kRecWords;
+          const u64 g0 = granule_load(rec + 0), g1 = granule_load(rec + 1);
+          const u64 g2 = granule_load(rec + 2), g3 = granule_load(rec + 3);
+          const u64 g4 = granule_load(rec + 4);
+          v0 = (unsigned)g0; v1 = (unsigned)g1; v2 = (unsigned)g2; v3 = (unsigned)g3; v4 = (unsigned)g4;
+          ok = ((unsigned)(g0 >> 32) == (unsigned)r) & ((unsigned)(g1 >> 32) == (unsigned)r) &
+               ((unsigned)(g2 >> 32) == (unsigned)r) & ((unsigned)(g3 >> 32) == (unsigned)r) &
+               ((unsigned)(g4 >> 32) == (unsigned)r);
         }
-        // all-gather: lane l < G polls workgroup l's record until its 5 tags match
-        unsigned v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
-        bool ok = lane >= G;
-        unsigned spins = 0;
-        bool failed = false;
-        for (;;) {
-          if (!ok) {
-            const u64 *rec = box + (size_t)lane * kRecWords;
-            const u64 g0 = granule_load(rec + 0), g1 = granule_load(rec + 1);
-            const u64 g2 = granule_load(rec + 2), g3 = granule_load(rec + 3);
-            const u64 g4 = granule_load(rec + 4);
-            v0 = (unsigned)g0; v1 = (unsigned)g1; v2 = (unsigned)g2; v3 = (unsigned)g3; v4 = (unsigned)g4;
-            ok = ((unsigned)(g0 >> 32) == (unsigned)r) & ((unsigned)(g1 >> 32) == (unsigned)r) &
-                 ((unsigned)(g2 >> 32) == (unsigned)r) & ((unsigned)(g3 >> 32) == (unsigned)r) &
-                 ((unsigned)(g4 >> 32) == (unsigned)r);
-          }
-          if (__all(ok)) break;
-          if (++spins > kSpinLimit) { failed = true; break; }
-          __builtin_amdgcn_s_sleep(1);
-        }
-        if (failed) {
-          if (lane == 0) { sh->fail = 1; atomicExch(status, 1); }
-        } else {
-          const int gb = lane < G ? (int)v0 : INT_MIN;
-          const int gm = eda_wave_max_i32(gb);
-          const unsigned gtk = (lane < G && gb == gm) ? fps_tiekey(v1, p_log2) : 0xFFFFFFFFu;
-          const unsigned gt = eda_wave_min_u32(gtk);
-          const int gl = __ffsll((long long)__ballot(gtk == gt)) - 1;
-          fk = __builtin_amdgcn_readlane((int)v1, gl);
-          fx = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)v2, gl));
-          fy = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)v3, gl));
-          fz = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)v4, gl));
-          if (gm < 0) {  // every point of the scene is invalid: reference emits index 0
-            fk = 0;
-          }
-        }
+        if (__all(ok)) break;
+        if (++spins > kSpinLimit) { failed = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (failed) {
+        if (lane == 0) { sh->fail = 1; atomicExch(status, 1); }
+      } else {
+        const int gb = lane < G ? (int)v0 : INT_MIN;
+        const int gm = eda_wave_max_i32(gb);
+        const unsigned gtk = (lane < G && gb == gm) ? fps_tiekey(v1, p_log2) : 0xFFFFFFFFu;
+        const unsigned gt = eda_wave_min_u32(gtk);
+        const int gl = __ffsll((long long)__ballot(gtk == gt)) - 1;
+        fk = __builtin_amdgcn_readlane((int)v1, gl);
+        fx = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)v2, gl));
+        fy = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)v3, gl));
+        fz = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)v4, gl));
+        if (gm < 0) fk = 0;   // every point of the scene is invalid: reference emits index 0
       }
       if (lane == 0) {
         sh->next_xyz[0] = fx; sh->next_xyz[1] = fy; sh->next_xyz[2] = fz;
@@ -209,8 +216,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz_al
     // If the winner is the all-invalid candidate (-1, k = 0) these coordinates are
     // meaningless, but then no point of the scene is ever updated, so they are unused.
     x1 = sh->next_xyz[0]; y1 = sh->next_xyz[1]; z1 = sh->next_xyz[2];
-    // No third barrier: wave slots are rewritten only after every wave has passed
-    // the barrier above, next_xyz only after the NEXT round's first barrier.
+    // next_xyz is rewritten only after the NEXT round's first barrier.
   }
 }
 
