@@ -141,26 +141,35 @@ __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz_al
     u64 *slot = &sh->slot[r % 3];
     {
       const int wm = eda_wave_max_i32(best_bits);
-      if (best_bits == wm) {       // several lanes only on exact distance ties
-        const u64 key = ((u64)((unsigned)wm ^ 0x80000000u) << 32) |
-                        (u64)(~fps_tiekey((unsigned)best_k, p_log2));
-        atomicMax(slot, key);
+      const bool cand = best_bits == wm;
+      const u64 ties = __ballot(cand);
+      // Exactly ONE lane per wave issues the LDS atomic (hipcc would otherwise serialise
+      // all tied lanes -- e.g. 64 padded or already-selected points -- through a readlane loop).
+      if (__popcll(ties) == 1) {
+        if (cand)
+          atomicMax(slot, ((u64)((unsigned)wm ^ 0x80000000u) << 32) |
+                              (u64)(~fps_tiekey((unsigned)best_k, p_log2)));
+      } else {
+        const unsigned tk = cand ? fps_tiekey((unsigned)best_k, p_log2) : 0xFFFFFFFFu;
+        const unsigned wt = eda_wave_min_u32(tk);
+        if (lane == 0) atomicMax(slot, ((u64)((unsigned)wm ^ 0x80000000u) << 32) | (u64)(~wt));
       }
       if (tid == 0) sh->slot[(r + 1) % 3] = 0;
     }
     __syncthreads();
-    const u64 wkey = *slot;
-    const int wbits = (int)((unsigned)(wkey >> 32) ^ 0x80000000u);
-    const int kw = (int)fps_untie(~(unsigned)wkey, p_log2);
-    // coordinates of this workgroup's candidate from the LDS copy
-    const int li = ((kw / T) / G) * T + (kw % T);
-    const float cx = lx[li], cy = ly[li], cz = lz[li];
     if (!CLUSTER) {
-      x1 = cx; y1 = cy; z1 = cz;
+      const int kw = (int)fps_untie(~(unsigned)*slot, p_log2);
+      x1 = lx[kw]; y1 = ly[kw]; z1 = lz[kw];     // G == 1: local slot index == point index
       if (tid == 0) idx[r] = kw;
       continue;
     }
-    if (wave == 0) {
+    if (wave == 0) {       // only wave 0 talks to the other workgroups; the rest wait at the barrier
+      const u64 wkey = *slot;
+      const int wbits = (int)((unsigned)(wkey >> 32) ^ 0x80000000u);
+      const int kw = (int)fps_untie(~(unsigned)wkey, p_log2);
+      // coordinates of this workgroup's candidate from the LDS copy
+      const int li = ((kw / T) / G) * T + (kw % T);
+      const float cx = lx[li], cy = ly[li], cz = lz[li];
       int fk = kw;
       float fx = cx, fy = cy, fz = cz;
       u64 *box = mail + (size_t)(r & 1) * kMaxG * kRecWords;
@@ -311,10 +320,10 @@ extern "C" int eda_furthest_point_sampling_f32(const float *xyz, int b, int n, i
     G = 1;
     if (n > 2048 && env_int("EDA_FPS_SMALL_T", 512) == 1024) { T = 1024; P = round_up_pow2((n + T - 1) / T); }
   } else {
-    T = env_int("EDA_FPS_T", 1024);
-    P = env_int("EDA_FPS_P", 8);
+    T = env_int("EDA_FPS_T", 512);       // measured on MI355X (B=8, N=50 000): (512,16) 4.41 ms,
+    P = env_int("EDA_FPS_P", 16);        // (1024,8) 4.75 ms, (512,8) 4.79 ms, (1024,4) 5.12 ms
     if (T != 512 && T != 1024) T = 1024;
-    if (!(P == 1 || P == 2 || P == 4 || P == 8 || (P == 16 && T == 512))) P = 8;
+    if (!(P == 1 || P == 2 || P == 4 || P == 8 || (P == 16 && T == 512))) { T = 512; P = 16; }
     const int chunks = (n + T - 1) / T;
     G = (chunks + P - 1) / P;
     if (G > kMaxG) {

@@ -86,6 +86,33 @@ __device__ __forceinline__ void stage_rows(float *lds, const float *base, long r
   }
 }
 
+// Software-pipelined staging: a tile's 16-byte pieces are first loaded into registers
+// (issue_rows, while the previous tile is being multiplied) and written to the other
+// LDS buffer afterwards (commit_rows) -- one barrier per tile, global latency hidden.
+struct RowStage { float4 r[3]; };
+
+__device__ __forceinline__ void issue_rows(RowStage &st, const float *base, long row_stride,
+                                           int row0, int nrows) {
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int i = threadIdx.x + THREADS * t;
+    const int row = i / 9, c4 = i - row * 9;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < TILE * 9 && row0 + row < nrows)
+      v = *reinterpret_cast<const float4 *>(base + (long)(row0 + row) * row_stride + 4 * c4);
+    st.r[t] = v;
+  }
+}
+
+__device__ __forceinline__ void commit_rows(float *lds, const RowStage &st) {
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int i = threadIdx.x + THREADS * t;
+    const int row = i / 9, c4 = i - row * 9;
+    if (i < TILE * 9) *reinterpret_cast<float4 *>(lds + row * HD + 4 * c4) = st.r[t];
+  }
+}
+
 // Dead-key flags of one 64-key tile, packed 4 per word: byte r of word w is 1 when
 // key k0 + 4w + r is padding (>= Lk) or masked.  Staged through LDS so that the
 // masking in the hot loop is branch-free (no predicated byte loads).
@@ -105,9 +132,9 @@ __device__ __forceinline__ void stage_dead(unsigned *flags, const unsigned char 
 
 // ============================================================== forward ======
 __global__ __launch_bounds__(THREADS) void mha_fwd_kernel(MhaArgs a) {
-  __shared__ __attribute__((aligned(16))) float Kl[TILE * HD];
-  __shared__ __attribute__((aligned(16))) float Vl[TILE * HD];
-  __shared__ unsigned deadl[TILE / 4];
+  __shared__ __attribute__((aligned(16))) float Kbuf[2][TILE * HD];
+  __shared__ __attribute__((aligned(16))) float Vbuf[2][TILE * HD];
+  __shared__ unsigned deadbuf[2][TILE / 4];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;
@@ -137,12 +164,20 @@ __global__ __launch_bounds__(THREADS) void mha_fwd_kernel(MhaArgs a) {
   float m = -INFINITY, lsum = 0.f;
   f32x4 o[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 
-  for (int k0 = 0; k0 < a.Lk; k0 += TILE) {
-    __syncthreads();
-    stage_rows(Kl, kbase, a.k_sl, k0, a.Lk);
-    stage_rows(Vl, vbase, a.v_sl, k0, a.Lk);
-    stage_dead(deadl, mrow, k0, a.Lk);
-    __syncthreads();
+  stage_rows(Kbuf[0], kbase, a.k_sl, 0, a.Lk);
+  stage_rows(Vbuf[0], vbase, a.v_sl, 0, a.Lk);
+  stage_dead(deadbuf[0], mrow, 0, a.Lk);
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = 0; k0 < a.Lk; k0 += TILE, cur ^= 1) {
+    const float *Kl = Kbuf[cur], *Vl = Vbuf[cur];
+    const unsigned *deadl = deadbuf[cur];
+    const bool more = k0 + TILE < a.Lk;
+    RowStage ks, vs;
+    if (more) {                       // next tile: global -> registers, overlapped with the MFMAs below
+      issue_rows(ks, kbase, a.k_sl, k0 + TILE, a.Lk);
+      issue_rows(vs, vbase, a.v_sl, k0 + TILE, a.Lk);
+    }
 
     f32x4 st[4];
 #pragma unroll
@@ -202,6 +237,12 @@ __global__ __launch_bounds__(THREADS) void mha_fwd_kernel(MhaArgs a) {
         o[1] = mfma4(vr[16 + c], pb, o[1]);
         o[2] = mfma4(c < 4 ? vr[32 + c] : 0.f, pb, o[2]);
       }
+    if (more) {                       // registers -> the other LDS buffer (its readers finished last iteration)
+      commit_rows(Kbuf[cur ^ 1], ks);
+      commit_rows(Vbuf[cur ^ 1], vs);
+      stage_dead(deadbuf[cur ^ 1], mrow, k0 + TILE, a.Lk);
+    }
+    __syncthreads();
   }
 
   if (qvalid) {
@@ -243,9 +284,9 @@ __global__ __launch_bounds__(256) void mha_delta_kernel(const float *__restrict_
 //   S^T = K Q^T, P^T = exp(S^T - lse);  dP^T = V dO^T;  dS^T = P^T o (dP^T_eff - delta)
 //   dQ^T[dim][query] += K^T dS^T    (then * scale)
 __global__ __launch_bounds__(THREADS) void mha_bwd_dq_kernel(MhaArgs a) {
-  __shared__ __attribute__((aligned(16))) float Kl[TILE * HD];
-  __shared__ __attribute__((aligned(16))) float Vl[TILE * HD];
-  __shared__ unsigned deadl[TILE / 4];
+  __shared__ __attribute__((aligned(16))) float Kbuf[2][TILE * HD];
+  __shared__ __attribute__((aligned(16))) float Vbuf[2][TILE * HD];
+  __shared__ unsigned deadbuf[2][TILE / 4];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;
@@ -278,12 +319,20 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_dq_kernel(MhaArgs a) {
   const unsigned rowbase = ((unsigned)bh * (unsigned)a.Lq + (unsigned)qi) * (unsigned)a.Lk;
 
   f32x4 dq[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-  for (int k0 = 0; k0 < a.Lk; k0 += TILE) {
-    __syncthreads();
-    stage_rows(Kl, kbase, a.k_sl, k0, a.Lk);
-    stage_rows(Vl, vbase, a.v_sl, k0, a.Lk);
-    stage_dead(deadl, mrow, k0, a.Lk);
-    __syncthreads();
+  stage_rows(Kbuf[0], kbase, a.k_sl, 0, a.Lk);
+  stage_rows(Vbuf[0], vbase, a.v_sl, 0, a.Lk);
+  stage_dead(deadbuf[0], mrow, 0, a.Lk);
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = 0; k0 < a.Lk; k0 += TILE, cur ^= 1) {
+    const float *Kl = Kbuf[cur], *Vl = Vbuf[cur];
+    const unsigned *deadl = deadbuf[cur];
+    const bool more = k0 + TILE < a.Lk;
+    RowStage ks, vs;
+    if (more) {
+      issue_rows(ks, kbase, a.k_sl, k0 + TILE, a.Lk);
+      issue_rows(vs, vbase, a.v_sl, k0 + TILE, a.Lk);
+    }
     f32x4 ds[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -317,6 +366,12 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_dq_kernel(MhaArgs a) {
         dq[1] = mfma4(kr[16 + c], sb, dq[1]);
         dq[2] = mfma4(c < 4 ? kr[32 + c] : 0.f, sb, dq[2]);
       }
+    if (more) {
+      commit_rows(Kbuf[cur ^ 1], ks);
+      commit_rows(Vbuf[cur ^ 1], vs);
+      stage_dead(deadbuf[cur ^ 1], mrow, k0 + TILE, a.Lk);
+    }
+    __syncthreads();
   }
   if (qvalid) {
     float *out = a.dq + ((long)b * a.Lq + qi) * (a.H * HD) + h * HD;
@@ -333,9 +388,9 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_dq_kernel(MhaArgs a) {
 //   S = Q K^T [query 4g+r][key l&15], P = exp(S - lse[query]);  dP = dO V^T
 //   dV^T[dim][key] += dO^T P_drop;  dS = P o (dP_eff - delta[query]);  dK^T[dim][key] += Q^T dS
 __global__ __launch_bounds__(THREADS) void mha_bwd_dkv_kernel(MhaArgs a) {
-  __shared__ __attribute__((aligned(16))) float Ql[TILE * HD];
-  __shared__ __attribute__((aligned(16))) float Dl[TILE * HD];
-  __shared__ float lse_l[TILE], delta_l[TILE];
+  __shared__ __attribute__((aligned(16))) float Qbuf[2][TILE * HD];
+  __shared__ __attribute__((aligned(16))) float Dbuf[2][TILE * HD];
+  __shared__ float lsebuf[2][TILE], deltabuf[2][TILE];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;
@@ -365,16 +420,27 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_dkv_kernel(MhaArgs a) {
 
   f32x4 dk[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
   f32x4 dv[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-  for (int q0 = 0; q0 < a.Lq; q0 += TILE) {
-    __syncthreads();
-    stage_rows(Ql, qbase, a.q_sl, q0, a.Lq);
-    stage_rows(Dl, dbase, a.do_sl, q0, a.Lq);
+  auto stage_stats = [&](int buf, int q0) {
     if (threadIdx.x < TILE) {
       const int qq = q0 + threadIdx.x;
-      lse_l[threadIdx.x] = qq < a.Lq ? a.lse[(long)bh * a.Lq + qq] : 0.f;
-      delta_l[threadIdx.x] = qq < a.Lq ? a.delta[(long)bh * a.Lq + qq] : 0.f;
+      lsebuf[buf][threadIdx.x] = qq < a.Lq ? a.lse[(long)bh * a.Lq + qq] : 0.f;
+      deltabuf[buf][threadIdx.x] = qq < a.Lq ? a.delta[(long)bh * a.Lq + qq] : 0.f;
     }
-    __syncthreads();
+  };
+  stage_rows(Qbuf[0], qbase, a.q_sl, 0, a.Lq);
+  stage_rows(Dbuf[0], dbase, a.do_sl, 0, a.Lq);
+  stage_stats(0, 0);
+  __syncthreads();
+  int cur = 0;
+  for (int q0 = 0; q0 < a.Lq; q0 += TILE, cur ^= 1) {
+    const float *Ql = Qbuf[cur], *Dl = Dbuf[cur];
+    const float *lse_l = lsebuf[cur], *delta_l = deltabuf[cur];
+    const bool more = q0 + TILE < a.Lq;
+    RowStage qs, dsg;
+    if (more) {
+      issue_rows(qs, qbase, a.q_sl, q0 + TILE, a.Lq);
+      issue_rows(dsg, dbase, a.do_sl, q0 + TILE, a.Lq);
+    }
     f32x4 pd[4], ds[4];     // dropped P (for dV) and dS (for dK), B-operand layout
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -416,6 +482,12 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_dkv_kernel(MhaArgs a) {
         dk[1] = mfma4(qr[16 + c], sb, dk[1]);
         dk[2] = mfma4(c < 4 ? qr[32 + c] : 0.f, sb, dk[2]);
       }
+    if (more) {
+      commit_rows(Qbuf[cur ^ 1], qs);
+      commit_rows(Dbuf[cur ^ 1], dsg);
+      stage_stats(cur ^ 1, q0 + TILE);
+    }
+    __syncthreads();
   }
   if (kvalid) {
     const long off = ((long)b * a.Lk + ki) * (a.H * HD) + h * HD;
