@@ -209,8 +209,8 @@ def main():
                     help="internal: run only the host-CPU leg and print its JSON object")
     ap.add_argument("--cpu-timeout", type=int, default=150)
     ap.add_argument("--no-butd", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="run the text encoder on the main stream instead of overlapping it with the point backbone")
+    ap.add_argument("--overlap", action="store_true",
+                    help="run the text encoder on a side stream underneath the point backbone (measured slower)")
     ap.add_argument("--split-graphs", action="store_true",
                     help="use the N>1 graph structure (two graphs, eager all-reduce slot) even at N=1")
     ap.add_argument("--kernel-steps", type=int, default=3,
@@ -245,7 +245,7 @@ def main():
     torch.manual_seed(0)                       # same init on every rank (DDP broadcast equivalent)
     model = BeaUTyDETR(num_queries=args.queries, butd=not args.no_butd).to(device).train()
     model.text_encoder.eval()                  # frozen (bdetr.py:78-80)
-    model.overlap_text_encoder = not args.no_overlap
+    model.overlap_text_encoder = args.overlap
     flat = FlatParams(model, reference_lr_groups)
     lrs = {"base": 1e-4, "backbone_net": 1e-3, "text_encoder": 1e-5}     # scripts/train_scanrefer.sh
     opt = torch.optim.AdamW([{"params": [gp], "lr": lrs[k]} for k, gp in flat.groups.items()],

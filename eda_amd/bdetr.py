@@ -55,7 +55,11 @@ class BeaUTyDETR(nn.Module):
         self.self_position_embedding = self_position_embedding
         self.contrastive_align_loss = contrastive_align_loss
         self.butd = butd
-        self.overlap_text_encoder = True      # run RoBERTa on a side stream under the point backbone
+        # Optional: run the text encoder on a second HIP stream underneath the point backbone.
+        # Measured on MI355X inside the replayed HIP graph it is a net loss (47.3 vs 46.1 ms/step:
+        # the fork/join and the contention with FPS's mailbox polling cost more than the overlap
+        # buys), so it is off by default.
+        self.overlap_text_encoder = False
         self._side_stream = None
 
         self.backbone_net = Pointnet2Backbone(input_feature_dim=input_feature_dim, width=1)
