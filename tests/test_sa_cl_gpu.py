@@ -1,0 +1,124 @@
+"""GPU parity of the channels-last set-abstraction kernels (csrc/sa_cl.hip) against
+plain fp32 torch references of the same ops, and of the fused SA fast path against
+the generic (reference-shaped) path of the same module at full size."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_bn_relu(z, gamma, beta, rm, rv, eps, momentum, training, pool):
+    y = F.batch_norm(z, rm, rv, gamma, beta, training, momentum, eps)
+    y = F.relu(y)
+    if pool > 1:
+        R, C = y.shape
+        y = y.view(R // pool, pool, C).max(dim=1)[0]
+    return y
+
+
+@pytest.mark.parametrize("R,C,pool,training", [
+    (4096, 64, 1, True), (8192, 128, 16, True), (2048, 288, 1, True), (6144, 256, 32, True),
+    (640, 16, 64, True), (4096, 64, 1, False), (2048, 32, 16, False), (100352, 128, 64, True),
+])
+def test_bn_relu_forward_backward(R, C, pool, training):
+    from eda_amd import sa_ops
+    torch.manual_seed(R + C)
+    dev = "cuda"
+    z = (torch.randn(R, C, device=dev) * 1.7 + 0.4).requires_grad_(True)
+    gamma = (torch.rand(C, device=dev) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, device=dev) * 0.2).requires_grad_(True)
+    rm0 = torch.randn(C, device=dev) * 0.1
+    rv0 = torch.rand(C, device=dev) + 0.5
+    rm_a, rv_a, rm_b, rv_b = rm0.clone(), rv0.clone(), rm0.clone(), rv0.clone()
+    out = sa_ops.BNReLUCL.apply(z, gamma, beta, rm_a, rv_a, 1e-5, 0.1, training, pool)
+    w = torch.randn_like(out)
+    (out * w).sum().backward()
+    got = [out.detach(), z.grad.clone(), gamma.grad.clone(), beta.grad.clone()]
+    for t in (z, gamma, beta):
+        t.grad = None
+    exp_out = _ref_bn_relu(z, gamma, beta, rm_b, rv_b, 1e-5, 0.1, training, pool)
+    (exp_out * w).sum().backward()
+    exp = [exp_out.detach(), z.grad, gamma.grad, beta.grad]
+    for name, g, e in zip(["out", "dz", "dgamma", "dbeta"], got, exp):
+        scale = e.abs().max().item() + 1e-9
+        err = (g - e).abs().max().item()
+        assert err <= 2e-4 * scale + 1e-6, (name, err, scale)
+    if training:
+        torch.testing.assert_close(rm_a, rm_b, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(rv_a, rv_b, rtol=1e-4, atol=1e-6)
+    else:
+        assert torch.equal(rm_a, rm0) and torch.equal(rv_a, rv0)
+
+
+@pytest.mark.parametrize("B,N,m,ns,C", [(2, 500, 40, 8, 0), (2, 3000, 128, 16, 3), (2, 2048, 256, 32, 128), (1, 700, 33, 5, 7)])
+def test_group_concat_cl_vs_reference_ops(B, N, m, ns, C):
+    """Fused gather/centre/scale/concat rows == QueryAndGroup of the reference-shaped ops."""
+    from eda_amd import sa_ops, pointnet2_utils as PU
+    rng = np.random.default_rng(N + C)
+    dev = "cuda"
+    xyz = torch.from_numpy(rng.uniform(-2, 2, (B, N, 3)).astype(np.float32)).to(dev)
+    new_xyz = xyz[:, :m].contiguous()
+    feats = torch.randn(B, C, N, device=dev, requires_grad=True) if C else None
+    idx = PU.ball_query(0.6, ns, xyz, new_xyz)
+    rows = sa_ops.GroupConcatCL.apply(xyz, new_xyz, feats.transpose(1, 2).contiguous() if C else None,
+                                      idx, 0.6, True)
+    qg = PU.QueryAndGroup(0.6, ns, use_xyz=True, ret_grouped_xyz=False, normalize_xyz=True)
+    ref = qg(xyz, new_xyz, feats)                                    # (B, 3+C, m, ns)
+    ref_rows = ref.permute(0, 2, 3, 1).reshape(B, m * ns, 3 + C)
+    assert torch.equal(rows, ref_rows)       # same fp32 ops (sub, mul by 1/r), pure copies otherwise
+    if C:
+        w = torch.randn_like(rows)
+        fcl = feats.detach().transpose(1, 2).contiguous().requires_grad_(True)
+        (sa_ops.GroupConcatCL.apply(xyz, new_xyz, fcl, idx, 0.6, True) * w).sum().backward()
+        (ref_rows * w).sum().backward()
+        torch.testing.assert_close(fcl.grad.transpose(1, 2), feats.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_pointwise_linear_split_k_gradient():
+    from eda_amd import sa_ops
+    torch.manual_seed(1)
+    a = torch.randn(131072, 24, device="cuda", requires_grad=True)
+    w = torch.randn(40, 24, 1, 1, device="cuda", requires_grad=True)
+    z = sa_ops.PointwiseLinearCL.apply(a, w)
+    g = torch.randn_like(z)
+    z.backward(g)
+    ga, gw = a.grad.clone(), w.grad.clone()
+    a.grad = None; w.grad = None
+    (a @ w.view(40, 24).t()).backward(g)
+    torch.testing.assert_close(ga, a.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gw, w.grad, rtol=1e-4, atol=1e-2)     # 131072-term sums in fp32
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_sa_fast_path_matches_generic_path_full_size(training):
+    """SA1 at BASELINE.json's size (B=2 here, N=50 000, 2048 centres x 64 neighbours): the
+    channels-last fast path and the reference-shaped generic path of the same module agree."""
+    from eda_amd import synthetic
+    from eda_amd.pointnet2_modules import PointnetSAModuleVotes
+    torch.manual_seed(0)
+    pc = torch.from_numpy(synthetic.batch([3, 4], 50000)).cuda()
+    xyz = pc[..., :3].contiguous()
+    feats = pc[..., 3:].transpose(1, 2).contiguous()
+    sa = PointnetSAModuleVotes(npoint=2048, radius=0.2, nsample=64, mlp=[3, 64, 64, 128], use_xyz=True,
+                               normalize_xyz=True).cuda().train(training)
+    import copy
+    sb = copy.deepcopy(sa)
+    f1 = feats.clone().requires_grad_(True)
+    f2 = feats.clone().requires_grad_(True)
+    x1, o1, i1 = sa(xyz, f1)
+    sb._fast_path = lambda _xyz: False          # force the generic path
+    x2, o2, i2 = sb(xyz, f2)
+    assert torch.equal(i1, i2) and torch.equal(x1, x2)
+    torch.testing.assert_close(o1, o2, rtol=2e-4, atol=2e-5)
+    w = torch.randn_like(o1)
+    (o1 * w).sum().backward()
+    (o2 * w).sum().backward()
+    torch.testing.assert_close(f1.grad, f2.grad, rtol=1e-3, atol=1e-4)
+    for (n1, p1), (n2, p2) in zip(sa.named_parameters(), sb.named_parameters()):
+        scale = p2.grad.abs().max().item() + 1e-9
+        assert (p1.grad - p2.grad).abs().max().item() <= 2e-3 * scale, n1
+    if training:
+        for (n1, b1), (n2, b2) in zip(sa.named_buffers(), sb.named_buffers()):
+            torch.testing.assert_close(b1.float(), b2.float(), rtol=1e-4, atol=1e-5, msg=n1)
