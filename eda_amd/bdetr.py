@@ -159,8 +159,8 @@ class BeaUTyDETR(nn.Module):
         end_points["tokenized"] = tok
         return end_points
 
-    def _generate_queries(self, xyz, features, end_points):
-        logits = self.points_obj_cls(features)
+    def _generate_queries(self, xyz, features, end_points, features_rows=None):
+        logits = self.points_obj_cls(features, seed_rows=features_rows)
         end_points["seeds_obj_cls_logits"] = logits
         sample_inds = torch.topk(torch.sigmoid(logits).squeeze(1), self.num_queries)[1].int()
         xyz, features, sample_inds = self.gsample_module(xyz, features, sample_inds)
@@ -179,15 +179,15 @@ class BeaUTyDETR(nn.Module):
 
         if self.butd:
             detected_mask = ~inputs["det_bbox_label_mask"]
-            box_emb = self.box_embeddings(inputs["det_boxes"])                          # (B,128,D)
+            box_emb = self.box_embeddings.rows(inputs["det_boxes"])                     # (B,D,128)
             cls_emb = self.class_embeddings(self.butd_class_embeddings(inputs["det_class_ids"]))
-            detected_feats = torch.cat([box_emb, cls_emb.transpose(1, 2)], 1).transpose(1, 2).contiguous()
+            detected_feats = torch.cat([box_emb, cls_emb], 2)                           # (B,D,288)
         else:
             detected_mask, detected_feats = None, None
 
         vis, text_feats = self.cross_encoder(
             vis_feats=points_features.transpose(1, 2).contiguous(),
-            pos_feats=self.pos_embed(points_xyz).transpose(1, 2).contiguous(),
+            pos_feats=self.pos_embed.rows(points_xyz),
             padding_mask=torch.zeros(points_xyz.shape[:2], dtype=torch.bool, device=points_xyz.device),
             text_feats=text_feats, text_padding_mask=text_padding_mask, end_points=end_points,
             detected_feats=detected_feats, detected_mask=detected_mask)
@@ -198,15 +198,16 @@ class BeaUTyDETR(nn.Module):
             end_points["proj_tokens"] = F.normalize(
                 self.contrastive_align_projection_text(text_feats), p=2, dim=-1)
 
-        end_points = self._generate_queries(points_xyz, points_features, end_points)
+        end_points = self._generate_queries(points_xyz, points_features, end_points, features_rows=vis)
         cluster_feature = end_points["query_points_feature"]     # (B, 288, Q)
         cluster_xyz = end_points["query_points_xyz"]             # (B, Q, 3)
-        query = self.decoder_query_proj(cluster_feature).transpose(1, 2).contiguous()
+        cluster_rows = cluster_feature.transpose(1, 2).contiguous()             # (B, Q, 288)
+        query = self.decoder_query_proj.rows(cluster_rows)
         if self.contrastive_align_loss:
             end_points["proposal_proj_queries"] = F.normalize(
                 self.contrastive_align_projection_image(query), p=2, dim=-1)
-        center, size = self.proposal_head(cluster_feature, base_xyz=cluster_xyz,
-                                          end_points=end_points, prefix="proposal_")
+        center, size = self.proposal_head(cluster_feature, base_xyz=cluster_xyz, end_points=end_points,
+                                          prefix="proposal_", features_rows=cluster_rows)
         base_xyz, base_size = center.detach().clone(), size.detach().clone()
 
         for i in range(self.num_decoder_layers):
@@ -225,9 +226,9 @@ class BeaUTyDETR(nn.Module):
             if self.contrastive_align_loss:
                 end_points[f"{prefix}proj_queries"] = F.normalize(
                     self.contrastive_align_projection_image(query), p=2, dim=-1)
-            center, size = self.prediction_heads[i](query.transpose(1, 2).contiguous(),
-                                                    base_xyz=cluster_xyz, end_points=end_points,
-                                                    prefix=prefix)
+            center, size = self.prediction_heads[i](query.transpose(1, 2), base_xyz=cluster_xyz,
+                                                    end_points=end_points, prefix=prefix,
+                                                    features_rows=query)
             base_xyz, base_size = center.detach().clone(), size.detach().clone()
         return end_points
 

@@ -13,7 +13,7 @@ import torch
 from torch import nn
 
 from .attention import MultiheadAttention
-from .nn_utils import Conv1dK1
+from .nn_utils import Conv1dK1, bn_relu_rows, rows_ok
 
 
 def _get_clones(module, n):
@@ -37,7 +37,21 @@ class PositionEmbeddingLearned(nn.Module):
             Conv1dK1(num_pos_feats, num_pos_feats, kernel_size=1))
 
     def forward(self, xyz):
+        """(B, N, 3 or 6) -> (B, F, N), the reference's layout."""
+        if rows_ok(xyz, self.position_embedding_head[0].out_channels):
+            return self.rows(xyz).transpose(1, 2)
         return self.position_embedding_head(xyz.transpose(1, 2).contiguous())
+
+    def rows(self, xyz):
+        """(B, N, 3 or 6) -> (B, N, F): the input already is channels-last, so the two 1x1
+        convolutions are row-major GEMMs around the fused BN+ReLU kernel (no transposes)."""
+        head = self.position_embedding_head
+        if not rows_ok(xyz, head[0].out_channels):
+            return self.forward(xyz).transpose(1, 2)
+        B, N, C = xyz.shape
+        h = head[0].rows(xyz.reshape(B * N, C))
+        h = bn_relu_rows(head[1], h)
+        return head[3].rows(h).view(B, N, -1)
 
 
 class CrossAttentionLayer(nn.Module):
@@ -177,7 +191,7 @@ class BiDecoderLayer(nn.Module):
     def forward(self, query, vis_feats, lang_feats, query_pos, padding_mask, text_key_padding_mask,
                 detected_feats=None, detected_mask=None):
         if self.self_posembed is not None:
-            pos = self.self_posembed(query_pos).transpose(1, 2)
+            pos = self.self_posembed.rows(query_pos)
         else:
             pos = torch.zeros_like(query)
         qp = query + pos
