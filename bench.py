@@ -203,7 +203,7 @@ def main():
     ap.add_argument("--queries", type=int, default=256)
     ap.add_argument("--tokens", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-scenes", type=int, default=2)
+    ap.add_argument("--cpu-scenes", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=64, help="cap on host threads of the CPU leg")
     ap.add_argument("--cpu-baseline-only", action="store_true",
                     help="internal: run only the host-CPU leg and print its JSON object")

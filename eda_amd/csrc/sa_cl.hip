@@ -383,6 +383,152 @@ __global__ __launch_bounds__(CL_THREADS) void bn_relu_bwd_stats_vec_kernel(
   }
 }
 
+// ---------------------------------------------------------------- small inputs
+// For the heads / positional embeddings (R = B*Q ~ 2048 rows) the multi-launch scheme
+// above is launch-bound.  Here ONE launch does everything: a workgroup owns 32 channels
+// (8 float4 column groups x 32 row lanes) for ALL rows, reduces its columns in LDS
+// (fp64 merge, no atomics), then sweeps the same rows again from L2 to apply.
+constexpr int SM_CG = 8;      // float4 column groups per workgroup
+constexpr int SM_RL = 32;     // row lanes
+
+__global__ __launch_bounds__(CL_THREADS) void bn_relu_small_fwd_kernel(
+    const float *__restrict__ z, int R, int C, const float *__restrict__ gamma,
+    const float *__restrict__ beta, float eps, float momentum, int training,
+    float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ mean_out,
+    float *__restrict__ rstd_out, float *__restrict__ scale_out, float *__restrict__ shift_out,
+    float *__restrict__ out) {
+  __shared__ float red[2][SM_CG * 4][SM_RL + 1];
+  __shared__ float sc_l[SM_CG * 4], sh_l[SM_CG * 4];
+  const int cgl = threadIdx.x & (SM_CG - 1), rl = threadIdx.x >> 3;
+  const int cg = blockIdx.x * SM_CG + cgl;
+  const bool valid = cg < C / 4;
+  const int c0 = cg * 4;
+  if (training) {
+    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (valid)
+      for (int r = rl; r < R; r += SM_RL) {
+        const float4 x = *reinterpret_cast<const float4 *>(z + (long)r * C + c0);
+        s[0] += x.x; s[1] += x.y; s[2] += x.z; s[3] += x.w;
+        q[0] += x.x * x.x; q[1] += x.y * x.y; q[2] += x.z * x.z; q[3] += x.w * x.w;
+      }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { red[0][cgl * 4 + v][rl] = s[v]; red[1][cgl * 4 + v][rl] = q[v]; }
+    __syncthreads();
+    if (threadIdx.x < SM_CG * 4) {
+      const int c = blockIdx.x * SM_CG * 4 + threadIdx.x;
+      if (c < C) {
+        double a = 0.0, b = 0.0;
+        for (int l = 0; l < SM_RL; ++l) { a += (double)red[0][threadIdx.x][l]; b += (double)red[1][threadIdx.x][l]; }
+        const double mean = a / (double)R;
+        double var = b / (double)R - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float meanf = (float)mean;
+        const float sc = gamma[c] * rstd, sh = beta[c] - meanf * sc;
+        mean_out[c] = meanf; rstd_out[c] = rstd; scale_out[c] = sc; shift_out[c] = sh;
+        sc_l[threadIdx.x] = sc; sh_l[threadIdx.x] = sh;
+        if (running_mean) {
+          const double unbiased = R > 1 ? var * (double)R / (double)(R - 1) : var;
+          running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
+          running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+      }
+    }
+  } else if (threadIdx.x < SM_CG * 4) {
+    const int c = blockIdx.x * SM_CG * 4 + threadIdx.x;
+    if (c < C) {
+      const float rstd = 1.f / sqrtf(running_var[c] + eps);
+      const float sc = gamma[c] * rstd, sh = beta[c] - running_mean[c] * sc;
+      mean_out[c] = running_mean[c]; rstd_out[c] = rstd; scale_out[c] = sc; shift_out[c] = sh;
+      sc_l[threadIdx.x] = sc; sh_l[threadIdx.x] = sh;
+    }
+  }
+  __syncthreads();
+  if (!valid) return;
+  const float sc0 = sc_l[cgl * 4], sc1 = sc_l[cgl * 4 + 1], sc2 = sc_l[cgl * 4 + 2], sc3 = sc_l[cgl * 4 + 3];
+  const float sh0 = sh_l[cgl * 4], sh1 = sh_l[cgl * 4 + 1], sh2 = sh_l[cgl * 4 + 2], sh3 = sh_l[cgl * 4 + 3];
+  for (int r = rl; r < R; r += SM_RL) {
+    const float4 x = *reinterpret_cast<const float4 *>(z + (long)r * C + c0);
+    float4 y;
+    y.x = fmaxf(x.x * sc0 + sh0, 0.f); y.y = fmaxf(x.y * sc1 + sh1, 0.f);
+    y.z = fmaxf(x.z * sc2 + sh2, 0.f); y.w = fmaxf(x.w * sc3 + sh3, 0.f);
+    *reinterpret_cast<float4 *>(out + (long)r * C + c0) = y;
+  }
+}
+
+__global__ __launch_bounds__(CL_THREADS) void bn_relu_small_bwd_kernel(
+    const float *__restrict__ da, const float *__restrict__ z, int R, int C,
+    const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ rstd,
+    const float *__restrict__ scale, const float *__restrict__ shift, int train,
+    double *__restrict__ s1_out, double *__restrict__ s2_out, float *__restrict__ dz) {
+  __shared__ float red[2][SM_CG * 4][SM_RL + 1];
+  __shared__ float ka_l[SM_CG * 4], kb_l[SM_CG * 4], kd_l[SM_CG * 4];
+  const int cgl = threadIdx.x & (SM_CG - 1), rl = threadIdx.x >> 3;
+  const int cg = blockIdx.x * SM_CG + cgl;
+  const bool valid = cg < C / 4;
+  const int c0 = cg * 4;
+  float sc[4] = {0, 0, 0, 0}, sh[4] = {0, 0, 0, 0}, mu[4] = {0, 0, 0, 0}, rs[4] = {0, 0, 0, 0};
+  if (valid) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { sc[v] = scale[c0 + v]; sh[v] = shift[c0 + v]; mu[v] = mean[c0 + v]; rs[v] = rstd[c0 + v]; }
+  }
+  float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+  if (valid)
+    for (int r = rl; r < R; r += SM_RL) {
+      const float4 x4 = *reinterpret_cast<const float4 *>(z + (long)r * C + c0);
+      const float4 d4 = *reinterpret_cast<const float4 *>(da + (long)r * C + c0);
+      const float x[4] = {x4.x, x4.y, x4.z, x4.w};
+      const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float dy = (x[v] * sc[v] + sh[v]) > 0.f ? d[v] : 0.f;
+        a1[v] += dy;
+        a2[v] += dy * (x[v] - mu[v]) * rs[v];
+      }
+    }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) { red[0][cgl * 4 + v][rl] = a1[v]; red[1][cgl * 4 + v][rl] = a2[v]; }
+  __syncthreads();
+  if (threadIdx.x < SM_CG * 4) {
+    const int c = blockIdx.x * SM_CG * 4 + threadIdx.x;
+    if (c < C) {
+      double t1 = 0.0, t2 = 0.0;
+      for (int l = 0; l < SM_RL; ++l) { t1 += (double)red[0][threadIdx.x][l]; t2 += (double)red[1][threadIdx.x][l]; }
+      s1_out[c] = t1; s2_out[c] = t2;
+      const float invR = 1.f / (float)R;
+      const float gr = gamma[c] * rstd[c];
+      ka_l[threadIdx.x] = gr;
+      if (train) {
+        const float k2 = rstd[c] * (float)t2 * invR;
+        kb_l[threadIdx.x] = -gr * k2;
+        kd_l[threadIdx.x] = gr * (mean[c] * k2 - (float)t1 * invR);
+      } else {
+        kb_l[threadIdx.x] = 0.f; kd_l[threadIdx.x] = 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  if (!valid) return;
+  float ka[4], kb[4], kd[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) { ka[v] = ka_l[cgl * 4 + v]; kb[v] = kb_l[cgl * 4 + v]; kd[v] = kd_l[cgl * 4 + v]; }
+  for (int r = rl; r < R; r += SM_RL) {
+    const float4 x4 = *reinterpret_cast<const float4 *>(z + (long)r * C + c0);
+    const float4 d4 = *reinterpret_cast<const float4 *>(da + (long)r * C + c0);
+    const float x[4] = {x4.x, x4.y, x4.z, x4.w};
+    const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+    float o[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float dy = (x[v] * sc[v] + sh[v]) > 0.f ? d[v] : 0.f;
+      o[v] = ka[v] * dy + kb[v] * x[v] + kd[v];
+    }
+    *reinterpret_cast<float4 *>(dz + (long)r * C + c0) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+constexpr long SMALL_ROWS = 16384;   // below this the single-launch kernels win
+
 int grid_for(long work_items) {
   long g = (work_items + CL_THREADS - 1) / CL_THREADS;
   if (g > 8192) g = 8192;
@@ -440,6 +586,15 @@ extern "C" int eda_bn_relu_fwd_f32(const float *z, long R, int C, const float *g
   EDA_CHECK_ARG(pool <= 255 && R % pool == 0, "rows must be a multiple of the pooling width");
   if (R == 0) return 0;
   EDA_CHECK_ARG(z && gamma && beta && mean && rstd && scale && shift && out, "null pointer");
+  if (pool == 1 && R <= SMALL_ROWS) {
+    EDA_CHECK_ARG(training || (running_mean && running_var), "eval mode needs running statistics");
+    const int nb = (C / 4 + SM_CG - 1) / SM_CG;
+    hipLaunchKernelGGL(bn_relu_small_fwd_kernel, dim3(nb), dim3(CL_THREADS), 0, stream, z, (int)R, C,
+                       gamma, beta, eps, momentum, training, running_mean, running_var, mean, rstd, scale,
+                       shift, out);
+    EDA_CHECK_LAUNCH();
+    return 0;
+  }
   if (training) {
     EDA_CHECK_ARG(ws, "workspace required");
     EDA_CHECK_HIP(hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, stream));
@@ -484,6 +639,13 @@ extern "C" int eda_bn_relu_bwd_f32(const float *dout, const unsigned char *argma
   if (R == 0) return 0;
   EDA_CHECK_ARG(dout && z && gamma && mean && rstd && scale && shift && ws && dz, "null pointer");
   EDA_CHECK_ARG(pool == 1 || argmax, "argmax required when pooling");
+  if (pool == 1 && R <= SMALL_ROWS) {
+    const int nb = (C / 4 + SM_CG - 1) / SM_CG;
+    hipLaunchKernelGGL(bn_relu_small_bwd_kernel, dim3(nb), dim3(CL_THREADS), 0, stream, dout, z, (int)R,
+                       C, gamma, mean, rstd, scale, shift, training, ws, ws + C, dz);
+    EDA_CHECK_LAUNCH();
+    return 0;
+  }
   EDA_CHECK_HIP(hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, stream));
   int nblocks = 1024;
   long rpb = (R + nblocks - 1) / nblocks;
