@@ -389,9 +389,10 @@ __global__ __launch_bounds__(CL_THREADS) void bn_relu_bwd_stats_vec_kernel(
 // (8 float4 column groups x 32 row lanes) for ALL rows, reduces its columns in LDS
 // (fp64 merge, no atomics), then sweeps the same rows again from L2 to apply.
 constexpr int SM_CG = 8;      // float4 column groups per workgroup
-constexpr int SM_RL = 32;     // row lanes
+constexpr int SM_RL = 128;    // row lanes (1024-thread workgroups: many loads in flight)
+constexpr int SM_THREADS = SM_CG * SM_RL;
 
-__global__ __launch_bounds__(CL_THREADS) void bn_relu_small_fwd_kernel(
+__global__ __launch_bounds__(SM_THREADS) void bn_relu_small_fwd_kernel(
     const float *__restrict__ z, int R, int C, const float *__restrict__ gamma,
     const float *__restrict__ beta, float eps, float momentum, int training,
     float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ mean_out,
@@ -406,6 +407,7 @@ __global__ __launch_bounds__(CL_THREADS) void bn_relu_small_fwd_kernel(
   if (training) {
     float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     if (valid)
+#pragma unroll 4
       for (int r = rl; r < R; r += SM_RL) {
         const float4 x = *reinterpret_cast<const float4 *>(z + (long)r * C + c0);
         s[0] += x.x; s[1] += x.y; s[2] += x.z; s[3] += x.w;
@@ -447,6 +449,7 @@ __global__ __launch_bounds__(CL_THREADS) void bn_relu_small_fwd_kernel(
   if (!valid) return;
   const float sc0 = sc_l[cgl * 4], sc1 = sc_l[cgl * 4 + 1], sc2 = sc_l[cgl * 4 + 2], sc3 = sc_l[cgl * 4 + 3];
   const float sh0 = sh_l[cgl * 4], sh1 = sh_l[cgl * 4 + 1], sh2 = sh_l[cgl * 4 + 2], sh3 = sh_l[cgl * 4 + 3];
+#pragma unroll 4
   for (int r = rl; r < R; r += SM_RL) {
     const float4 x = *reinterpret_cast<const float4 *>(z + (long)r * C + c0);
     float4 y;
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(CL_THREADS) void bn_relu_small_fwd_kernel(
   }
 }
 
-__global__ __launch_bounds__(CL_THREADS) void bn_relu_small_bwd_kernel(
+__global__ __launch_bounds__(SM_THREADS) void bn_relu_small_bwd_kernel(
     const float *__restrict__ da, const float *__restrict__ z, int R, int C,
     const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ rstd,
     const float *__restrict__ scale, const float *__restrict__ shift, int train,
@@ -474,6 +477,7 @@ __global__ __launch_bounds__(CL_THREADS) void bn_relu_small_bwd_kernel(
   }
   float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
   if (valid)
+#pragma unroll 4
     for (int r = rl; r < R; r += SM_RL) {
       const float4 x4 = *reinterpret_cast<const float4 *>(z + (long)r * C + c0);
       const float4 d4 = *reinterpret_cast<const float4 *>(da + (long)r * C + c0);
@@ -512,6 +516,7 @@ __global__ __launch_bounds__(CL_THREADS) void bn_relu_small_bwd_kernel(
   float ka[4], kb[4], kd[4];
 #pragma unroll
   for (int v = 0; v < 4; ++v) { ka[v] = ka_l[cgl * 4 + v]; kb[v] = kb_l[cgl * 4 + v]; kd[v] = kd_l[cgl * 4 + v]; }
+#pragma unroll 4
   for (int r = rl; r < R; r += SM_RL) {
     const float4 x4 = *reinterpret_cast<const float4 *>(z + (long)r * C + c0);
     const float4 d4 = *reinterpret_cast<const float4 *>(da + (long)r * C + c0);
@@ -527,7 +532,7 @@ __global__ __launch_bounds__(CL_THREADS) void bn_relu_small_bwd_kernel(
   }
 }
 
-constexpr long SMALL_ROWS = 16384;   // below this the single-launch kernels win
+constexpr long SMALL_ROWS = 4096;    // below this the single-launch kernels win
 
 int grid_for(long work_items) {
   long g = (work_items + CL_THREADS - 1) / CL_THREADS;
@@ -589,7 +594,7 @@ extern "C" int eda_bn_relu_fwd_f32(const float *z, long R, int C, const float *g
   if (pool == 1 && R <= SMALL_ROWS) {
     EDA_CHECK_ARG(training || (running_mean && running_var), "eval mode needs running statistics");
     const int nb = (C / 4 + SM_CG - 1) / SM_CG;
-    hipLaunchKernelGGL(bn_relu_small_fwd_kernel, dim3(nb), dim3(CL_THREADS), 0, stream, z, (int)R, C,
+    hipLaunchKernelGGL(bn_relu_small_fwd_kernel, dim3(nb), dim3(SM_THREADS), 0, stream, z, (int)R, C,
                        gamma, beta, eps, momentum, training, running_mean, running_var, mean, rstd, scale,
                        shift, out);
     EDA_CHECK_LAUNCH();
@@ -641,7 +646,7 @@ extern "C" int eda_bn_relu_bwd_f32(const float *dout, const unsigned char *argma
   EDA_CHECK_ARG(pool == 1 || argmax, "argmax required when pooling");
   if (pool == 1 && R <= SMALL_ROWS) {
     const int nb = (C / 4 + SM_CG - 1) / SM_CG;
-    hipLaunchKernelGGL(bn_relu_small_bwd_kernel, dim3(nb), dim3(CL_THREADS), 0, stream, dout, z, (int)R,
+    hipLaunchKernelGGL(bn_relu_small_bwd_kernel, dim3(nb), dim3(SM_THREADS), 0, stream, dout, z, (int)R,
                        C, gamma, mean, rstd, scale, shift, training, ws, ws + C, dz);
     EDA_CHECK_LAUNCH();
     return 0;
