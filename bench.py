@@ -289,29 +289,39 @@ def main():
             for _ in range(2):
                 eager_step()
         torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        if world == 1 and not args.split_graphs:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_loss = eager_step()
+        barrier_sync = (lambda: (dist.barrier() if world > 1 else None, torch.cuda.synchronize()))
+        barrier_sync()
+        # thread-local capture mode: calls from other threads (RCCL's watchdog) must not
+        # invalidate the capture.
+        mode = dict(capture_error_mode="thread_local")
+        try:
+            if world == 1 and not args.split_graphs:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, **mode):
+                    static_loss = eager_step()
 
-            def step():
-                graph.replay()
-                return static_loss
-        else:
-            g_fb, g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            pool = torch.cuda.graph_pool_handle()
-            with torch.cuda.graph(g_fb, pool=pool):
-                static_loss = fwd_bwd()
-            with torch.cuda.graph(g_up, pool=pool):
-                update()
+                def step():
+                    graph.replay()
+                    return static_loss
+            else:
+                g_fb, g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                pool = torch.cuda.graph_pool_handle()
+                with torch.cuda.graph(g_fb, pool=pool, **mode):
+                    static_loss = fwd_bwd()
+                with torch.cuda.graph(g_up, pool=pool, **mode):
+                    update()
 
-            def step():
-                g_fb.replay()
-                flat.all_reduce_mean(world)
-                g_up.replay()
-                return static_loss
-        log("step captured in HIP graph(s)")
+                def step():
+                    g_fb.replay()
+                    flat.all_reduce_mean(world)
+                    g_up.replay()
+                    return static_loss
+            log("step captured in HIP graph(s)")
+        except Exception as exc:     # never lose the run to a capture problem: fall back to eager launches
+            log(f"graph capture failed ({type(exc).__name__}: {exc}); falling back to eager launches")
+            torch.cuda.synchronize()
+            args.graph = 0
+            step = eager_step
 
     for _ in range(args.warmup):
         step()
@@ -399,7 +409,9 @@ def main():
                        "scenes_per_gpu": args.per_gpu, "global_batch": args.per_gpu * world,
                        "points": args.points, "queries": args.queries, "tokens": args.tokens,
                        "parallelism": f"dp{world}", "batchnorm": "per-GPU statistics",
-                       "launch": "hipGraph replay of the whole step" if args.graph else "eager",
+                       "launch": ("eager" if not args.graph else "hipGraph replay of the whole step" if world == 1
+                                  and not args.split_graphs else
+                                  "two hipGraphs (fwd+bwd | clip+AdamW) with the RCCL all-reduce between them"),
                        "text_encoder": "RoBERTa-base random-init frozen"},
             "roofline": roofline,
             "roofline_mfma": roofline_mfma,
