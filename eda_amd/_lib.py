@@ -23,7 +23,8 @@ SIGNATURES = {
     "eda_furthest_point_sampling_f32": (_i, [_p, _i, _i, _i, _p, _p, _sz, _p]),
     "eda_gather_points_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "eda_gather_points_grad_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
-    "eda_ball_query_f32": (_i, [_p, _p, _i, _i, _i, _f, _i, _p, _p]),
+    "eda_ball_query_workspace_bytes": (_sz, [_i, _i, _i]),
+    "eda_ball_query_f32": (_i, [_p, _p, _i, _i, _i, _f, _i, _p, _p, _sz, _p]),
     "eda_group_points_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "eda_group_points_grad_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "eda_three_nn_f32": (_i, [_p, _p, _i, _i, _i, _p, _p, _p]),

@@ -155,9 +155,15 @@ def ball_query(new_xyz, xyz, radius, nsample):
     m = new_xyz.shape[1]
     nsample = int(nsample)
     idx = torch.empty((new_xyz.shape[0], m, nsample), dtype=torch.int32, device=new_xyz.device)
+    L = _lib.lib()
+    ws, ws_bytes = None, 0
+    if n >= 4096:                      # large scenes: uniform-grid candidate search needs scratch
+        ws_bytes = L.eda_ball_query_workspace_bytes(b, n, m)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=new_xyz.device)
     with torch.cuda.device(new_xyz.device), _timed('ball_query', (b, n, m, nsample)):
-        rc = _lib.lib().eda_ball_query_f32(new_xyz.data_ptr(), xyz.data_ptr(), b, n, m,
-                                           float(radius), nsample, idx.data_ptr(), _stream())
+        rc = L.eda_ball_query_f32(new_xyz.data_ptr(), xyz.data_ptr(), b, n, m, float(radius), nsample,
+                                  idx.data_ptr(), ws.data_ptr() if ws is not None else None, ws_bytes,
+                                  _stream())
     _lib.check(rc, "eda_ball_query_f32")
     return idx
 

@@ -78,10 +78,16 @@ int eda_gather_points_grad_f32(const float *grad_out, const int *idx, int b,
  *          query_ball_point_kernel    src/ball_query_gpu.cu:14-59
  * new_xyz (b,m,3), xyz (b,n,3) -> idx (b,m,nsample): the first `nsample`
  * points with d2 < radius^2 in ascending index order, padded with the first
- * hit; an empty ball yields an all-zero row.                               */
+ * hit; an empty ball yields an all-zero row.
+
+ * ws: optional scratch of eda_ball_query_workspace_bytes(b,n,m) bytes.  With it,
+ * scenes of n >= 4096 points use a uniform-grid candidate search (cells >= 1.001 *
+ * radius, 3x3x3 neighbourhood, hits ranked by index) instead of the brute-force
+ * index-ordered scan; the result is identical.  ws == NULL always scans.       */
+size_t eda_ball_query_workspace_bytes(int b, int n, int m);
 int eda_ball_query_f32(const float *new_xyz, const float *xyz, int b, int n,
                        int m, float radius, int nsample, int *idx,
-                       void *stream);
+                       void *ws, size_t ws_bytes, void *stream);
 
 /* ---- grouping ---------------------------------------------------------
  * replaces group_points()        src/group_points.cpp:17-40, group_points_gpu.cu:13-45
