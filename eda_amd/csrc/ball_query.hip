@@ -372,7 +372,7 @@ extern "C" int eda_ball_query_f32(const float *new_xyz, const float *xyz, int b,
   int *pt_slot = reinterpret_cast<int *>(w);                     w += ((sizeof(int) * (size_t)b * n + 63) / 64) * 64;
   float4 *sorted = reinterpret_cast<float4 *>(w);
 
-  EDA_CHECK_HIP(hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t)b * GQ_NC, stream));
+  { const int zrc__ = eda_zero_async(cell_count, sizeof(int) * (size_t)b * GQ_NC, stream); if (zrc__) return zrc__; }
   hipLaunchKernelGGL(gq_bbox_kernel, dim3(b), dim3(1024), 0, stream, xyz, n, radius, gp);
   EDA_CHECK_LAUNCH();
   const dim3 pgrid((unsigned)((n + 255) / 256), (unsigned)b);

@@ -102,3 +102,8 @@ __device__ __forceinline__ unsigned eda_wave_min_u32(unsigned v) {
 __device__ __forceinline__ int eda_lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
+
+// Zero-fill on the stream with a kernel (not hipMemsetAsync): memset NODES of a captured
+// HIP graph were observed to race with the kernel nodes that consume the zeroed buffer
+// on ROCm 7.2 (ball-query cell table corrupted under graph replay), kernel nodes are not.
+int eda_zero_async(void *ptr, size_t bytes, hipStream_t stream);

@@ -347,7 +347,7 @@ extern "C" int eda_furthest_point_sampling_f32(const float *xyz, int b, int n, i
     return EDA_ERR_UNSUPPORTED;
   }
 
-  EDA_CHECK_HIP(hipMemsetAsync(ws, 0, eda_fps_workspace_bytes(b, n, m), stream));
+  { const int zrc__ = eda_zero_async(ws, eda_fps_workspace_bytes(b, n, m), stream); if (zrc__) return zrc__; }
   int *status = reinterpret_cast<int *>(ws);
   u64 *mail = reinterpret_cast<u64 *>(reinterpret_cast<unsigned char *>(ws) + kStatusBytes);
 

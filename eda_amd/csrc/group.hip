@@ -165,7 +165,7 @@ extern "C" int eda_group_points_grad_f32(const float *grad_out, const int *idx, 
   const long long J = (long long)npoints * nsample;
   if (b == 0 || c == 0 || n == 0) return 0;
   EDA_CHECK_ARG(grad_points, "null pointer");
-  EDA_CHECK_HIP(hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * c * n, stream));
+  { const int zrc__ = eda_zero_async(grad_points, sizeof(float) * (size_t)b * c * n, stream); if (zrc__) return zrc__; }
   if (J == 0) return 0;
   EDA_CHECK_ARG(grad_out && idx, "null pointer");
   EDA_CHECK_ARG(J < (1ll << 31) && b <= 65535 && (c + GP_CT - 1) / GP_CT <= 65535, "shape too large");
@@ -201,7 +201,7 @@ extern "C" int eda_gather_points_grad_f32(const float *grad_out, const int *idx,
   EDA_CHECK_ARG(b >= 0 && c >= 0 && n >= 0 && m >= 0, "negative dimension");
   if (b == 0 || c == 0 || n == 0) return 0;
   EDA_CHECK_ARG(grad_points, "null pointer");
-  EDA_CHECK_HIP(hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * c * n, stream));
+  { const int zrc__ = eda_zero_async(grad_points, sizeof(float) * (size_t)b * c * n, stream); if (zrc__) return zrc__; }
   if (m == 0) return 0;
   EDA_CHECK_ARG(grad_out && idx, "null pointer");
   EDA_CHECK_ARG(b <= 65535 && c <= 65535, "shape too large");

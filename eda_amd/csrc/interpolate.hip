@@ -161,7 +161,7 @@ extern "C" int eda_three_interpolate_grad_f32(const float *grad_out, const int *
   EDA_CHECK_ARG(b >= 0 && c >= 0 && n >= 0 && m >= 0, "negative dimension");
   if (b == 0 || c == 0 || m == 0) return 0;
   EDA_CHECK_ARG(grad_points, "null pointer");
-  EDA_CHECK_HIP(hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * c * m, stream));
+  { const int zrc__ = eda_zero_async(grad_points, sizeof(float) * (size_t)b * c * m, stream); if (zrc__) return zrc__; }
   if (n == 0) return 0;
   EDA_CHECK_ARG(grad_out && idx && weight, "null pointer");
   EDA_CHECK_ARG(b <= 65535 && (c + 7) / 8 <= 65535, "shape too large");

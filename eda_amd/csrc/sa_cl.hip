@@ -566,7 +566,7 @@ extern "C" int eda_group_concat_cl_grad_f32(const float *dx, const int *idx, int
   EDA_CHECK_ARG(b >= 0 && n >= 0 && m >= 0 && ns >= 0 && c >= 0, "negative dimension");
   if (b == 0 || n == 0 || c == 0) return 0;
   EDA_CHECK_ARG(dfeats_cl, "null pointer");
-  EDA_CHECK_HIP(hipMemsetAsync(dfeats_cl, 0, sizeof(float) * (size_t)b * n * c, stream));
+  { const int zrc__ = eda_zero_async(dfeats_cl, sizeof(float) * (size_t)b * n * c, stream); if (zrc__) return zrc__; }
   if (m == 0 || ns == 0) return 0;
   EDA_CHECK_ARG(dx && idx && b <= 65535, "bad arguments");
   const long total = (long)m * ns * c;
@@ -602,7 +602,7 @@ extern "C" int eda_bn_relu_fwd_f32(const float *z, long R, int C, const float *g
   }
   if (training) {
     EDA_CHECK_ARG(ws, "workspace required");
-    EDA_CHECK_HIP(hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, stream));
+    { const int zrc__ = eda_zero_async(ws, sizeof(double) * 2 * C, stream); if (zrc__) return zrc__; }
     const int cgroups = C / 4;
     int nblocks = 2048;
     long rpb = (R + nblocks - 1) / nblocks;
@@ -651,7 +651,7 @@ extern "C" int eda_bn_relu_bwd_f32(const float *dout, const unsigned char *argma
     EDA_CHECK_LAUNCH();
     return 0;
   }
-  EDA_CHECK_HIP(hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, stream));
+  { const int zrc__ = eda_zero_async(ws, sizeof(double) * 2 * C, stream); if (zrc__) return zrc__; }
   int nblocks = 1024;
   long rpb = (R + nblocks - 1) / nblocks;
   if (rpb < 64) rpb = 64;
