@@ -1,0 +1,20 @@
+"""The HIP-graph-replayed training step (what bench.py times) must compute the same thing as
+eager launches of the same step: first loss identical, later losses / parameters equal to the
+noise of fp32 atomics.  (Guards e.g. against mis-ordered memset nodes under graph replay.)"""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+def test_graph_replay_matches_eager_training_steps():
+    import check_graph_vs_eager as C
+    losses, bad, rel = C.compare(steps=3, scenes=2, points=20000, tokens=24, verbose=False,
+                                 num_queries=64, num_decoder_layers=2)
+    assert abs(losses["eager"][0] - losses["graph"][0]) <= 1e-5 * abs(losses["eager"][0])
+    assert bad < 2e-3, losses
+    assert rel < 1e-3

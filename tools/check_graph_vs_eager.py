@@ -23,20 +23,19 @@ def no_dropout(m):
             mod.dropout = 0.0
 
 
-def make(seed, dev):
+def make(seed, dev, **kw):
     torch.manual_seed(seed)
-    m = BeaUTyDETR().to(dev).train()
+    m = BeaUTyDETR(**kw).to(dev).train()
     m.text_encoder.eval()
     no_dropout(m)
     return m
 
 
-def main():
+def compare(steps=4, scenes=8, points=50000, tokens=80, verbose=True, **model_kw):
     dev = torch.device("cuda", 0)
-    steps = int(os.environ.get("STEPS", 4))
-    a = make(0, dev)
+    a = make(0, dev, **model_kw)
     b = copy.deepcopy(a)
-    inputs = bench.make_inputs(0, 8, dev, 50000, 80)
+    inputs = bench.make_inputs(0, scenes, dev, points, tokens)
     losses = {}
     for name, model, use_graph in (("eager", a, False), ("graph", b, True)):
         flat = FlatParams(model)
@@ -70,13 +69,20 @@ def main():
                 out.append(float(step().detach()))
         torch.cuda.synchronize()
         losses[name] = out
-        print(name, ["%.6f" % v for v in out])
+        if verbose:
+            print(name, ["%.6f" % v for v in out])
     pa = torch.cat([p.detach().reshape(-1) for p in a.parameters() if p.requires_grad])
     pb = torch.cat([p.detach().reshape(-1) for p in b.parameters() if p.requires_grad])
     rel = ((pa - pb).abs().max() / pa.abs().max()).item()
-    print("max |param diff| / max |param| after %d steps: %.3e" % (steps, rel))
     bad = max(abs(x - y) / max(abs(x), 1e-9) for x, y in zip(losses["eager"], losses["graph"]))
-    print("max relative loss difference: %.3e" % bad)
+    if verbose:
+        print("max |param diff| / max |param| after %d steps: %.3e" % (steps, rel))
+        print("max relative loss difference: %.3e" % bad)
+    return losses, bad, rel
+
+
+def main():
+    losses, bad, rel = compare(steps=int(os.environ.get("STEPS", 4)))
     assert bad < 2e-3 and rel < 1e-3, "graph replay diverges from eager execution"
     print("OK: graph replay == eager (to atomics-level noise)")
 
