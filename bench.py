@@ -91,7 +91,8 @@ def synthetic_loss(end_points):
     no host sync (SURVEY.md §8d 'Loss for bwd')."""
     loss = end_points["seeds_obj_cls_logits"].pow(2).mean()
     proj_tokens = end_points["proj_tokens"]
-    for p in ["proposal_", "0head_", "1head_", "2head_", "3head_", "4head_", "last_"]:
+    prefixes = [k[:-len("center")] for k in end_points if k.endswith("center")]   # proposal_, {i}head_, last_
+    for p in prefixes:
         loss = loss + end_points[f"{p}center"].pow(2).sum(-1).mean()
         loss = loss + end_points[f"{p}pred_size"].pow(2).sum(-1).mean()
         loss = loss + end_points[f"{p}sem_cls_scores"].pow(2).mean()
