@@ -380,7 +380,9 @@ def main():
         kernels.sort(key=lambda k: -k["ms"] * k["calls_per_step"])
         native_ms = sum(k["ms"] * k["calls_per_step"] for k in kernels)
         # dominant HBM-priced kernel (FPS is latency-bound: reported as us/round below)
-        hbm = [k for k in kernels if k["alg_bytes"] > 0 and k["op"] != "furthest_point_sampling"]
+        # HBM-priced candidates: launches that move at least 32 MB (smaller ones are launch- or
+        # latency-bound and are listed in `kernels` only); FPS is latency-bound and reported below.
+        hbm = [k for k in kernels if k["alg_bytes"] >= (32 << 20) and k["op"] != "furthest_point_sampling"]
         dom = hbm[0] if hbm else None
         roofline = None
         if dom:

@@ -407,7 +407,7 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_fwd_kernel(
   if (training) {
     float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     if (valid)
-#pragma unroll 4
+#pragma unroll 8
       for (int r = rl; r < R; r += SM_RL) {
         const float4 x = *reinterpret_cast<const float4 *>(z + (long)r * C + c0);
         s[0] += x.x; s[1] += x.y; s[2] += x.z; s[3] += x.w;
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_fwd_kernel(
   if (!valid) return;
   const float sc0 = sc_l[cgl * 4], sc1 = sc_l[cgl * 4 + 1], sc2 = sc_l[cgl * 4 + 2], sc3 = sc_l[cgl * 4 + 3];
   const float sh0 = sh_l[cgl * 4], sh1 = sh_l[cgl * 4 + 1], sh2 = sh_l[cgl * 4 + 2], sh3 = sh_l[cgl * 4 + 3];
-#pragma unroll 4
+#pragma unroll 8
   for (int r = rl; r < R; r += SM_RL) {
     const float4 x = *reinterpret_cast<const float4 *>(z + (long)r * C + c0);
     float4 y;
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_bwd_kernel(
   }
   float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
   if (valid)
-#pragma unroll 4
+#pragma unroll 8
     for (int r = rl; r < R; r += SM_RL) {
       const float4 x4 = *reinterpret_cast<const float4 *>(z + (long)r * C + c0);
       const float4 d4 = *reinterpret_cast<const float4 *>(da + (long)r * C + c0);
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_bwd_kernel(
   float ka[4], kb[4], kd[4];
 #pragma unroll
   for (int v = 0; v < 4; ++v) { ka[v] = ka_l[cgl * 4 + v]; kb[v] = kb_l[cgl * 4 + v]; kd[v] = kd_l[cgl * 4 + v]; }
-#pragma unroll 4
+#pragma unroll 8
   for (int r = rl; r < R; r += SM_RL) {
     const float4 x4 = *reinterpret_cast<const float4 *>(z + (long)r * C + c0);
     const float4 d4 = *reinterpret_cast<const float4 *>(da + (long)r * C + c0);
