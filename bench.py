@@ -210,6 +210,8 @@ def main():
                     help="internal: run only the host-CPU leg and print its JSON object")
     ap.add_argument("--cpu-timeout", type=int, default=150)
     ap.add_argument("--no-butd", action="store_true")
+    ap.add_argument("--blas", choices=["default", "rocblas", "hipblaslt"], default="default",
+                    help="torch.backends.cuda.preferred_blas_library for the library GEMMs")
     ap.add_argument("--overlap", action="store_true",
                     help="run the text encoder on a side stream underneath the point backbone (measured slower)")
     ap.add_argument("--split-graphs", action="store_true",
@@ -242,6 +244,8 @@ def main():
     from eda_amd import ext
     from eda_amd.bdetr import BeaUTyDETR
     from eda_amd.parallel import FlatParams, reference_lr_groups
+    if args.blas != "default":
+        torch.backends.cuda.preferred_blas_library("cublas" if args.blas == "rocblas" else "cublaslt")
 
     torch.manual_seed(0)                       # same init on every rank (DDP broadcast equivalent)
     model = BeaUTyDETR(num_queries=args.queries, butd=not args.no_butd).to(device).train()

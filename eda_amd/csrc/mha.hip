@@ -303,7 +303,17 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_dq_kernel(MhaArgs a) {
     dreg[s] = qvalid ? drow[4 * s + g] : 0.f;
   }
   const float lse = qvalid ? a.lse[(long)bh * a.Lq + qi] : 0.f;
-  const float delta = qvalid ? a.delta[(long)bh * a.Lq + qi] : 0.f;
+  // delta = rowsum(dO * O): each of the 4 lane groups holds 9 of the 36 head dims of its query;
+  // computed here (and published for the dK/dV kernel, which runs after this one) instead of
+  // in a separate pre-pass launch.
+  float delta = 0.f;
+  {
+    const float *orow = a.o + (long)b * a.o_sb + (long)(qvalid ? qi : 0) * a.o_sl + h * HD;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) delta += qvalid ? dreg[s] * orow[4 * s + g] : 0.f;
+    delta = xor_sum(delta);
+    if (qvalid && g == 0) const_cast<float *>(a.delta)[(long)bh * a.Lq + qi] = delta;
+  }
 
   const float *kbase = a.k + (long)b * a.k_sb + h * HD;
   const float *vbase = a.v + (long)b * a.v_sb + h * HD;
@@ -559,11 +569,9 @@ extern "C" int eda_mha_bwd_f32(const float *q, const float *k, const float *v, l
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.p_drop = p_drop; a.seed_ptr = seed_ptr;
   a.salt = salt; a.dout = dout; a.do_sb = do_sb; a.do_sl = do_sl; a.delta = delta_ws; a.dq = dq;
   a.dk = dk; a.dv = dv;
+  a.o = const_cast<float *>(out); a.o_sb = (long)Lq * H * HD; a.o_sl = (long)H * HD;
   if (Lq > 0) {
-    const long n = (long)B * H * Lq;
-    hipLaunchKernelGGL(mha_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, out,
-                       dout, (long)Lq * H * HD, (long)H * HD, do_sb, do_sl, B, H, Lq, delta_ws);
-    EDA_CHECK_LAUNCH();
+    // (delta = rowsum(dO * O) is computed inside the dQ kernel and published for dK/dV)
     const dim3 gq((unsigned)((Lq + WAVES * 16 - 1) / (WAVES * 16)), (unsigned)(B * H));
     hipLaunchKernelGGL(mha_bwd_dq_kernel, gq, dim3(THREADS), 0, stream, a);
     EDA_CHECK_LAUNCH();
