@@ -385,12 +385,18 @@ __global__ __launch_bounds__(CL_THREADS) void bn_relu_bwd_stats_vec_kernel(
 
 // ---------------------------------------------------------------- small inputs
 // For the heads / positional embeddings (R = B*Q ~ 2048 rows) the multi-launch scheme
-// above is launch-bound.  Here ONE launch does everything: a workgroup owns 32 channels
-// (8 float4 column groups x 32 row lanes) for ALL rows, reduces its columns in LDS
-// (fp64 merge, no atomics), then sweeps the same rows again from L2 to apply.
-constexpr int SM_CG = 8;      // float4 column groups per workgroup
-constexpr int SM_RL = 128;    // row lanes (1024-thread workgroups: many loads in flight)
-constexpr int SM_THREADS = SM_CG * SM_RL;
+// above is launch-bound.  Here ONE launch does everything: a 1024-thread workgroup owns one
+// float4 column group (4 channels) for ALL rows -- C/4 workgroups, every thread only 2-4 rows,
+// so all loads are in flight at once; column sums by wave shuffles + a 16-entry LDS merge in
+// fp64; the second sweep re-reads the same rows from L2.
+constexpr int SM_THREADS = 1024;
+constexpr int SM_WAVES = SM_THREADS / 64;
+
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
 
 __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_fwd_kernel(
     const float *__restrict__ z, int R, int C, const float *__restrict__ gamma,
@@ -398,59 +404,54 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_fwd_kernel(
     float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ mean_out,
     float *__restrict__ rstd_out, float *__restrict__ scale_out, float *__restrict__ shift_out,
     float *__restrict__ out) {
-  __shared__ float red[2][SM_CG * 4][SM_RL + 1];
-  __shared__ float sc_l[SM_CG * 4], sh_l[SM_CG * 4];
-  const int cgl = threadIdx.x & (SM_CG - 1), rl = threadIdx.x >> 3;
-  const int cg = blockIdx.x * SM_CG + cgl;
-  const bool valid = cg < C / 4;
-  const int c0 = cg * 4;
+  __shared__ float red[8][SM_WAVES];
+  __shared__ float sc_l[4], sh_l[4];
+  const int c0 = blockIdx.x * 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (training) {
     float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-    if (valid)
-#pragma unroll 8
-      for (int r = rl; r < R; r += SM_RL) {
-        const float4 x = *reinterpret_cast<const float4 *>(z + (long)r * C + c0);
-        s[0] += x.x; s[1] += x.y; s[2] += x.z; s[3] += x.w;
-        q[0] += x.x * x.x; q[1] += x.y * x.y; q[2] += x.z * x.z; q[3] += x.w * x.w;
-      }
+#pragma unroll 4
+    for (int r = threadIdx.x; r < R; r += SM_THREADS) {
+      const float4 x = *reinterpret_cast<const float4 *>(z + (long)r * C + c0);
+      s[0] += x.x; s[1] += x.y; s[2] += x.z; s[3] += x.w;
+      q[0] += x.x * x.x; q[1] += x.y * x.y; q[2] += x.z * x.z; q[3] += x.w * x.w;
+    }
 #pragma unroll
-    for (int v = 0; v < 4; ++v) { red[0][cgl * 4 + v][rl] = s[v]; red[1][cgl * 4 + v][rl] = q[v]; }
+    for (int v = 0; v < 4; ++v) {
+      const float a = wave_sum64(s[v]), b = wave_sum64(q[v]);
+      if (lane == 0) { red[v][wave] = a; red[4 + v][wave] = b; }
+    }
     __syncthreads();
-    if (threadIdx.x < SM_CG * 4) {
-      const int c = blockIdx.x * SM_CG * 4 + threadIdx.x;
-      if (c < C) {
-        double a = 0.0, b = 0.0;
-        for (int l = 0; l < SM_RL; ++l) { a += (double)red[0][threadIdx.x][l]; b += (double)red[1][threadIdx.x][l]; }
-        const double mean = a / (double)R;
-        double var = b / (double)R - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float meanf = (float)mean;
-        const float sc = gamma[c] * rstd, sh = beta[c] - meanf * sc;
-        mean_out[c] = meanf; rstd_out[c] = rstd; scale_out[c] = sc; shift_out[c] = sh;
-        sc_l[threadIdx.x] = sc; sh_l[threadIdx.x] = sh;
-        if (running_mean) {
-          const double unbiased = R > 1 ? var * (double)R / (double)(R - 1) : var;
-          running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
-          running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-        }
+    if (threadIdx.x < 4) {
+      const int c = c0 + threadIdx.x;
+      double a = 0.0, b = 0.0;
+      for (int w = 0; w < SM_WAVES; ++w) { a += (double)red[threadIdx.x][w]; b += (double)red[4 + threadIdx.x][w]; }
+      const double mean = a / (double)R;
+      double var = b / (double)R - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+      const float meanf = (float)mean;
+      const float sc = gamma[c] * rstd, sh = beta[c] - meanf * sc;
+      mean_out[c] = meanf; rstd_out[c] = rstd; scale_out[c] = sc; shift_out[c] = sh;
+      sc_l[threadIdx.x] = sc; sh_l[threadIdx.x] = sh;
+      if (running_mean) {
+        const double unbiased = R > 1 ? var * (double)R / (double)(R - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
       }
     }
-  } else if (threadIdx.x < SM_CG * 4) {
-    const int c = blockIdx.x * SM_CG * 4 + threadIdx.x;
-    if (c < C) {
-      const float rstd = 1.f / sqrtf(running_var[c] + eps);
-      const float sc = gamma[c] * rstd, sh = beta[c] - running_mean[c] * sc;
-      mean_out[c] = running_mean[c]; rstd_out[c] = rstd; scale_out[c] = sc; shift_out[c] = sh;
-      sc_l[threadIdx.x] = sc; sh_l[threadIdx.x] = sh;
-    }
+  } else if (threadIdx.x < 4) {
+    const int c = c0 + threadIdx.x;
+    const float rstd = 1.f / sqrtf(running_var[c] + eps);
+    const float sc = gamma[c] * rstd, sh = beta[c] - running_mean[c] * sc;
+    mean_out[c] = running_mean[c]; rstd_out[c] = rstd; scale_out[c] = sc; shift_out[c] = sh;
+    sc_l[threadIdx.x] = sc; sh_l[threadIdx.x] = sh;
   }
   __syncthreads();
-  if (!valid) return;
-  const float sc0 = sc_l[cgl * 4], sc1 = sc_l[cgl * 4 + 1], sc2 = sc_l[cgl * 4 + 2], sc3 = sc_l[cgl * 4 + 3];
-  const float sh0 = sh_l[cgl * 4], sh1 = sh_l[cgl * 4 + 1], sh2 = sh_l[cgl * 4 + 2], sh3 = sh_l[cgl * 4 + 3];
-#pragma unroll 8
-  for (int r = rl; r < R; r += SM_RL) {
+  const float sc0 = sc_l[0], sc1 = sc_l[1], sc2 = sc_l[2], sc3 = sc_l[3];
+  const float sh0 = sh_l[0], sh1 = sh_l[1], sh2 = sh_l[2], sh3 = sh_l[3];
+#pragma unroll 4
+  for (int r = threadIdx.x; r < R; r += SM_THREADS) {
     const float4 x = *reinterpret_cast<const float4 *>(z + (long)r * C + c0);
     float4 y;
     y.x = fmaxf(x.x * sc0 + sh0, 0.f); y.y = fmaxf(x.y * sc1 + sh1, 0.f);
@@ -464,60 +465,55 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_bwd_kernel(
     const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ rstd,
     const float *__restrict__ scale, const float *__restrict__ shift, int train,
     double *__restrict__ s1_out, double *__restrict__ s2_out, float *__restrict__ dz) {
-  __shared__ float red[2][SM_CG * 4][SM_RL + 1];
-  __shared__ float ka_l[SM_CG * 4], kb_l[SM_CG * 4], kd_l[SM_CG * 4];
-  const int cgl = threadIdx.x & (SM_CG - 1), rl = threadIdx.x >> 3;
-  const int cg = blockIdx.x * SM_CG + cgl;
-  const bool valid = cg < C / 4;
-  const int c0 = cg * 4;
-  float sc[4] = {0, 0, 0, 0}, sh[4] = {0, 0, 0, 0}, mu[4] = {0, 0, 0, 0}, rs[4] = {0, 0, 0, 0};
-  if (valid) {
+  __shared__ float red[8][SM_WAVES];
+  __shared__ float ka_l[4], kb_l[4], kd_l[4];
+  const int c0 = blockIdx.x * 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float sc[4], sh[4], mu[4], rs[4];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) { sc[v] = scale[c0 + v]; sh[v] = shift[c0 + v]; mu[v] = mean[c0 + v]; rs[v] = rstd[c0 + v]; }
-  }
+  for (int v = 0; v < 4; ++v) { sc[v] = scale[c0 + v]; sh[v] = shift[c0 + v]; mu[v] = mean[c0 + v]; rs[v] = rstd[c0 + v]; }
   float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
-  if (valid)
-#pragma unroll 8
-    for (int r = rl; r < R; r += SM_RL) {
-      const float4 x4 = *reinterpret_cast<const float4 *>(z + (long)r * C + c0);
-      const float4 d4 = *reinterpret_cast<const float4 *>(da + (long)r * C + c0);
-      const float x[4] = {x4.x, x4.y, x4.z, x4.w};
-      const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll 4
+  for (int r = threadIdx.x; r < R; r += SM_THREADS) {
+    const float4 x4 = *reinterpret_cast<const float4 *>(z + (long)r * C + c0);
+    const float4 d4 = *reinterpret_cast<const float4 *>(da + (long)r * C + c0);
+    const float x[4] = {x4.x, x4.y, x4.z, x4.w};
+    const float d[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const float dy = (x[v] * sc[v] + sh[v]) > 0.f ? d[v] : 0.f;
-        a1[v] += dy;
-        a2[v] += dy * (x[v] - mu[v]) * rs[v];
-      }
+    for (int v = 0; v < 4; ++v) {
+      const float dy = (x[v] * sc[v] + sh[v]) > 0.f ? d[v] : 0.f;
+      a1[v] += dy;
+      a2[v] += dy * (x[v] - mu[v]) * rs[v];
     }
+  }
 #pragma unroll
-  for (int v = 0; v < 4; ++v) { red[0][cgl * 4 + v][rl] = a1[v]; red[1][cgl * 4 + v][rl] = a2[v]; }
+  for (int v = 0; v < 4; ++v) {
+    const float a = wave_sum64(a1[v]), b = wave_sum64(a2[v]);
+    if (lane == 0) { red[v][wave] = a; red[4 + v][wave] = b; }
+  }
   __syncthreads();
-  if (threadIdx.x < SM_CG * 4) {
-    const int c = blockIdx.x * SM_CG * 4 + threadIdx.x;
-    if (c < C) {
-      double t1 = 0.0, t2 = 0.0;
-      for (int l = 0; l < SM_RL; ++l) { t1 += (double)red[0][threadIdx.x][l]; t2 += (double)red[1][threadIdx.x][l]; }
-      s1_out[c] = t1; s2_out[c] = t2;
-      const float invR = 1.f / (float)R;
-      const float gr = gamma[c] * rstd[c];
-      ka_l[threadIdx.x] = gr;
-      if (train) {
-        const float k2 = rstd[c] * (float)t2 * invR;
-        kb_l[threadIdx.x] = -gr * k2;
-        kd_l[threadIdx.x] = gr * (mean[c] * k2 - (float)t1 * invR);
-      } else {
-        kb_l[threadIdx.x] = 0.f; kd_l[threadIdx.x] = 0.f;
-      }
+  if (threadIdx.x < 4) {
+    const int c = c0 + threadIdx.x;
+    double t1 = 0.0, t2 = 0.0;
+    for (int w = 0; w < SM_WAVES; ++w) { t1 += (double)red[threadIdx.x][w]; t2 += (double)red[4 + threadIdx.x][w]; }
+    s1_out[c] = t1; s2_out[c] = t2;
+    const float invR = 1.f / (float)R;
+    const float gr = gamma[c] * rstd[c];
+    ka_l[threadIdx.x] = gr;
+    if (train) {
+      const float k2 = rstd[c] * (float)t2 * invR;
+      kb_l[threadIdx.x] = -gr * k2;
+      kd_l[threadIdx.x] = gr * (mean[c] * k2 - (float)t1 * invR);
+    } else {
+      kb_l[threadIdx.x] = 0.f; kd_l[threadIdx.x] = 0.f;
     }
   }
   __syncthreads();
-  if (!valid) return;
   float ka[4], kb[4], kd[4];
 #pragma unroll
-  for (int v = 0; v < 4; ++v) { ka[v] = ka_l[cgl * 4 + v]; kb[v] = kb_l[cgl * 4 + v]; kd[v] = kd_l[cgl * 4 + v]; }
-#pragma unroll 8
-  for (int r = rl; r < R; r += SM_RL) {
+  for (int v = 0; v < 4; ++v) { ka[v] = ka_l[v]; kb[v] = kb_l[v]; kd[v] = kd_l[v]; }
+#pragma unroll 4
+  for (int r = threadIdx.x; r < R; r += SM_THREADS) {
     const float4 x4 = *reinterpret_cast<const float4 *>(z + (long)r * C + c0);
     const float4 d4 = *reinterpret_cast<const float4 *>(da + (long)r * C + c0);
     const float x[4] = {x4.x, x4.y, x4.z, x4.w};
@@ -532,7 +528,7 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_bwd_kernel(
   }
 }
 
-constexpr long SMALL_ROWS = 4096;    // below this the single-launch kernels win
+constexpr long SMALL_ROWS = 8192;    // below this the single-launch kernels win
 
 int grid_for(long work_items) {
   long g = (work_items + CL_THREADS - 1) / CL_THREADS;
@@ -593,7 +589,7 @@ extern "C" int eda_bn_relu_fwd_f32(const float *z, long R, int C, const float *g
   EDA_CHECK_ARG(z && gamma && beta && mean && rstd && scale && shift && out, "null pointer");
   if (pool == 1 && R <= SMALL_ROWS) {
     EDA_CHECK_ARG(training || (running_mean && running_var), "eval mode needs running statistics");
-    const int nb = (C / 4 + SM_CG - 1) / SM_CG;
+    const int nb = C / 4;
     hipLaunchKernelGGL(bn_relu_small_fwd_kernel, dim3(nb), dim3(SM_THREADS), 0, stream, z, (int)R, C,
                        gamma, beta, eps, momentum, training, running_mean, running_var, mean, rstd, scale,
                        shift, out);
@@ -645,7 +641,7 @@ extern "C" int eda_bn_relu_bwd_f32(const float *dout, const unsigned char *argma
   EDA_CHECK_ARG(dout && z && gamma && mean && rstd && scale && shift && ws && dz, "null pointer");
   EDA_CHECK_ARG(pool == 1 || argmax, "argmax required when pooling");
   if (pool == 1 && R <= SMALL_ROWS) {
-    const int nb = (C / 4 + SM_CG - 1) / SM_CG;
+    const int nb = C / 4;
     hipLaunchKernelGGL(bn_relu_small_bwd_kernel, dim3(nb), dim3(SM_THREADS), 0, stream, dout, z, (int)R,
                        C, gamma, mean, rstd, scale, shift, training, ws, ws + C, dz);
     EDA_CHECK_LAUNCH();
