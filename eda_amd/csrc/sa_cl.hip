@@ -528,7 +528,7 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_bwd_kernel(
   }
 }
 
-constexpr long SMALL_ROWS = 8192;    // below this the single-launch kernels win
+constexpr long SMALL_ROWS = 4096;    // below this the single-launch kernels win (at 8192 rows the strided sweep loses)
 
 int grid_for(long work_items) {
   long g = (work_items + CL_THREADS - 1) / CL_THREADS;
