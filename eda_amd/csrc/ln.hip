@@ -1,0 +1,198 @@
+// ln.hip -- fused residual + dropout + LayerNorm for gfx950.
+//
+// The reference's post-norm blocks (models/encoder_decoder_layers.py:94-96,106-122,154-156,
+// 184-186,371-405) all have the shape   x = norm(x + dropout(y))   with y coming out of an
+// attention out-projection or the second FFN linear: three launches forward (dropout, add,
+// layer_norm) and about five backward in stock PyTorch.  Here: one forward kernel (one wave
+// per row of d_model = 288 features, statistics by wave reductions, two-pass variance like
+// torch) and one backward kernel that produces dx, dy (dropout mask regenerated from the same
+// counter-based hash as the attention kernels) and accumulates d(gamma), d(beta).
+#include "eda_common.h"
+
+namespace {
+
+constexpr int LN_THREADS = 256;
+constexpr int LN_MAXI = 16;            // features per lane: C <= 1024
+
+__device__ __forceinline__ unsigned ln_hash32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float ln_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+struct LnDrop {
+  bool on; unsigned seed, thresh; float inv_keep;
+};
+__device__ __forceinline__ LnDrop ln_drop(float p, const unsigned long long *seed_ptr, unsigned salt) {
+  LnDrop d; d.on = p > 0.f; d.seed = 0; d.thresh = 0; d.inv_keep = 1.f;
+  if (d.on) {
+    d.seed = ln_hash32((unsigned)(*seed_ptr) * 0x9E3779B1u + salt);
+    d.thresh = (unsigned)((double)p * 4294967296.0);
+    d.inv_keep = 1.f / (1.f - p);
+  }
+  return d;
+}
+
+template <int NI>
+__global__ __launch_bounds__(LN_THREADS) void add_dropout_ln_fwd_kernel(
+    const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ gamma,
+    const float *__restrict__ beta, long R, int C, float eps, float p,
+    const unsigned long long *seed_ptr, unsigned salt, float *__restrict__ out,
+    float *__restrict__ mean_out, float *__restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (LN_THREADS / 64) + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const LnDrop d = ln_drop(p, seed_ptr, salt);
+  float v[NI];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int c = lane + 64 * i;
+    float t = 0.f;
+    if (c < C) {
+      float yy = y[row * C + c];
+      if (d.on) yy = ln_hash32(d.seed ^ (unsigned)(row * C + c)) >= d.thresh ? yy * d.inv_keep : 0.f;
+      t = x[row * C + c] + yy;
+    }
+    v[i] = t;
+    s += t;
+  }
+  const float mean = ln_wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int c = lane + 64 * i;
+    const float dlt = c < C ? v[i] - mean : 0.f;
+    q += dlt * dlt;
+  }
+  const float rstd = 1.f / sqrtf(ln_wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int c = lane + 64 * i;
+    if (c < C) out[row * C + c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+  }
+  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+template <int NI>
+__global__ __launch_bounds__(LN_THREADS) void add_dropout_ln_bwd_kernel(
+    const float *__restrict__ dout, const float *__restrict__ x, const float *__restrict__ y,
+    const float *__restrict__ gamma, const float *__restrict__ mean_in,
+    const float *__restrict__ rstd_in, long R, int C, float p, const unsigned long long *seed_ptr,
+    unsigned salt, float *__restrict__ dx, float *__restrict__ dy, float *__restrict__ dgamma,
+    float *__restrict__ dbeta) {
+  __shared__ float red[2][LN_THREADS / 64][64 * NI];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const LnDrop d = ln_drop(p, seed_ptr, salt);
+  float g[NI], dg[NI], db[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int c = lane + 64 * i;
+    g[i] = c < C ? gamma[c] : 0.f;
+    dg[i] = 0.f; db[i] = 0.f;
+  }
+  const long nwaves = (long)gridDim.x * (LN_THREADS / 64);
+  for (long row = (long)blockIdx.x * (LN_THREADS / 64) + wave; row < R; row += nwaves) {
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float xh[NI], gd[NI];
+    bool keep[NI];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = lane + 64 * i;
+      float xhat = 0.f, go = 0.f;
+      keep[i] = true;
+      if (c < C) {
+        float yy = y[row * C + c];
+        if (d.on) {
+          keep[i] = ln_hash32(d.seed ^ (unsigned)(row * C + c)) >= d.thresh;
+          yy = keep[i] ? yy * d.inv_keep : 0.f;
+        }
+        xhat = (x[row * C + c] + yy - mean) * rstd;
+        go = dout[row * C + c];
+        dg[i] += go * xhat;
+        db[i] += go;
+      }
+      xh[i] = xhat;
+      gd[i] = go * g[i];
+      s1 += gd[i];
+      s2 += gd[i] * xhat;
+    }
+    s1 = ln_wave_sum(s1) / (float)C;
+    s2 = ln_wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = lane + 64 * i;
+      if (c < C) {
+        const float dv = rstd * (gd[i] - s1 - xh[i] * s2);
+        dx[row * C + c] = dv;
+        dy[row * C + c] = d.on ? (keep[i] ? dv * d.inv_keep : 0.f) : dv;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) { red[0][wave][lane + 64 * i] = dg[i]; red[1][wave][lane + 64 * i] = db[i]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += LN_THREADS) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < LN_THREADS / 64; ++w) { a += red[0][w][c]; b += red[1][w][c]; }
+    atomicAdd(dgamma + c, a);
+    atomicAdd(dbeta + c, b);
+  }
+}
+
+}  // namespace
+
+#define LN_DISPATCH(NI_EXPR, KERNEL, GRID, ...)                                                   \
+  do {                                                                                             \
+    const int ni__ = (NI_EXPR);                                                                    \
+    if (ni__ <= 5) hipLaunchKernelGGL(KERNEL<5>, GRID, dim3(LN_THREADS), 0, stream, __VA_ARGS__);  \
+    else if (ni__ <= 8) hipLaunchKernelGGL(KERNEL<8>, GRID, dim3(LN_THREADS), 0, stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL<LN_MAXI>, GRID, dim3(LN_THREADS), 0, stream, __VA_ARGS__);      \
+  } while (0)
+
+extern "C" int eda_add_dropout_ln_fwd_f32(const float *x, const float *y, const float *gamma,
+                                          const float *beta, long R, int C, float eps, float p_drop,
+                                          const unsigned long long *seed_ptr, unsigned salt,
+                                          float *out, float *mean, float *rstd, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(R >= 0 && C > 0 && C <= 64 * LN_MAXI, "bad dimension (C <= 1024)");
+  if (R == 0) return 0;
+  EDA_CHECK_ARG(x && y && gamma && beta && out && mean && rstd, "null pointer");
+  EDA_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed_ptr), "bad dropout arguments");
+  EDA_CHECK_ARG(R * C < (1ll << 32), "R*C must fit the 32-bit dropout counter");
+  const dim3 grid((unsigned)((R + LN_THREADS / 64 - 1) / (LN_THREADS / 64)));
+  LN_DISPATCH((C + 63) / 64, add_dropout_ln_fwd_kernel, grid, x, y, gamma, beta, R, C, eps, p_drop,
+              seed_ptr, salt, out, mean, rstd);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}
+
+// dgamma / dbeta (C floats each) are zeroed here and accumulated with fp32 atomics.
+extern "C" int eda_add_dropout_ln_bwd_f32(const float *dout, const float *x, const float *y,
+                                          const float *gamma, const float *mean, const float *rstd,
+                                          long R, int C, float p_drop,
+                                          const unsigned long long *seed_ptr, unsigned salt,
+                                          float *dx, float *dy, float *dgamma, float *dbeta,
+                                          void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(R >= 0 && C > 0 && C <= 64 * LN_MAXI, "bad dimension (C <= 1024)");
+  EDA_CHECK_ARG(dgamma && dbeta, "null pointer");
+  { const int rc = eda_zero_async(dgamma, sizeof(float) * C, stream); if (rc) return rc; }
+  { const int rc = eda_zero_async(dbeta, sizeof(float) * C, stream); if (rc) return rc; }
+  if (R == 0) return 0;
+  EDA_CHECK_ARG(dout && x && y && gamma && mean && rstd && dx && dy, "null pointer");
+  long blocks = (R + 31) / 32;            // ~8 rows per wave: keeps the atomics to <= 256 x 2C
+  if (blocks > 256) blocks = 256;
+  if (blocks < 1) blocks = 1;
+  const dim3 grid((unsigned)blocks);
+  LN_DISPATCH((C + 63) / 64, add_dropout_ln_bwd_kernel, grid, dout, x, y, gamma, mean, rstd, R, C, p_drop,
+              seed_ptr, salt, dx, dy, dgamma, dbeta);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}

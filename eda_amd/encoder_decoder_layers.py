@@ -13,6 +13,7 @@ import torch
 from torch import nn
 
 from .attention import MultiheadAttention
+from .fused_ln import add_dropout_layer_norm, new_salt_base
 from .nn_utils import Conv1dK1, bn_relu_rows, rows_ok
 
 
@@ -23,6 +24,13 @@ def _get_clones(module, n):
 def _ffn(d_model, dim_feedforward, dropout):
     return nn.Sequential(nn.Linear(d_model, dim_feedforward), nn.ReLU(), nn.Dropout(dropout),
                          nn.Linear(dim_feedforward, d_model), nn.Dropout(dropout))
+
+
+def _ffn_residual_norm(x, ffn, norm, training, salt):
+    """norm(x + ffn(x)) where ffn = Linear, ReLU, Dropout, Linear, Dropout: the last Dropout is
+    applied inside the fused residual+LayerNorm kernel."""
+    h = ffn[3](ffn[2](ffn[1](ffn[0](x))))
+    return add_dropout_layer_norm(x, h, norm, ffn[4].p, training, salt)
 
 
 class PositionEmbeddingLearned(nn.Module):
@@ -75,23 +83,25 @@ class CrossAttentionLayer(nn.Module):
             self.cross_d = MultiheadAttention(d_model, n_heads, dropout=dropout)
             self.dropout_d = nn.Dropout(dropout)
             self.norm_d = nn.LayerNorm(d_model)
+        self._salt = new_salt_base()
 
     def forward(self, vis_feats, vis_key_padding_mask, text_feats, text_key_padding_mask,
                 pos_feats, detected_feats=None, detected_mask=None):
         # text attends to points: no positional term on the keys (:80-93)
         t2 = self.cross_lv(text_feats, vis_feats, vis_feats,
                            key_padding_mask=vis_key_padding_mask, batch_first=True)[0]
-        text_out = self.norm_lv(text_feats + self.dropout_lv(t2))
-        text_out = self.norm_lv2(text_out + self.ffn_lv(text_out))
+        tr, sb = self.training, self._salt
+        text_out = add_dropout_layer_norm(text_feats, t2, self.norm_lv, self.dropout_lv.p, tr, sb)
+        text_out = _ffn_residual_norm(text_out, self.ffn_lv, self.norm_lv2, tr, sb + 1)
         # points attend to the ORIGINAL text (:99-105), position added to the query only
         v2 = self.cross_vl(vis_feats + pos_feats, text_feats, text_feats,
                            key_padding_mask=text_key_padding_mask, batch_first=True)[0]
-        vis = self.norm_vl(vis_feats + self.dropout_vl(v2))
+        vis = add_dropout_layer_norm(vis_feats, v2, self.norm_vl, self.dropout_vl.p, tr, sb + 2)
         if detected_feats is not None and self.use_butd_enc_attn:
             v2 = self.cross_d(vis, detected_feats, detected_feats,
                               key_padding_mask=detected_mask, batch_first=True)[0]
-            vis = self.norm_d(vis + self.dropout_d(v2))
-        vis = self.norm_vl2(vis + self.ffn_vl(vis))
+            vis = add_dropout_layer_norm(vis, v2, self.norm_d, self.dropout_d.p, tr, sb + 3)
+        vis = _ffn_residual_norm(vis, self.ffn_vl, self.norm_vl2, tr, sb + 4)
         return vis, text_out
 
 
@@ -103,11 +113,12 @@ class TransformerEncoderLayerNoFFN(nn.Module):
         self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
         self.norm1 = nn.LayerNorm(d_model)
         self.dropout1 = nn.Dropout(dropout)
+        self._salt = new_salt_base()
 
     def forward(self, src, src_mask=None, src_key_padding_mask=None, batch_first=False):
         src2 = self.self_attn(src, src, src, attn_mask=src_mask,
                               key_padding_mask=src_key_padding_mask, batch_first=batch_first)[0]
-        return self.norm1(src + self.dropout1(src2))
+        return add_dropout_layer_norm(src, src2, self.norm1, self.dropout1.p, self.training, self._salt)
 
 
 class PosTransformerEncoderLayerNoFFN(TransformerEncoderLayerNoFFN):
@@ -117,7 +128,7 @@ class PosTransformerEncoderLayerNoFFN(TransformerEncoderLayerNoFFN):
         qk = src + pos
         src2 = self.self_attn(qk, qk, src, attn_mask=src_mask,
                               key_padding_mask=src_key_padding_mask, batch_first=batch_first)[0]
-        return self.norm1(src + self.dropout1(src2))
+        return add_dropout_layer_norm(src, src2, self.norm1, self.dropout1.p, self.training, self._salt)
 
 
 class BiEncoderLayer(nn.Module):
@@ -150,6 +161,11 @@ class BiEncoder(nn.Module):
         super().__init__()
         self.layers = _get_clones(bi_layer, num_layers)
         self.num_layers = num_layers
+        # clones share initial weights (as in the reference) but must not share dropout streams
+        for layer in self.layers:
+            for m in layer.modules():
+                if hasattr(m, "_salt") and not isinstance(m, MultiheadAttention):
+                    m._salt = new_salt_base()
 
     def forward(self, vis_feats, pos_feats, padding_mask, text_feats, text_padding_mask,
                 end_points={}, detected_feats=None, detected_mask=None):
@@ -187,6 +203,7 @@ class BiDecoderLayer(nn.Module):
             self.self_posembed = PositionEmbeddingLearned(6, d_model)
         else:
             self.self_posembed = None
+        self._salt = new_salt_base()
 
     def forward(self, query, vis_feats, lang_feats, query_pos, padding_mask, text_key_padding_mask,
                 detected_feats=None, detected_mask=None):
@@ -196,15 +213,16 @@ class BiDecoderLayer(nn.Module):
             pos = torch.zeros_like(query)
         qp = query + pos
         q2 = self.self_attn(qp, qp, query, key_padding_mask=padding_mask, batch_first=True)[0]
-        query = self.norm1(query + self.dropout1(q2))
+        tr, sb = self.training, self._salt
+        query = add_dropout_layer_norm(query, q2, self.norm1, self.dropout1.p, tr, sb)
         q2 = self.cross_l(query + pos, lang_feats, lang_feats,
                           key_padding_mask=text_key_padding_mask, batch_first=True)[0]
-        query = self.norm_l(query + self.dropout_l(q2))
+        query = add_dropout_layer_norm(query, q2, self.norm_l, self.dropout_l.p, tr, sb + 1)
         if detected_feats is not None:
             q2 = self.cross_d(query + pos, detected_feats, detected_feats,
                               key_padding_mask=detected_mask, batch_first=True)[0]
-            query = self.norm_d(query + self.dropout_d(q2))
+            query = add_dropout_layer_norm(query, q2, self.norm_d, self.dropout_d.p, tr, sb + 2)
         q2 = self.cross_v(query + pos, vis_feats, vis_feats, key_padding_mask=None, batch_first=True)[0]
-        query = self.norm_v(query + self.dropout_v(q2))
-        query = self.norm2(query + self.ffn(query))
+        query = add_dropout_layer_norm(query, q2, self.norm_v, self.dropout_v.p, tr, sb + 3)
+        query = _ffn_residual_norm(query, self.ffn, self.norm2, tr, sb + 4)
         return query.contiguous()

@@ -1,0 +1,75 @@
+"""LayerNorm(x + dropout(y)) as one fused HIP kernel pair (csrc/ln.hip).
+
+Every post-norm block of the reference's encoder/decoder has this shape
+(models/encoder_decoder_layers.py:94-96,106-122,154-156,184-186,371-405).  On the GPU the
+three stock launches (dropout, add, layer_norm) and their ~five backward launches become one
+forward and one backward kernel; on CPU tensors (host-logic tests) the same expression is
+evaluated with plain torch ops.
+"""
+import itertools
+
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import _lib
+from .attention import dropout_state
+from .ext import _timed
+
+_salt_counter = itertools.count(1 << 20)       # distinct from the attention call-site salts
+
+
+def new_salt_base():
+    return next(_salt_counter) * 16
+
+
+class _AddDropoutLN(Function):
+    @staticmethod
+    def forward(ctx, x, y, gamma, beta, eps, p_drop, salt):
+        shape = x.shape
+        C = shape[-1]
+        x2 = x.reshape(-1, C).contiguous()
+        y2 = y.reshape(-1, C).contiguous()
+        R = x2.shape[0]
+        dev = x.device
+        out = torch.empty_like(x2)
+        stats = torch.empty((2, R), dtype=torch.float32, device=dev)
+        seed = dropout_state(dev) if p_drop > 0 else None
+        with torch.cuda.device(dev), _timed("add_dropout_ln_fwd", (R, C)):
+            rc = _lib.lib().eda_add_dropout_ln_fwd_f32(
+                x2.data_ptr(), y2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), R, C, float(eps),
+                float(p_drop), seed.data_ptr() if seed is not None else None, int(salt),
+                out.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+                torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "eda_add_dropout_ln_fwd_f32")
+        ctx.save_for_backward(x2, y2, gamma, stats)
+        ctx.cfg = (float(p_drop), int(salt), shape)
+        return out.view(shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, y2, gamma, stats = ctx.saved_tensors
+        p_drop, salt, shape = ctx.cfg
+        R, C = x2.shape
+        dev = x2.device
+        dout = dout.reshape(R, C).contiguous()
+        dx = torch.empty_like(x2)
+        dy = torch.empty_like(x2)
+        dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
+        seed = dropout_state(dev) if p_drop > 0 else None
+        with torch.cuda.device(dev), _timed("add_dropout_ln_bwd", (R, C)):
+            rc = _lib.lib().eda_add_dropout_ln_bwd_f32(
+                dout.data_ptr(), x2.data_ptr(), y2.data_ptr(), gamma.data_ptr(), stats[0].data_ptr(),
+                stats[1].data_ptr(), R, C, p_drop, seed.data_ptr() if seed is not None else None, salt,
+                dx.data_ptr(), dy.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
+                torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "eda_add_dropout_ln_bwd_f32")
+        return dx.view(shape), dy.view(shape), dgb[0], dgb[1], None, None, None
+
+
+def add_dropout_layer_norm(x, y, norm, p_drop, training, salt):
+    """norm(x + dropout(y, p_drop)) for an nn.LayerNorm `norm` over the last dimension."""
+    p = float(p_drop) if training else 0.0
+    if x.is_cuda and norm.elementwise_affine and x.shape[-1] <= 1024 and x.dtype == torch.float32:
+        return _AddDropoutLN.apply(x, y, norm.weight, norm.bias, norm.eps, p, salt)
+    return norm(x + F.dropout(y, p, training=p > 0))

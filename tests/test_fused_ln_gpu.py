@@ -1,0 +1,59 @@
+"""Fused LayerNorm(x + dropout(y)) (csrc/ln.hip) against a plain fp32 torch reference."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(8, 1024, 288), (8, 80, 288), (3, 7, 288), (2, 256, 64), (5, 300), (4, 16, 1000)])
+def test_forward_backward_no_dropout(shape):
+    from eda_amd.fused_ln import add_dropout_layer_norm
+    torch.manual_seed(sum(shape))
+    C = shape[-1]
+    norm = torch.nn.LayerNorm(C).cuda()
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5); norm.bias.normal_(0, 0.2)
+    x = torch.randn(*shape, device="cuda", requires_grad=True)
+    y = torch.randn(*shape, device="cuda", requires_grad=True)
+    w = torch.randn(*shape, device="cuda")
+    out = add_dropout_layer_norm(x, y, norm, 0.1, False, 5)
+    (out * w).sum().backward()
+    got = [out.detach(), x.grad.clone(), y.grad.clone(), norm.weight.grad.clone(), norm.bias.grad.clone()]
+    for t in (x, y, norm.weight, norm.bias):
+        t.grad = None
+    ref = norm(x + y)
+    (ref * w).sum().backward()
+    exp = [ref.detach(), x.grad, y.grad, norm.weight.grad, norm.bias.grad]
+    for name, g, e in zip(["out", "dx", "dy", "dgamma", "dbeta"], got, exp):
+        scale = e.abs().max().item() + 1e-9
+        assert (g - e).abs().max().item() <= 1e-4 * scale + 2e-6, (name, (g - e).abs().max().item(), scale)
+
+
+def test_dropout_path():
+    from eda_amd import attention
+    from eda_amd.fused_ln import add_dropout_layer_norm, _AddDropoutLN
+    torch.manual_seed(0)
+    B, L, C = 4, 512, 288
+    norm = torch.nn.LayerNorm(C).cuda()
+    x = torch.randn(B, L, C, device="cuda")
+    y = torch.randn(B, L, C, device="cuda")
+    attention.dropout_state("cuda").fill_(3)
+    o1 = add_dropout_layer_norm(x, y, norm, 0.1, True, 7)
+    o2 = add_dropout_layer_norm(x, y, norm, 0.1, True, 7)
+    assert torch.equal(o1, o2)                                   # same step + site -> same mask
+    assert not torch.equal(o1, add_dropout_layer_norm(x, y, norm, 0.1, True, 8))
+    attention.advance_dropout_state("cuda")
+    assert not torch.equal(o1, add_dropout_layer_norm(x, y, norm, 0.1, True, 7))
+    # recover the mask through the backward: with x = 0, gamma = 1 the gradient w.r.t. y is zero
+    # exactly where y was dropped
+    xg = torch.zeros(1, 4096, C, device="cuda")
+    yg = torch.randn(1, 4096, C, device="cuda", requires_grad=True)
+    out = _AddDropoutLN.apply(xg, yg, torch.ones(C, device="cuda"), torch.zeros(C, device="cuda"), 1e-5, 0.25, 11)
+    out.backward(torch.randn_like(out))
+    dropped = (yg.grad == 0).float().mean().item()
+    assert abs(dropped - 0.25) < 0.01, dropped
+    # forward consistent with that mask: out == LN(y * mask / (1-p))
+    mask = (yg.grad != 0).float()
+    ref = F.layer_norm(yg.detach() * mask / 0.75, (C,))
+    torch.testing.assert_close(out.detach(), ref, rtol=1e-4, atol=1e-5)
