@@ -78,13 +78,16 @@ __global__ __launch_bounds__(LN_THREADS) void add_dropout_ln_fwd_kernel(
   if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 }
 
+// Backward.  One wave per row, two rows in flight per wave; the per-feature sums for
+// d(gamma)/d(beta) are accumulated in registers over the wave's rows, merged over the block's
+// 4 waves in LDS and written as ONE partial row per block (no atomics); ln_reduce_partials
+// then adds the <= 1024 partial rows.
 template <int NI>
 __global__ __launch_bounds__(LN_THREADS) void add_dropout_ln_bwd_kernel(
     const float *__restrict__ dout, const float *__restrict__ x, const float *__restrict__ y,
     const float *__restrict__ gamma, const float *__restrict__ mean_in,
     const float *__restrict__ rstd_in, long R, int C, float p, const unsigned long long *seed_ptr,
-    unsigned salt, float *__restrict__ dx, float *__restrict__ dy, float *__restrict__ dgamma,
-    float *__restrict__ dbeta) {
+    unsigned salt, float *__restrict__ dx, float *__restrict__ dy, float *__restrict__ partial) {
   __shared__ float red[2][LN_THREADS / 64][64 * NI];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const LnDrop d = ln_drop(p, seed_ptr, salt);
@@ -96,54 +99,95 @@ __global__ __launch_bounds__(LN_THREADS) void add_dropout_ln_bwd_kernel(
     dg[i] = 0.f; db[i] = 0.f;
   }
   const long nwaves = (long)gridDim.x * (LN_THREADS / 64);
-  for (long row = (long)blockIdx.x * (LN_THREADS / 64) + wave; row < R; row += nwaves) {
-    const float mean = mean_in[row], rstd = rstd_in[row];
-    float xh[NI], gd[NI];
-    bool keep[NI];
-    float s1 = 0.f, s2 = 0.f;
+  for (long row0 = (long)blockIdx.x * (LN_THREADS / 64) + wave; row0 < R; row0 += 2 * nwaves) {
+    // two independent rows (row0, row0 + nwaves) so that both rows' loads are in flight together
+    float xv[2][NI], yv[2][NI], gv[2][NI];
+    float mean[2], rstd[2];
+    bool live[2];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int c = lane + 64 * i;
-      float xhat = 0.f, go = 0.f;
-      keep[i] = true;
-      if (c < C) {
-        float yy = y[row * C + c];
+    for (int u = 0; u < 2; ++u) {
+      const long row = row0 + u * nwaves;
+      live[u] = row < R;
+      mean[u] = live[u] ? mean_in[row] : 0.f;
+      rstd[u] = live[u] ? rstd_in[row] : 0.f;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int c = lane + 64 * i;
+        const bool ok = live[u] && c < C;
+        xv[u][i] = ok ? x[row * C + c] : 0.f;
+        yv[u][i] = ok ? y[row * C + c] : 0.f;
+        gv[u][i] = ok ? dout[row * C + c] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (!live[u]) continue;                  // wave-uniform
+      const long row = row0 + u * nwaves;
+      float xh[NI], gd[NI];
+      bool keep[NI];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int c = lane + 64 * i;
+        keep[i] = true;
+        float yy = yv[u][i];
         if (d.on) {
           keep[i] = ln_hash32(d.seed ^ (unsigned)(row * C + c)) >= d.thresh;
           yy = keep[i] ? yy * d.inv_keep : 0.f;
         }
-        xhat = (x[row * C + c] + yy - mean) * rstd;
-        go = dout[row * C + c];
+        const float xhat = c < C ? (xv[u][i] + yy - mean[u]) * rstd[u] : 0.f;
+        const float go = gv[u][i];
         dg[i] += go * xhat;
         db[i] += go;
+        xh[i] = xhat;
+        gd[i] = go * g[i];
+        s1 += gd[i];
+        s2 += gd[i] * xhat;
       }
-      xh[i] = xhat;
-      gd[i] = go * g[i];
-      s1 += gd[i];
-      s2 += gd[i] * xhat;
-    }
-    s1 = ln_wave_sum(s1) / (float)C;
-    s2 = ln_wave_sum(s2) / (float)C;
+      s1 = ln_wave_sum(s1) / (float)C;
+      s2 = ln_wave_sum(s2) / (float)C;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int c = lane + 64 * i;
-      if (c < C) {
-        const float dv = rstd * (gd[i] - s1 - xh[i] * s2);
-        dx[row * C + c] = dv;
-        dy[row * C + c] = d.on ? (keep[i] ? dv * d.inv_keep : 0.f) : dv;
+      for (int i = 0; i < NI; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C) {
+          const float dv = rstd[u] * (gd[i] - s1 - xh[i] * s2);
+          dx[row * C + c] = dv;
+          dy[row * C + c] = d.on ? (keep[i] ? dv * d.inv_keep : 0.f) : dv;
+        }
       }
     }
   }
 #pragma unroll
   for (int i = 0; i < NI; ++i) { red[0][wave][lane + 64 * i] = dg[i]; red[1][wave][lane + 64 * i] = db[i]; }
   __syncthreads();
+  float *prow = partial + (long)blockIdx.x * 2 * C;
   for (int c = threadIdx.x; c < C; c += LN_THREADS) {
     float a = 0.f, b = 0.f;
 #pragma unroll
     for (int w = 0; w < LN_THREADS / 64; ++w) { a += red[0][w][c]; b += red[1][w][c]; }
-    atomicAdd(dgamma + c, a);
-    atomicAdd(dbeta + c, b);
+    prow[c] = a;
+    prow[C + c] = b;
   }
+}
+
+// dgamma[c] = sum_blocks partial[b][c], dbeta[c] = sum_blocks partial[b][C + c]
+__global__ __launch_bounds__(256) void ln_reduce_partials_kernel(const float *__restrict__ partial,
+                                                                 int nblocks, int C,
+                                                                 float *__restrict__ dgamma,
+                                                                 float *__restrict__ dbeta) {
+  const int i = blockIdx.x * 256 + threadIdx.x;      // over 2*C
+  if (i >= 2 * C) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 3 < nblocks; b += 4) {
+    s0 += partial[(long)b * 2 * C + i];
+    s1 += partial[(long)(b + 1) * 2 * C + i];
+    s2 += partial[(long)(b + 2) * 2 * C + i];
+    s3 += partial[(long)(b + 3) * 2 * C + i];
+  }
+  for (; b < nblocks; ++b) s0 += partial[(long)b * 2 * C + i];
+  const float s = (s0 + s1) + (s2 + s3);
+  if (i < C) dgamma[i] = s; else dbeta[i - C] = s;
 }
 
 }  // namespace
@@ -173,26 +217,44 @@ extern "C" int eda_add_dropout_ln_fwd_f32(const float *x, const float *y, const 
   return 0;
 }
 
-// dgamma / dbeta (C floats each) are zeroed here and accumulated with fp32 atomics.
+#define LN_BWD_MAX_BLOCKS 1024
+
+extern "C" size_t eda_add_dropout_ln_bwd_workspace_bytes(long R, int C) {
+  (void)R;
+  return sizeof(float) * (size_t)LN_BWD_MAX_BLOCKS * 2 * (size_t)(C > 0 ? C : 0);
+}
+
+// ws: eda_add_dropout_ln_bwd_workspace_bytes(R, C) bytes of scratch (per-block partial sums).
 extern "C" int eda_add_dropout_ln_bwd_f32(const float *dout, const float *x, const float *y,
                                           const float *gamma, const float *mean, const float *rstd,
                                           long R, int C, float p_drop,
                                           const unsigned long long *seed_ptr, unsigned salt,
                                           float *dx, float *dy, float *dgamma, float *dbeta,
-                                          void *stream_) {
+                                          void *ws, size_t ws_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EDA_CHECK_ARG(R >= 0 && C > 0 && C <= 64 * LN_MAXI, "bad dimension (C <= 1024)");
   EDA_CHECK_ARG(dgamma && dbeta, "null pointer");
-  { const int rc = eda_zero_async(dgamma, sizeof(float) * C, stream); if (rc) return rc; }
-  { const int rc = eda_zero_async(dbeta, sizeof(float) * C, stream); if (rc) return rc; }
-  if (R == 0) return 0;
-  EDA_CHECK_ARG(dout && x && y && gamma && mean && rstd && dx && dy, "null pointer");
-  long blocks = (R + 31) / 32;            // ~8 rows per wave: keeps the atomics to <= 256 x 2C
-  if (blocks > 256) blocks = 256;
+  if (R == 0) {
+    { const int rc = eda_zero_async(dgamma, sizeof(float) * C, stream); if (rc) return rc; }
+    { const int rc = eda_zero_async(dbeta, sizeof(float) * C, stream); if (rc) return rc; }
+    return 0;
+  }
+  EDA_CHECK_ARG(dout && x && y && gamma && mean && rstd && dx && dy && ws, "null pointer");
+  if (ws_bytes < eda_add_dropout_ln_bwd_workspace_bytes(R, C)) {
+    eda_set_error("add_dropout_ln_bwd: workspace too small");
+    return EDA_ERR_WORKSPACE;
+  }
+  // 8 rows per block (2 per wave, both in flight) up to 1024 blocks, then grid-stride
+  long blocks = (R + 7) / 8;
+  if (blocks > LN_BWD_MAX_BLOCKS) blocks = LN_BWD_MAX_BLOCKS;
   if (blocks < 1) blocks = 1;
   const dim3 grid((unsigned)blocks);
+  float *partial = reinterpret_cast<float *>(ws);
   LN_DISPATCH((C + 63) / 64, add_dropout_ln_bwd_kernel, grid, dout, x, y, gamma, mean, rstd, R, C, p_drop,
-              seed_ptr, salt, dx, dy, dgamma, dbeta);
+              seed_ptr, salt, dx, dy, partial);
+  EDA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(ln_reduce_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, partial,
+                     (int)blocks, C, dgamma, dbeta);
   EDA_CHECK_LAUNCH();
   return 0;
 }

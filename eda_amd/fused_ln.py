@@ -56,13 +56,16 @@ class _AddDropoutLN(Function):
         dx = torch.empty_like(x2)
         dy = torch.empty_like(x2)
         dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        ws_bytes = L.eda_add_dropout_ln_bwd_workspace_bytes(R, C)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
         seed = dropout_state(dev) if p_drop > 0 else None
         with torch.cuda.device(dev), _timed("add_dropout_ln_bwd", (R, C)):
-            rc = _lib.lib().eda_add_dropout_ln_bwd_f32(
+            rc = L.eda_add_dropout_ln_bwd_f32(
                 dout.data_ptr(), x2.data_ptr(), y2.data_ptr(), gamma.data_ptr(), stats[0].data_ptr(),
                 stats[1].data_ptr(), R, C, p_drop, seed.data_ptr() if seed is not None else None, salt,
-                dx.data_ptr(), dy.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
-                torch.cuda.current_stream().cuda_stream)
+                dx.data_ptr(), dy.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(),
+                ws_bytes, torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "eda_add_dropout_ln_bwd_f32")
         return dx.view(shape), dy.view(shape), dgb[0], dgb[1], None, None, None
 
