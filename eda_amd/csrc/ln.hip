@@ -170,24 +170,28 @@ __global__ __launch_bounds__(LN_THREADS) void add_dropout_ln_bwd_kernel(
   }
 }
 
-// dgamma[c] = sum_blocks partial[b][c], dbeta[c] = sum_blocks partial[b][C + c]
-__global__ __launch_bounds__(256) void ln_reduce_partials_kernel(const float *__restrict__ partial,
-                                                                 int nblocks, int C,
-                                                                 float *__restrict__ dgamma,
-                                                                 float *__restrict__ dbeta) {
-  const int i = blockIdx.x * 256 + threadIdx.x;      // over 2*C
-  if (i >= 2 * C) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int b = 0;
-  for (; b + 3 < nblocks; b += 4) {
-    s0 += partial[(long)b * 2 * C + i];
-    s1 += partial[(long)(b + 1) * 2 * C + i];
-    s2 += partial[(long)(b + 2) * 2 * C + i];
-    s3 += partial[(long)(b + 3) * 2 * C + i];
+// dgamma[c] = sum_blocks partial[b][c], dbeta[c] = sum_blocks partial[b][C + c].
+// A 1024-thread block owns 64 of the 2C columns with 16 row lanes each (many loads in flight).
+__global__ __launch_bounds__(1024) void ln_reduce_partials_kernel(const float *__restrict__ partial,
+                                                                  int nblocks, int C,
+                                                                  float *__restrict__ dgamma,
+                                                                  float *__restrict__ dbeta) {
+  __shared__ float red[16][65];
+  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + col;               // over 2*C
+  float s = 0.f;
+  if (i < 2 * C) {
+#pragma unroll 8
+    for (int b = rl; b < nblocks; b += 16) s += partial[(long)b * 2 * C + i];
   }
-  for (; b < nblocks; ++b) s0 += partial[(long)b * 2 * C + i];
-  const float s = (s0 + s1) + (s2 + s3);
-  if (i < C) dgamma[i] = s; else dbeta[i - C] = s;
+  red[rl][col] = s;
+  __syncthreads();
+  if (rl == 0 && i < 2 * C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][col];
+    if (i < C) dgamma[i] = t; else dbeta[i - C] = t;
+  }
 }
 
 }  // namespace
@@ -253,7 +257,7 @@ extern "C" int eda_add_dropout_ln_bwd_f32(const float *dout, const float *x, con
   LN_DISPATCH((C + 63) / 64, add_dropout_ln_bwd_kernel, grid, dout, x, y, gamma, mean, rstd, R, C, p_drop,
               seed_ptr, salt, dx, dy, partial);
   EDA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ln_reduce_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, partial,
+  hipLaunchKernelGGL(ln_reduce_partials_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, stream, partial,
                      (int)blocks, C, dgamma, dbeta);
   EDA_CHECK_LAUNCH();
   return 0;
