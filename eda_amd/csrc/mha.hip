@@ -33,8 +33,8 @@ namespace {
 constexpr int HD = 36;            // head dim
 constexpr int KSTEPS = HD / 4;    // 9 MFMA k-steps for a 36-deep contraction
 constexpr int TILE = 64;          // rows of the streamed operand staged in LDS per iteration
-constexpr int WAVES = 4;
-constexpr int THREADS = WAVES * 64;
+// Waves per workgroup: 4 for long sequences (one K/V tile shared by 64 queries), 1 for the
+// short decoder / text shapes so that they still spread over >= 1024 workgroups.
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -75,9 +75,10 @@ __device__ __forceinline__ float xor_sum(float v) {
 
 // Stage TILE rows x 36 floats of one head into LDS (row stride 36), zero-filling
 // rows >= nrows.  16-byte global loads, 16-byte LDS stores.
+template <int NW>
 __device__ __forceinline__ void stage_rows(float *lds, const float *base, long row_stride,
                                            int row0, int nrows) {
-  for (int i = threadIdx.x; i < TILE * 9; i += THREADS) {
+  for (int i = threadIdx.x; i < TILE * 9; i += NW * 64) {
     const int row = i / 9, c4 = i - row * 9;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row0 + row < nrows)
@@ -89,13 +90,14 @@ __device__ __forceinline__ void stage_rows(float *lds, const float *base, long r
 // Software-pipelined staging: a tile's 16-byte pieces are first loaded into registers
 // (issue_rows, while the previous tile is being multiplied) and written to the other
 // LDS buffer afterwards (commit_rows) -- one barrier per tile, global latency hidden.
-struct RowStage { float4 r[3]; };
+template <int NW> struct RowStage { float4 r[(TILE * 9 + NW * 64 - 1) / (NW * 64)]; };
 
-__device__ __forceinline__ void issue_rows(RowStage &st, const float *base, long row_stride,
+template <int NW>
+__device__ __forceinline__ void issue_rows(RowStage<NW> &st, const float *base, long row_stride,
                                            int row0, int nrows) {
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int i = threadIdx.x + THREADS * t;
+  for (int t = 0; t < (TILE * 9 + NW * 64 - 1) / (NW * 64); ++t) {
+    const int i = threadIdx.x + NW * 64 * t;
     const int row = i / 9, c4 = i - row * 9;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < TILE * 9 && row0 + row < nrows)
@@ -104,10 +106,11 @@ __device__ __forceinline__ void issue_rows(RowStage &st, const float *base, long
   }
 }
 
-__device__ __forceinline__ void commit_rows(float *lds, const RowStage &st) {
+template <int NW>
+__device__ __forceinline__ void commit_rows(float *lds, const RowStage<NW> &st) {
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int i = threadIdx.x + THREADS * t;
+  for (int t = 0; t < (TILE * 9 + NW * 64 - 1) / (NW * 64); ++t) {
+    const int i = threadIdx.x + NW * 64 * t;
     const int row = i / 9, c4 = i - row * 9;
     if (i < TILE * 9) *reinterpret_cast<float4 *>(lds + row * HD + 4 * c4) = st.r[t];
   }
@@ -131,7 +134,8 @@ __device__ __forceinline__ void stage_dead(unsigned *flags, const unsigned char 
 }
 
 // ============================================================== forward ======
-__global__ __launch_bounds__(THREADS) void mha_fwd_kernel(MhaArgs a) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void mha_fwd_kernel(MhaArgs a) {
   __shared__ __attribute__((aligned(16))) float Kbuf[2][TILE * HD];
   __shared__ __attribute__((aligned(16))) float Vbuf[2][TILE * HD];
   __shared__ unsigned deadbuf[2][TILE / 4];
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(THREADS) void mha_fwd_kernel(MhaArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;
   const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
-  const int qi = blockIdx.x * (WAVES * 16) + wave * 16 + c;
+  const int qi = blockIdx.x * (NW * 16) + wave * 16 + c;
   const bool qvalid = qi < a.Lq;
 
   const float *qrow = a.q + (long)b * a.q_sb + (long)(qvalid ? qi : 0) * a.q_sl + h * HD;
@@ -164,8 +168,8 @@ __global__ __launch_bounds__(THREADS) void mha_fwd_kernel(MhaArgs a) {
   float m = -INFINITY, lsum = 0.f;
   f32x4 o[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 
-  stage_rows(Kbuf[0], kbase, a.k_sl, 0, a.Lk);
-  stage_rows(Vbuf[0], vbase, a.v_sl, 0, a.Lk);
+  stage_rows<NW>(Kbuf[0], kbase, a.k_sl, 0, a.Lk);
+  stage_rows<NW>(Vbuf[0], vbase, a.v_sl, 0, a.Lk);
   stage_dead(deadbuf[0], mrow, 0, a.Lk);
   __syncthreads();
   int cur = 0;
@@ -173,18 +177,23 @@ __global__ __launch_bounds__(THREADS) void mha_fwd_kernel(MhaArgs a) {
     const float *Kl = Kbuf[cur], *Vl = Vbuf[cur];
     const unsigned *deadl = deadbuf[cur];
     const bool more = k0 + TILE < a.Lk;
-    RowStage ks, vs;
+    RowStage<NW> ks, vs;
     if (more) {                       // next tile: global -> registers, overlapped with the MFMAs below
-      issue_rows(ks, kbase, a.k_sl, k0 + TILE, a.Lk);
-      issue_rows(vs, vbase, a.v_sl, k0 + TILE, a.Lk);
+      issue_rows<NW>(ks, kbase, a.k_sl, k0 + TILE, a.Lk);
+      issue_rows<NW>(vs, vbase, a.v_sl, k0 + TILE, a.Lk);
     }
 
+    // 16-key sub-tiles that lie entirely beyond Lk (e.g. 3 of 8 when Lk = 80) are skipped:
+    // their probabilities are zero anyway (workgroup-uniform condition).
+    const int nsub = min(4, (a.Lk - k0 + 15) / 16);
     f32x4 st[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f32x4 acc = {0, 0, 0, 0};
+      if (j < nsub) {
 #pragma unroll
-      for (int s = 0; s < KSTEPS; ++s) acc = mfma4(Kl[(16 * j + c) * HD + 4 * s + g], qreg[s], acc);
+        for (int s = 0; s < KSTEPS; ++s) acc = mfma4(Kl[(16 * j + c) * HD + 4 * s + g], qreg[s], acc);
+      }
       st[j] = acc;
     }
     float tmax = -INFINITY;
@@ -229,6 +238,7 @@ __global__ __launch_bounds__(THREADS) void mha_fwd_kernel(MhaArgs a) {
     // O^T[dim][query] += V^T P^T
 #pragma unroll
     for (int j = 0; j < 4; ++j)
+      if (j < nsub)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const float *vr = Vl + (16 * j + 4 * g + t) * HD;
@@ -238,8 +248,8 @@ __global__ __launch_bounds__(THREADS) void mha_fwd_kernel(MhaArgs a) {
         o[2] = mfma4(c < 4 ? vr[32 + c] : 0.f, pb, o[2]);
       }
     if (more) {                       // registers -> the other LDS buffer (its readers finished last iteration)
-      commit_rows(Kbuf[cur ^ 1], ks);
-      commit_rows(Vbuf[cur ^ 1], vs);
+      commit_rows<NW>(Kbuf[cur ^ 1], ks);
+      commit_rows<NW>(Vbuf[cur ^ 1], vs);
       stage_dead(deadbuf[cur ^ 1], mrow, k0 + TILE, a.Lk);
     }
     __syncthreads();
@@ -283,7 +293,8 @@ __global__ __launch_bounds__(256) void mha_delta_kernel(const float *__restrict_
 // lane owns query (l&15); streams K/V tiles.
 //   S^T = K Q^T, P^T = exp(S^T - lse);  dP^T = V dO^T;  dS^T = P^T o (dP^T_eff - delta)
 //   dQ^T[dim][query] += K^T dS^T    (then * scale)
-__global__ __launch_bounds__(THREADS) void mha_bwd_dq_kernel(MhaArgs a) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void mha_bwd_dq_kernel(MhaArgs a) {
   __shared__ __attribute__((aligned(16))) float Kbuf[2][TILE * HD];
   __shared__ __attribute__((aligned(16))) float Vbuf[2][TILE * HD];
   __shared__ unsigned deadbuf[2][TILE / 4];
@@ -291,7 +302,7 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_dq_kernel(MhaArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;
   const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
-  const int qi = blockIdx.x * (WAVES * 16) + wave * 16 + c;
+  const int qi = blockIdx.x * (NW * 16) + wave * 16 + c;
   const bool qvalid = qi < a.Lq;
 
   const float *qrow = a.q + (long)b * a.q_sb + (long)(qvalid ? qi : 0) * a.q_sl + h * HD;
@@ -329,8 +340,8 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_dq_kernel(MhaArgs a) {
   const unsigned rowbase = ((unsigned)bh * (unsigned)a.Lq + (unsigned)qi) * (unsigned)a.Lk;
 
   f32x4 dq[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-  stage_rows(Kbuf[0], kbase, a.k_sl, 0, a.Lk);
-  stage_rows(Vbuf[0], vbase, a.v_sl, 0, a.Lk);
+  stage_rows<NW>(Kbuf[0], kbase, a.k_sl, 0, a.Lk);
+  stage_rows<NW>(Vbuf[0], vbase, a.v_sl, 0, a.Lk);
   stage_dead(deadbuf[0], mrow, 0, a.Lk);
   __syncthreads();
   int cur = 0;
@@ -338,19 +349,22 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_dq_kernel(MhaArgs a) {
     const float *Kl = Kbuf[cur], *Vl = Vbuf[cur];
     const unsigned *deadl = deadbuf[cur];
     const bool more = k0 + TILE < a.Lk;
-    RowStage ks, vs;
+    RowStage<NW> ks, vs;
     if (more) {
-      issue_rows(ks, kbase, a.k_sl, k0 + TILE, a.Lk);
-      issue_rows(vs, vbase, a.v_sl, k0 + TILE, a.Lk);
+      issue_rows<NW>(ks, kbase, a.k_sl, k0 + TILE, a.Lk);
+      issue_rows<NW>(vs, vbase, a.v_sl, k0 + TILE, a.Lk);
     }
+    const int nsub = min(4, (a.Lk - k0 + 15) / 16);
     f32x4 ds[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f32x4 sacc = {0, 0, 0, 0}, pacc = {0, 0, 0, 0};
+      if (j < nsub) {
 #pragma unroll
-      for (int s = 0; s < KSTEPS; ++s) {
-        sacc = mfma4(Kl[(16 * j + c) * HD + 4 * s + g], qreg[s], sacc);
-        pacc = mfma4(Vl[(16 * j + c) * HD + 4 * s + g], dreg[s], pacc);
+        for (int s = 0; s < KSTEPS; ++s) {
+          sacc = mfma4(Kl[(16 * j + c) * HD + 4 * s + g], qreg[s], sacc);
+          pacc = mfma4(Vl[(16 * j + c) * HD + 4 * s + g], dreg[s], pacc);
+        }
       }
       const unsigned dw = deadl[4 * j + g];
 #pragma unroll
@@ -368,6 +382,7 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_dq_kernel(MhaArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
+      if (j < nsub)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const float *kr = Kl + (16 * j + 4 * g + t) * HD;
@@ -377,8 +392,8 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_dq_kernel(MhaArgs a) {
         dq[2] = mfma4(c < 4 ? kr[32 + c] : 0.f, sb, dq[2]);
       }
     if (more) {
-      commit_rows(Kbuf[cur ^ 1], ks);
-      commit_rows(Vbuf[cur ^ 1], vs);
+      commit_rows<NW>(Kbuf[cur ^ 1], ks);
+      commit_rows<NW>(Vbuf[cur ^ 1], vs);
       stage_dead(deadbuf[cur ^ 1], mrow, k0 + TILE, a.Lk);
     }
     __syncthreads();
@@ -397,7 +412,8 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_dq_kernel(MhaArgs a) {
 // lane owns key (l&15); streams Q/dO tiles (plus their lse/delta).
 //   S = Q K^T [query 4g+r][key l&15], P = exp(S - lse[query]);  dP = dO V^T
 //   dV^T[dim][key] += dO^T P_drop;  dS = P o (dP_eff - delta[query]);  dK^T[dim][key] += Q^T dS
-__global__ __launch_bounds__(THREADS) void mha_bwd_dkv_kernel(MhaArgs a) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void mha_bwd_dkv_kernel(MhaArgs a) {
   __shared__ __attribute__((aligned(16))) float Qbuf[2][TILE * HD];
   __shared__ __attribute__((aligned(16))) float Dbuf[2][TILE * HD];
   __shared__ float lsebuf[2][TILE], deltabuf[2][TILE];
@@ -405,7 +421,7 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_dkv_kernel(MhaArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;
   const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
-  const int ki = blockIdx.x * (WAVES * 16) + wave * 16 + c;
+  const int ki = blockIdx.x * (NW * 16) + wave * 16 + c;
   const bool kvalid = ki < a.Lk;
   const bool kdead = !kvalid || (a.mask && a.mask[(long)b * a.Lk + (kvalid ? ki : 0)]);
 
@@ -437,8 +453,8 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_dkv_kernel(MhaArgs a) {
       deltabuf[buf][threadIdx.x] = qq < a.Lq ? a.delta[(long)bh * a.Lq + qq] : 0.f;
     }
   };
-  stage_rows(Qbuf[0], qbase, a.q_sl, 0, a.Lq);
-  stage_rows(Dbuf[0], dbase, a.do_sl, 0, a.Lq);
+  stage_rows<NW>(Qbuf[0], qbase, a.q_sl, 0, a.Lq);
+  stage_rows<NW>(Dbuf[0], dbase, a.do_sl, 0, a.Lq);
   stage_stats(0, 0);
   __syncthreads();
   int cur = 0;
@@ -446,19 +462,22 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_dkv_kernel(MhaArgs a) {
     const float *Ql = Qbuf[cur], *Dl = Dbuf[cur];
     const float *lse_l = lsebuf[cur], *delta_l = deltabuf[cur];
     const bool more = q0 + TILE < a.Lq;
-    RowStage qs, dsg;
+    RowStage<NW> qs, dsg;
     if (more) {
-      issue_rows(qs, qbase, a.q_sl, q0 + TILE, a.Lq);
-      issue_rows(dsg, dbase, a.do_sl, q0 + TILE, a.Lq);
+      issue_rows<NW>(qs, qbase, a.q_sl, q0 + TILE, a.Lq);
+      issue_rows<NW>(dsg, dbase, a.do_sl, q0 + TILE, a.Lq);
     }
+    const int nsub = min(4, (a.Lq - q0 + 15) / 16);
     f32x4 pd[4], ds[4];     // dropped P (for dV) and dS (for dK), B-operand layout
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f32x4 sacc = {0, 0, 0, 0}, pacc = {0, 0, 0, 0};
+      if (j < nsub) {
 #pragma unroll
-      for (int s = 0; s < KSTEPS; ++s) {
-        sacc = mfma4(Ql[(16 * j + c) * HD + 4 * s + g], kreg[s], sacc);
-        pacc = mfma4(Dl[(16 * j + c) * HD + 4 * s + g], vreg[s], pacc);
+        for (int s = 0; s < KSTEPS; ++s) {
+          sacc = mfma4(Ql[(16 * j + c) * HD + 4 * s + g], kreg[s], sacc);
+          pacc = mfma4(Dl[(16 * j + c) * HD + 4 * s + g], vreg[s], pacc);
+        }
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -480,6 +499,7 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_dkv_kernel(MhaArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
+      if (j < nsub)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const float *qr = Ql + (16 * j + 4 * g + t) * HD;
@@ -493,8 +513,8 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_dkv_kernel(MhaArgs a) {
         dk[2] = mfma4(c < 4 ? qr[32 + c] : 0.f, sb, dk[2]);
       }
     if (more) {
-      commit_rows(Qbuf[cur ^ 1], qs);
-      commit_rows(Dbuf[cur ^ 1], dsg);
+      commit_rows<NW>(Qbuf[cur ^ 1], qs);
+      commit_rows<NW>(Dbuf[cur ^ 1], dsg);
       stage_stats(cur ^ 1, q0 + TILE);
     }
     __syncthreads();
@@ -512,6 +532,13 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_dkv_kernel(MhaArgs a) {
       *reinterpret_cast<float4 *>(ov + 32) = make_float4(dv[2][0], dv[2][1], dv[2][2], dv[2][3]);
     }
   }
+}
+
+// 4 waves per workgroup share one staged tile; with few resident rows (L <= 256 at B*H = 64) that
+// leaves most CUs with a single workgroup, so those shapes use 1-wave workgroups instead.
+int pick_waves(int resident_rows, int bh) {
+  if (getenv("EDA_MHA_WAVES")) return atoi(getenv("EDA_MHA_WAVES")) == 1 ? 1 : 4;
+  return ((long)((resident_rows + 63) / 64) * bh < 768) ? 1 : 4;
 }
 
 bool mult4(long v) { return (v & 3) == 0; }
@@ -540,8 +567,13 @@ extern "C" int eda_mha_fwd_f32(const float *q, const float *k, const float *v, l
   a.v_sb = v_sb; a.v_sl = v_sl; a.o = out; a.o_sb = (long)Lq * H * HD; a.o_sl = (long)H * HD;
   a.lse = lse; a.mask = key_padding_mask; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale;
   a.p_drop = p_drop; a.seed_ptr = seed_ptr; a.salt = salt;
-  const dim3 grid((unsigned)((Lq + WAVES * 16 - 1) / (WAVES * 16)), (unsigned)(B * H));
-  hipLaunchKernelGGL(mha_fwd_kernel, grid, dim3(THREADS), 0, stream, a);
+  if (pick_waves(Lq, B * H) == 1) {
+    hipLaunchKernelGGL(mha_fwd_kernel<1>, dim3((unsigned)((Lq + 15) / 16), (unsigned)(B * H)), dim3(64), 0,
+                       stream, a);
+  } else {
+    hipLaunchKernelGGL(mha_fwd_kernel<4>, dim3((unsigned)((Lq + 63) / 64), (unsigned)(B * H)), dim3(256), 0,
+                       stream, a);
+  }
   EDA_CHECK_LAUNCH();
   return 0;
 }
@@ -572,13 +604,21 @@ extern "C" int eda_mha_bwd_f32(const float *q, const float *k, const float *v, l
   a.o = const_cast<float *>(out); a.o_sb = (long)Lq * H * HD; a.o_sl = (long)H * HD;
   if (Lq > 0) {
     // (delta = rowsum(dO * O) is computed inside the dQ kernel and published for dK/dV)
-    const dim3 gq((unsigned)((Lq + WAVES * 16 - 1) / (WAVES * 16)), (unsigned)(B * H));
-    hipLaunchKernelGGL(mha_bwd_dq_kernel, gq, dim3(THREADS), 0, stream, a);
+    if (pick_waves(Lq, B * H) == 1)
+      hipLaunchKernelGGL(mha_bwd_dq_kernel<1>, dim3((unsigned)((Lq + 15) / 16), (unsigned)(B * H)), dim3(64),
+                         0, stream, a);
+    else
+      hipLaunchKernelGGL(mha_bwd_dq_kernel<4>, dim3((unsigned)((Lq + 63) / 64), (unsigned)(B * H)), dim3(256),
+                         0, stream, a);
     EDA_CHECK_LAUNCH();
   }
   if (Lk > 0) {
-    const dim3 gk((unsigned)((Lk + WAVES * 16 - 1) / (WAVES * 16)), (unsigned)(B * H));
-    hipLaunchKernelGGL(mha_bwd_dkv_kernel, gk, dim3(THREADS), 0, stream, a);
+    if (pick_waves(Lk, B * H) == 1)
+      hipLaunchKernelGGL(mha_bwd_dkv_kernel<1>, dim3((unsigned)((Lk + 15) / 16), (unsigned)(B * H)), dim3(64),
+                         0, stream, a);
+    else
+      hipLaunchKernelGGL(mha_bwd_dkv_kernel<4>, dim3((unsigned)((Lk + 63) / 64), (unsigned)(B * H)), dim3(256),
+                         0, stream, a);
     EDA_CHECK_LAUNCH();
   }
   return 0;
