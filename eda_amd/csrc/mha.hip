@@ -534,11 +534,14 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dkv_kernel(MhaArgs a) {
   }
 }
 
-// 4 waves per workgroup share one staged tile; with few resident rows (L <= 256 at B*H = 64) that
-// leaves most CUs with a single workgroup, so those shapes use 1-wave workgroups instead.
+// 4 waves per workgroup share one staged tile.  A 1-wave variant (4x more workgroups for the
+// short decoder / text shapes) was measured slower on every EDA shape (rocprofv3 kernel
+// durations, e.g. 256x1024 dK/dV 90 -> 152 us, 256x80 fwd 13.0 -> 16.9 us: each workgroup then
+// stages all of K/V alone), so it is only reachable through EDA_MHA_WAVES=1 for experiments.
 int pick_waves(int resident_rows, int bh) {
+  (void)resident_rows; (void)bh;
   if (getenv("EDA_MHA_WAVES")) return atoi(getenv("EDA_MHA_WAVES")) == 1 ? 1 : 4;
-  return ((long)((resident_rows + 63) / 64) * bh < 768) ? 1 : 4;
+  return 4;
 }
 
 bool mult4(long v) { return (v & 3) == 0; }
