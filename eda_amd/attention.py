@@ -147,8 +147,10 @@ class MultiheadAttention(nn.Module):
         return new
 
     def forward(self, query, key, value, key_padding_mask=None, need_weights=False,
-                attn_mask=None, batch_first=False):
-        """Returns (output, None).  Inputs are (L,B,F) unless batch_first (then (B,L,F))."""
+                attn_mask=None, batch_first=False, defer_out_bias=False):
+        """Returns (output, None).  Inputs are (L,B,F) unless batch_first (then (B,L,F)).
+        With defer_out_bias the out-projection is applied WITHOUT its bias and (output, bias) is
+        returned: the caller's fused residual+LayerNorm kernel adds it (fused_ln.py)."""
         if attn_mask is not None:
             raise NotImplementedError("EDA always passes attn_mask=None")
         if not batch_first:
@@ -169,7 +171,7 @@ class MultiheadAttention(nn.Module):
             v = F.linear(value, W[2 * d:], b[2 * d:])
         o = attention_core(q, k, v, key_padding_mask, self.num_heads,
                            self.dropout if self.training else 0.0, self._salt)
-        o = self.out_proj(o)
+        o = F.linear(o, self.out_proj.weight, None if defer_out_bias else self.out_proj.bias)
         if not batch_first:
             o = o.transpose(0, 1)
-        return o, None
+        return o, (self.out_proj.bias if defer_out_bias else None)

@@ -39,8 +39,8 @@ __device__ __forceinline__ LnDrop ln_drop(float p, const unsigned long long *see
 
 template <int NI>
 __global__ __launch_bounds__(LN_THREADS) void add_dropout_ln_fwd_kernel(
-    const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ gamma,
-    const float *__restrict__ beta, long R, int C, float eps, float p,
+    const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ ybias,
+    const float *__restrict__ gamma, const float *__restrict__ beta, long R, int C, float eps, float p,
     const unsigned long long *seed_ptr, unsigned salt, float *__restrict__ out,
     float *__restrict__ mean_out, float *__restrict__ rstd_out) {
   const int lane = threadIdx.x & 63;
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(LN_THREADS) void add_dropout_ln_fwd_kernel(
     const int c = lane + 64 * i;
     float t = 0.f;
     if (c < C) {
-      float yy = y[row * C + c];
+      float yy = y[row * C + c] + (ybias ? ybias[c] : 0.f);
       if (d.on) yy = ln_hash32(d.seed ^ (unsigned)(row * C + c)) >= d.thresh ? yy * d.inv_keep : 0.f;
       t = x[row * C + c] + yy;
     }
@@ -85,18 +85,20 @@ __global__ __launch_bounds__(LN_THREADS) void add_dropout_ln_fwd_kernel(
 template <int NI>
 __global__ __launch_bounds__(LN_THREADS) void add_dropout_ln_bwd_kernel(
     const float *__restrict__ dout, const float *__restrict__ x, const float *__restrict__ y,
-    const float *__restrict__ gamma, const float *__restrict__ mean_in,
-    const float *__restrict__ rstd_in, long R, int C, float p, const unsigned long long *seed_ptr,
-    unsigned salt, float *__restrict__ dx, float *__restrict__ dy, float *__restrict__ partial) {
-  __shared__ float red[2][LN_THREADS / 64][64 * NI];
+    const float *__restrict__ ybias, const float *__restrict__ gamma,
+    const float *__restrict__ mean_in, const float *__restrict__ rstd_in, long R, int C, float p,
+    const unsigned long long *seed_ptr, unsigned salt, float *__restrict__ dx,
+    float *__restrict__ dy, float *__restrict__ partial) {
+  __shared__ float red[3][LN_THREADS / 64][64 * NI];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const LnDrop d = ln_drop(p, seed_ptr, salt);
-  float g[NI], dg[NI], db[NI];
+  float g[NI], yb[NI], dg[NI], db[NI], dyb[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int c = lane + 64 * i;
     g[i] = c < C ? gamma[c] : 0.f;
-    dg[i] = 0.f; db[i] = 0.f;
+    yb[i] = (ybias && c < C) ? ybias[c] : 0.f;
+    dg[i] = 0.f; db[i] = 0.f; dyb[i] = 0.f;
   }
   const long nwaves = (long)gridDim.x * (LN_THREADS / 64);
   for (long row0 = (long)blockIdx.x * (LN_THREADS / 64) + wave; row0 < R; row0 += 2 * nwaves) {
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(LN_THREADS) void add_dropout_ln_bwd_kernel(
       for (int i = 0; i < NI; ++i) {
         const int c = lane + 64 * i;
         keep[i] = true;
-        float yy = yv[u][i];
+        float yy = yv[u][i] + yb[i];
         if (d.on) {
           keep[i] = ln_hash32(d.seed ^ (unsigned)(row * C + c)) >= d.thresh;
           yy = keep[i] ? yy * d.inv_keep : 0.f;
@@ -151,46 +153,50 @@ __global__ __launch_bounds__(LN_THREADS) void add_dropout_ln_bwd_kernel(
         const int c = lane + 64 * i;
         if (c < C) {
           const float dv = rstd[u] * (gd[i] - s1 - xh[i] * s2);
+          const float dyv = d.on ? (keep[i] ? dv * d.inv_keep : 0.f) : dv;
           dx[row * C + c] = dv;
-          dy[row * C + c] = d.on ? (keep[i] ? dv * d.inv_keep : 0.f) : dv;
+          dy[row * C + c] = dyv;
+          dyb[i] += dyv;            // gradient of the bias that was added to y (if any)
         }
       }
     }
   }
 #pragma unroll
-  for (int i = 0; i < NI; ++i) { red[0][wave][lane + 64 * i] = dg[i]; red[1][wave][lane + 64 * i] = db[i]; }
+  for (int i = 0; i < NI; ++i) {
+    red[0][wave][lane + 64 * i] = dg[i]; red[1][wave][lane + 64 * i] = db[i]; red[2][wave][lane + 64 * i] = dyb[i];
+  }
   __syncthreads();
-  float *prow = partial + (long)blockIdx.x * 2 * C;
+  float *prow = partial + (long)blockIdx.x * 3 * C;
   for (int c = threadIdx.x; c < C; c += LN_THREADS) {
-    float a = 0.f, b = 0.f;
+    float a = 0.f, b = 0.f, e = 0.f;
 #pragma unroll
-    for (int w = 0; w < LN_THREADS / 64; ++w) { a += red[0][w][c]; b += red[1][w][c]; }
+    for (int w = 0; w < LN_THREADS / 64; ++w) { a += red[0][w][c]; b += red[1][w][c]; e += red[2][w][c]; }
     prow[c] = a;
     prow[C + c] = b;
+    prow[2 * C + c] = e;
   }
 }
 
-// dgamma[c] = sum_blocks partial[b][c], dbeta[c] = sum_blocks partial[b][C + c].
-// A 1024-thread block owns 64 of the 2C columns with 16 row lanes each (many loads in flight).
+// out3[0..C) = d(gamma), [C..2C) = d(beta), [2C..3C) = d(y-bias): sums of the per-block partial rows.
+// A 1024-thread block owns 64 of the 3C columns with 16 row lanes each (many loads in flight).
 __global__ __launch_bounds__(1024) void ln_reduce_partials_kernel(const float *__restrict__ partial,
                                                                   int nblocks, int C,
-                                                                  float *__restrict__ dgamma,
-                                                                  float *__restrict__ dbeta) {
+                                                                  float *__restrict__ out3) {
   __shared__ float red[16][65];
   const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + col;               // over 2*C
+  const int i = blockIdx.x * 64 + col;               // over 3*C
   float s = 0.f;
-  if (i < 2 * C) {
+  if (i < 3 * C) {
 #pragma unroll 8
-    for (int b = rl; b < nblocks; b += 16) s += partial[(long)b * 2 * C + i];
+    for (int b = rl; b < nblocks; b += 16) s += partial[(long)b * 3 * C + i];
   }
   red[rl][col] = s;
   __syncthreads();
-  if (rl == 0 && i < 2 * C) {
+  if (rl == 0 && i < 3 * C) {
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k][col];
-    if (i < C) dgamma[i] = t; else dbeta[i - C] = t;
+    out3[i] = t;
   }
 }
 
@@ -204,8 +210,9 @@ __global__ __launch_bounds__(1024) void ln_reduce_partials_kernel(const float *_
     else hipLaunchKernelGGL(KERNEL<LN_MAXI>, GRID, dim3(LN_THREADS), 0, stream, __VA_ARGS__);      \
   } while (0)
 
-extern "C" int eda_add_dropout_ln_fwd_f32(const float *x, const float *y, const float *gamma,
-                                          const float *beta, long R, int C, float eps, float p_drop,
+extern "C" int eda_add_dropout_ln_fwd_f32(const float *x, const float *y, const float *y_bias,
+                                          const float *gamma, const float *beta, long R, int C,
+                                          float eps, float p_drop,
                                           const unsigned long long *seed_ptr, unsigned salt,
                                           float *out, float *mean, float *rstd, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -215,7 +222,7 @@ extern "C" int eda_add_dropout_ln_fwd_f32(const float *x, const float *y, const 
   EDA_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed_ptr), "bad dropout arguments");
   EDA_CHECK_ARG(R * C < (1ll << 32), "R*C must fit the 32-bit dropout counter");
   const dim3 grid((unsigned)((R + LN_THREADS / 64 - 1) / (LN_THREADS / 64)));
-  LN_DISPATCH((C + 63) / 64, add_dropout_ln_fwd_kernel, grid, x, y, gamma, beta, R, C, eps, p_drop,
+  LN_DISPATCH((C + 63) / 64, add_dropout_ln_fwd_kernel, grid, x, y, y_bias, gamma, beta, R, C, eps, p_drop,
               seed_ptr, salt, out, mean, rstd);
   EDA_CHECK_LAUNCH();
   return 0;
@@ -225,24 +232,21 @@ extern "C" int eda_add_dropout_ln_fwd_f32(const float *x, const float *y, const 
 
 extern "C" size_t eda_add_dropout_ln_bwd_workspace_bytes(long R, int C) {
   (void)R;
-  return sizeof(float) * (size_t)LN_BWD_MAX_BLOCKS * 2 * (size_t)(C > 0 ? C : 0);
+  return sizeof(float) * (size_t)LN_BWD_MAX_BLOCKS * 3 * (size_t)(C > 0 ? C : 0);
 }
 
+// grads3: 3*C floats out = [d(gamma) | d(beta) | d(y_bias)].
 // ws: eda_add_dropout_ln_bwd_workspace_bytes(R, C) bytes of scratch (per-block partial sums).
 extern "C" int eda_add_dropout_ln_bwd_f32(const float *dout, const float *x, const float *y,
-                                          const float *gamma, const float *mean, const float *rstd,
-                                          long R, int C, float p_drop,
+                                          const float *y_bias, const float *gamma, const float *mean,
+                                          const float *rstd, long R, int C, float p_drop,
                                           const unsigned long long *seed_ptr, unsigned salt,
-                                          float *dx, float *dy, float *dgamma, float *dbeta,
-                                          void *ws, size_t ws_bytes, void *stream_) {
+                                          float *dx, float *dy, float *grads3, void *ws,
+                                          size_t ws_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EDA_CHECK_ARG(R >= 0 && C > 0 && C <= 64 * LN_MAXI, "bad dimension (C <= 1024)");
-  EDA_CHECK_ARG(dgamma && dbeta, "null pointer");
-  if (R == 0) {
-    { const int rc = eda_zero_async(dgamma, sizeof(float) * C, stream); if (rc) return rc; }
-    { const int rc = eda_zero_async(dbeta, sizeof(float) * C, stream); if (rc) return rc; }
-    return 0;
-  }
+  EDA_CHECK_ARG(grads3, "null pointer");
+  if (R == 0) return eda_zero_async(grads3, sizeof(float) * 3 * C, stream);
   EDA_CHECK_ARG(dout && x && y && gamma && mean && rstd && dx && dy && ws, "null pointer");
   if (ws_bytes < eda_add_dropout_ln_bwd_workspace_bytes(R, C)) {
     eda_set_error("add_dropout_ln_bwd: workspace too small");
@@ -254,11 +258,11 @@ extern "C" int eda_add_dropout_ln_bwd_f32(const float *dout, const float *x, con
   if (blocks < 1) blocks = 1;
   const dim3 grid((unsigned)blocks);
   float *partial = reinterpret_cast<float *>(ws);
-  LN_DISPATCH((C + 63) / 64, add_dropout_ln_bwd_kernel, grid, dout, x, y, gamma, mean, rstd, R, C, p_drop,
-              seed_ptr, salt, dx, dy, partial);
+  LN_DISPATCH((C + 63) / 64, add_dropout_ln_bwd_kernel, grid, dout, x, y, y_bias, gamma, mean, rstd, R, C,
+              p_drop, seed_ptr, salt, dx, dy, partial);
   EDA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ln_reduce_partials_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, stream, partial,
-                     (int)blocks, C, dgamma, dbeta);
+  hipLaunchKernelGGL(ln_reduce_partials_kernel, dim3((3 * C + 63) / 64), dim3(1024), 0, stream, partial,
+                     (int)blocks, C, grads3);
   EDA_CHECK_LAUNCH();
   return 0;
 }

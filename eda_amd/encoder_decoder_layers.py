@@ -10,10 +10,11 @@ Internally everything stays batch-first (B, N, F).
 from copy import deepcopy
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from .attention import MultiheadAttention
-from .fused_ln import add_dropout_layer_norm, new_salt_base
+from .fused_ln import add_dropout_layer_norm, fuses_bias, new_salt_base
 from .nn_utils import Conv1dK1, bn_relu_rows, rows_ok
 
 
@@ -29,8 +30,19 @@ def _ffn(d_model, dim_feedforward, dropout):
 def _ffn_residual_norm(x, ffn, norm, training, salt):
     """norm(x + ffn(x)) where ffn = Linear, ReLU, Dropout, Linear, Dropout: the last Dropout is
     applied inside the fused residual+LayerNorm kernel."""
-    h = ffn[3](ffn[2](ffn[1](ffn[0](x))))
-    return add_dropout_layer_norm(x, h, norm, ffn[4].p, training, salt)
+    h = ffn[2](ffn[1](ffn[0](x)))
+    if fuses_bias(x, norm):      # second linear's bias (and its gradient) ride in the LN kernels
+        return add_dropout_layer_norm(x, F.linear(h, ffn[3].weight), norm, ffn[4].p, training, salt,
+                                      y_bias=ffn[3].bias)
+    return add_dropout_layer_norm(x, ffn[3](h), norm, ffn[4].p, training, salt)
+
+
+def _attn_residual_norm(attn, x, q, k, v, mask, norm, p_drop, training, salt, batch_first=True):
+    """norm(x + dropout(attn(q, k, v))): the out-projection bias is deferred to the fused
+    residual+LayerNorm kernel whenever that kernel runs."""
+    y, y_bias = attn(q, k, v, key_padding_mask=mask, batch_first=batch_first,
+                     defer_out_bias=fuses_bias(x, norm))
+    return add_dropout_layer_norm(x, y, norm, p_drop, training, salt, y_bias=y_bias)
 
 
 class PositionEmbeddingLearned(nn.Module):
@@ -88,19 +100,17 @@ class CrossAttentionLayer(nn.Module):
     def forward(self, vis_feats, vis_key_padding_mask, text_feats, text_key_padding_mask,
                 pos_feats, detected_feats=None, detected_mask=None):
         # text attends to points: no positional term on the keys (:80-93)
-        t2 = self.cross_lv(text_feats, vis_feats, vis_feats,
-                           key_padding_mask=vis_key_padding_mask, batch_first=True)[0]
         tr, sb = self.training, self._salt
-        text_out = add_dropout_layer_norm(text_feats, t2, self.norm_lv, self.dropout_lv.p, tr, sb)
+        text_out = _attn_residual_norm(self.cross_lv, text_feats, text_feats, vis_feats, vis_feats,
+                                       vis_key_padding_mask, self.norm_lv, self.dropout_lv.p, tr, sb)
         text_out = _ffn_residual_norm(text_out, self.ffn_lv, self.norm_lv2, tr, sb + 1)
         # points attend to the ORIGINAL text (:99-105), position added to the query only
-        v2 = self.cross_vl(vis_feats + pos_feats, text_feats, text_feats,
-                           key_padding_mask=text_key_padding_mask, batch_first=True)[0]
-        vis = add_dropout_layer_norm(vis_feats, v2, self.norm_vl, self.dropout_vl.p, tr, sb + 2)
+        vis = _attn_residual_norm(self.cross_vl, vis_feats, vis_feats + pos_feats, text_feats,
+                                  text_feats, text_key_padding_mask, self.norm_vl, self.dropout_vl.p,
+                                  tr, sb + 2)
         if detected_feats is not None and self.use_butd_enc_attn:
-            v2 = self.cross_d(vis, detected_feats, detected_feats,
-                              key_padding_mask=detected_mask, batch_first=True)[0]
-            vis = add_dropout_layer_norm(vis, v2, self.norm_d, self.dropout_d.p, tr, sb + 3)
+            vis = _attn_residual_norm(self.cross_d, vis, vis, detected_feats, detected_feats,
+                                      detected_mask, self.norm_d, self.dropout_d.p, tr, sb + 3)
         vis = _ffn_residual_norm(vis, self.ffn_vl, self.norm_vl2, tr, sb + 4)
         return vis, text_out
 
@@ -116,9 +126,9 @@ class TransformerEncoderLayerNoFFN(nn.Module):
         self._salt = new_salt_base()
 
     def forward(self, src, src_mask=None, src_key_padding_mask=None, batch_first=False):
-        src2 = self.self_attn(src, src, src, attn_mask=src_mask,
-                              key_padding_mask=src_key_padding_mask, batch_first=batch_first)[0]
-        return add_dropout_layer_norm(src, src2, self.norm1, self.dropout1.p, self.training, self._salt)
+        assert src_mask is None, "EDA always passes attn_mask=None"
+        return _attn_residual_norm(self.self_attn, src, src, src, src, src_key_padding_mask,
+                                   self.norm1, self.dropout1.p, self.training, self._salt, batch_first)
 
 
 class PosTransformerEncoderLayerNoFFN(TransformerEncoderLayerNoFFN):
@@ -126,9 +136,9 @@ class PosTransformerEncoderLayerNoFFN(TransformerEncoderLayerNoFFN):
 
     def forward(self, src, pos, src_mask=None, src_key_padding_mask=None, batch_first=False):
         qk = src + pos
-        src2 = self.self_attn(qk, qk, src, attn_mask=src_mask,
-                              key_padding_mask=src_key_padding_mask, batch_first=batch_first)[0]
-        return add_dropout_layer_norm(src, src2, self.norm1, self.dropout1.p, self.training, self._salt)
+        assert src_mask is None, "EDA always passes attn_mask=None"
+        return _attn_residual_norm(self.self_attn, src, qk, qk, src, src_key_padding_mask,
+                                   self.norm1, self.dropout1.p, self.training, self._salt, batch_first)
 
 
 class BiEncoderLayer(nn.Module):
@@ -212,17 +222,16 @@ class BiDecoderLayer(nn.Module):
         else:
             pos = torch.zeros_like(query)
         qp = query + pos
-        q2 = self.self_attn(qp, qp, query, key_padding_mask=padding_mask, batch_first=True)[0]
         tr, sb = self.training, self._salt
-        query = add_dropout_layer_norm(query, q2, self.norm1, self.dropout1.p, tr, sb)
-        q2 = self.cross_l(query + pos, lang_feats, lang_feats,
-                          key_padding_mask=text_key_padding_mask, batch_first=True)[0]
-        query = add_dropout_layer_norm(query, q2, self.norm_l, self.dropout_l.p, tr, sb + 1)
+        query = _attn_residual_norm(self.self_attn, query, qp, qp, query, padding_mask, self.norm1,
+                                    self.dropout1.p, tr, sb)
+        query = _attn_residual_norm(self.cross_l, query, query + pos, lang_feats, lang_feats,
+                                    text_key_padding_mask, self.norm_l, self.dropout_l.p, tr, sb + 1)
         if detected_feats is not None:
-            q2 = self.cross_d(query + pos, detected_feats, detected_feats,
-                              key_padding_mask=detected_mask, batch_first=True)[0]
-            query = add_dropout_layer_norm(query, q2, self.norm_d, self.dropout_d.p, tr, sb + 2)
-        q2 = self.cross_v(query + pos, vis_feats, vis_feats, key_padding_mask=None, batch_first=True)[0]
-        query = add_dropout_layer_norm(query, q2, self.norm_v, self.dropout_v.p, tr, sb + 3)
+            query = _attn_residual_norm(self.cross_d, query, query + pos, detected_feats,
+                                        detected_feats, detected_mask, self.norm_d, self.dropout_d.p,
+                                        tr, sb + 2)
+        query = _attn_residual_norm(self.cross_v, query, query + pos, vis_feats, vis_feats, None,
+                                    self.norm_v, self.dropout_v.p, tr, sb + 3)
         query = _ffn_residual_norm(query, self.ffn, self.norm2, tr, sb + 4)
         return query.contiguous()

@@ -1,10 +1,13 @@
-"""LayerNorm(x + dropout(y)) as one fused HIP kernel pair (csrc/ln.hip).
+"""LayerNorm(x + dropout(y + bias)) as one fused HIP kernel pair (csrc/ln.hip).
 
 Every post-norm block of the reference's encoder/decoder has this shape
 (models/encoder_decoder_layers.py:94-96,106-122,154-156,184-186,371-405).  On the GPU the
 three stock launches (dropout, add, layer_norm) and their ~five backward launches become one
 forward and one backward kernel; on CPU tensors (host-logic tests) the same expression is
-evaluated with plain torch ops.
+evaluated with plain torch ops.  `y_bias` is the bias of the linear that produced y (attention
+out-projection / second FFN linear) when the caller applied that linear without it: adding it
+here is free, and so is its gradient (a third column sum next to d(gamma), d(beta)), which
+saves the separate row-reduction launch autograd would otherwise spend on it.
 """
 import itertools
 
@@ -25,7 +28,7 @@ def new_salt_base():
 
 class _AddDropoutLN(Function):
     @staticmethod
-    def forward(ctx, x, y, gamma, beta, eps, p_drop, salt):
+    def forward(ctx, x, y, y_bias, gamma, beta, eps, p_drop, salt):
         shape = x.shape
         C = shape[-1]
         x2 = x.reshape(-1, C).contiguous()
@@ -37,42 +40,54 @@ class _AddDropoutLN(Function):
         seed = dropout_state(dev) if p_drop > 0 else None
         with torch.cuda.device(dev), _timed("add_dropout_ln_fwd", (R, C)):
             rc = _lib.lib().eda_add_dropout_ln_fwd_f32(
-                x2.data_ptr(), y2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), R, C, float(eps),
+                x2.data_ptr(), y2.data_ptr(), y_bias.data_ptr() if y_bias is not None else None,
+                gamma.data_ptr(), beta.data_ptr(), R, C, float(eps),
                 float(p_drop), seed.data_ptr() if seed is not None else None, int(salt),
                 out.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
                 torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "eda_add_dropout_ln_fwd_f32")
-        ctx.save_for_backward(x2, y2, gamma, stats)
+        ctx.save_for_backward(x2, y2, gamma, stats, y_bias)
         ctx.cfg = (float(p_drop), int(salt), shape)
         return out.view(shape)
 
     @staticmethod
     def backward(ctx, dout):
-        x2, y2, gamma, stats = ctx.saved_tensors
+        x2, y2, gamma, stats, y_bias = ctx.saved_tensors
         p_drop, salt, shape = ctx.cfg
         R, C = x2.shape
         dev = x2.device
         dout = dout.reshape(R, C).contiguous()
         dx = torch.empty_like(x2)
         dy = torch.empty_like(x2)
-        dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
+        g3 = torch.empty((3, C), dtype=torch.float32, device=dev)
         L = _lib.lib()
         ws_bytes = L.eda_add_dropout_ln_bwd_workspace_bytes(R, C)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
         seed = dropout_state(dev) if p_drop > 0 else None
         with torch.cuda.device(dev), _timed("add_dropout_ln_bwd", (R, C)):
             rc = L.eda_add_dropout_ln_bwd_f32(
-                dout.data_ptr(), x2.data_ptr(), y2.data_ptr(), gamma.data_ptr(), stats[0].data_ptr(),
-                stats[1].data_ptr(), R, C, p_drop, seed.data_ptr() if seed is not None else None, salt,
-                dx.data_ptr(), dy.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(),
-                ws_bytes, torch.cuda.current_stream().cuda_stream)
+                dout.data_ptr(), x2.data_ptr(), y2.data_ptr(),
+                y_bias.data_ptr() if y_bias is not None else None, gamma.data_ptr(),
+                stats[0].data_ptr(), stats[1].data_ptr(), R, C, p_drop,
+                seed.data_ptr() if seed is not None else None, salt, dx.data_ptr(), dy.data_ptr(),
+                g3.data_ptr(), ws.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "eda_add_dropout_ln_bwd_f32")
-        return dx.view(shape), dy.view(shape), dgb[0], dgb[1], None, None, None
+        return (dx.view(shape), dy.view(shape), g3[2] if y_bias is not None else None, g3[0], g3[1],
+                None, None, None)
 
 
-def add_dropout_layer_norm(x, y, norm, p_drop, training, salt):
-    """norm(x + dropout(y, p_drop)) for an nn.LayerNorm `norm` over the last dimension."""
+def fuses_bias(x, norm):
+    """True when add_dropout_layer_norm takes the HIP path for (x, norm), i.e. when a caller may
+    apply the preceding linear without its bias and hand the bias over as `y_bias`."""
+    return (x.is_cuda and norm.elementwise_affine and x.shape[-1] <= 1024
+            and x.dtype == torch.float32)
+
+
+def add_dropout_layer_norm(x, y, norm, p_drop, training, salt, y_bias=None):
+    """norm(x + dropout(y + y_bias, p_drop)) for an nn.LayerNorm `norm` over the last dim."""
     p = float(p_drop) if training else 0.0
-    if x.is_cuda and norm.elementwise_affine and x.shape[-1] <= 1024 and x.dtype == torch.float32:
-        return _AddDropoutLN.apply(x, y, norm.weight, norm.bias, norm.eps, p, salt)
+    if fuses_bias(x, norm):
+        return _AddDropoutLN.apply(x, y, y_bias, norm.weight, norm.bias, norm.eps, p, salt)
+    if y_bias is not None:
+        y = y + y_bias
     return norm(x + F.dropout(y, p, training=p > 0))

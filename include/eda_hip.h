@@ -178,21 +178,23 @@ int eda_bn_relu_bwd_f32(const float *dout, const unsigned char *argmax, const fl
                         float *dz, void *stream);
 
 /* ---- fused residual + dropout + LayerNorm ----------------------------------
- * out = LayerNorm(x + dropout(y)) over the last dimension of (R,C) rows: the post-norm
- * blocks of models/encoder_decoder_layers.py:94-96,106-122,154-156,184-186,371-405
- * (`x = norm(x + dropout(y))`).  mean/rstd (R floats each) are kept for the backward,
- * which returns dx, dy (R,C) and d(gamma), d(beta) (C) using `ws` scratch for per-block partial sums.  Dropout mask:
- * the same counter-based hash as eda_mha_*, regenerated in the backward.             */
-int eda_add_dropout_ln_fwd_f32(const float *x, const float *y, const float *gamma,
-                               const float *beta, long R, int C, float eps, float p_drop,
-                               const unsigned long long *seed_ptr, unsigned salt, float *out,
-                               float *mean, float *rstd, void *stream);
+ * out = LayerNorm(x + dropout(y + y_bias)) over the last dimension of (R,C) rows: the
+ * post-norm blocks of models/encoder_decoder_layers.py:94-96,106-122,154-156,184-186,371-405
+ * (`x = norm(x + dropout(y))`, y = output of an attention out-projection or FFN linear whose
+ * bias y_bias (C floats, may be NULL) is added here so that its gradient comes out of the
+ * backward for free).  mean/rstd (R floats each) are kept for the backward, which returns
+ * dx, dy (R,C) and grads3 = [d(gamma) | d(beta) | d(y_bias)] (3*C floats) using `ws` scratch
+ * for per-block partial sums.  Dropout mask: the same counter-based hash as eda_mha_*.  */
+int eda_add_dropout_ln_fwd_f32(const float *x, const float *y, const float *y_bias,
+                               const float *gamma, const float *beta, long R, int C, float eps,
+                               float p_drop, const unsigned long long *seed_ptr, unsigned salt,
+                               float *out, float *mean, float *rstd, void *stream);
 size_t eda_add_dropout_ln_bwd_workspace_bytes(long R, int C);
 int eda_add_dropout_ln_bwd_f32(const float *dout, const float *x, const float *y,
-                               const float *gamma, const float *mean, const float *rstd, long R,
-                               int C, float p_drop, const unsigned long long *seed_ptr,
-                               unsigned salt, float *dx, float *dy, float *dgamma, float *dbeta,
-                               void *ws, size_t ws_bytes, void *stream);
+                               const float *y_bias, const float *gamma, const float *mean,
+                               const float *rstd, long R, int C, float p_drop,
+                               const unsigned long long *seed_ptr, unsigned salt, float *dx,
+                               float *dy, float *grads3, void *ws, size_t ws_bytes, void *stream);
 
 #ifdef __cplusplus
 }

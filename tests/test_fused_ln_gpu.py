@@ -49,7 +49,7 @@ def test_dropout_path():
     # exactly where y was dropped
     xg = torch.zeros(1, 4096, C, device="cuda")
     yg = torch.randn(1, 4096, C, device="cuda", requires_grad=True)
-    out = _AddDropoutLN.apply(xg, yg, torch.ones(C, device="cuda"), torch.zeros(C, device="cuda"), 1e-5, 0.25, 11)
+    out = _AddDropoutLN.apply(xg, yg, None, torch.ones(C, device="cuda"), torch.zeros(C, device="cuda"), 1e-5, 0.25, 11)
     out.backward(torch.randn_like(out))
     dropped = (yg.grad == 0).float().mean().item()
     assert abs(dropped - 0.25) < 0.01, dropped
@@ -57,3 +57,36 @@ def test_dropout_path():
     mask = (yg.grad != 0).float()
     ref = F.layer_norm(yg.detach() * mask / 0.75, (C,))
     torch.testing.assert_close(out.detach(), ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape,p", [((8, 256, 288), 0.0), ((3, 77, 288), 0.1), ((2, 5, 96), 0.3)])
+def test_deferred_bias(shape, p):
+    """y_bias: same output as adding the bias to y beforehand; d(bias) = column sums of dy."""
+    from eda_amd import attention
+    from eda_amd.fused_ln import add_dropout_layer_norm
+    torch.manual_seed(1 + sum(shape))
+    C = shape[-1]
+    norm = torch.nn.LayerNorm(C).cuda()
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5); norm.bias.normal_(0, 0.2)
+    x = torch.randn(*shape, device="cuda", requires_grad=True)
+    y = torch.randn(*shape, device="cuda", requires_grad=True)
+    bias = torch.randn(C, device="cuda", requires_grad=True)
+    w = torch.randn(*shape, device="cuda")
+    attention.dropout_state("cuda").fill_(9)
+    out = add_dropout_layer_norm(x, y, norm, p, True, 21, y_bias=bias)
+    (out * w).sum().backward()
+    got = [out.detach(), x.grad.clone(), y.grad.clone(), bias.grad.clone(), norm.weight.grad.clone(),
+           norm.bias.grad.clone()]
+    for t in (x, y, bias, norm.weight, norm.bias):
+        t.grad = None
+    # the dropout hash depends only on (step, site, element index): pre-adding the bias must give
+    # the identical mask and hence the identical result
+    yb = (y + bias)
+    ref = add_dropout_layer_norm(x, yb, norm, p, True, 21)
+    (ref * w).sum().backward()
+    exp = [ref.detach(), x.grad, y.grad, bias.grad, norm.weight.grad, norm.bias.grad]
+    for name, g, e in zip(["out", "dx", "dy", "dbias", "dgamma", "dbeta"], got, exp):
+        scale = e.abs().max().item() + 1e-9
+        assert (g - e).abs().max().item() <= 1e-4 * scale + 2e-6, (name, (g - e).abs().max().item(), scale)
+    assert torch.equal(got[0], exp[0])
