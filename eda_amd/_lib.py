@@ -42,7 +42,7 @@ SIGNATURES = {
     "eda_mha_fwd_f32": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _l, _p, _i, _i, _i, _i, _i, _f, _f,
                             _p, _u, _p, _p, _p]),
     "eda_mha_bwd_f32": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _l, _p, _i, _i, _i, _i, _i, _f, _f,
-                            _p, _u, _p, _p, _p, _l, _l, _p, _p, _p, _p, _p]),
+                            _p, _u, _p, _p, _p, _l, _l, _p, _p, _p, _p, _l, _l, _l, _l, _l, _l, _p]),
 }
 
 _lib = None

@@ -99,9 +99,94 @@ class _FusedMHA(Function):
                 B, num_heads, Lq, Lk, hd, hd ** -0.5, p_drop,
                 seed.data_ptr() if seed is not None else None, salt, out.data_ptr(), lse.data_ptr(),
                 dout.data_ptr(), dout.stride(0), dout.stride(1), delta.data_ptr(), dq.data_ptr(),
-                dk.data_ptr(), dv.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                dk.data_ptr(), dv.data_ptr(), dq.stride(0), dq.stride(1), dk.stride(0), dk.stride(1),
+                dv.stride(0), dv.stride(1), torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "eda_mha_bwd_f32")
         return dq, dk, dv, None, None, None, None
+
+
+class _ProjectedMHA(Function):
+    """In-projection + attention core as ONE autograd node (GPU training path of
+    MultiheadAttention).  `groups` lists, per distinct input tensor, the row range [lo, hi) of
+    in_proj_weight it is multiplied with -- ((0, 3d),) for self-attention, ((0, d), (d, 3d))
+    when key is value, ((0, 2d), (2d, 3d)) when query is key, three ranges otherwise -- so each
+    input costs one packed GEMM and q/k/v are column views of the packed results.  Compared with
+    F.linear + split + _FusedMHA under autograd, the backward writes dq/dk/dv straight into the
+    packed gradient buffers (no cat), the weight/bias gradients straight into their row ranges
+    of ONE (3d,d)/(3d) buffer (no zero-fill + copy + add per slice), and skips nothing else:
+    the GEMMs are the same library calls."""
+
+    @staticmethod
+    def forward(ctx, W, b, mask, num_heads, p_drop, salt, groups, *xs):
+        d = W.shape[1]
+        dev = W.device
+        B = xs[0].shape[0]
+        x2s, Ps, cols = [], [], {}
+        for x, (lo, hi) in zip(xs, groups):
+            x2 = x.reshape(-1, d)
+            P = torch.addmm(b[lo:hi], x2, W[lo:hi].t()).view(B, -1, hi - lo)
+            x2s.append(x2)
+            Ps.append(P)
+            for j in range(lo // d, hi // d):
+                cols[j] = (len(Ps) - 1, j * d - lo)
+        q, k, v = (Ps[g][..., c:c + d] for g, c in (cols[0], cols[1], cols[2]))
+        Lq, Lk = q.shape[1], k.shape[1]
+        hd = d // num_heads
+        out = torch.empty((B, Lq, d), dtype=torch.float32, device=dev)
+        lse = torch.empty((B, num_heads, Lq), dtype=torch.float32, device=dev)
+        m8 = mask.contiguous().view(torch.uint8) if mask is not None else None
+        seed = dropout_state(dev) if p_drop > 0 else None
+        with torch.cuda.device(dev), _timed('mha_fwd', (B, num_heads, Lq, Lk)):
+            rc = _lib.lib().eda_mha_fwd_f32(
+                q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
+                k.stride(1), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else None,
+                B, num_heads, Lq, Lk, hd, hd ** -0.5, float(p_drop),
+                seed.data_ptr() if seed is not None else None, int(salt), out.data_ptr(),
+                lse.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "eda_mha_fwd_f32")
+        ctx.save_for_backward(W, out, lse, *x2s, *Ps)
+        ctx.mask8 = m8
+        ctx.cfg = (num_heads, float(p_drop), int(salt), groups, cols, [x.shape for x in xs])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        num_heads, p_drop, salt, groups, cols, shapes = ctx.cfg
+        n = len(groups)
+        W, out, lse = ctx.saved_tensors[:3]
+        x2s, Ps = ctx.saved_tensors[3:3 + n], ctx.saved_tensors[3 + n:]
+        d = W.shape[1]
+        dev = W.device
+        dout = _rows(dout)
+        q, k, v = (Ps[g][..., c:c + d] for g, c in (cols[0], cols[1], cols[2]))
+        B, Lq, Lk = q.shape[0], q.shape[1], k.shape[1]
+        hd = d // num_heads
+        dPs = [torch.empty_like(P) for P in Ps]
+        dq, dk, dv = (dPs[g][..., c:c + d] for g, c in (cols[0], cols[1], cols[2]))
+        delta = torch.empty((B, num_heads, Lq), dtype=torch.float32, device=dev)
+        m8 = ctx.mask8
+        seed = dropout_state(dev) if p_drop > 0 else None
+        with torch.cuda.device(dev), _timed('mha_bwd', (B, num_heads, Lq, Lk)):
+            rc = _lib.lib().eda_mha_bwd_f32(
+                q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
+                k.stride(1), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else None,
+                B, num_heads, Lq, Lk, hd, hd ** -0.5, p_drop,
+                seed.data_ptr() if seed is not None else None, salt, out.data_ptr(), lse.data_ptr(),
+                dout.data_ptr(), dout.stride(0), dout.stride(1), delta.data_ptr(), dq.data_ptr(),
+                dk.data_ptr(), dv.data_ptr(), dq.stride(0), dq.stride(1), dk.stride(0), dk.stride(1),
+                dv.stride(0), dv.stride(1), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "eda_mha_bwd_f32")
+        dW = torch.empty_like(W) if ctx.needs_input_grad[0] else None
+        db = torch.empty((W.shape[0],), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        dxs = []
+        for i, (lo, hi) in enumerate(groups):
+            dP2 = dPs[i].view(-1, hi - lo)
+            if dW is not None:
+                torch.mm(dP2.t(), x2s[i], out=dW[lo:hi])
+            if db is not None:
+                torch.sum(dP2, dim=0, out=db[lo:hi])
+            dxs.append(torch.mm(dP2, W[lo:hi]).view(shapes[i]) if ctx.needs_input_grad[7 + i] else None)
+        return (dW, db, None, None, None, None, None, *dxs)
 
 
 def _hip_core(q, k, v, key_padding_mask, num_heads, dropout_p, salt):
@@ -153,10 +238,28 @@ class MultiheadAttention(nn.Module):
         returned: the caller's fused residual+LayerNorm kernel adds it (fused_ln.py)."""
         if attn_mask is not None:
             raise NotImplementedError("EDA always passes attn_mask=None")
+        same_qk, same_kv = query is key, key is value
         if not batch_first:
-            query, key, value = (t.transpose(0, 1) for t in (query, key, value))
+            query = query.transpose(0, 1)
+            key = query if same_qk else key.transpose(0, 1)
+            value = key if same_kv else value.transpose(0, 1)
         d = self.embed_dim
         W, b = self.in_proj_weight, self.in_proj_bias
+        if query.is_cuda and _core is _hip_core:
+            if query is key and key is value:
+                groups, xs = ((0, 3 * d),), (query,)
+            elif key is value:
+                groups, xs = ((0, d), (d, 3 * d)), (query, key)
+            elif query is key:
+                groups, xs = ((0, 2 * d), (2 * d, 3 * d)), (query, value)
+            else:
+                groups, xs = ((0, d), (d, 2 * d), (2 * d, 3 * d)), (query, key, value)
+            o = _ProjectedMHA.apply(W, b, key_padding_mask, self.num_heads,
+                                    self.dropout if self.training else 0.0, self._salt, groups, *xs)
+            o = F.linear(o, self.out_proj.weight, None if defer_out_bias else self.out_proj.bias)
+            if not batch_first:
+                o = o.transpose(0, 1)
+            return o, (self.out_proj.bias if defer_out_bias else None)
         if query is key and key is value:
             q, k, v = F.linear(query, W, b).split(d, dim=-1)
         elif key is value:

@@ -50,7 +50,8 @@ struct MhaArgs {
   // backward
   const float *dout; long do_sb, do_sl;       // (B,Lq,288)
   const float *delta;                         // (B,H,Lq) rowsum(dO * O)
-  float *dq, *dk, *dv;                        // contiguous (B,L,288)
+  float *dq, *dk, *dv;                        // (B,L,288) rows, strided like q/k/v
+  long dq_sb, dq_sl, dk_sb, dk_sl, dv_sb, dv_sl;
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dq_kernel(MhaArgs a) {
     __syncthreads();
   }
   if (qvalid) {
-    float *out = a.dq + ((long)b * a.Lq + qi) * (a.H * HD) + h * HD;
+    float *out = a.dq + (long)b * a.dq_sb + (long)qi * a.dq_sl + h * HD;
     const float sc = a.scale;
     *reinterpret_cast<float4 *>(out + 4 * g) = make_float4(dq[0][0] * sc, dq[0][1] * sc, dq[0][2] * sc, dq[0][3] * sc);
     *reinterpret_cast<float4 *>(out + 16 + 4 * g) = make_float4(dq[1][0] * sc, dq[1][1] * sc, dq[1][2] * sc, dq[1][3] * sc);
@@ -520,9 +521,9 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dkv_kernel(MhaArgs a) {
     __syncthreads();
   }
   if (kvalid) {
-    const long off = ((long)b * a.Lk + ki) * (a.H * HD) + h * HD;
     const float sc = a.scale;
-    float *ok = a.dk + off, *ov = a.dv + off;
+    float *ok = a.dk + (long)b * a.dk_sb + (long)ki * a.dk_sl + h * HD;
+    float *ov = a.dv + (long)b * a.dv_sb + (long)ki * a.dv_sl + h * HD;
     *reinterpret_cast<float4 *>(ok + 4 * g) = make_float4(dk[0][0] * sc, dk[0][1] * sc, dk[0][2] * sc, dk[0][3] * sc);
     *reinterpret_cast<float4 *>(ok + 16 + 4 * g) = make_float4(dk[1][0] * sc, dk[1][1] * sc, dk[1][2] * sc, dk[1][3] * sc);
     *reinterpret_cast<float4 *>(ov + 4 * g) = make_float4(dv[0][0], dv[0][1], dv[0][2], dv[0][3]);
@@ -587,14 +588,17 @@ extern "C" int eda_mha_bwd_f32(const float *q, const float *k, const float *v, l
                                int head_dim, float scale, float p_drop,
                                const unsigned long long *seed_ptr, unsigned salt, const float *out,
                                const float *lse, const float *dout, long do_sb, long do_sl,
-                               float *delta_ws, float *dq, float *dk, float *dv, void *stream_) {
+                               float *delta_ws, float *dq, float *dk, float *dv, long dq_sb,
+                               long dq_sl, long dk_sb, long dk_sl, long dv_sb, long dv_sl,
+                               void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EDA_CHECK_ARG(head_dim == HD, "only head_dim 36 (d_model 288 / 8 heads) is built");
   EDA_CHECK_ARG(B >= 0 && H > 0 && Lq >= 0 && Lk >= 0, "bad dimension");
   if (B == 0) return 0;
   EDA_CHECK_ARG(q && k && v && out && lse && dout && delta_ws && dq && dk && dv, "null pointer");
   EDA_CHECK_ARG(mult4(q_sb) && mult4(q_sl) && mult4(k_sb) && mult4(k_sl) && mult4(v_sb) && mult4(v_sl) &&
-                    mult4(do_sb) && mult4(do_sl) && al16(q) && al16(k) && al16(v) && al16(out) &&
+                    mult4(do_sb) && mult4(do_sl) && mult4(dq_sb) && mult4(dq_sl) && mult4(dk_sb) &&
+                    mult4(dk_sl) && mult4(dv_sb) && mult4(dv_sl) && al16(q) && al16(k) && al16(v) && al16(out) &&
                     al16(dout) && al16(dq) && al16(dk) && al16(dv),
                 "rows must be 16-byte aligned");
   EDA_CHECK_ARG((long)B * H <= 65535, "B*H too large");
@@ -604,6 +608,7 @@ extern "C" int eda_mha_bwd_f32(const float *q, const float *k, const float *v, l
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.p_drop = p_drop; a.seed_ptr = seed_ptr;
   a.salt = salt; a.dout = dout; a.do_sb = do_sb; a.do_sl = do_sl; a.delta = delta_ws; a.dq = dq;
   a.dk = dk; a.dv = dv;
+  a.dq_sb = dq_sb; a.dq_sl = dq_sl; a.dk_sb = dk_sb; a.dk_sl = dk_sl; a.dv_sb = dv_sb; a.dv_sl = dv_sl;
   a.o = const_cast<float *>(out); a.o_sb = (long)Lq * H * HD; a.o_sl = (long)H * HD;
   if (Lq > 0) {
     // (delta = rowsum(dO * O) is computed inside the dQ kernel and published for dK/dV)

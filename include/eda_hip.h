@@ -136,7 +136,8 @@ int eda_mha_fwd_f32(const float *q, const float *k, const float *v, long q_sb, l
                     int head_dim, float scale, float p_drop,
                     const unsigned long long *seed_ptr, unsigned salt, float *out,
                     float *lse, void *stream);
-/* Backward of the above: dq (B,Lq,H*36), dk, dv (B,Lk,H*36) dense outputs;
+/* Backward of the above: dq (B,Lq,H*36), dk, dv (B,Lk,H*36) with their own element strides
+ * (batch, row), so that the gradients of a packed q|k|v projection land in one buffer;
  * delta_ws: (B,H,Lq) floats of scratch.                                      */
 int eda_mha_bwd_f32(const float *q, const float *k, const float *v, long q_sb, long q_sl,
                     long k_sb, long k_sl, long v_sb, long v_sl,
@@ -144,7 +145,8 @@ int eda_mha_bwd_f32(const float *q, const float *k, const float *v, long q_sb, l
                     int head_dim, float scale, float p_drop,
                     const unsigned long long *seed_ptr, unsigned salt, const float *out,
                     const float *lse, const float *dout, long do_sb, long do_sl,
-                    float *delta_ws, float *dq, float *dk, float *dv, void *stream);
+                    float *delta_ws, float *dq, float *dk, float *dv, long dq_sb, long dq_sl,
+                    long dk_sb, long dk_sl, long dv_sb, long dv_sl, void *stream);
 
 /* ---- set-abstraction grouped MLP, channels-last pipeline -----------------
  * Rows are positions (scene, centre j, neighbour k) of a (b*m*ns, C) matrix.

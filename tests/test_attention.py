@@ -145,15 +145,52 @@ def test_fused_dropout_statistics_and_gradient_consistency():
 
 
 @pytest.mark.gpu
-def test_module_on_gpu_matches_torch_multiheadattention():
+@pytest.mark.parametrize("case", ["self", "posself", "cross", "distinct"])
+@pytest.mark.parametrize("batch_first", [True, False])
+def test_module_on_gpu_matches_torch_multiheadattention(case, batch_first):
+    """Output AND every gradient (inputs, packed in-projection weight/bias, out-projection) of the
+    one-node in-projection + fused core against torch.nn.MultiheadAttention."""
     from eda_amd import attention
     torch.manual_seed(0)
     ref = torch.nn.MultiheadAttention(288, 8, dropout=0.1).eval().cuda()
     mine = attention.MultiheadAttention(288, 8, dropout=0.1).eval().cuda()
+    with torch.no_grad():
+        ref.in_proj_bias.normal_(0, 0.1); ref.out_proj.bias.normal_(0, 0.1)
     mine.load_state_dict(ref.state_dict())
     B, Lq, Lk = 4, 256, 80
-    x = torch.randn(B, Lq, 288, device="cuda"); mem = torch.randn(B, Lk, 288, device="cuda")
-    mask = _mask(B, Lk, 2).cuda()
-    exp = ref(x.transpose(0, 1), mem.transpose(0, 1), mem.transpose(0, 1), key_padding_mask=mask)[0].transpose(0, 1)
-    got = mine(x, mem, mem, key_padding_mask=mask, batch_first=True)[0]
-    torch.testing.assert_close(got, exp, rtol=1e-4, atol=2e-5)
+    leaves = [torch.randn(B, Lq, 288, device="cuda", requires_grad=True),
+              torch.randn(B, Lq, 288, device="cuda", requires_grad=True),
+              torch.randn(B, Lk, 288, device="cuda", requires_grad=True),
+              torch.randn(B, Lk, 288, device="cuda", requires_grad=True)]
+    w = torch.randn(B, Lq, 288, device="cuda")
+
+    def run(mod, is_ref):
+        x, pos, mem, mem2 = leaves
+        if case == "self":
+            q = k = v = x; mask = _mask(B, Lq, 1).cuda()
+        elif case == "posself":
+            q = k = x + pos; v = x; mask = None
+        elif case == "cross":
+            q = x + pos; k = v = mem; mask = _mask(B, Lk, 2).cuda()
+        else:
+            q = x; k = mem; v = mem2; mask = _mask(B, Lk, 3).cuda()
+        if is_ref or not batch_first:
+            qt = q.transpose(0, 1)
+            kt = qt if k is q else k.transpose(0, 1)
+            vt = kt if v is k else (qt if v is q else v.transpose(0, 1))
+            out = mod(qt, kt, vt, key_padding_mask=mask)[0].transpose(0, 1)
+        else:
+            out = mod(q, k, v, key_padding_mask=mask, batch_first=True)[0]
+        params = [mod.in_proj_weight, mod.in_proj_bias, mod.out_proj.weight, mod.out_proj.bias]
+        grads = torch.autograd.grad((out * w).sum(), leaves + params, allow_unused=True)
+        return [out.detach()] + list(grads)
+
+    exp = run(ref, True)
+    got = run(mine, False)
+    names = ["out", "dx", "dpos", "dmem", "dmem2", "dW_in", "db_in", "dW_out", "db_out"]
+    for name, g, e in zip(names, got, exp):
+        assert (g is None) == (e is None), name
+        if e is None:
+            continue
+        scale = e.abs().max().item() + 1e-9
+        assert (g - e).abs().max().item() <= 2e-4 * scale + 1e-6, (name, (g - e).abs().max().item(), scale)
