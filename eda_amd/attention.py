@@ -23,6 +23,7 @@ from torch.autograd import Function
 
 from . import _lib
 from .ext import _timed
+from .nn_utils import colsum
 
 _dropout_state = {}      # device -> int64 counter tensor read by the kernels
 _salt_counter = itertools.count(1)
@@ -184,7 +185,7 @@ class _ProjectedMHA(Function):
             if dW is not None:
                 torch.mm(dP2.t(), x2s[i], out=dW[lo:hi])
             if db is not None:
-                torch.sum(dP2, dim=0, out=db[lo:hi])
+                colsum(dP2, out=db[lo:hi])
             dxs.append(torch.mm(dP2, W[lo:hi]).view(shapes[i]) if ctx.needs_input_grad[7 + i] else None)
         return (dW, db, None, None, None, None, None, *dxs)
 

@@ -23,13 +23,13 @@ import torch.nn.functional as F
 
 from .backbone_module import Pointnet2Backbone
 from .encoder_decoder_layers import BiDecoderLayer, BiEncoder, BiEncoderLayer, PositionEmbeddingLearned
-from .nn_utils import Conv1dK1
+from .nn_utils import Conv1dK1, Linear, deferred_bn_counters
 from .modules import ClsAgnosticPredictHead, GeneralSamplingModule, PointsObjClsModule
 
 
 def _mlp3(d_in, d_out):
-    return nn.Sequential(nn.Linear(d_in, d_in), nn.ReLU(), nn.Linear(d_in, d_in), nn.ReLU(),
-                         nn.Linear(d_in, d_out))
+    return nn.Sequential(Linear(d_in, d_in), nn.ReLU(), Linear(d_in, d_in), nn.ReLU(),
+                         Linear(d_in, d_out))
 
 
 def _load_text_stack(data_path):
@@ -70,7 +70,7 @@ class BeaUTyDETR(nn.Module):
         for p in self.text_encoder.parameters():
             p.requires_grad = False
         self.text_projector = nn.Sequential(
-            nn.Linear(self.text_encoder.config.hidden_size, d_model),
+            Linear(self.text_encoder.config.hidden_size, d_model),
             nn.LayerNorm(d_model, eps=1e-12), nn.Dropout(0.1))
 
         if self.butd:
@@ -82,7 +82,7 @@ class BeaUTyDETR(nn.Module):
             # the reference sets requires_grad on the MODULE (bdetr.py:95), so the table
             # stays trainable and takes part in the gradient all-reduce; kept on purpose.
             self.butd_class_embeddings.requires_grad = False
-            self.class_embeddings = nn.Linear(768, d_model - 128)
+            self.class_embeddings = Linear(768, d_model - 128)
             self.box_embeddings = PositionEmbeddingLearned(6, 128)
 
         self.pos_embed = PositionEmbeddingLearned(3, d_model)
@@ -171,6 +171,10 @@ class BeaUTyDETR(nn.Module):
 
     # ----------------------------------------------------------------- forward
     def forward(self, inputs):
+        with deferred_bn_counters():
+            return self._forward(inputs)
+
+    def _forward(self, inputs):
         end_points = self._run_backbones(inputs)
         points_xyz = end_points["fp2_xyz"]                       # (B, 1024, 3)
         points_features = end_points["fp2_features"]             # (B, 288, 1024)

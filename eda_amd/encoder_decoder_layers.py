@@ -15,7 +15,7 @@ from torch import nn
 
 from .attention import MultiheadAttention
 from .fused_ln import add_dropout_layer_norm, fuses_bias, new_salt_base
-from .nn_utils import Conv1dK1, bn_relu_rows, rows_ok
+from .nn_utils import Conv1dK1, Linear, bn_relu_rows, rows_ok
 
 
 def _get_clones(module, n):
@@ -23,8 +23,8 @@ def _get_clones(module, n):
 
 
 def _ffn(d_model, dim_feedforward, dropout):
-    return nn.Sequential(nn.Linear(d_model, dim_feedforward), nn.ReLU(), nn.Dropout(dropout),
-                         nn.Linear(dim_feedforward, d_model), nn.Dropout(dropout))
+    return nn.Sequential(Linear(d_model, dim_feedforward), nn.ReLU(), nn.Dropout(dropout),
+                         Linear(dim_feedforward, d_model), nn.Dropout(dropout))
 
 
 def _ffn_residual_norm(x, ffn, norm, training, salt):

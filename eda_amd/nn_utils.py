@@ -10,6 +10,71 @@ contract) and run one batched GEMM instead.
 import torch
 from torch import nn
 import torch.nn.functional as F
+from torch.autograd import Function
+
+_colsum_counters = {}
+
+
+def colsum(x2, out=None):
+    """out[c] = sum_r x2[r, c] for a 2-D fp32 GPU matrix: ONE launch of csrc/colsum.hip (the
+    bias gradient of a pointwise linear layer).  All calls on a device share one ticket-counter
+    array and therefore must be issued on one stream at a time (autograd's backward is)."""
+    from . import _lib
+    from .ext import _timed
+    assert x2.dim() == 2 and x2.is_cuda and x2.dtype == torch.float32
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    R, C = x2.shape
+    dev = x2.device
+    if out is None:
+        out = torch.empty((C,), dtype=torch.float32, device=dev)
+    cnt = _colsum_counters.get(dev)
+    if cnt is None or cnt.numel() * 64 < C:
+        cnt = _colsum_counters[dev] = torch.zeros((max(4096, (C + 63) // 64),), dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    ws_bytes = L.eda_colsum_workspace_bytes(R, C)
+    ws = torch.empty((max(ws_bytes, 4),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev), _timed("colsum", (R, C)):
+        rc = L.eda_colsum_f32(x2.data_ptr(), R, C, x2.stride(0) if R > 1 else C, out.data_ptr(), ws.data_ptr(),
+                              ws_bytes, cnt.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "eda_colsum_f32")
+    return out
+
+
+class _LinearRows(Function):
+    """y = x W^T + b over the last dimension -- the library GEMMs autograd would use, with the
+    bias gradient from colsum() instead of a framework reduction."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x2 = x.reshape(-1, x.shape[-1])
+        y = torch.mm(x2, W.t()) if b is None else torch.addmm(b, x2, W.t())
+        ctx.save_for_backward(x2, W)
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W = ctx.saved_tensors
+        dy2 = dy.reshape(-1, W.shape[0])
+        dx = torch.mm(dy2, W).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dW = torch.mm(dy2.t(), x2) if ctx.needs_input_grad[1] else None
+        db = colsum(dy2) if ctx.needs_input_grad[2] else None
+        return dx, dW, db
+
+
+def linear_rows(x, weight, bias):
+    """F.linear(x, weight, bias); on the GPU (fp32) with the one-launch bias gradient."""
+    if x.is_cuda and bias is not None and x.dtype == torch.float32 and x.numel() > 0:
+        return _LinearRows.apply(x, weight, bias)
+    return F.linear(x, weight, bias)
+
+
+class Linear(nn.Linear):
+    """nn.Linear (same parameters / state_dict) routed through linear_rows."""
+
+    def forward(self, x):
+        return linear_rows(x, self.weight, self.bias)
 
 
 class Conv1dK1(nn.Conv1d):
@@ -19,7 +84,7 @@ class Conv1dK1(nn.Conv1d):
 
     def rows(self, x):
         """Channels-last form: x (..., Cin) -> (..., Cout), one row-major GEMM, no transposes."""
-        return F.linear(x, self.weight.squeeze(-1), self.bias)
+        return linear_rows(x, self.weight.squeeze(-1), self.bias)
 
     def forward(self, x):                                  # (B, Cin, M)
         y = torch.matmul(self.weight.squeeze(-1), x)
@@ -39,6 +104,37 @@ class Conv2dK1(nn.Conv2d):
         return y.view(B, self.out_channels, H, W)
 
 
+_deferred_counters = None
+
+
+class deferred_bn_counters:
+    """Inside this context the `num_batches_tracked += 1` of every BatchNorm that runs in
+    training mode is collected and applied by ONE multi-tensor launch at exit instead of ~70
+    single-element kernels (the values afterwards are the same)."""
+
+    def __enter__(self):
+        global _deferred_counters
+        self.prev, _deferred_counters = _deferred_counters, []
+        return self
+
+    def __exit__(self, *exc):
+        global _deferred_counters
+        mine, _deferred_counters = _deferred_counters, self.prev
+        by_count = {}
+        for t, n in {id(t): (t, sum(u is t for u in mine)) for t in mine}.values():
+            by_count.setdefault(n, []).append(t)        # a module that ran twice counts twice
+        for n, ts in by_count.items():
+            torch._foreach_add_(ts, n)
+        return False
+
+
+def bump_batches_tracked(bn):
+    if _deferred_counters is not None:
+        _deferred_counters.append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked.add_(1)
+
+
 def bn_relu_rows(bn, z):
     """relu(BatchNorm1d/2d `bn`(z)) for channels-last rows z (R, C) on the GPU: the fused
     HIP kernel of csrc/sa_cl.hip (batch statistics + running-stat update in training)."""
@@ -46,7 +142,7 @@ def bn_relu_rows(bn, z):
     out = sa_ops.BNReLUCL.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
                                 bn.momentum, bn.training, 1)
     if bn.training and bn.track_running_stats:
-        bn.num_batches_tracked.add_(1)
+        bump_batches_tracked(bn)
     return out
 
 

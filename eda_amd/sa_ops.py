@@ -8,6 +8,7 @@ from torch.autograd import Function
 
 from . import _lib
 from .ext import _timed
+from .nn_utils import bump_batches_tracked
 
 
 def _stream():
@@ -155,5 +156,5 @@ def shared_mlp_rows(mlp, rows, pool):
         x = BNReLUCL.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
                            bn.momentum, training, pool if last else 1)
         if training and bn.track_running_stats:
-            bn.num_batches_tracked.add_(1)
+            bump_batches_tracked(bn)
     return x

@@ -198,6 +198,18 @@ int eda_add_dropout_ln_bwd_f32(const float *dout, const float *x, const float *y
                                const unsigned long long *seed_ptr, unsigned salt, float *dx,
                                float *dy, float *grads3, void *ws, size_t ws_bytes, void *stream);
 
+/* ---- column sums (bias gradients) ------------------------------------------
+ * out[c] = sum_r x[r*ld + c] for a row-major (R,C) matrix: d(bias) of every pointwise linear
+ * layer on the path (what autograd's AddmmBackward / the reference's nn.Linear, nn.Conv1d(k=1)
+ * backward compute with a framework reduction, e.g. models/encoder_decoder_layers.py:47-75,
+ * models/modules.py:66-86 in training).  One launch; `ws` = eda_colsum_workspace_bytes(R,C)
+ * bytes of scratch; `counters` = at least (C+63)/64 unsigned ints owned by the caller, zero
+ * before the first use (the kernel leaves them zero); calls sharing `counters` must be ordered
+ * on one stream.  The summation order is fixed (run-to-run deterministic).  */
+size_t eda_colsum_workspace_bytes(long R, int C);
+int eda_colsum_f32(const float *x, long R, int C, long ld, float *out, void *ws, size_t ws_bytes,
+                   unsigned *counters, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

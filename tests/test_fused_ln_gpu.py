@@ -90,3 +90,38 @@ def test_deferred_bias(shape, p):
         scale = e.abs().max().item() + 1e-9
         assert (g - e).abs().max().item() <= 1e-4 * scale + 2e-6, (name, (g - e).abs().max().item(), scale)
     assert torch.equal(got[0], exp[0])
+
+
+@pytest.mark.parametrize("R,C", [(8192, 576), (2048, 288), (640, 864), (2048, 3), (1, 288), (77, 130), (100000, 64),
+                                 (5, 1000)])
+def test_colsum(R, C):
+    """csrc/colsum.hip against an fp64 column sum; repeated calls reuse the self-resetting counters."""
+    from eda_amd.nn_utils import colsum
+    torch.manual_seed(R + C)
+    x = torch.randn(R, C, device="cuda")
+    exp = x.double().sum(0)
+    for _ in range(3):
+        got = colsum(x)
+        assert (got.double() - exp).abs().max().item() <= 1e-5 * (x.abs().double().sum(0).max().item() + 1)
+    assert torch.equal(colsum(x), got)                       # deterministic order
+    # strided rows (a column slice of a wider matrix) and an `out` slice
+    wide = torch.randn(R, C + 8, device="cuda")
+    out = torch.zeros(C + 4, device="cuda")
+    colsum(wide[:, 4:4 + C], out=out[2:2 + C])
+    e2 = wide[:, 4:4 + C].double().sum(0)
+    assert (out[2:2 + C].double() - e2).abs().max().item() <= 1e-5 * (wide.abs().double().sum(0).max().item() + 1)
+    assert out[:2].abs().sum().item() == 0 and out[2 + C:].abs().sum().item() == 0
+
+
+def test_linear_rows_matches_torch():
+    from eda_amd.nn_utils import linear_rows
+    torch.manual_seed(3)
+    x = torch.randn(8, 256, 288, device="cuda", requires_grad=True)
+    W = torch.randn(64, 288, device="cuda", requires_grad=True)
+    b = torch.randn(64, device="cuda", requires_grad=True)
+    w = torch.randn(8, 256, 64, device="cuda")
+    got = torch.autograd.grad((linear_rows(x, W, b) * w).sum(), [x, W, b])
+    exp = torch.autograd.grad((F.linear(x, W, b) * w).sum(), [x, W, b])
+    torch.testing.assert_close(linear_rows(x, W, b), F.linear(x, W, b), rtol=1e-5, atol=1e-5)
+    for g, e in zip(got, exp):
+        torch.testing.assert_close(g, e, rtol=1e-4, atol=1e-4)

@@ -33,7 +33,8 @@ def main():
     for _ in range(3):
         step()
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    want_stack = bool(os.environ.get("STACKS"))
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=want_stack) as prof:
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
@@ -46,7 +47,34 @@ def main():
     print(f"device time per step: {tot / steps / 1e3:.2f} ms over {sum(r[1] for r in rows) / steps:.0f} kernels/step")
     for k, c, t in rows[:45]:
         print(f"{t / steps / 1e3:8.3f} ms/step {100 * t / tot:5.1f}%  x{c / steps:6.1f}  {k[:120]}")
+    # which aten / autograd ops launch them (self device time of the CPU-side op)
+    ops = [(e.key, e.count, e.self_device_time_total) for e in ka
+           if e.device_type.name == "CPU" and e.self_device_time_total > 0]
+    ops.sort(key=lambda r: -r[2])
+    print("---- by launching op (self device time) ----")
+    for k, c, t in ops[:int(os.environ.get("TOP_OPS", 50))]:
+        print(f"{t / steps / 1e3:8.3f} ms/step  x{c / steps:6.1f}  {k[:100]}")
+    if want_stack:
+        stacks(prof, steps)
+
+
+def stacks(prof, steps):
+    """STACKS=aten::copy_,aten::add_ ...: for those ops, the python frames that issued them."""
+    import collections
+    want = set(os.environ["STACKS"].split(","))
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for e in prof.events():
+        if e.name in want and e.self_device_time_total > 0:
+            fr = [f for f in (e.stack or []) if "/repo/" in f and "profile_step" not in f][:3]
+            key = (e.name, " <- ".join(f.split("/repo/")[-1] for f in fr) or
+                   " <- ".join((e.stack or ["?"])[:3]))
+            agg[key][0] += 1
+            agg[key][1] += e.self_device_time_total
+    print("---- stacks ----")
+    for (name, where), (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:80]:
+        print(f"{t / steps / 1e3:7.3f} ms x{c / steps:6.1f} {name}  {where[:200]}")
 
 
 if __name__ == "__main__":
     main()
+
