@@ -34,7 +34,7 @@ SIGNATURES = {
     "eda_group_concat_cl_grad_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "eda_bn_relu_fwd_f32": (_i, [_p, _l, _i, _p, _p, _f, _f, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p,
                                 _p, _p]),
-    "eda_bn_relu_bwd_f32": (_i, [_p, _p, _p, _l, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
+    "eda_bn_relu_bwd_f32": (_i, [_p, _p, _p, _l, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
     "eda_add_dropout_ln_fwd_f32": (_i, [_p, _p, _p, _p, _p, _l, _i, _f, _f, _p, _u, _p, _p, _p, _p]),
     "eda_add_dropout_ln_bwd_workspace_bytes": (_sz, [_l, _i]),
     "eda_add_dropout_ln_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _i, _f, _p, _u, _p, _p, _p, _p, _sz,

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(CL_THREADS) void bn_relu_bwd_apply_kernel(
     const float *__restrict__ rstd, const float *__restrict__ scale,
     const float *__restrict__ shift, const float *__restrict__ gamma,
     const double *__restrict__ s1, const double *__restrict__ s2, int train,
-    float *__restrict__ dz) {
+    float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dz) {
   const int cgroups = C / 4;
   const int rpp = CL_THREADS / cgroups;
   const int tcol = threadIdx.x % cgroups, trow = threadIdx.x / cgroups;
@@ -294,6 +294,7 @@ __global__ __launch_bounds__(CL_THREADS) void bn_relu_bwd_apply_kernel(
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     const int c = c0 + v;
+    if (blockIdx.x == 0 && trow == 0) { dbeta[c] = (float)s1[c]; dgamma[c] = (float)s2[c]; }
     sc[v] = scale[c]; sh[v] = shift[c];
     const float gr = gamma[c] * rstd[c];
     ka[v] = gr;
@@ -464,7 +465,8 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_bwd_kernel(
     const float *__restrict__ da, const float *__restrict__ z, int R, int C,
     const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ rstd,
     const float *__restrict__ scale, const float *__restrict__ shift, int train,
-    double *__restrict__ s1_out, double *__restrict__ s2_out, float *__restrict__ dz) {
+    double *__restrict__ s1_out, double *__restrict__ s2_out, float *__restrict__ dgamma,
+    float *__restrict__ dbeta, float *__restrict__ dz) {
   __shared__ float red[8][SM_WAVES];
   __shared__ float ka_l[4], kb_l[4], kd_l[4];
   const int c0 = blockIdx.x * 4;
@@ -497,6 +499,7 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_bwd_kernel(
     double t1 = 0.0, t2 = 0.0;
     for (int w = 0; w < SM_WAVES; ++w) { t1 += (double)red[threadIdx.x][w]; t2 += (double)red[4 + threadIdx.x][w]; }
     s1_out[c] = t1; s2_out[c] = t2;
+    dbeta[c] = (float)t1; dgamma[c] = (float)t2;
     const float invR = 1.f / (float)R;
     const float gr = gamma[c] * rstd[c];
     ka_l[threadIdx.x] = gr;
@@ -634,16 +637,21 @@ extern "C" int eda_bn_relu_fwd_f32(const float *z, long R, int C, const float *g
 extern "C" int eda_bn_relu_bwd_f32(const float *dout, const unsigned char *argmax, const float *z,
                                    long R, int C, int pool, const float *gamma, const float *mean,
                                    const float *rstd, const float *scale, const float *shift,
-                                   int training, double *ws, float *dz, void *stream_) {
+                                   int training, double *ws, float *dgamma, float *dbeta, float *dz,
+                                   void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EDA_CHECK_ARG(R >= 0 && C > 0 && pool >= 1 && C % 4 == 0 && C <= 1024, "bad dimension");
-  if (R == 0) return 0;
+  EDA_CHECK_ARG(dgamma && dbeta, "null pointer");
+  if (R == 0) {
+    const int z1 = eda_zero_async(dgamma, sizeof(float) * C, stream);
+    return z1 ? z1 : eda_zero_async(dbeta, sizeof(float) * C, stream);
+  }
   EDA_CHECK_ARG(dout && z && gamma && mean && rstd && scale && shift && ws && dz, "null pointer");
   EDA_CHECK_ARG(pool == 1 || argmax, "argmax required when pooling");
   if (pool == 1 && R <= SMALL_ROWS) {
     const int nb = C / 4;
     hipLaunchKernelGGL(bn_relu_small_bwd_kernel, dim3(nb), dim3(SM_THREADS), 0, stream, dout, z, (int)R,
-                       C, gamma, mean, rstd, scale, shift, training, ws, ws + C, dz);
+                       C, gamma, mean, rstd, scale, shift, training, ws, ws + C, dgamma, dbeta, dz);
     EDA_CHECK_LAUNCH();
     return 0;
   }
@@ -664,11 +672,11 @@ extern "C" int eda_bn_relu_bwd_f32(const float *dout, const unsigned char *argma
   if (pool > 1)
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<true>, dim3(apply_grid), dim3(CL_THREADS), 0, stream,
                        dout, argmax, z, R, C, pool, mean, rstd, scale, shift, gamma, ws, ws + C, training,
-                       dz);
+                       dgamma, dbeta, dz);
   else
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<false>, dim3(apply_grid), dim3(CL_THREADS), 0, stream,
                        dout, argmax, z, R, C, pool, mean, rstd, scale, shift, gamma, ws, ws + C, training,
-                       dz);
+                       dgamma, dbeta, dz);
   EDA_CHECK_LAUNCH();
   return 0;
 }

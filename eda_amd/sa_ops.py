@@ -132,15 +132,15 @@ class BNReLUCL(Function):
         dout = dout.contiguous()
         dz = torch.empty_like(z)
         ws = torch.empty((2 * C,), dtype=torch.float64, device=z.device)
+        dgb = torch.empty((2, C), dtype=torch.float32, device=z.device)
         with torch.cuda.device(z.device), _timed('bn_relu_bwd', (R, C, pool, int(training))):
             rc = _lib.lib().eda_bn_relu_bwd_f32(
                 dout.data_ptr(), argmax.data_ptr() if argmax is not None else None, z.data_ptr(), R, C,
                 pool, gamma.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
-                stats[3].data_ptr(), int(training), ws.data_ptr(), dz.data_ptr(), _stream())
+                stats[3].data_ptr(), int(training), ws.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
+                dz.data_ptr(), _stream())
         _lib.check(rc, "eda_bn_relu_bwd_f32")
-        dbeta = ws[:C].float()
-        dgamma = ws[C:].float()
-        return dz, dgamma, dbeta, None, None, None, None, None, None
+        return dz, dgb[0], dgb[1], None, None, None, None, None, None
 
 
 def shared_mlp_rows(mlp, rows, pool):

@@ -168,7 +168,7 @@ int eda_group_concat_cl_grad_f32(const float *dx, const int *idx, int b, int n, 
  * out = relu(bn(z)) (R,C), or with pool > 1 its max over each `pool` consecutive rows
  * (R/pool,C) plus the arg-max row (bytes).  mean/rstd/scale/shift (C each) are kept
  * for the backward.  ws: 2*C doubles.
- * eda_bn_relu_bwd_f32: dz (R,C); on return ws[0..C) = d(beta), ws[C..2C) = d(gamma).  */
+ * eda_bn_relu_bwd_f32: dz (R,C), dgamma, dbeta (C floats each); ws: 2*C doubles of scratch.  */
 int eda_bn_relu_fwd_f32(const float *z, long R, int C, const float *gamma, const float *beta,
                         float eps, float momentum, int training, float *running_mean,
                         float *running_var, int pool, double *ws, float *mean, float *rstd,
@@ -177,7 +177,7 @@ int eda_bn_relu_fwd_f32(const float *z, long R, int C, const float *gamma, const
 int eda_bn_relu_bwd_f32(const float *dout, const unsigned char *argmax, const float *z, long R,
                         int C, int pool, const float *gamma, const float *mean, const float *rstd,
                         const float *scale, const float *shift, int training, double *ws,
-                        float *dz, void *stream);
+                        float *dgamma, float *dbeta, float *dz, void *stream);
 
 /* ---- fused residual + dropout + LayerNorm ----------------------------------
  * out = LayerNorm(x + dropout(y + y_bias)) over the last dimension of (R,C) rows: the
