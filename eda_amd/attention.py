@@ -23,7 +23,7 @@ from torch.autograd import Function
 
 from . import _lib
 from .ext import _timed
-from .nn_utils import colsum
+from .nn_utils import colsum, linear_rows, wgrad
 
 _dropout_state = {}      # device -> int64 counter tensor read by the kernels
 _salt_counter = itertools.count(1)
@@ -183,8 +183,9 @@ class _ProjectedMHA(Function):
         for i, (lo, hi) in enumerate(groups):
             dP2 = dPs[i].view(-1, hi - lo)
             if dW is not None:
-                torch.mm(dP2.t(), x2s[i], out=dW[lo:hi])
-            if db is not None:
+                wgrad(dP2, x2s[i], dW=dW[lo:hi], db=db[lo:hi] if db is not None else None,
+                      want_db=db is not None)
+            elif db is not None:
                 colsum(dP2, out=db[lo:hi])
             dxs.append(torch.mm(dP2, W[lo:hi]).view(shapes[i]) if ctx.needs_input_grad[7 + i] else None)
         return (dW, db, None, None, None, None, None, *dxs)
@@ -257,7 +258,7 @@ class MultiheadAttention(nn.Module):
                 groups, xs = ((0, d), (d, 2 * d), (2 * d, 3 * d)), (query, key, value)
             o = _ProjectedMHA.apply(W, b, key_padding_mask, self.num_heads,
                                     self.dropout if self.training else 0.0, self._salt, groups, *xs)
-            o = F.linear(o, self.out_proj.weight, None if defer_out_bias else self.out_proj.bias)
+            o = linear_rows(o, self.out_proj.weight, None if defer_out_bias else self.out_proj.bias)
             if not batch_first:
                 o = o.transpose(0, 1)
             return o, (self.out_proj.bias if defer_out_bias else None)

@@ -1,0 +1,226 @@
+// wgrad.hip -- weight gradient of a pointwise linear layer, dW = dY^T X (+ d(bias) = column
+// sums of dY), for the shapes of this path: SMALL output (M x N = 64..864 x 128..288), LONG
+// reduction (K = rows = 640..8192).  The library GEMM picks 32x32 macro-tiles with no K split
+// for these and reaches 21-29 TFLOP/s fp32 (14 us at K=2048, 47 us at K=8192 for 288x288,
+// tools/bench_dw.py); the ~135 of them per training step are a third of all GEMM time.
+//
+// Formulation: both operands are K-major exactly as they lie in memory (dY is (K,M) rows, X is
+// (K,N) rows), which is the native operand order of v_mfma_f32_16x16x4_f32:
+//   A: lane l holds dY[k + (l>>4)][m + (l&15)],  B: lane l holds X[k + (l>>4)][n + (l&15)],
+// so a K-chunk is staged into LDS as a plain row copy (16-byte loads, no transposes anywhere).
+//
+// Decomposition: a workgroup of 12 waves (3 per SIMD) owns a 96x96 output tile (288, 576 and
+// 864 are multiples of 96) for one K split; it walks its split in 64-row chunks with the next
+// chunk's global loads in flight during the MFMAs.  The splits' partial tiles go to a
+// workspace and a second small kernel adds them in split order (deterministic); with one
+// split the first kernel writes dW directly.  Workgroups of the first column tile also sum
+// their dY chunk's columns from LDS: d(bias) costs no extra pass over dY.
+#include "eda_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WG_T 96            // output tile edge
+#define WG_KC 64           // K rows per LDS chunk
+#define WG_THREADS 768     // 12 waves: 3 per SIMD
+#define WG_LD 2            // float4 loads per thread per operand per chunk (64 rows * 24 float4 / 768)
+#define WG_STRIDE 112      // LDS row stride in floats: 96 + 16 so that the four K rows of one MFMA
+                           // operand read (lanes 0-15, 16-31, ...) fall on disjoint banks
+
+__global__ __launch_bounds__(WG_THREADS) void wgrad_partial_kernel(
+    const float *__restrict__ dy, long ld_dy, const float *__restrict__ x, long ld_x, long K, int M,
+    int N, int chunks_per_split, int tiles_n, int ntiles, int nsplits, float *__restrict__ out,
+    float *__restrict__ db_out, float *__restrict__ partial) {
+  __shared__ float As[WG_KC][WG_STRIDE];
+  __shared__ float Bs[WG_KC][WG_STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // wave w owns a 16 x 48 strip of the tile: rows 16*wm.., columns 48*wh + {0,16,32}.  One A
+  // operand feeds three MFMAs whose accumulators are independent (no dependent-issue stalls).
+  const int wm = w >> 1, wh = w & 1;
+  // XCD-aware placement: consecutive workgroup ids go round-robin to the 8 XCDs (each with its
+  // own L2), so id%8 picks the XCD and ALL output tiles of a K split are given to one XCD:
+  // the split's dY / X rows are then re-read from that L2 by the other tiles (3-9x re-use).
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int s = xcd + 8 * (j / ntiles);
+  if (s >= nsplits) return;
+  const int tile = j - (j / ntiles) * ntiles;
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * WG_T, n0 = tn * WG_T;
+  const long kbeg = (long)s * chunks_per_split * WG_KC;
+  long kend = kbeg + (long)chunks_per_split * WG_KC;
+  if (kend > K) kend = K;
+
+  float4 ra[WG_LD], rb[WG_LD];
+  int lrow[WG_LD], lcol[WG_LD];
+#pragma unroll
+  for (int i = 0; i < WG_LD; ++i) {
+    const int idx = tid + WG_THREADS * i;
+    lrow[i] = idx / (WG_T / 4);
+    lcol[i] = (idx - lrow[i] * (WG_T / 4)) * 4;
+  }
+  auto fetch = [&](long k0) {
+#pragma unroll
+    for (int i = 0; i < WG_LD; ++i) {
+      const long k = k0 + lrow[i];
+      const bool rowok = k < kend;
+      ra[i] = (rowok && m0 + lcol[i] < M) ? *reinterpret_cast<const float4 *>(dy + k * ld_dy + m0 + lcol[i])
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[i] = (rowok && n0 + lcol[i] < N) ? *reinterpret_cast<const float4 *>(x + k * ld_x + n0 + lcol[i])
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  f32x4 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool active = (m0 + 16 * wm < M) && (n0 + 48 * wh < N);
+  const bool do_db = db_out != nullptr && tn == 0 && tid < WG_T;
+  float dbsum = 0.f;
+  const float *ap = &As[lane >> 4][16 * wm + (lane & 15)];
+  const float *bp = &Bs[lane >> 4][48 * wh + (lane & 15)];
+
+  if (kbeg < kend) fetch(kbeg);
+  for (long k0 = kbeg; k0 < kend; k0 += WG_KC) {
+#pragma unroll
+    for (int i = 0; i < WG_LD; ++i) {
+      *reinterpret_cast<float4 *>(&As[lrow[i]][lcol[i]]) = ra[i];
+      *reinterpret_cast<float4 *>(&Bs[lrow[i]][lcol[i]]) = rb[i];
+    }
+    __syncthreads();
+    if (k0 + WG_KC < kend) fetch(k0 + WG_KC);
+    if (active) {
+      // all 16 K steps' operands into registers first (one LDS latency per chunk), then MFMAs
+      float av[WG_KC / 4], bv[3][WG_KC / 4];
+#pragma unroll
+      for (int kk = 0; kk < WG_KC / 4; ++kk) {
+        av[kk] = ap[kk * 4 * WG_STRIDE];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) bv[t][kk] = bp[kk * 4 * WG_STRIDE + 16 * t];
+      }
+      __builtin_amdgcn_sched_barrier(0);     // keep the loads ahead of the MFMAs (the scheduler sinks them)
+#pragma unroll
+      for (int kk = 0; kk < WG_KC / 4; ++kk) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv[t][kk], acc[t], 0, 0, 0);
+      }
+    }
+    if (do_db) {
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+      for (int r = 0; r < WG_KC; r += 4) {
+        t0 += As[r][tid]; t1 += As[r + 1][tid]; t2 += As[r + 2][tid]; t3 += As[r + 3][tid];
+      }
+      dbsum += (t0 + t1) + (t2 + t3);
+    }
+    __syncthreads();
+  }
+  // One split: this workgroup owns the final tile.  Otherwise its partial tile goes to the
+  // workspace slab of split s ((M*N + M) floats: tile data, then the d(bias) partials).
+  const long MN = (long)M * N;
+  float *o = nsplits == 1 ? out : partial + (long)s * (MN + M);
+  float *od = nsplits == 1 ? db_out : o + MN;
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int col = n0 + 48 * wh + 16 * t + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 16 * wm + 4 * (lane >> 4) + r;
+        if (row < M && col < N) o[(long)row * N + col] = acc[t][r];
+      }
+    }
+  }
+  if (do_db && m0 + tid < M) od[m0 + tid] = dbsum;
+}
+
+// dW[e] = sum_s slab[s][e] (float4 per thread) and db[m] = sum_s slab[s][M*N + m], in split
+// order (deterministic).  (Folding this into the first kernel -- last workgroup per tile, ticket
+// counter -- was measured 2x SLOWER: one workgroup walking 16-32 slabs is latency-bound.)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, int S,
+                                                           long MN, int M, float *__restrict__ dW,
+                                                           float *__restrict__ db) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n4 = MN / 4, slab = MN + M;
+  if (i < n4) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int s = 0; s < S; ++s) {
+      const float4 v = *reinterpret_cast<const float4 *>(partial + (long)s * slab + 4 * i);
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    *reinterpret_cast<float4 *>(dW + 4 * i) = t;
+  } else if (db != nullptr && i < n4 + M) {
+    const int m = (int)(i - n4);
+    float t = 0.f;
+#pragma unroll 8
+    for (int s = 0; s < S; ++s) t += partial[(long)s * slab + MN + m];
+    db[m] = t;
+  }
+}
+
+namespace {
+struct WgPlan { int tiles_m, tiles_n, splits, cps; };
+WgPlan wg_plan(long K, int M, int N) {
+  WgPlan p;
+  p.tiles_m = (M + WG_T - 1) / WG_T;
+  p.tiles_n = (N + WG_T - 1) / WG_T;
+  const long nchunks = (K + WG_KC - 1) / WG_KC;
+  static int target = -1;
+  if (target < 0) {
+    const char *e = getenv("EDA_WGRAD_WGS");
+    target = e ? atoi(e) : 144;     // measured best for the 288x288 outputs (tools/bench_dw.py)
+    if (target < 1) target = 1;
+  }
+  long want = (target + p.tiles_m * p.tiles_n - 1) / (p.tiles_m * p.tiles_n);   // splits for ~target workgroups
+  if (want > nchunks) want = nchunks;
+  if (want < 1) want = 1;
+  if (want >= 8) want = (want + 7) / 8 * 8;        // whole rounds of the 8 XCDs
+  if (want > nchunks) want = nchunks;
+  p.cps = (int)((nchunks + want - 1) / want);
+  if (p.cps < 1) p.cps = 1;
+  p.splits = (int)((nchunks + p.cps - 1) / p.cps);
+  if (p.splits < 1) p.splits = 1;
+  return p;
+}
+}  // namespace
+
+extern "C" size_t eda_wgrad_workspace_bytes(long K, int M, int N) {
+  if (K <= 0 || M <= 0 || N <= 0) return 0;
+  const WgPlan p = wg_plan(K, M, N);
+  if (p.splits == 1) return 0;
+  return sizeof(float) * (size_t)p.splits * ((size_t)M * N + M);   // (M*N + M) % 4 == 0: rows stay 16-byte aligned
+}
+
+extern "C" int eda_wgrad_f32(const float *dy, long ld_dy, const float *x, long ld_x, long K, int M, int N,
+                             float *dW, float *db, void *ws, size_t ws_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(K >= 0 && M > 0 && N > 0, "bad dimension");
+  EDA_CHECK_ARG(M % 4 == 0 && N % 4 == 0 && ld_dy % 4 == 0 && ld_x % 4 == 0 && ld_dy >= M && ld_x >= N,
+                "M, N and the row strides must be multiples of 4");
+  EDA_CHECK_ARG(dW, "null pointer");
+  if (K == 0) {
+    const int z1 = eda_zero_async(dW, sizeof(float) * (size_t)M * N, stream);
+    if (z1 || !db) return z1;
+    return eda_zero_async(db, sizeof(float) * M, stream);
+  }
+  EDA_CHECK_ARG(dy && x, "null pointer");
+  EDA_CHECK_ARG(((uintptr_t)dy % 16 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dW % 16 == 0),
+                "operands must be 16-byte aligned");
+  const WgPlan p = wg_plan(K, M, N);
+  const int ntiles = p.tiles_m * p.tiles_n;
+  if (p.splits > 1 && (!ws || ws_bytes < eda_wgrad_workspace_bytes(K, M, N) || (uintptr_t)ws % 16 != 0)) {
+    eda_set_error("wgrad: workspace too small or misaligned");
+    return EDA_ERR_WORKSPACE;
+  }
+  const dim3 grid((unsigned)(8 * ntiles * ((p.splits + 7) / 8)));
+  hipLaunchKernelGGL(wgrad_partial_kernel, grid, dim3(WG_THREADS), 0, stream, dy, ld_dy, x, ld_x, K, M, N,
+                     p.cps, p.tiles_n, ntiles, p.splits, dW, db, reinterpret_cast<float *>(ws));
+  EDA_CHECK_LAUNCH();
+  if (p.splits > 1) {
+    const long items = (long)M * N / 4 + (db ? M : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const float *>(ws), p.splits, (long)M * N, M, dW, db);
+    EDA_CHECK_LAUNCH();
+  }
+  return 0;
+}

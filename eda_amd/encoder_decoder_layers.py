@@ -15,7 +15,7 @@ from torch import nn
 
 from .attention import MultiheadAttention
 from .fused_ln import add_dropout_layer_norm, fuses_bias, new_salt_base
-from .nn_utils import Conv1dK1, Linear, bn_relu_rows, rows_ok
+from .nn_utils import Conv1dK1, Linear, bn_relu_rows, linear_rows, rows_ok
 
 
 def _get_clones(module, n):
@@ -32,7 +32,7 @@ def _ffn_residual_norm(x, ffn, norm, training, salt):
     applied inside the fused residual+LayerNorm kernel."""
     h = ffn[2](ffn[1](ffn[0](x)))
     if fuses_bias(x, norm):      # second linear's bias (and its gradient) ride in the LN kernels
-        return add_dropout_layer_norm(x, F.linear(h, ffn[3].weight), norm, ffn[4].p, training, salt,
+        return add_dropout_layer_norm(x, linear_rows(h, ffn[3].weight, None), norm, ffn[4].p, training, salt,
                                       y_bias=ffn[3].bias)
     return add_dropout_layer_norm(x, ffn[3](h), norm, ffn[4].p, training, salt)
 

@@ -15,6 +15,14 @@ from torch.autograd import Function
 _colsum_counters = {}
 
 
+def _ticket_counters(dev, n):
+    """The per-device array of self-resetting ticket counters of csrc/colsum.hip / wgrad.hip."""
+    cnt = _colsum_counters.get(dev)
+    if cnt is None or cnt.numel() < n:
+        cnt = _colsum_counters[dev] = torch.zeros((max(4096, n),), dtype=torch.int32, device=dev)
+    return cnt
+
+
 def colsum(x2, out=None):
     """out[c] = sum_r x2[r, c] for a 2-D fp32 GPU matrix: ONE launch of csrc/colsum.hip (the
     bias gradient of a pointwise linear layer).  All calls on a device share one ticket-counter
@@ -28,9 +36,7 @@ def colsum(x2, out=None):
     dev = x2.device
     if out is None:
         out = torch.empty((C,), dtype=torch.float32, device=dev)
-    cnt = _colsum_counters.get(dev)
-    if cnt is None or cnt.numel() * 64 < C:
-        cnt = _colsum_counters[dev] = torch.zeros((max(4096, (C + 63) // 64),), dtype=torch.int32, device=dev)
+    cnt = _ticket_counters(dev, (C + 63) // 64)
     L = _lib.lib()
     ws_bytes = L.eda_colsum_workspace_bytes(R, C)
     ws = torch.empty((max(ws_bytes, 4),), dtype=torch.uint8, device=dev)
@@ -41,9 +47,49 @@ def colsum(x2, out=None):
     return out
 
 
+def wgrad(dy2, x2, dW=None, db=None, want_db=True):
+    """(dW, db) = (dy2^T x2, column sums of dy2) for 2-D fp32 GPU matrices dy2 (K,M), x2 (K,N):
+    the split-K MFMA kernel of csrc/wgrad.hip when the shapes allow 16-byte rows, else the
+    library GEMM + colsum.  dW / db may be preallocated (contiguous) destinations."""
+    from . import _lib
+    from .ext import _timed
+    K, M = dy2.shape
+    N = x2.shape[1]
+    dev = dy2.device
+    if dy2.stride(1) != 1:
+        dy2 = dy2.contiguous()
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    if dW is None:
+        dW = torch.empty((M, N), dtype=torch.float32, device=dev)
+    if want_db and db is None:
+        db = torch.empty((M,), dtype=torch.float32, device=dev)
+    ok = (M % 4 == 0 and N % 4 == 0 and K > 0 and (K == 1 or (dy2.stride(0) % 4 == 0 and x2.stride(0) % 4 == 0))
+          and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0 and dW.data_ptr() % 16 == 0
+          and dW.is_contiguous() and 32 <= N <= 288 and 32 <= M <= 288)
+    # (measured, tools/bench_dw.py: for outputs up to 288x288 the split-K kernel + free db beats
+    # library GEMM + colsum by 5 us at K=2048 and 20 us at K=8192; for the packed 576/864-row
+    # in-projections the library's 77 TFLOP/s wins, so those keep torch.mm + colsum)
+    if not ok:
+        torch.mm(dy2.t(), x2, out=dW)
+        if want_db:
+            colsum(dy2, out=db)
+        return dW, (db if want_db else None)
+    L = _lib.lib()
+    ws_bytes = L.eda_wgrad_workspace_bytes(K, M, N)
+    ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev), _timed("wgrad", (K, M, N)):
+        rc = L.eda_wgrad_f32(dy2.data_ptr(), dy2.stride(0) if K > 1 else M, x2.data_ptr(),
+                             x2.stride(0) if K > 1 else N, K, M, N, dW.data_ptr(),
+                             db.data_ptr() if want_db else None, ws.data_ptr(), ws_bytes,
+                             torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "eda_wgrad_f32")
+    return dW, (db if want_db else None)
+
+
 class _LinearRows(Function):
-    """y = x W^T + b over the last dimension -- the library GEMMs autograd would use, with the
-    bias gradient from colsum() instead of a framework reduction."""
+    """y = x W^T + b over the last dimension.  Forward and dX are the library GEMMs autograd
+    would use; dW (and the bias gradient, for free) come from wgrad()."""
 
     @staticmethod
     def forward(ctx, x, W, b):
@@ -51,6 +97,7 @@ class _LinearRows(Function):
         y = torch.mm(x2, W.t()) if b is None else torch.addmm(b, x2, W.t())
         ctx.save_for_backward(x2, W)
         ctx.xshape = x.shape
+        ctx.has_bias = b is not None
         return y.view(*x.shape[:-1], W.shape[0])
 
     @staticmethod
@@ -58,14 +105,17 @@ class _LinearRows(Function):
         x2, W = ctx.saved_tensors
         dy2 = dy.reshape(-1, W.shape[0])
         dx = torch.mm(dy2, W).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dW = torch.mm(dy2.t(), x2) if ctx.needs_input_grad[1] else None
-        db = colsum(dy2) if ctx.needs_input_grad[2] else None
+        dW = db = None
+        if ctx.needs_input_grad[1]:
+            dW, db = wgrad(dy2, x2, want_db=ctx.has_bias and ctx.needs_input_grad[2])
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy2)
         return dx, dW, db
 
 
 def linear_rows(x, weight, bias):
-    """F.linear(x, weight, bias); on the GPU (fp32) with the one-launch bias gradient."""
-    if x.is_cuda and bias is not None and x.dtype == torch.float32 and x.numel() > 0:
+    """F.linear(x, weight, bias); on the GPU (fp32) its backward uses wgrad() for dW and db."""
+    if x.is_cuda and x.dtype == torch.float32 and x.numel() > 0:
         return _LinearRows.apply(x, weight, bias)
     return F.linear(x, weight, bias)
 

@@ -210,6 +210,19 @@ size_t eda_colsum_workspace_bytes(long R, int C);
 int eda_colsum_f32(const float *x, long R, int C, long ld, float *out, void *ws, size_t ws_bytes,
                    unsigned *counters, void *stream);
 
+/* ---- weight gradient of a pointwise linear layer ---------------------------
+ * dW (M,N) = dY^T X for dY (K,M) and X (K,N) row-major with row strides ld_dy, ld_x, and
+ * optionally db (M) = column sums of dY (db may be NULL): what autograd computes for every
+ * nn.Linear / nn.Conv1d(k=1) / in-projection of the encoder-decoder in training
+ * (models/encoder_decoder_layers.py:47-75, models/modules.py:66-86, models/bdetr.py:96-143).
+ * fp32 MFMA with fp32 accumulation; K is split over workgroups and the partial tiles are added
+ * in a fixed order (deterministic) by a second small kernel.  M, N, ld_dy, ld_x multiples
+ * of 4; dW contiguous.  ws: eda_wgrad_workspace_bytes(K, M, N) bytes of scratch (16-byte
+ * aligned).                                                                       */
+size_t eda_wgrad_workspace_bytes(long K, int M, int N);
+int eda_wgrad_f32(const float *dy, long ld_dy, const float *x, long ld_x, long K, int M, int N,
+                  float *dW, float *db, void *ws, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
