@@ -395,6 +395,11 @@ def main():
                             "frac": round(dom["gbs"] / HBM_PEAK_GBS, 5), "traffic": None,
                             "ms_per_launch": dom["ms"], "alg_bytes_per_launch": dom["alg_bytes"],
                             "ms_per_step": round(dom["ms"] * dom["calls_per_step"], 4)}
+        # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
+        # WRITE_SIZE), measured offline for this build and shape: profiles/r01f_mha_pmc_traffic.md
+        # and profiles/r01d_summary.md.  None for shapes that were not profiled.
+        pmc_traffic = {("mha_bwd", (8, 8, 1024, 1024)): 242.8e6, ("mha_fwd", (8, 8, 1024, 1024)): 87.9e6,
+                       ("bn_relu_bwd", (1048576, 64, 1, 1)): None}
         mf = [k for k in kernels if k["tflops"]]
         roofline_mfma = None
         if mf:
@@ -402,7 +407,11 @@ def main():
             top = max(mf, key=lambda k: k["ms"] * k["calls_per_step"])
             roofline_mfma = {"kernel": f"{top['op']}{tuple(top['dims'])}", "bound": "mfma",
                              "achieved": top["tflops"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(top["tflops"] / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                             "frac": round(top["tflops"] / MFMA_F32_PEAK_TFLOPS, 4),
+                             "traffic": pmc_traffic.get((top["op"], tuple(top["dims"]))),
+                             "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE, bytes per launch, "
+                                               "profiles/r01f_mha_pmc_traffic.md",
+                             "alg_flops_per_launch": algorithmic_flops((top["op"],) + tuple(top["dims"])),
                              "ms_per_launch": top["ms"], "dtype": "f32 in / f32 accumulate MFMA",
                              "ms_per_step": round(top["ms"] * top["calls_per_step"], 4)}
         # `roofline` = whichever of the two roofline-priced kernels takes more of the step (the

@@ -143,8 +143,11 @@ __global__ __launch_bounds__(NW * 64) void mha_fwd_kernel(MhaArgs a) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;
-  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
-  const int qi = blockIdx.x * (NW * 16) + wave * 16 + c;
+  // grid = (B*H, row tiles): consecutive workgroup ids (round-robin over the 8 XCDs) are
+  // different heads, so every row tile of one (scene, head) lands on ONE XCD and its K/V (Q/dO)
+  // rows are fetched into one L2 instead of all eight.
+  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const int qi = blockIdx.y * (NW * 16) + wave * 16 + c;
   const bool qvalid = qi < a.Lq;
 
   const float *qrow = a.q + (long)b * a.q_sb + (long)(qvalid ? qi : 0) * a.q_sl + h * HD;
@@ -302,8 +305,11 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dq_kernel(MhaArgs a) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;
-  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
-  const int qi = blockIdx.x * (NW * 16) + wave * 16 + c;
+  // grid = (B*H, row tiles): consecutive workgroup ids (round-robin over the 8 XCDs) are
+  // different heads, so every row tile of one (scene, head) lands on ONE XCD and its K/V (Q/dO)
+  // rows are fetched into one L2 instead of all eight.
+  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const int qi = blockIdx.y * (NW * 16) + wave * 16 + c;
   const bool qvalid = qi < a.Lq;
 
   const float *qrow = a.q + (long)b * a.q_sb + (long)(qvalid ? qi : 0) * a.q_sl + h * HD;
@@ -421,8 +427,8 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dkv_kernel(MhaArgs a) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;
-  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
-  const int ki = blockIdx.x * (NW * 16) + wave * 16 + c;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;   // (B*H, key tiles): see mha_fwd_kernel
+  const int ki = blockIdx.y * (NW * 16) + wave * 16 + c;
   const bool kvalid = ki < a.Lk;
   const bool kdead = !kvalid || (a.mask && a.mask[(long)b * a.Lk + (kvalid ? ki : 0)]);
 
@@ -572,10 +578,10 @@ extern "C" int eda_mha_fwd_f32(const float *q, const float *k, const float *v, l
   a.lse = lse; a.mask = key_padding_mask; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale;
   a.p_drop = p_drop; a.seed_ptr = seed_ptr; a.salt = salt;
   if (pick_waves(Lq, B * H) == 1) {
-    hipLaunchKernelGGL(mha_fwd_kernel<1>, dim3((unsigned)((Lq + 15) / 16), (unsigned)(B * H)), dim3(64), 0,
+    hipLaunchKernelGGL(mha_fwd_kernel<1>, dim3((unsigned)(B * H), (unsigned)((Lq + 15) / 16)), dim3(64), 0,
                        stream, a);
   } else {
-    hipLaunchKernelGGL(mha_fwd_kernel<4>, dim3((unsigned)((Lq + 63) / 64), (unsigned)(B * H)), dim3(256), 0,
+    hipLaunchKernelGGL(mha_fwd_kernel<4>, dim3((unsigned)(B * H), (unsigned)((Lq + 63) / 64)), dim3(256), 0,
                        stream, a);
   }
   EDA_CHECK_LAUNCH();
@@ -613,19 +619,19 @@ extern "C" int eda_mha_bwd_f32(const float *q, const float *k, const float *v, l
   if (Lq > 0) {
     // (delta = rowsum(dO * O) is computed inside the dQ kernel and published for dK/dV)
     if (pick_waves(Lq, B * H) == 1)
-      hipLaunchKernelGGL(mha_bwd_dq_kernel<1>, dim3((unsigned)((Lq + 15) / 16), (unsigned)(B * H)), dim3(64),
+      hipLaunchKernelGGL(mha_bwd_dq_kernel<1>, dim3((unsigned)(B * H), (unsigned)((Lq + 15) / 16)), dim3(64),
                          0, stream, a);
     else
-      hipLaunchKernelGGL(mha_bwd_dq_kernel<4>, dim3((unsigned)((Lq + 63) / 64), (unsigned)(B * H)), dim3(256),
+      hipLaunchKernelGGL(mha_bwd_dq_kernel<4>, dim3((unsigned)(B * H), (unsigned)((Lq + 63) / 64)), dim3(256),
                          0, stream, a);
     EDA_CHECK_LAUNCH();
   }
   if (Lk > 0) {
     if (pick_waves(Lk, B * H) == 1)
-      hipLaunchKernelGGL(mha_bwd_dkv_kernel<1>, dim3((unsigned)((Lk + 15) / 16), (unsigned)(B * H)), dim3(64),
+      hipLaunchKernelGGL(mha_bwd_dkv_kernel<1>, dim3((unsigned)(B * H), (unsigned)((Lk + 15) / 16)), dim3(64),
                          0, stream, a);
     else
-      hipLaunchKernelGGL(mha_bwd_dkv_kernel<4>, dim3((unsigned)((Lk + 63) / 64), (unsigned)(B * H)), dim3(256),
+      hipLaunchKernelGGL(mha_bwd_dkv_kernel<4>, dim3((unsigned)(B * H), (unsigned)((Lk + 63) / 64)), dim3(256),
                          0, stream, a);
     EDA_CHECK_LAUNCH();
   }
