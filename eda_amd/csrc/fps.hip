@@ -48,6 +48,12 @@ __device__ __forceinline__ unsigned fps_tiekey(unsigned k, int p) {
   return (hi << (31 - p)) | (k >> p);
 }
 
+// Scope note (measured, round 1): all workgroups of a scene can be placed on ONE XCD, whose L2
+// would then be a sufficient coherence point -- but gfx950 offers no scope that bypasses the
+// per-CU L1 while still hitting the local L2: workgroup scope (sc0) may hit L1 outside
+// threadgroup-split mode (polls read stale lines for ~100 us; `buffer_inv sc0` does not help),
+// and agent scope (sc1) is coherent across the eight L2s through the fabric, the ~1 us
+// hand-off these granules pay.
 __device__ __forceinline__ void granule_store(u64 *p, unsigned tag, unsigned value) {
   __hip_atomic_store(p, ((u64)tag << 32) | (u64)value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

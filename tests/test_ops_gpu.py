@@ -82,6 +82,8 @@ def test_golden_vectors(ext, path):
     (2, 2048, 1024, {}), (2, 2049, 300, dict(dup=0.1)), (1, 8192, 512, dict(quant=8)),
     (2, 8193, 200, dict(dup=0.05)), (1, 20000, 700, dict(quant=16, origin=0.001)),
     (3, 50000, 300, dict(dup=0.02, origin=0.0005)),
+    (8, 50000, 64, {}),                       # bench geometry: 8 clusters of 7 workgroups, one per XCD
+    (38, 50000, 12, dict(dup=0.01)),          # more scenes than one launch holds (36): two launches
 ])
 def test_fps_vs_oracle(ext, oracle, mode, b, n, m, kw):
     rng = np.random.default_rng(n * 7 + m + mode)
