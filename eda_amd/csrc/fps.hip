@@ -235,6 +235,311 @@ __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz_al
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Speculative cluster kernel: K candidates per hand-off.
+//
+// The cluster kernel above pays one cross-workgroup hand-off (~1.1 us of its 2.2 us round) per
+// sample.  Here every hand-off carries each workgroup's TOP-K candidates under the reference's
+// total order (distance bits, then minimum tie key).  From the gathered G*K candidates every
+// workgroup derives the global top-K c0 > c1 > ... and accepts a PREFIX of it as the next
+// samples, exactly as the sequential algorithm would have chosen them:
+//   * c0 is the next sample by definition;
+//   * after the update with c0 every point's key can only DROP (d' = min(d, |p-c0|^2), tie key
+//     unchanged) and c0's own distance becomes 0.  So if c1's distance is unchanged --
+//     |c1-c0|^2 >= d(c1), the same canonical arithmetic the update uses -- and d(c1) > 0, then
+//     c1 is still above every other point: it IS the sample after c0.  Inductively c_i is
+//     accepted iff all earlier candidates were and |c_i-c_j|^2 >= d(c_i) for every j < i and
+//     d(c_i) > 0 (with d = 0 the already-chosen points tie and the tie key decides: stop).
+// Furthest points are mutually far apart, so the whole prefix is accepted most of the time: on
+// the bench clouds K = 4 needs 592 hand-offs for 2047 samples.  The accepted centres are
+// applied in ONE register pass (min over up to K distances), in which each thread also rebuilds
+// its sorted top-K list; waves merge by K rounds of (DPP max, pop), workgroups and the cluster
+// by K rounds of DPP arg-max over one key per lane (fps_topk_rank; an all-pairs rank through
+// LDS broadcasts or v_readlane was measured 1.5-2x slower: 64-bit compares are not cheap).  Results are bit-identical to the sequential
+// kernels (tests/test_ops_gpu.py::test_fps_vs_oracle).
+constexpr int kSpecMaxG = 16;                    // 64 poll lanes / K=4 candidates each
+constexpr int kSpecRecWords = 5 * 4;             // K=4 candidates x (bits, k, x, y, z) granules
+
+template <int K>
+struct FpsSpecShared {
+  u64 wkey[16][K];        // per wave: its top-K keys (up to 16 waves)
+  int gc[K][5];           // global top-K staging: bits, k, x, y, z
+  float cand[K][4];       // accepted-prefix candidates: x, y, z, (unused)
+  int cand_k[K];
+  int nvalid;
+  int fail;
+};
+
+// Rank (0..K-1) of this lane's key among the K largest keys of the wave, K for all other lanes;
+// key 0 = "no entry".  K rounds of wave arg-max (DPP) with the winner retiring; equal keys (only
+// the all-invalid candidate) retire in lane order.
+template <int K>
+__device__ __forceinline__ int fps_topk_rank(u64 key, int lane) {
+  int hi = (int)((unsigned)(key >> 32) ^ 0x80000000u);     // signed order == key order; 0 -> INT_MIN
+  int lo = (int)((unsigned)key ^ 0x80000000u);
+  bool live = key != 0ull;
+  int rank = K;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const int mh = eda_wave_max_i32(live ? hi : INT_MIN);
+    const bool cnd = live && hi == mh;
+    const u64 ties = __ballot(cnd);
+    int wl = -1;
+    if (__popcll(ties) == 1) {
+      wl = __ffsll((long long)ties) - 1;
+    } else if (ties != 0ull) {
+      const int ml = eda_wave_max_i32(cnd ? lo : INT_MIN);
+      wl = __ffsll((long long)__ballot(cnd && lo == ml)) - 1;
+    }
+    if (lane == wl) { rank = i; live = false; }
+  }
+  return rank;
+}
+
+__device__ __forceinline__ u64 fps_key(int bits, unsigned k, int p_log2) {
+  return ((u64)((unsigned)bits ^ 0x80000000u) << 32) | (u64)(~fps_tiekey(k, p_log2));
+}
+
+template <int MODE, int T, int P, int K>
+__global__ __launch_bounds__(T) void fps_spec_kernel(const float *__restrict__ xyz_all, int n, int m,
+                                                     int *__restrict__ idx_all, int S, int G, int p_log2,
+                                                     u64 *mail_all, int *status) {
+  static_assert(K == 4, "record layout and poll-lane mapping are written for K = 4");
+  constexpr int NW = T / 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *lx = reinterpret_cast<float *>(smem);
+  float *ly = lx + T * P;
+  float *lz = ly + T * P;
+  FpsSpecShared<K> *sh = reinterpret_cast<FpsSpecShared<K> *>(lz + T * P);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int scene = blockIdx.x % S;
+  const int w = blockIdx.x / S;
+  const float *xyz = xyz_all + (size_t)scene * n * 3;
+  int *idx = idx_all + (size_t)scene * m;
+  u64 *mail = mail_all + (size_t)scene * 2 * kMaxG * kRecWords;     // same footprint as fps_kernel
+  if (m <= 0) return;
+
+  float px[P], py[P], pz[P], pt[P];
+  int pk[P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    const long long k = ((long long)(j * G + w)) * T + tid;
+    float x = 0.f, y = 0.f, z = 0.f;
+    bool valid = k < n;
+    if (valid) {
+      x = xyz[k * 3 + 0]; y = xyz[k * 3 + 1]; z = xyz[k * 3 + 2];
+      const float mag = eda_sumsq3<MODE>(x, y, z);
+      valid = !((double)mag <= 1e-3);
+    }
+    px[j] = x; py[j] = y; pz[j] = z;
+    pt[j] = valid ? 1e10f : -1.0f;
+    pk[j] = valid ? (int)k : 0;
+    lx[j * T + tid] = x; ly[j * T + tid] = y; lz[j * T + tid] = z;
+  }
+  if (tid == 0) { sh->fail = 0; sh->nvalid = 1; }
+  if (tid < 3) sh->cand[0][tid] = xyz[tid];       // first sample is index 0
+  if (w == 0 && tid == 0) idx[0] = 0;
+  __syncthreads();
+
+  int r = 1;                 // next output position
+  unsigned h = 0;            // hand-off counter = mailbox tag
+#ifdef EDA_FPS_PROFILE
+  unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = __builtin_readcyclecounter();
+#define FPS_MARK(i) do { const unsigned long long tn = __builtin_readcyclecounter(); acc[i] += tn - tp; tp = tn; } while (0)
+#else
+#define FPS_MARK(i) do { } while (0)
+#endif
+  while (r < m) {
+    ++h;
+    const int nc = sh->nvalid;
+    float cx[K], cy[K], cz[K];
+#pragma unroll
+    for (int c = 0; c < K; ++c) { cx[c] = sh->cand[c][0]; cy[c] = sh->cand[c][1]; cz[c] = sh->cand[c][2]; }
+
+    // ---- 1. apply the nc accepted centres; rebuild this thread's sorted top-K --------------
+    int lb[K], lk[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) { lb[i] = INT_MIN; lk[i] = 0; }
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      float t = pt[j];
+#pragma unroll
+      for (int c = 0; c < K; ++c) {
+        if (c < nc) {
+          const float d = eda_sumsq3<MODE>(px[j] - cx[c], py[j] - cy[c], pz[j] - cz[c]);
+          t = fminf(d, t);                 // invalid points stay at -1
+        }
+      }
+      pt[j] = t;
+      int vb = __float_as_int(t), vk = pk[j];   // t >= 0 or == -1: signed int order == float order
+      // insertion with strict '>' (an equal earlier entry, i.e. a lower k of this thread, stays ahead)
+#pragma unroll
+      for (int i = 0; i < K; ++i) {
+        const bool gt = vb > lb[i];
+        const int ob = lb[i], ok = lk[i];
+        lb[i] = gt ? vb : ob; lk[i] = gt ? vk : ok;
+        vb = gt ? ob : vb;   vk = gt ? ok : vk;
+      }
+    }
+
+    FPS_MARK(0);
+    // ---- 2. wave top-K: K rounds of (wave arg-max of the list heads, winner pops) -----------
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const int hb = lb[0];
+      const int wm = eda_wave_max_i32(hb);
+      const bool cnd = hb == wm;
+      const u64 ties = __ballot(cnd);
+      int wl;
+      if (__popcll(ties) == 1) {
+        wl = __ffsll((long long)ties) - 1;
+      } else {
+        const unsigned tk = cnd ? fps_tiekey((unsigned)lk[0], p_log2) : 0xFFFFFFFFu;
+        const unsigned wt = eda_wave_min_u32(tk);
+        wl = __ffsll((long long)__ballot(cnd && tk == wt)) - 1;
+      }
+      const int wk = __builtin_amdgcn_readlane(lk[0], wl);
+      if (lane == 0) sh->wkey[wave][i] = wm == INT_MIN ? 0ull : fps_key(wm, (unsigned)wk, p_log2);
+      if (lane == wl) {
+#pragma unroll
+        for (int q = 0; q + 1 < K; ++q) { lb[q] = lb[q + 1]; lk[q] = lk[q + 1]; }
+        lb[K - 1] = INT_MIN; lk[K - 1] = 0;
+      }
+    }
+    FPS_MARK(1);
+    __syncthreads();
+    FPS_MARK(2);
+
+    if (wave == 0) {
+      // ---- 3. workgroup top-K of the NW*K wave keys (one per lane); publish -------------------
+      u64 *box = mail + (size_t)(h & 1) * kMaxG * kRecWords;
+      {
+        const u64 *flat = &sh->wkey[0][0];
+        const bool have = lane < NW * K;
+        const u64 mine = have ? flat[lane] : 0ull;
+        const int rank = fps_topk_rank<K>(mine, lane);
+        if (have && rank < K) {
+          const int bits = (int)((unsigned)(mine >> 32) ^ 0x80000000u);
+          int kw = 0;
+          float qx = 0.f, qy = 0.f, qz = 0.f;
+          if (mine != 0ull) {
+            kw = (int)fps_untie(~(unsigned)mine, p_log2);
+            const int li = ((kw / T) / G) * T + (kw % T);
+            qx = lx[li]; qy = ly[li]; qz = lz[li];
+          }
+          u64 *rec = box + (size_t)w * kSpecRecWords + (size_t)rank * 5;
+          granule_store(rec + 0, h, mine != 0ull ? (unsigned)bits : (unsigned)INT_MIN);
+          granule_store(rec + 1, h, (unsigned)kw);
+          granule_store(rec + 2, h, __float_as_uint(qx));
+          granule_store(rec + 3, h, __float_as_uint(qy));
+          granule_store(rec + 4, h, __float_as_uint(qz));
+        }
+      }
+      FPS_MARK(3);
+      // ---- 4. all-gather: lane l < G*K polls candidate l%K of workgroup l/K ------------------
+      unsigned v0 = (unsigned)INT_MIN, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+      const bool poller = lane < G * K;
+      bool ok = !poller;
+      unsigned spins = 0;
+      bool failed = false;
+      for (;;) {
+        if (!ok) {
+          const u64 *rec = box + (size_t)(lane / K) * kSpecRecWords + (size_t)(lane % K) * 5;
+          const u64 g0 = granule_load(rec + 0), g1 = granule_load(rec + 1);
+          const u64 g2 = granule_load(rec + 2), g3 = granule_load(rec + 3);
+          const u64 g4 = granule_load(rec + 4);
+          v0 = (unsigned)g0; v1 = (unsigned)g1; v2 = (unsigned)g2; v3 = (unsigned)g3; v4 = (unsigned)g4;
+          ok = ((unsigned)(g0 >> 32) == h) & ((unsigned)(g1 >> 32) == h) & ((unsigned)(g2 >> 32) == h) &
+               ((unsigned)(g3 >> 32) == h) & ((unsigned)(g4 >> 32) == h);
+        }
+        if (__all(ok)) break;
+        if (++spins > kSpinLimit) { failed = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      FPS_MARK(4);
+      if (failed) {
+        if (lane == 0) { sh->fail = 1; atomicExch(status, 1); }
+      } else {
+        // ---- 5. global top-K of the G*K gathered keys (one per lane) --------------------------
+        const u64 mine = (poller && (int)v0 != INT_MIN) ? fps_key((int)v0, v1, p_log2) : 0ull;
+        if (lane < K) sh->gc[lane][0] = __float_as_int(-1.0f);        // "no such candidate"
+        const int rank = fps_topk_rank<K>(mine, lane);
+        if (poller && rank < K) {       // candidate `rank` of the global order
+          sh->gc[rank][0] = (int)v0 == INT_MIN ? __float_as_int(-1.0f) : (int)v0;
+          sh->gc[rank][1] = (int)v1; sh->gc[rank][2] = (int)v2; sh->gc[rank][3] = (int)v3; sh->gc[rank][4] = (int)v4;
+        }
+        int ck[K]; float qx[K], qy[K], qz[K], qd[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {   // LDS broadcasts; a wave's LDS operations execute in order
+          qd[i] = __int_as_float(sh->gc[i][0]);
+          ck[i] = sh->gc[i][1];
+          qx[i] = __int_as_float(sh->gc[i][2]); qy[i] = __int_as_float(sh->gc[i][3]); qz[i] = __int_as_float(sh->gc[i][4]);
+        }
+        // ---- 6. accept the prefix the sequential algorithm would produce ---------------------
+        int nv = 1;
+        bool chain = true;
+#pragma unroll
+        for (int i = 1; i < K; ++i) {
+          bool good = chain && qd[i] > 0.f;
+#pragma unroll
+          for (int j = 0; j < i; ++j) {
+            const float d = eda_sumsq3<MODE>(qx[i] - qx[j], qy[i] - qy[j], qz[i] - qz[j]);
+            good = good && (d >= qd[i]);
+          }
+          chain = good;
+          nv += good ? 1 : 0;
+        }
+        if (nv > m - r) nv = m - r;
+        if (qd[0] < 0.f) ck[0] = 0;          // every point invalid: the reference emits index 0
+        if (lane == 0) {
+          sh->nvalid = nv;
+#pragma unroll
+          for (int i = 0; i < K; ++i) {
+            sh->cand[i][0] = qx[i]; sh->cand[i][1] = qy[i]; sh->cand[i][2] = qz[i];
+            if (w == 0 && i < nv) idx[r + i] = ck[i];
+          }
+        }
+      }
+    }
+    FPS_MARK(5);
+    __syncthreads();
+    FPS_MARK(6);
+    if (sh->fail) return;
+    r += sh->nvalid;
+    // sh->cand / nvalid are rewritten only after the next hand-off's first barrier
+  }
+#ifdef EDA_FPS_PROFILE
+  if (w == 0 && tid == 0 && scene == 0)
+    for (int i = 0; i < 7; ++i) status[16 + i] = (int)(acc[i] >> 4);
+#endif
+  // diagnostic: hand-offs this scene needed (ints 4.. of the status block; tools/fps_handoffs.py)
+  if (w == 0 && tid == 0 && scene < 56) status[4 + scene] = (int)h;
+}
+
+template <int MODE, int T, int P>
+int launch_fps_spec(const float *xyz, int n, int m, int *idx, int S, int G, int p_log2, u64 *mail,
+                    int *status, hipStream_t stream) {
+  const size_t lds = (size_t)T * P * 3 * sizeof(float) + sizeof(FpsSpecShared<4>);
+  auto kern = fps_spec_kernel<MODE, T, P, 4>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      eda_set_error("fps: cannot raise dynamic LDS to %zu bytes: %s", lds, hipGetErrorString(e));
+      return (int)e;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(S * G), dim3(T), lds, stream, xyz, n, m, idx, S, G, p_log2, mail, status);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    eda_set_error("fps: launch failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
 template <int MODE, int T, int P, bool CLUSTER>
 int launch_fps(const float *xyz, int n, int m, int *idx, int S, int G, int p_log2, u64 *mail,
                int *status, hipStream_t stream) {
@@ -326,8 +631,13 @@ extern "C" int eda_furthest_point_sampling_f32(const float *xyz, int b, int n, i
     G = 1;
     if (n > 2048 && env_int("EDA_FPS_SMALL_T", 512) == 1024) { T = 1024; P = round_up_pow2((n + T - 1) / T); }
   } else {
-    T = env_int("EDA_FPS_T", 512);       // measured on MI355X (B=8, N=50 000): (512,16) 4.41 ms,
-    P = env_int("EDA_FPS_P", 16);        // (1024,8) 4.75 ms, (512,8) 4.79 ms, (1024,4) 5.12 ms
+    // measured on MI355X (B=8, N=50 000 -> 2048).  Speculative K=4 kernel: (512,8) 3.1 ms,
+    // (512,16) 3.8 ms.  Sequential cluster kernel (EDA_FPS_SPEC=0): (512,16) 4.41 ms,
+    // (1024,8) 4.75 ms, (512,8) 4.79 ms, (1024,4) 5.12 ms.
+    const bool want_spec = env_int("EDA_FPS_SPEC", 1) != 0;
+    const int p_dflt = (want_spec && ((n + 511) / 512 + 7) / 8 <= kSpecMaxG) ? 8 : 16;
+    T = env_int("EDA_FPS_T", 512);
+    P = env_int("EDA_FPS_P", p_dflt);
     if (T != 512 && T != 1024) T = 1024;
     if (!(P == 1 || P == 2 || P == 4 || P == 8 || (P == 16 && T == 512))) { T = 512; P = 16; }
     const int chunks = (n + T - 1) / T;
@@ -358,13 +668,22 @@ extern "C" int eda_furthest_point_sampling_f32(const float *xyz, int b, int n, i
   u64 *mail = reinterpret_cast<u64 *>(reinterpret_cast<unsigned char *>(ws) + kStatusBytes);
 
   const int mode = g_eda_fma_mode;
+  // clusters of the default geometry run the speculative K=4 kernel (EDA_FPS_SPEC=0: one sample
+  // per hand-off, the kernel above)
+  const bool use_spec = G > 1 && G <= kSpecMaxG && T == 512 && (P == 16 || P == 8) && env_int("EDA_FPS_SPEC", 1) != 0;
   for (int s0 = 0; s0 < b; s0 += scenes_per_launch) {
     const int S = (b - s0) < scenes_per_launch ? (b - s0) : scenes_per_launch;
     const float *x = xyz + (size_t)s0 * n * 3;
     int *o = idx + (size_t)s0 * m;
     u64 *mb = mail + (size_t)s0 * 2 * kMaxG * kRecWords;
     int rc;
-    if (G == 1) {
+    if (use_spec && P == 8) {
+      rc = mode == 0 ? launch_fps_spec<0, 512, 8>(x, n, m, o, S, G, p_log2, mb, status, stream)
+                     : launch_fps_spec<1, 512, 8>(x, n, m, o, S, G, p_log2, mb, status, stream);
+    } else if (use_spec) {
+      rc = mode == 0 ? launch_fps_spec<0, 512, 16>(x, n, m, o, S, G, p_log2, mb, status, stream)
+                     : launch_fps_spec<1, 512, 16>(x, n, m, o, S, G, p_log2, mb, status, stream);
+    } else if (G == 1) {
       if (T == 512)
         rc = mode == 0 ? dispatch_p<0, 512, false>(P, x, n, m, o, S, G, p_log2, mb, status, stream)
                        : dispatch_p<1, 512, false>(P, x, n, m, o, S, G, p_log2, mb, status, stream);
