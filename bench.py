@@ -212,6 +212,9 @@ def main():
     ap.add_argument("--no-butd", action="store_true")
     ap.add_argument("--blas", choices=["default", "rocblas", "hipblaslt"], default="default",
                     help="torch.backends.cuda.preferred_blas_library for the library GEMMs")
+    ap.add_argument("--defer-wgrad", type=int, default=1,
+                    help="1: queue the pointwise layers' weight gradients during the backward and compute them "
+                         "in one grouped kernel (eda_amd/wgrad_queue.py); 0: compute each where autograd reaches it")
     ap.add_argument("--overlap", action="store_true",
                     help="run the text encoder on a side stream underneath the point backbone (measured slower)")
     ap.add_argument("--split-graphs", action="store_true",
@@ -262,7 +265,11 @@ def main():
     def fwd_bwd():
         attention.advance_dropout_state(device)      # new attention-dropout masks every step
         loss = synthetic_loss(model(inputs))
-        loss.backward()
+        if args.defer_wgrad:
+            with flat.deferred_wgrad():              # weight gradients: one grouped kernel after the backward
+                loss.backward()
+        else:
+            loss.backward()
         flat.collect_grads()
         return loss
 

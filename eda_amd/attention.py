@@ -145,7 +145,7 @@ class _ProjectedMHA(Function):
                 seed.data_ptr() if seed is not None else None, int(salt), out.data_ptr(),
                 lse.data_ptr(), torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "eda_mha_fwd_f32")
-        ctx.save_for_backward(W, out, lse, *x2s, *Ps)
+        ctx.save_for_backward(W, out, lse, b, *x2s, *Ps)
         ctx.mask8 = m8
         ctx.cfg = (num_heads, float(p_drop), int(salt), groups, cols, [x.shape for x in xs])
         return out
@@ -154,8 +154,8 @@ class _ProjectedMHA(Function):
     def backward(ctx, dout):
         num_heads, p_drop, salt, groups, cols, shapes = ctx.cfg
         n = len(groups)
-        W, out, lse = ctx.saved_tensors[:3]
-        x2s, Ps = ctx.saved_tensors[3:3 + n], ctx.saved_tensors[3 + n:]
+        W, out, lse, bias = ctx.saved_tensors[:4]
+        x2s, Ps = ctx.saved_tensors[4:4 + n], ctx.saved_tensors[4 + n:]
         d = W.shape[1]
         dev = W.device
         dout = _rows(dout)
@@ -177,8 +177,20 @@ class _ProjectedMHA(Function):
                 dk.data_ptr(), dv.data_ptr(), dq.stride(0), dq.stride(1), dk.stride(0), dk.stride(1),
                 dv.stride(0), dv.stride(1), torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "eda_mha_bwd_f32")
-        dW = torch.empty_like(W) if ctx.needs_input_grad[0] else None
-        db = torch.empty((W.shape[0],), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        from . import wgrad_queue
+        qd = wgrad_queue.active
+        deferred = False
+        if qd is not None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            # all row ranges of the packed weight / bias go to the deferred queue, or none
+            plans = [qd.plan(W[lo:hi], bias[lo:hi], dPs[i].view(-1, hi - lo), x2s[i])
+                     for i, (lo, hi) in enumerate(groups)]
+            if all(pl is not None for pl in plans):
+                for i, (lo, hi) in enumerate(groups):
+                    qd.submit(W[lo:hi], bias[lo:hi], dPs[i].view(-1, hi - lo), x2s[i], planned=plans[i])
+                deferred = True
+        dW = torch.empty_like(W) if ctx.needs_input_grad[0] and not deferred else None
+        db = (torch.empty((W.shape[0],), dtype=torch.float32, device=dev)
+              if ctx.needs_input_grad[1] and not deferred else None)
         dxs = []
         for i, (lo, hi) in enumerate(groups):
             dP2 = dPs[i].view(-1, hi - lo)

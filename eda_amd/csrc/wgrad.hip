@@ -158,6 +158,140 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Grouped form: ALL the weight gradients of a backward pass in one launch.
+//
+// A weight gradient is not needed until the optimizer step, so the host queues (dY, X) pairs
+// during the backward (eda_amd/wgrad_queue.py) and hands them over together.  Work unit = one
+// 96x96 tile of one TARGET (a weight matrix); a target may have several JOBS (a module applied
+// at several places: their dY^T X are summed in the accumulators, in job order).  With
+// ~1700 tiles in flight there is no K split, hence no partial tiles and no second pass, every
+// element has ONE writer (deterministic), and the launch/latency floor that dominates the
+// one-at-a-time kernels above (14 us for 0.34 GFLOP) is paid once.
+//
+// Descriptors (device arrays of 64-bit words, built by the host):
+//   task   = {target (or -1: padding), tm, tn, unused}; task id % 8 = the XCD it runs on
+//   target = {dW, db or 0, M, N, first job, job count, accumulate (0: store, 1: add to dW/db), unused}
+//   job    = {dY, ld_dy, X, ld_x, K, unused x3}
+__global__ __launch_bounds__(WG_THREADS) void wgrad_grouped_kernel(const long long *__restrict__ tasks,
+                                                                   const long long *__restrict__ targets,
+                                                                   const long long *__restrict__ jobs) {
+  __shared__ float As[WG_KC][WG_STRIDE];
+  __shared__ float Bs[WG_KC][WG_STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wh = w & 1;
+  const long long *tk = tasks + (long)blockIdx.x * 4;
+  if (tk[0] < 0) return;                   // padding task (the host pads the 8 per-XCD lists to one depth)
+  const long long *tg = targets + tk[0] * 8;
+  const int tm = (int)tk[1], tn = (int)tk[2];
+  float *dW = reinterpret_cast<float *>(tg[0]);
+  float *db = reinterpret_cast<float *>(tg[1]);
+  const int M = (int)tg[2], N = (int)tg[3];
+  const int job0 = (int)tg[4], njobs = (int)tg[5];
+  const bool accumulate = tg[6] != 0;
+  const int m0 = tm * WG_T, n0 = tn * WG_T;
+
+  float4 ra[WG_LD], rb[WG_LD];
+  int lrow[WG_LD], lcol[WG_LD];
+#pragma unroll
+  for (int i = 0; i < WG_LD; ++i) {
+    const int idx = tid + WG_THREADS * i;
+    lrow[i] = idx / (WG_T / 4);
+    lcol[i] = (idx - lrow[i] * (WG_T / 4)) * 4;
+  }
+  f32x4 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool active = (m0 + 16 * wm < M) && (n0 + 48 * wh < N);
+  const bool do_db = db != nullptr && tn == 0 && tid < WG_T;
+  float dbsum = 0.f;
+  const float *ap = &As[lane >> 4][16 * wm + (lane & 15)];
+  const float *bp = &Bs[lane >> 4][48 * wh + (lane & 15)];
+
+  for (int jb = 0; jb < njobs; ++jb) {
+    const long long *jd = jobs + (long)(job0 + jb) * 8;
+    const float *dy = reinterpret_cast<const float *>(jd[0]);
+    const long ld_dy = (long)jd[1];
+    const float *x = reinterpret_cast<const float *>(jd[2]);
+    const long ld_x = (long)jd[3];
+    const long K = (long)jd[4];
+    auto fetch = [&](long k0) {
+#pragma unroll
+      for (int i = 0; i < WG_LD; ++i) {
+        const long k = k0 + lrow[i];
+        const bool rowok = k < K;
+        ra[i] = (rowok && m0 + lcol[i] < M) ? *reinterpret_cast<const float4 *>(dy + k * ld_dy + m0 + lcol[i])
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        rb[i] = (rowok && n0 + lcol[i] < N) ? *reinterpret_cast<const float4 *>(x + k * ld_x + n0 + lcol[i])
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    if (K > 0) fetch(0);
+    for (long k0 = 0; k0 < K; k0 += WG_KC) {
+#pragma unroll
+      for (int i = 0; i < WG_LD; ++i) {
+        *reinterpret_cast<float4 *>(&As[lrow[i]][lcol[i]]) = ra[i];
+        *reinterpret_cast<float4 *>(&Bs[lrow[i]][lcol[i]]) = rb[i];
+      }
+      __syncthreads();
+      if (k0 + WG_KC < K) fetch(k0 + WG_KC);
+      if (active) {
+        float av[WG_KC / 4], bv[3][WG_KC / 4];
+#pragma unroll
+        for (int kk = 0; kk < WG_KC / 4; ++kk) {
+          av[kk] = ap[kk * 4 * WG_STRIDE];
+#pragma unroll
+          for (int t = 0; t < 3; ++t) bv[t][kk] = bp[kk * 4 * WG_STRIDE + 16 * t];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < WG_KC / 4; ++kk) {
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv[t][kk], acc[t], 0, 0, 0);
+        }
+      }
+      if (do_db) {
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+        for (int r = 0; r < WG_KC; r += 4) {
+          t0 += As[r][tid]; t1 += As[r + 1][tid]; t2 += As[r + 2][tid]; t3 += As[r + 3][tid];
+        }
+        dbsum += (t0 + t1) + (t2 + t3);
+      }
+      __syncthreads();
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int col = n0 + 48 * wh + 16 * t + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 16 * wm + 4 * (lane >> 4) + r;
+        if (row < M && col < N) {
+          float *o = dW + (long)row * N + col;
+          *o = accumulate ? *o + acc[t][r] : acc[t][r];
+        }
+      }
+    }
+  }
+  if (do_db && m0 + tid < M) db[m0 + tid] = accumulate ? db[m0 + tid] + dbsum : dbsum;
+}
+
+extern "C" int eda_wgrad_grouped_f32(const long long *tasks, int ntasks, const long long *targets,
+                                     const long long *jobs, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(ntasks >= 0, "bad dimension");
+  if (ntasks == 0) return 0;
+  EDA_CHECK_ARG(tasks && targets && jobs, "null pointer");
+  hipLaunchKernelGGL(wgrad_grouped_kernel, dim3((unsigned)ntasks), dim3(WG_THREADS), 0, stream, tasks, targets,
+                     jobs);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}
+
 namespace {
 struct WgPlan { int tiles_m, tiles_n, splits, cps; };
 WgPlan wg_plan(long K, int M, int N) {

@@ -95,17 +95,23 @@ class _LinearRows(Function):
     def forward(ctx, x, W, b):
         x2 = x.reshape(-1, x.shape[-1])
         y = torch.mm(x2, W.t()) if b is None else torch.addmm(b, x2, W.t())
-        ctx.save_for_backward(x2, W)
+        ctx.save_for_backward(x2, W, b)
         ctx.xshape = x.shape
         ctx.has_bias = b is not None
         return y.view(*x.shape[:-1], W.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x2, W = ctx.saved_tensors
+        from . import wgrad_queue
+        x2, W, b = ctx.saved_tensors
         dy2 = dy.reshape(-1, W.shape[0])
         dx = torch.mm(dy2, W).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         dW = db = None
+        q = wgrad_queue.active
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if (q is not None and ctx.needs_input_grad[1] and (want_db or not ctx.has_bias)
+                and q.submit(W, b if want_db else None, dy2, x2)):
+            return dx, None, None          # written into the gradient buffer by the queue's flush
         if ctx.needs_input_grad[1]:
             dW, db = wgrad(dy2, x2, want_db=ctx.has_bias and ctx.needs_input_grad[2])
         elif ctx.has_bias and ctx.needs_input_grad[2]:

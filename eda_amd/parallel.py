@@ -14,6 +14,8 @@ optimizer updates -- one fused AdamW kernel per learning-rate group instead of o
 per ~50 parameter tensors.  Batch-norm statistics stay per-GPU (8 scenes x >= 4096
 positions per channel); that deviation from SyncBN is stated in DESIGN.md.
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -57,18 +59,62 @@ class FlatParams:
             lo, hi = bounds.get(k, (off, off))
             bounds[k] = (min(lo, off), off + p.numel())
             off += p.numel()
+        from .wgrad_queue import WgradQueue
+        self.queue = WgradQueue(self._locate_grad)
+        if dev.type == "cuda":
+            self.queue.reserve(dev)              # pinned staging must exist before any stream capture
+        self._prefilled = False
+        self._deferred_ptrs = set()
         self.groups = {}
         for k, (lo, hi) in bounds.items():
             gp = torch.nn.Parameter(self.flat_param[lo:hi], requires_grad=True)
             gp.grad = self.flat_grad[lo:hi]
             self.groups[k] = gp
 
+    def _locate_grad(self, t):
+        """The slice of the flat GRADIENT buffer that corresponds to `t`, a contiguous view into
+        the flat PARAMETER buffer (a whole parameter, a squeezed conv weight, a row range of a
+        packed in-projection ...); None for anything else."""
+        if not t.is_contiguous() or t.dtype != torch.float32 or t.device != self.flat_param.device:
+            return None
+        off = t.data_ptr() - self.flat_param.data_ptr()
+        if off < 0 or off % 4 or off // 4 + t.numel() > self.flat_param.numel():
+            return None
+        off //= 4
+        return self.flat_grad[off:off + t.numel()].view(t.shape)
+
+    @contextlib.contextmanager
+    def deferred_wgrad(self):
+        """Run the backward pass inside this context: the weight / bias gradients of the
+        pointwise linear layers are queued (eda_amd/wgrad_queue.py) and written into the flat
+        gradient buffer by ONE grouped kernel when the context exits; collect_grads() then only
+        gathers what autograd still produced itself."""
+        from . import wgrad_queue
+        self.flat_grad.fill_(0.0)          # (a kernel, not a memset node: see DESIGN.md on graphs)
+        prev, wgrad_queue.active = wgrad_queue.active, self.queue
+        try:
+            yield self.queue
+        finally:
+            wgrad_queue.active = prev
+            self._deferred_ptrs = self.queue.touched()
+            self.queue.flush()
+            self._prefilled = True
+
     def collect_grads(self):
         """Gather the gradients autograd produced this step into the flat buffer
         (multi-tensor copy) and release them, so the next backward again ASSIGNS
         instead of accumulating."""
         have = [(v, p.grad) for v, p in zip(self._grad_views, self.params) if p.grad is not None]
-        if len(have) != len(self.params):
+        if self._prefilled:
+            # deferred_wgrad() zeroed the buffer and its flush wrote the queued gradients; a
+            # parameter that ALSO got a gradient from autograd (used outside the queue) adds to it
+            both = [(v, g) for v, g in have if v.data_ptr() in self._deferred_ptrs]
+            have = [(v, g) for v, g in have if v.data_ptr() not in self._deferred_ptrs]
+            if both:
+                torch._foreach_add_([v for v, _ in both], [g for _, g in both])
+            self._prefilled = False
+            self._deferred_ptrs = set()
+        elif len(have) != len(self.params):
             self.flat_grad.zero_()
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])

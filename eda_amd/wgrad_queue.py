@@ -1,0 +1,182 @@
+"""Deferred weight gradients: every `dW = dY^T X` (+ bias gradient) of a backward pass in ONE
+launch of csrc/wgrad.hip's grouped kernel.
+
+A weight gradient is only consumed by the optimizer step, so nothing forces it to be computed
+where autograd reaches the layer.  While a queue is active (``FlatParams.deferred_wgrad()``), the
+pointwise-linear autograd nodes of the path (``nn_utils._LinearRows``, ``attention._ProjectedMHA``)
+hand their (dY, X) pair to the queue instead of launching a GEMM, and return no gradient for the
+weight / bias; ``flush()`` then writes all of them straight into the flat gradient buffer:
+~200 launch-latency-bound GEMMs + column sums (5-6 ms of a 37 ms step on MI355X) become one
+kernel with ~1700 independent 96x96 tiles in flight.  Modules applied at several places (the
+contrastive projections run on every decoder layer) become several JOBS of one TARGET and are
+summed inside the kernel's accumulators -- one writer per element, fixed order, deterministic.
+
+Outside such a context nothing changes: gradients are computed immediately and returned to
+autograd (that path is what the parity tests exercise against the reference goldens).
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .ext import _timed
+
+active = None          # the queue that autograd nodes submit to, or None
+_TILE = 96
+_MAX_K = 1 << 15       # a tile walks all K rows serially; longer reductions keep their split-K paths
+
+
+class WgradQueue:
+    def __init__(self, locate):
+        """locate(t) -> the gradient-buffer view matching parameter view `t`, or None."""
+        self.locate = locate
+        self._targets = {}       # dW data_ptr -> [dW, db, M, N, [(dy2, x2), ...]]
+        self._ring = []          # descriptor staging: [pinned host words, device words, copy-done event]
+        self._ring_pos = 0
+
+    _RING = 3
+    _WORDS = 1 << 17             # 1 MiB of descriptors per slot (bench step: ~15 k words)
+
+    def reserve(self, device):
+        """Allocate the descriptor staging buffers.  Must happen outside stream capture (pinned
+        allocation is not capturable); FlatParams does it at construction."""
+        if not self._ring:
+            for _ in range(self._RING):
+                self._ring.append([torch.empty((self._WORDS,), dtype=torch.int64, pin_memory=True),
+                                   torch.empty((self._WORDS,), dtype=torch.int64, device=device), None])
+
+    # ------------------------------------------------------------------ submit
+    @staticmethod
+    def _operand_ok(t, cols):
+        return (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] == cols
+                and t.stride(1) == 1 and (t.shape[0] <= 1 or t.stride(0) % 4 == 0) and t.data_ptr() % 16 == 0)
+
+    def plan(self, W, b, dy2, x2):
+        """The (dW, db) gradient views this job would write, or None if it is not eligible."""
+        if W.dim() != 2 or not W.is_contiguous():
+            return None
+        M, N = W.shape
+        K = dy2.shape[0]
+        if M % 4 or N % 4 or M < 16 or N < 16 or K < 1 or K > _MAX_K or x2.shape[0] != K:
+            return None
+        if not (self._operand_ok(dy2, M) and self._operand_ok(x2, N)):
+            return None
+        gW = self.locate(W)
+        if gW is None:
+            return None
+        gb = None
+        if b is not None:
+            gb = self.locate(b)
+            if gb is None:
+                return None
+        return gW, gb
+
+    def submit(self, W, b, dy2, x2, planned=None):
+        """Queue dW(W) += dy2^T x2 (and db(b) += column sums of dy2).  False = not eligible: the
+        caller computes the gradient itself."""
+        planned = planned or self.plan(W, b, dy2, x2)
+        if planned is None:
+            return False
+        gW, gb = planned
+        key = gW.data_ptr()
+        t = self._targets.get(key)
+        if t is None:
+            t = self._targets[key] = [gW, gb, W.shape[0], W.shape[1], []]
+        else:
+            if (t[2], t[3]) != tuple(W.shape) or (gb is None) != (t[1] is None):
+                return False
+        t[4].append((dy2, x2))
+        return True
+
+    def __len__(self):
+        return sum(len(t[4]) for t in self._targets.values())
+
+    def touched(self):
+        """data_ptr of every gradient view (weights and biases) that flush() will write."""
+        out = set()
+        for gW, gb, *_ in self._targets.values():
+            out.add(gW.data_ptr())
+            if gb is not None:
+                out.add(gb.data_ptr())
+        return out
+
+    # ------------------------------------------------------------------- flush
+    def flush(self, accumulate=False):
+        """Launch the grouped kernel for everything queued (stores, or adds with accumulate=True)
+        and drop the references to the queued activations."""
+        targets = list(self._targets.values())
+        self._targets = {}
+        if not targets:
+            return 0
+        dev = targets[0][0].device
+        # cost of a tile = rows it walks; place whole targets on one XCD (workgroup id % 8), big first
+        costs = [sum(dy.shape[0] for dy, _ in t[4]) for t in targets]
+        order = sorted(range(len(targets)), key=lambda i: -costs[i] * ((targets[i][2] + _TILE - 1) // _TILE)
+                       * ((targets[i][3] + _TILE - 1) // _TILE))
+        lanes = [[] for _ in range(8)]
+        load = [0] * 8
+        for i in order:
+            tm_n, tn_n = (targets[i][2] + _TILE - 1) // _TILE, (targets[i][3] + _TILE - 1) // _TILE
+            x = min(range(8), key=load.__getitem__)
+            load[x] += costs[i] * tm_n * tn_n
+            for tm in range(tm_n):
+                for tn in range(tn_n):
+                    lanes[x].append((costs[i], i, tm, tn))
+        depth = max(len(l) for l in lanes)
+        ntasks = 8 * depth
+        task_arr = np.zeros((ntasks, 4), dtype=np.int64)
+        task_arr[:, 0] = -1                                   # padding tasks exit immediately
+        for x, l in enumerate(lanes):
+            l.sort(key=lambda e: -e[0])
+            for slot, (_, i, tm, tn) in enumerate(l):
+                task_arr[slot * 8 + x] = (i, tm, tn, 0)
+        njobs = sum(len(t[4]) for t in targets)
+        targ_arr = np.zeros((len(targets), 8), dtype=np.int64)
+        job_arr = np.zeros((njobs, 8), dtype=np.int64)
+        j = 0
+        for i, (gW, gb, M, N, jobs) in enumerate(targets):
+            targ_arr[i] = (gW.data_ptr(), gb.data_ptr() if gb is not None else 0, M, N, j, len(jobs),
+                           1 if accumulate else 0, 0)
+            for dy2, x2 in jobs:
+                K = dy2.shape[0]
+                job_arr[j] = (dy2.data_ptr(), dy2.stride(0) if K > 1 else M, x2.data_ptr(),
+                              x2.stride(0) if K > 1 else N, K, 0, 0, 0)
+                j += 1
+        words = np.concatenate([task_arr.ravel(), targ_arr.ravel(), job_arr.ravel()])
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not self._ring:
+            if capturing:
+                raise RuntimeError("WgradQueue.reserve() must be called before stream capture")
+            self.reserve(dev)
+        if words.size > self._WORDS:
+            raise RuntimeError(f"wgrad queue: {words.size} descriptor words exceed the staging buffer")
+        # A ring of pinned staging slots: a slot is rewritten only after the copy that last read it
+        # has completed.  A captured graph keeps replaying the copy from the slot it was captured
+        # with, so that slot leaves the ring for good.
+        slot = self._ring[self._ring_pos]
+        if capturing:
+            self._ring.pop(self._ring_pos)
+            if not self._ring:
+                self._ring_pos = 0
+            else:
+                self._ring_pos %= len(self._ring)
+        else:
+            self._ring_pos = (self._ring_pos + 1) % len(self._ring)
+            if slot[2] is not None:
+                slot[2].synchronize()
+        host, desc = slot[0], slot[1]
+        host.numpy()[:words.size] = words
+        desc[:words.size].copy_(host[:words.size], non_blocking=True)
+        if capturing:
+            self._captured = getattr(self, "_captured", []) + [slot]      # keep alive for the replays
+        else:
+            slot[2] = torch.cuda.Event()
+            slot[2].record()
+        base = desc.data_ptr()
+        with torch.cuda.device(dev), _timed("wgrad_grouped", (len(targets), njobs, ntasks)):
+            rc = _lib.lib().eda_wgrad_grouped_f32(base, ntasks, base + 8 * task_arr.size,
+                                                  base + 8 * (task_arr.size + targ_arr.size),
+                                                  torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "eda_wgrad_grouped_f32")
+        # dY / X of the jobs and `desc` stay referenced by `targets` / this frame until here; the
+        # caching allocator only re-uses their memory for work queued later on this stream.
+        return njobs

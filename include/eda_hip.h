@@ -198,6 +198,16 @@ int eda_add_dropout_ln_bwd_f32(const float *dout, const float *x, const float *y
                                const unsigned long long *seed_ptr, unsigned salt, float *dx,
                                float *dy, float *grads3, void *ws, size_t ws_bytes, void *stream);
 
+/* Grouped form: every queued weight gradient of a backward pass in ONE launch (no K split, one
+ * writer per element).  Device arrays of 64-bit words, host-built (eda_amd/wgrad_queue.py):
+ *   tasks[ntasks][4]  = {target index, tile row, tile column, 0}           (96x96 tiles)
+ *   targets[..][8]    = {dW pointer, db pointer or 0, M, N, first job, job count, accumulate, 0}
+ *   jobs[..][8]       = {dY pointer, ld_dy, X pointer, ld_x, K, 0, 0, 0}
+ * dW (M,N) contiguous = (accumulate ? dW : 0) + sum over the target's jobs of dY^T X; db likewise
+ * the column sums of the jobs' dY.  Same alignment rules as eda_wgrad_f32.                 */
+int eda_wgrad_grouped_f32(const long long *tasks, int ntasks, const long long *targets,
+                          const long long *jobs, void *stream);
+
 /* ---- column sums (bias gradients) ------------------------------------------
  * out[c] = sum_r x[r*ld + c] for a row-major (R,C) matrix: d(bias) of every pointwise linear
  * layer on the path (what autograd's AddmmBackward / the reference's nn.Linear, nn.Conv1d(k=1)

@@ -1,0 +1,91 @@
+"""Deferred weight gradients (eda_amd/wgrad_queue.py + the grouped kernel of csrc/wgrad.hip):
+same flat gradient buffer as the immediate path, which itself is checked against the reference
+goldens elsewhere."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_grouped_kernel_vs_fp64():
+    """Several targets, one of them fed by three jobs of different K, through the queue."""
+    from eda_amd.wgrad_queue import WgradQueue
+    torch.manual_seed(0)
+    shapes = [(288, 288), (864, 288), (64, 288), (256, 288), (100, 36)]
+    params = torch.zeros(sum(m * n + m for m, n in shapes), device="cuda")
+    grads = torch.full_like(params, 7.0)
+
+    def locate(t):
+        off = (t.data_ptr() - params.data_ptr()) // 4
+        return grads[off:off + t.numel()].view(t.shape)
+    q = WgradQueue(locate)
+    off = 0
+    expect = []
+    for i, (m, n) in enumerate(shapes):
+        W = params[off:off + m * n].view(m, n); off += m * n
+        b = params[off:off + m]; off += m
+        eW = torch.zeros(m, n, dtype=torch.float64, device="cuda")
+        eb = torch.zeros(m, dtype=torch.float64, device="cuda")
+        for K in ([2048, 640, 77] if i == 0 else [8192] if i == 1 else [300]):
+            dy = torch.randn(K, m, device="cuda")
+            x = torch.randn(K, n, device="cuda")
+            assert q.submit(W, b if i != 2 else None, dy, x)
+            eW += dy.double().t() @ x.double()
+            eb += dy.double().sum(0)
+        expect.append((W, b if i != 2 else None, eW, eb))
+    assert len(q) == 7
+    q.flush()
+    for W, b, eW, eb in expect:
+        gW = locate(W)
+        assert (gW.double() - eW).abs().max().item() <= 3e-5 * eW.abs().max().item() + 1e-3
+        if b is not None:
+            assert (locate(b).double() - eb).abs().max().item() <= 3e-5 * eb.abs().max().item() + 1e-3
+        else:
+            assert (grads[(W.data_ptr() - params.data_ptr()) // 4 + W.numel():][:W.shape[0]] == 7).all()
+    assert len(q) == 0
+
+
+def test_not_eligible_falls_back():
+    from eda_amd.wgrad_queue import WgradQueue
+    q = WgradQueue(lambda t: None)                     # nothing is located: every job is refused
+    W = torch.zeros(288, 288, device="cuda")
+    assert not q.submit(W, None, torch.randn(64, 288, device="cuda"), torch.randn(64, 288, device="cuda"))
+    q2 = WgradQueue(lambda t: torch.zeros_like(t))
+    assert not q2.submit(torch.zeros(3, 288, device="cuda"), None, torch.randn(64, 3, device="cuda"),
+                         torch.randn(64, 288, device="cuda"))    # M = 3: not a multiple of 4
+
+
+def _small_model_step(defer):
+    from eda_amd import attention
+    from eda_amd.encoder_decoder_layers import BiDecoderLayer
+    from eda_amd.parallel import FlatParams
+    torch.manual_seed(1)
+    layer = BiDecoderLayer(288, 8, 256, dropout=0.0, self_position_embedding="loc_learned", butd=True).cuda().train()
+    flat = FlatParams(layer)
+    torch.manual_seed(2)
+    B, Q = 4, 256
+    query = torch.randn(B, Q, 288, device="cuda", requires_grad=True)
+    vis = torch.randn(B, 512, 288, device="cuda")
+    lang = torch.randn(B, 40, 288, device="cuda")
+    det = torch.randn(B, 32, 288, device="cuda")
+    qpos = torch.rand(B, Q, 6, device="cuda")
+    out = layer(query, vis, lang, qpos, None, None, detected_feats=det, detected_mask=None)
+    loss = (out * torch.randn_like(out)).sum()
+    if defer:
+        with flat.deferred_wgrad() as q:
+            loss.backward()
+            n = len(q)
+        assert n > 10                                   # the layer's linears really were queued
+    else:
+        loss.backward()
+    flat.collect_grads()
+    return flat.flat_grad.clone(), query.grad.clone()
+
+
+def test_decoder_layer_flat_grads_match_immediate_path():
+    g0, dq0 = _small_model_step(False)
+    g1, dq1 = _small_model_step(True)
+    assert torch.equal(dq0, dq1)                                   # input gradients do not involve the queue
+    scale = g0.abs().max().item()
+    assert (g0 - g1).abs().max().item() <= 2e-4 * scale, ((g0 - g1).abs().max().item(), scale)
+    assert g0.abs().sum().item() > 0

@@ -31,7 +31,31 @@ def make(seed, dev, **kw):
     return m
 
 
-def compare(steps=4, scenes=8, points=50000, tokens=80, verbose=True, **model_kw):
+def compare_grads(scenes=2, points=20000, tokens=24, **model_kw):
+    """Flat gradient of ONE backward pass of the full model: weight gradients where autograd
+    reaches them vs deferred to the grouped kernel (FlatParams.deferred_wgrad).  Returns
+    (max |difference| / max |gradient|, number of queued jobs)."""
+    dev = torch.device("cuda", 0)
+    a = make(0, dev, **model_kw)
+    b = copy.deepcopy(a)
+    inputs = bench.make_inputs(0, scenes, dev, points, tokens)
+    grads, njobs = [], 0
+    for model, defer in ((a, False), (b, True)):
+        flat = FlatParams(model)
+        loss = bench.synthetic_loss(model(inputs))
+        if defer:
+            with flat.deferred_wgrad() as q:
+                loss.backward()
+                njobs = len(q)
+        else:
+            loss.backward()
+        flat.collect_grads()
+        grads.append(flat.flat_grad.clone())
+    torch.cuda.synchronize()
+    return ((grads[0] - grads[1]).abs().max() / grads[0].abs().max()).item(), njobs
+
+
+def compare(steps=4, scenes=8, points=50000, tokens=80, verbose=True, defer_in_graph=True, **model_kw):
     dev = torch.device("cuda", 0)
     a = make(0, dev, **model_kw)
     b = copy.deepcopy(a)
@@ -44,7 +68,11 @@ def compare(steps=4, scenes=8, points=50000, tokens=80, verbose=True, **model_kw
 
         def step():
             loss = bench.synthetic_loss(model(inputs))
-            loss.backward()
+            if use_graph and defer_in_graph:       # the bench configuration: graph + deferred weight gradients
+                with flat.deferred_wgrad():
+                    loss.backward()
+            else:
+                loss.backward()
             flat.collect_grads()
             flat.clip_grad_norm_(0.1)
             opt.step()
