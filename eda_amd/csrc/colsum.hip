@@ -106,6 +106,115 @@ __global__ __launch_bounds__(CS_THREADS) void colsum_kernel(const float *__restr
   }
 }
 
+
+// Weighted column sums: out[m][c] = sum_r w[r][m] * x[r][c] for MW <= 4 weight columns, and
+// wsum[m] = sum_r w[r][m].  This is the weight (and bias) gradient of a pointwise layer with 1-4
+// OUTPUT channels (box centre / size residuals, objectness: dW = dY^T X with dY only MW wide),
+// which the library GEMM runs as a 41 us 32x16 macro-tile kernel; here x is streamed once,
+// like a column sum.  Same grid, ticket and slab-order reduction as colsum_kernel.
+template <int MW>
+__global__ __launch_bounds__(CS_THREADS) void wcolsum_kernel(const float *__restrict__ x, long R, int C,
+                                                             long ld, const float *__restrict__ w, long ldw,
+                                                             int rows_per_slab, float *__restrict__ out,
+                                                             float *__restrict__ wsum,
+                                                             float *__restrict__ partial,
+                                                             unsigned *__restrict__ counters) {
+  __shared__ float red[MW][16][65];
+  __shared__ float wred[MW][16];
+  __shared__ int is_last;
+  const int tid = threadIdx.x;
+  const int cg = blockIdx.x, slab = blockIdx.y, nslab = gridDim.y;
+  const int c0 = cg * 64;
+  const long r0 = (long)slab * rows_per_slab;
+  long r1 = r0 + rows_per_slab;
+  if (r1 > R) r1 = R;
+  const int cl = tid & 15, rl = tid >> 4;
+  const int c = c0 + 4 * cl;
+  float4 acc[MW];
+  float ws[MW];
+#pragma unroll
+  for (int m = 0; m < MW; ++m) { acc[m] = make_float4(0.f, 0.f, 0.f, 0.f); ws[m] = 0.f; }
+  if (c < C) {
+#pragma unroll 2
+    for (long r = r0 + rl; r < r1; r += 16) {
+      const float4 v = *reinterpret_cast<const float4 *>(x + r * ld + c);
+#pragma unroll
+      for (int m = 0; m < MW; ++m) {
+        const float wv = w[r * ldw + m];
+        acc[m].x += wv * v.x; acc[m].y += wv * v.y; acc[m].z += wv * v.z; acc[m].w += wv * v.w;
+        ws[m] += wv;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MW; ++m) {
+    red[m][rl][4 * cl + 0] = acc[m].x; red[m][rl][4 * cl + 1] = acc[m].y;
+    red[m][rl][4 * cl + 2] = acc[m].z; red[m][rl][4 * cl + 3] = acc[m].w;
+    if (cl == 0) wred[m][rl] = ws[m];
+  }
+  __syncthreads();
+  // slab layout in `partial`: [slab][MW][C] then, after all slabs, [slab][MW] weight sums
+  float *psum = partial + (long)nslab * MW * C;
+  if (tid < 64 && c0 + tid < C) {
+#pragma unroll
+    for (int m = 0; m < MW; ++m) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += red[m][k][tid];
+      if (nslab == 1) out[(long)m * C + c0 + tid] = t;
+      else __hip_atomic_store(&partial[((long)slab * MW + m) * C + c0 + tid], t, __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (cg == 0 && tid < MW) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += wred[tid][k];
+    if (nslab == 1) { if (wsum) wsum[tid] = t; }
+    else __hip_atomic_store(&psum[(long)slab * MW + tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (nslab == 1) return;
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned ticket = __hip_atomic_fetch_add(&counters[cg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = ticket == (unsigned)(nslab - 1);
+  }
+  __syncthreads();
+  if (!is_last) return;
+  {
+    const int col = tid & 63, sl = tid >> 6;
+#pragma unroll
+    for (int m = 0; m < MW; ++m) {
+      float t = 0.f;
+      if (c0 + col < C) {
+        float v[CS_MAX_SLABS / 4];
+#pragma unroll
+        for (int i = 0; i < CS_MAX_SLABS / 4; ++i) {
+          const int s = sl + 4 * i;
+          v[i] = s < nslab ? __hip_atomic_load(&partial[((long)s * MW + m) * C + c0 + col], __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT)
+                           : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < CS_MAX_SLABS / 4; ++i) t += v[i];
+      }
+      __syncthreads();
+      red[0][sl][col] = t;
+      __syncthreads();
+      if (tid < 64 && c0 + tid < C)
+        out[(long)m * C + c0 + tid] = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);
+    }
+    // every column group waits for ALL slabs, so the last block of group 0 can also finish wsum
+    if (cg == 0 && wsum && tid < MW) {
+      float t = 0.f;
+      for (int s = 0; s < nslab; ++s)
+        t += __hip_atomic_load(&psum[(long)s * MW + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      wsum[tid] = t;
+    }
+    if (tid == 0) __hip_atomic_store(&counters[cg], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 static int cs_slabs(long R, int C) {
   const int cgs = (C + 63) / 64;
   long slabs = (R + 63) / 64;                 // >= 64 rows per slab
@@ -142,6 +251,46 @@ extern "C" int eda_colsum_f32(const float *x, long R, int C, long ld, float *out
   else
     hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(CS_THREADS), 0, stream, x, R, C, ld, rows_per_slab,
                        out, reinterpret_cast<float *>(ws), counters);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" size_t eda_wcolsum_workspace_bytes(long R, int C, int MW) {
+  if (R <= 0 || C <= 0 || MW <= 0) return 0;
+  return sizeof(float) * (size_t)cs_slabs(R, C) * (size_t)MW * ((size_t)C + 1);
+}
+
+extern "C" int eda_wcolsum_f32(const float *x, long R, int C, long ld, const float *w, long ldw, int MW,
+                               float *out, float *wsum, void *ws, size_t ws_bytes, unsigned *counters,
+                               void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(R >= 0 && C > 0 && ld >= C && MW >= 1 && MW <= 4 && ldw >= MW, "bad dimension (1 <= MW <= 4)");
+  EDA_CHECK_ARG(out, "null pointer");
+  if (R == 0) {
+    const int z1 = eda_zero_async(out, sizeof(float) * (size_t)MW * C, stream);
+    if (z1 || !wsum) return z1;
+    return eda_zero_async(wsum, sizeof(float) * MW, stream);
+  }
+  EDA_CHECK_ARG(x && w && counters, "null pointer");
+  EDA_CHECK_ARG(C % 4 == 0 && ld % 4 == 0 && (uintptr_t)x % 16 == 0, "x rows must be 16-byte aligned");
+  const int slabs = cs_slabs(R, C);
+  if (slabs > 1 && (!ws || ws_bytes < eda_wcolsum_workspace_bytes(R, C, MW))) {
+    eda_set_error("wcolsum: workspace too small");
+    return EDA_ERR_WORKSPACE;
+  }
+  const int rows_per_slab = (int)((R + slabs - 1) / slabs);
+  const dim3 grid((unsigned)((C + 63) / 64), (unsigned)slabs);
+  float *partial = reinterpret_cast<float *>(ws);
+#define WCS_LAUNCH(MWC)                                                                                   \
+  hipLaunchKernelGGL(wcolsum_kernel<MWC>, grid, dim3(CS_THREADS), 0, stream, x, R, C, ld, w, ldw, rows_per_slab, \
+                     out, wsum, partial, counters)
+  switch (MW) {
+    case 1: WCS_LAUNCH(1); break;
+    case 2: WCS_LAUNCH(2); break;
+    case 3: WCS_LAUNCH(3); break;
+    default: WCS_LAUNCH(4); break;
+  }
+#undef WCS_LAUNCH
   EDA_CHECK_LAUNCH();
   return 0;
 }

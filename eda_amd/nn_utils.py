@@ -64,6 +64,20 @@ def wgrad(dy2, x2, dW=None, db=None, want_db=True):
         dW = torch.empty((M, N), dtype=torch.float32, device=dev)
     if want_db and db is None:
         db = torch.empty((M,), dtype=torch.float32, device=dev)
+    if (M <= 4 and N % 4 == 0 and K > 0 and (K == 1 or x2.stride(0) % 4 == 0) and x2.data_ptr() % 16 == 0
+            and dW.is_contiguous()):
+        # 1-4 output channels: dW = weighted column sums of x (csrc/colsum.hip), db for free
+        L = _lib.lib()
+        ws_bytes = L.eda_wcolsum_workspace_bytes(K, N, M)
+        ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
+        cnt = _ticket_counters(dev, (N + 63) // 64)
+        with torch.cuda.device(dev), _timed("wcolsum", (K, M, N)):
+            rc = L.eda_wcolsum_f32(x2.data_ptr(), K, N, x2.stride(0) if K > 1 else N, dy2.data_ptr(),
+                                   dy2.stride(0) if K > 1 else M, M, dW.data_ptr(),
+                                   db.data_ptr() if want_db else None, ws.data_ptr(), ws_bytes,
+                                   cnt.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "eda_wcolsum_f32")
+        return dW, (db if want_db else None)
     ok = (M % 4 == 0 and N % 4 == 0 and K > 0 and (K == 1 or (dy2.stride(0) % 4 == 0 and x2.stride(0) % 4 == 0))
           and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0 and dW.data_ptr() % 16 == 0
           and dW.is_contiguous() and 32 <= N <= 288 and 32 <= M <= 288)

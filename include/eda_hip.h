@@ -233,6 +233,15 @@ size_t eda_wgrad_workspace_bytes(long K, int M, int N);
 int eda_wgrad_f32(const float *dy, long ld_dy, const float *x, long ld_x, long K, int M, int N,
                   float *dW, float *db, void *ws, size_t ws_bytes, void *stream);
 
+/* Weighted column sums: out[m][c] = sum_r w[r*ldw + m] * x[r*ld + c] (m < MW <= 4) and
+ * wsum[m] = sum_r w[r*ldw + m] (wsum may be NULL): the weight and bias gradient of a pointwise
+ * layer with 1-4 output channels (box centre / size / objectness heads, models/modules.py:66-86,
+ * 150-175), dW = dY^T X with dY = w.  Workspace / counters as for eda_colsum_f32.        */
+size_t eda_wcolsum_workspace_bytes(long R, int C, int MW);
+int eda_wcolsum_f32(const float *x, long R, int C, long ld, const float *w, long ldw, int MW,
+                    float *out, float *wsum, void *ws, size_t ws_bytes, unsigned *counters,
+                    void *stream);
+
 #ifdef __cplusplus
 }
 #endif

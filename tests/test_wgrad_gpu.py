@@ -44,11 +44,28 @@ def test_wgrad_strided_operands_and_slices():
     assert (dW[:d] == 7).all() and (db[:d] == 7).all()
 
 
+@pytest.mark.parametrize("K,M,N", [(2048, 3, 288), (2048, 1, 288), (8192, 4, 256), (77, 2, 64), (1, 3, 288),
+                                   (100000, 3, 128)])
+def test_wgrad_few_output_channels(K, M, N):
+    """1-4 output channels (box centre / size / objectness heads): weighted column sums (colsum.hip)."""
+    from eda_amd.nn_utils import wgrad
+    torch.manual_seed(K + M)
+    dy = torch.randn(K, M, device="cuda")
+    x = torch.randn(K, N, device="cuda")
+    for _ in range(2):                                   # second call: the ticket counters were left at zero
+        dW, db = wgrad(dy, x)
+        eW = dy.double().t() @ x.double()
+        assert (dW.double() - eW).abs().max().item() <= 2e-5 * (dy.abs().double().t() @ x.abs().double()).max().item()
+        assert (db.double() - dy.double().sum(0)).abs().max().item() <= 2e-5 * dy.abs().double().sum(0).max().item() + 1e-6
+    dW2, none = wgrad(dy, x, want_db=False)
+    assert none is None and torch.equal(dW2, dW)
+
+
 def test_wgrad_fallback_shapes():
-    """Output widths the MFMA kernel does not take (3 box coordinates) go through the library."""
+    """Shapes neither kernel takes (input width not a multiple of 4) go through the library."""
     from eda_amd.nn_utils import wgrad
     dy = torch.randn(2048, 3, device="cuda")
-    x = torch.randn(2048, 288, device="cuda")
+    x = torch.randn(2048, 6, device="cuda")
     dW, db = wgrad(dy, x)
     torch.testing.assert_close(dW, dy.t() @ x, rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(db, dy.sum(0), rtol=1e-4, atol=1e-3)

@@ -27,7 +27,8 @@ def main():
 
     def step():
         loss = bench.synthetic_loss(model(inputs))
-        loss.backward()
+        with grads.deferred_wgrad():
+            loss.backward()
         grads.collect_grads()
         grads.clip_grad_norm_(0.1)
         opt.step()
