@@ -32,9 +32,11 @@ SIGNATURES = {
     "eda_three_interpolate_grad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "eda_group_concat_cl_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p, _p]),
     "eda_group_concat_cl_grad_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "eda_bn_relu_dropout_max_rows": (_l, []),
     "eda_bn_relu_fwd_f32": (_i, [_p, _l, _i, _p, _p, _f, _f, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p,
-                                _p, _p]),
-    "eda_bn_relu_bwd_f32": (_i, [_p, _p, _p, _l, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
+                                _p, _f, _p, _u, _p]),
+    "eda_bn_relu_bwd_f32": (_i, [_p, _p, _p, _l, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _f, _p, _u,
+                                _p]),
     "eda_add_dropout_ln_fwd_f32": (_i, [_p, _p, _p, _p, _p, _l, _i, _f, _f, _p, _u, _p, _p, _p, _p]),
     "eda_add_dropout_ln_bwd_workspace_bytes": (_sz, [_l, _i]),
     "eda_add_dropout_ln_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _i, _f, _p, _u, _p, _p, _p, _p, _sz,

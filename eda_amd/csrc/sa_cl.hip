@@ -399,14 +399,35 @@ __device__ __forceinline__ float wave_sum64(float v) {
   return v;
 }
 
+// Element dropout fused behind the ReLU (the heads' Conv-BN-ReLU-Dropout): the same counter-based
+// hash as csrc/ln.hip (step counter x call-site salt, element index), regenerated in the backward.
+struct BnDrop { bool on; unsigned seed, thresh; float inv_keep; };
+__device__ __forceinline__ unsigned bn_hash32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ BnDrop bn_drop(float p, const unsigned long long *seed_ptr, unsigned salt) {
+  BnDrop d; d.on = p > 0.f && seed_ptr != nullptr; d.seed = 0; d.thresh = 0; d.inv_keep = 1.f;
+  if (d.on) {
+    d.seed = bn_hash32((unsigned)(*seed_ptr) * 0x9E3779B1u + salt);
+    d.thresh = (unsigned)((double)p * 4294967296.0);
+    d.inv_keep = 1.f / (1.f - p);
+  }
+  return d;
+}
+__device__ __forceinline__ float bn_keep(const BnDrop &d, unsigned idx) {
+  return bn_hash32(d.seed ^ idx) >= d.thresh ? d.inv_keep : 0.f;
+}
+
 __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_fwd_kernel(
     const float *__restrict__ z, int R, int C, const float *__restrict__ gamma,
     const float *__restrict__ beta, float eps, float momentum, int training,
     float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ mean_out,
     float *__restrict__ rstd_out, float *__restrict__ scale_out, float *__restrict__ shift_out,
-    float *__restrict__ out) {
+    float *__restrict__ out, float p_drop, const unsigned long long *seed_ptr, unsigned salt) {
   __shared__ float red[8][SM_WAVES];
   __shared__ float sc_l[4], sh_l[4];
+  const BnDrop dr = bn_drop(p_drop, seed_ptr, salt);
   const int c0 = blockIdx.x * 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (training) {
@@ -457,6 +478,10 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_fwd_kernel(
     float4 y;
     y.x = fmaxf(x.x * sc0 + sh0, 0.f); y.y = fmaxf(x.y * sc1 + sh1, 0.f);
     y.z = fmaxf(x.z * sc2 + sh2, 0.f); y.w = fmaxf(x.w * sc3 + sh3, 0.f);
+    if (dr.on) {
+      const unsigned e = (unsigned)(r * C + c0);
+      y.x *= bn_keep(dr, e); y.y *= bn_keep(dr, e + 1); y.z *= bn_keep(dr, e + 2); y.w *= bn_keep(dr, e + 3);
+    }
     *reinterpret_cast<float4 *>(out + (long)r * C + c0) = y;
   }
 }
@@ -466,9 +491,11 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_bwd_kernel(
     const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ rstd,
     const float *__restrict__ scale, const float *__restrict__ shift, int train,
     double *__restrict__ s1_out, double *__restrict__ s2_out, float *__restrict__ dgamma,
-    float *__restrict__ dbeta, float *__restrict__ dz) {
+    float *__restrict__ dbeta, float *__restrict__ dz, float p_drop, const unsigned long long *seed_ptr,
+    unsigned salt) {
   __shared__ float red[8][SM_WAVES];
   __shared__ float ka_l[4], kb_l[4], kd_l[4];
+  const BnDrop dr = bn_drop(p_drop, seed_ptr, salt);
   const int c0 = blockIdx.x * 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float sc[4], sh[4], mu[4], rs[4];
@@ -480,7 +507,11 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_bwd_kernel(
     const float4 x4 = *reinterpret_cast<const float4 *>(z + (long)r * C + c0);
     const float4 d4 = *reinterpret_cast<const float4 *>(da + (long)r * C + c0);
     const float x[4] = {x4.x, x4.y, x4.z, x4.w};
-    const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+    float d[4] = {d4.x, d4.y, d4.z, d4.w};
+    if (dr.on) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) d[v] *= bn_keep(dr, (unsigned)(r * C + c0 + v));
+    }
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const float dy = (x[v] * sc[v] + sh[v]) > 0.f ? d[v] : 0.f;
@@ -520,7 +551,11 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_bwd_kernel(
     const float4 x4 = *reinterpret_cast<const float4 *>(z + (long)r * C + c0);
     const float4 d4 = *reinterpret_cast<const float4 *>(da + (long)r * C + c0);
     const float x[4] = {x4.x, x4.y, x4.z, x4.w};
-    const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+    float d[4] = {d4.x, d4.y, d4.z, d4.w};
+    if (dr.on) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) d[v] *= bn_keep(dr, (unsigned)(r * C + c0 + v));
+    }
     float o[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -579,13 +614,21 @@ extern "C" int eda_group_concat_cl_grad_f32(const float *dx, const int *idx, int
 // consecutive rows when pool > 1).  ws: 2*C doubles (zeroed here).  Outputs: mean,
 // rstd, scale, shift (C floats each, kept for the backward), and either a (R,C) or
 // pooled (R/pool,C) + argmax (R/pool,C bytes).
+extern "C" long eda_bn_relu_dropout_max_rows(void) { return SMALL_ROWS; }
+
 extern "C" int eda_bn_relu_fwd_f32(const float *z, long R, int C, const float *gamma,
                                    const float *beta, float eps, float momentum, int training,
                                    float *running_mean, float *running_var, int pool,
                                    double *ws, float *mean, float *rstd, float *scale, float *shift,
-                                   float *out, unsigned char *argmax, void *stream_) {
+                                   float *out, unsigned char *argmax, float p_drop,
+                                   const unsigned long long *seed_ptr, unsigned salt, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EDA_CHECK_ARG(R >= 0 && C > 0 && pool >= 1, "bad dimension");
+  EDA_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed_ptr), "bad dropout arguments");
+  if (p_drop > 0.f && !(pool == 1 && R <= SMALL_ROWS)) {
+    eda_set_error("bn_relu: fused dropout is built for pool == 1 and R <= eda_bn_relu_dropout_max_rows() only");
+    return EDA_ERR_UNSUPPORTED;
+  }
   EDA_CHECK_ARG(C % 4 == 0 && C <= 1024, "channel count must be a multiple of 4 (<= 1024)");
   EDA_CHECK_ARG(pool <= 255 && R % pool == 0, "rows must be a multiple of the pooling width");
   if (R == 0) return 0;
@@ -595,7 +638,7 @@ extern "C" int eda_bn_relu_fwd_f32(const float *z, long R, int C, const float *g
     const int nb = C / 4;
     hipLaunchKernelGGL(bn_relu_small_fwd_kernel, dim3(nb), dim3(SM_THREADS), 0, stream, z, (int)R, C,
                        gamma, beta, eps, momentum, training, running_mean, running_var, mean, rstd, scale,
-                       shift, out);
+                       shift, out, p_drop, seed_ptr, salt);
     EDA_CHECK_LAUNCH();
     return 0;
   }
@@ -638,9 +681,15 @@ extern "C" int eda_bn_relu_bwd_f32(const float *dout, const unsigned char *argma
                                    long R, int C, int pool, const float *gamma, const float *mean,
                                    const float *rstd, const float *scale, const float *shift,
                                    int training, double *ws, float *dgamma, float *dbeta, float *dz,
+                                   float p_drop, const unsigned long long *seed_ptr, unsigned salt,
                                    void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EDA_CHECK_ARG(R >= 0 && C > 0 && pool >= 1 && C % 4 == 0 && C <= 1024, "bad dimension");
+  EDA_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed_ptr), "bad dropout arguments");
+  if (p_drop > 0.f && !(pool == 1 && R <= SMALL_ROWS)) {
+    eda_set_error("bn_relu: fused dropout is built for pool == 1 and R <= eda_bn_relu_dropout_max_rows() only");
+    return EDA_ERR_UNSUPPORTED;
+  }
   EDA_CHECK_ARG(dgamma && dbeta, "null pointer");
   if (R == 0) {
     const int z1 = eda_zero_async(dgamma, sizeof(float) * C, stream);
@@ -651,7 +700,8 @@ extern "C" int eda_bn_relu_bwd_f32(const float *dout, const unsigned char *argma
   if (pool == 1 && R <= SMALL_ROWS) {
     const int nb = C / 4;
     hipLaunchKernelGGL(bn_relu_small_bwd_kernel, dim3(nb), dim3(SM_THREADS), 0, stream, dout, z, (int)R,
-                       C, gamma, mean, rstd, scale, shift, training, ws, ws + C, dgamma, dbeta, dz);
+                       C, gamma, mean, rstd, scale, shift, training, ws, ws + C, dgamma, dbeta, dz, p_drop,
+                       seed_ptr, salt);
     EDA_CHECK_LAUNCH();
     return 0;
   }

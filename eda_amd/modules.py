@@ -59,8 +59,8 @@ class ThreeLayerMLP(nn.Module):
     def rows(self, x):
         """x (R, dim) rows -> (R, out_dim): GEMM -> fused BN+ReLU -> dropout, twice, then GEMM."""
         n = self.net
-        h = n[3](bn_relu_rows(n[1], n[0].rows(x)))
-        h = n[7](bn_relu_rows(n[5], n[4].rows(h)))
+        h = bn_relu_rows(n[1], n[0].rows(x), dropout=n[3])
+        h = bn_relu_rows(n[5], n[4].rows(h), dropout=n[7])
         return n[8].rows(h)
 
 

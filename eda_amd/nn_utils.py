@@ -205,14 +205,35 @@ def bump_batches_tracked(bn):
         bn.num_batches_tracked.add_(1)
 
 
-def bn_relu_rows(bn, z):
+_bn_drop_salts = {}
+_bn_drop_rows = None
+
+
+def bn_relu_rows(bn, z, dropout=None):
     """relu(BatchNorm1d/2d `bn`(z)) for channels-last rows z (R, C) on the GPU: the fused
-    HIP kernel of csrc/sa_cl.hip (batch statistics + running-stat update in training)."""
+    HIP kernel of csrc/sa_cl.hip (batch statistics + running-stat update in training).
+    `dropout`: an nn.Dropout to apply behind the ReLU (the heads' Conv-BN-ReLU-Dropout); in
+    training it is folded into the same kernel when the row count allows, with this repo's
+    counter-based mask (deviations) instead of torch's Philox stream."""
+    global _bn_drop_rows
     from . import sa_ops
+    p, salt = 0.0, 0
+    if dropout is not None and dropout.training and dropout.p > 0:
+        if _bn_drop_rows is None:
+            from . import _lib
+            _bn_drop_rows = _lib.lib().eda_bn_relu_dropout_max_rows()
+        if z.shape[0] <= _bn_drop_rows:
+            p = float(dropout.p)
+            salt = _bn_drop_salts.get(id(dropout))
+            if salt is None:
+                from .fused_ln import new_salt_base
+                salt = _bn_drop_salts[id(dropout)] = new_salt_base() + 7
     out = sa_ops.BNReLUCL.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
-                                bn.momentum, bn.training, 1)
+                                bn.momentum, bn.training, 1, p, salt)
     if bn.training and bn.track_running_stats:
         bump_batches_tracked(bn)
+    if dropout is not None and p == 0.0:
+        out = dropout(out)
     return out
 
 

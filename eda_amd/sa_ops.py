@@ -99,7 +99,10 @@ class BNReLUCL(Function):
     """relu(batch_norm(z)) on rows z (R,C), optionally max-pooled over `pool` consecutive rows."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, running_mean, running_var, eps, momentum, training, pool):
+    def forward(ctx, z, gamma, beta, running_mean, running_var, eps, momentum, training, pool,
+                p_drop=0.0, salt=0):
+        """p_drop > 0: element dropout behind the ReLU inside the same kernel (small-row path
+        only: pool == 1 and R <= eda_bn_relu_dropout_max_rows(); see nn_utils.bn_relu_rows)."""
         _need_gpu(z)
         z = z.contiguous()
         R, C = z.shape
@@ -112,23 +115,31 @@ class BNReLUCL(Function):
         else:
             out = torch.empty((R, C), dtype=torch.float32, device=dev)
             argmax = None
+        seed = None
+        if p_drop > 0:
+            from .attention import dropout_state
+            seed = dropout_state(dev)
         with torch.cuda.device(dev), _timed('bn_relu_fwd', (R, C, pool, int(bool(training)))):
             rc = _lib.lib().eda_bn_relu_fwd_f32(
                 z.data_ptr(), R, C, gamma.data_ptr(), beta.data_ptr(), float(eps), float(momentum),
                 int(bool(training)), running_mean.data_ptr(), running_var.data_ptr(), int(pool),
                 ws.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
                 stats[3].data_ptr(), out.data_ptr(), argmax.data_ptr() if argmax is not None else None,
-                _stream())
+                float(p_drop), seed.data_ptr() if seed is not None else None, int(salt), _stream())
         _lib.check(rc, "eda_bn_relu_fwd_f32")
         ctx.save_for_backward(z, gamma, stats, argmax)
-        ctx.cfg = (int(pool), bool(training))
+        ctx.cfg = (int(pool), bool(training), float(p_drop), int(salt))
         return out
 
     @staticmethod
     def backward(ctx, dout):
         z, gamma, stats, argmax = ctx.saved_tensors
-        pool, training = ctx.cfg
+        pool, training, p_drop, salt = ctx.cfg
         R, C = z.shape
+        seed = None
+        if p_drop > 0:
+            from .attention import dropout_state
+            seed = dropout_state(z.device)
         dout = dout.contiguous()
         dz = torch.empty_like(z)
         ws = torch.empty((2 * C,), dtype=torch.float64, device=z.device)
@@ -138,9 +149,9 @@ class BNReLUCL(Function):
                 dout.data_ptr(), argmax.data_ptr() if argmax is not None else None, z.data_ptr(), R, C,
                 pool, gamma.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
                 stats[3].data_ptr(), int(training), ws.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
-                dz.data_ptr(), _stream())
+                dz.data_ptr(), p_drop, seed.data_ptr() if seed is not None else None, salt, _stream())
         _lib.check(rc, "eda_bn_relu_bwd_f32")
-        return dz, dgb[0], dgb[1], None, None, None, None, None, None
+        return dz, dgb[0], dgb[1], None, None, None, None, None, None, None, None
 
 
 def shared_mlp_rows(mlp, rows, pool):

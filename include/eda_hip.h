@@ -168,16 +168,22 @@ int eda_group_concat_cl_grad_f32(const float *dx, const int *idx, int b, int n, 
  * out = relu(bn(z)) (R,C), or with pool > 1 its max over each `pool` consecutive rows
  * (R/pool,C) plus the arg-max row (bytes).  mean/rstd/scale/shift (C each) are kept
  * for the backward.  ws: 2*C doubles.
- * eda_bn_relu_bwd_f32: dz (R,C), dgamma, dbeta (C floats each); ws: 2*C doubles of scratch.  */
+ * eda_bn_relu_bwd_f32: dz (R,C), dgamma, dbeta (C floats each); ws: 2*C doubles of scratch.
+ * p_drop > 0: element dropout AFTER the ReLU fused into the same pass (the heads'
+ * Conv-BN-ReLU-Dropout, models/modules.py:66-86), mask = the counter hash of eda_mha_* /
+ * eda_add_dropout_ln_* on (seed_ptr, salt, element index); built for pool == 1 and
+ * R <= eda_bn_relu_dropout_max_rows() (else EDA_ERR_UNSUPPORTED; pass 0 and drop separately). */
+long eda_bn_relu_dropout_max_rows(void);
 int eda_bn_relu_fwd_f32(const float *z, long R, int C, const float *gamma, const float *beta,
                         float eps, float momentum, int training, float *running_mean,
                         float *running_var, int pool, double *ws, float *mean, float *rstd,
                         float *scale, float *shift, float *out, unsigned char *argmax,
-                        void *stream);
+                        float p_drop, const unsigned long long *seed_ptr, unsigned salt, void *stream);
 int eda_bn_relu_bwd_f32(const float *dout, const unsigned char *argmax, const float *z, long R,
                         int C, int pool, const float *gamma, const float *mean, const float *rstd,
                         const float *scale, const float *shift, int training, double *ws,
-                        float *dgamma, float *dbeta, float *dz, void *stream);
+                        float *dgamma, float *dbeta, float *dz, float p_drop,
+                        const unsigned long long *seed_ptr, unsigned salt, void *stream);
 
 /* ---- fused residual + dropout + LayerNorm ----------------------------------
  * out = LayerNorm(x + dropout(y + y_bias)) over the last dimension of (R,C) rows: the

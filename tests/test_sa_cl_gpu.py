@@ -126,3 +126,48 @@ def test_sa_fast_path_matches_generic_path_full_size(training):
     if training:
         for (n1, b1), (n2, b2) in zip(sa.named_buffers(), sb.named_buffers()):
             torch.testing.assert_close(b1.float(), b2.float(), rtol=1e-4, atol=1e-5, msg=n1)
+
+
+@pytest.mark.parametrize("R,C,p", [(2048, 288, 0.3), (100, 64, 0.5), (4096, 128, 0.1)])
+def test_bn_relu_fused_dropout(R, C, p):
+    """Dropout behind the ReLU inside the small-row BN kernel: keep-rate, 1/(1-p) scaling, and a
+    backward that uses exactly the forward's mask (checked against torch ops with that mask)."""
+    from eda_amd import attention
+    from eda_amd.sa_ops import BNReLUCL
+    torch.manual_seed(R + C)
+    z = (torch.randn(R, C, device="cuda") * 2 + 0.5).requires_grad_(True)
+    gamma = (torch.rand(C, device="cuda") + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, device="cuda") * 0.3).requires_grad_(True)
+    w = torch.randn(R, C, device="cuda")
+    attention.dropout_state("cuda").fill_(5)
+
+    def run(pd, salt):
+        rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+        return BNReLUCL.apply(z, gamma, beta, rm, rv, 1e-5, 0.1, True, 1, pd, salt)
+    a = run(0.0, 0).detach()
+    out = run(p, 77)
+    assert torch.equal(out, run(p, 77))                     # same step + site -> same mask
+    assert not torch.equal(out, run(p, 78))
+    pos = a > 0
+    kept = (out != 0) & pos
+    rate = 1.0 - kept.sum().item() / pos.sum().item()
+    assert abs(rate - p) < 0.02, rate
+    torch.testing.assert_close(out[kept], a[kept] / (1 - p), rtol=1e-5, atol=1e-6)
+    assert (out[~kept] == 0).all()
+    got = torch.autograd.grad((out * w).sum(), [z, gamma, beta])
+    mask = kept.float() / (1 - p)
+    ref = torch.relu(torch.nn.functional.batch_norm(z, None, None, gamma, beta, True, 0.1, 1e-5))
+    exp = torch.autograd.grad((ref * mask * w).sum(), [z, gamma, beta])
+    for g, e, name in zip(got, exp, ["dz", "dgamma", "dbeta"]):
+        scale = e.abs().max().item() + 1e-9
+        assert (g - e).abs().max().item() <= 2e-4 * scale, (name, (g - e).abs().max().item(), scale)
+
+
+def test_bn_relu_fused_dropout_refuses_large_rows():
+    from eda_amd import _lib
+    from eda_amd.sa_ops import BNReLUCL
+    R = _lib.lib().eda_bn_relu_dropout_max_rows() + 64
+    z = torch.randn(R, 64, device="cuda")
+    g, b = torch.ones(64, device="cuda"), torch.zeros(64, device="cuda")
+    with pytest.raises(RuntimeError, match="fused dropout"):
+        BNReLUCL.apply(z, g, b, torch.zeros(64, device="cuda"), torch.ones(64, device="cuda"), 1e-5, 0.1, True, 1, 0.3, 1)
