@@ -93,6 +93,8 @@ class _FusedMHA(Function):
         delta = torch.empty((B, num_heads, Lq), dtype=torch.float32, device=q.device)
         m8 = ctx.mask8
         seed = dropout_state(q.device) if p_drop > 0 else None
+        ws_bytes = _lib.lib().eda_mha_bwd_workspace_bytes(B, num_heads, Lq, Lk)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=q.device) if ws_bytes else None
         with torch.cuda.device(q.device), _timed('mha_bwd', (B, num_heads, Lq, Lk)):
             rc = _lib.lib().eda_mha_bwd_f32(
                 q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
@@ -101,7 +103,8 @@ class _FusedMHA(Function):
                 seed.data_ptr() if seed is not None else None, salt, out.data_ptr(), lse.data_ptr(),
                 dout.data_ptr(), dout.stride(0), dout.stride(1), delta.data_ptr(), dq.data_ptr(),
                 dk.data_ptr(), dv.data_ptr(), dq.stride(0), dq.stride(1), dk.stride(0), dk.stride(1),
-                dv.stride(0), dv.stride(1), torch.cuda.current_stream().cuda_stream)
+                dv.stride(0), dv.stride(1), ws.data_ptr() if ws is not None else None, ws_bytes,
+                torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "eda_mha_bwd_f32")
         return dq, dk, dv, None, None, None, None
 
@@ -167,6 +170,8 @@ class _ProjectedMHA(Function):
         delta = torch.empty((B, num_heads, Lq), dtype=torch.float32, device=dev)
         m8 = ctx.mask8
         seed = dropout_state(dev) if p_drop > 0 else None
+        ws_bytes = _lib.lib().eda_mha_bwd_workspace_bytes(B, num_heads, Lq, Lk)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
         with torch.cuda.device(dev), _timed('mha_bwd', (B, num_heads, Lq, Lk)):
             rc = _lib.lib().eda_mha_bwd_f32(
                 q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
@@ -175,7 +180,8 @@ class _ProjectedMHA(Function):
                 seed.data_ptr() if seed is not None else None, salt, out.data_ptr(), lse.data_ptr(),
                 dout.data_ptr(), dout.stride(0), dout.stride(1), delta.data_ptr(), dq.data_ptr(),
                 dk.data_ptr(), dv.data_ptr(), dq.stride(0), dq.stride(1), dk.stride(0), dk.stride(1),
-                dv.stride(0), dv.stride(1), torch.cuda.current_stream().cuda_stream)
+                dv.stride(0), dv.stride(1), ws.data_ptr() if ws is not None else None, ws_bytes,
+                torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "eda_mha_bwd_f32")
         from . import wgrad_queue
         qd = wgrad_queue.active

@@ -52,6 +52,9 @@ struct MhaArgs {
   const float *delta;                         // (B,H,Lq) rowsum(dO * O)
   float *dq, *dk, *dv;                        // (B,L,288) rows, strided like q/k/v
   long dq_sb, dq_sl, dk_sb, dk_sl, dv_sb, dv_sl;
+  // dK/dV with the query range split over gridDim.z workgroups (short Lk): partial results
+  int q_split_rows;                           // queries per split (multiple of TILE); 0 = no split
+  float *dkv_part;                            // [split][dk|dv][B][Lk][H*36] dense
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -460,15 +463,18 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dkv_kernel(MhaArgs a) {
       deltabuf[buf][threadIdx.x] = qq < a.Lq ? a.delta[(long)bh * a.Lq + qq] : 0.f;
     }
   };
-  stage_rows<NW>(Qbuf[0], qbase, a.q_sl, 0, a.Lq);
-  stage_rows<NW>(Dbuf[0], dbase, a.do_sl, 0, a.Lq);
-  stage_stats(0, 0);
+  // query range of this workgroup: everything, or split blockIdx.z of the range
+  const int qbeg = a.q_split_rows ? (int)blockIdx.z * a.q_split_rows : 0;
+  const int qend = a.q_split_rows ? min(a.Lq, qbeg + a.q_split_rows) : a.Lq;
+  stage_rows<NW>(Qbuf[0], qbase, a.q_sl, qbeg, a.Lq);
+  stage_rows<NW>(Dbuf[0], dbase, a.do_sl, qbeg, a.Lq);
+  stage_stats(0, qbeg);
   __syncthreads();
   int cur = 0;
-  for (int q0 = 0; q0 < a.Lq; q0 += TILE, cur ^= 1) {
+  for (int q0 = qbeg; q0 < qend; q0 += TILE, cur ^= 1) {
     const float *Ql = Qbuf[cur], *Dl = Dbuf[cur];
     const float *lse_l = lsebuf[cur], *delta_l = deltabuf[cur];
-    const bool more = q0 + TILE < a.Lq;
+    const bool more = q0 + TILE < qend;
     RowStage<NW> qs, dsg;
     if (more) {
       issue_rows<NW>(qs, qbase, a.q_sl, q0 + TILE, a.Lq);
@@ -530,6 +536,11 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dkv_kernel(MhaArgs a) {
     const float sc = a.scale;
     float *ok = a.dk + (long)b * a.dk_sb + (long)ki * a.dk_sl + h * HD;
     float *ov = a.dv + (long)b * a.dv_sb + (long)ki * a.dv_sl + h * HD;
+    if (a.q_split_rows) {       // partial of this query split, dense (B,Lk,H*36); summed by mha_dkv_reduce_kernel
+      const long per = (long)a.B * a.Lk * (a.H * HD);
+      float *pbase = a.dkv_part + (long)blockIdx.z * 2 * per + ((long)b * a.Lk + ki) * (a.H * HD) + h * HD;
+      ok = pbase; ov = pbase + per;
+    }
     *reinterpret_cast<float4 *>(ok + 4 * g) = make_float4(dk[0][0] * sc, dk[0][1] * sc, dk[0][2] * sc, dk[0][3] * sc);
     *reinterpret_cast<float4 *>(ok + 16 + 4 * g) = make_float4(dk[1][0] * sc, dk[1][1] * sc, dk[1][2] * sc, dk[1][3] * sc);
     *reinterpret_cast<float4 *>(ov + 4 * g) = make_float4(dv[0][0], dv[0][1], dv[0][2], dv[0][3]);
@@ -539,6 +550,28 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dkv_kernel(MhaArgs a) {
       *reinterpret_cast<float4 *>(ov + 32) = make_float4(dv[2][0], dv[2][1], dv[2][2], dv[2][3]);
     }
   }
+}
+
+// dk/dv = sum over the query splits of the dense partials, written with the outputs' strides.
+__global__ __launch_bounds__(256) void mha_dkv_reduce_kernel(const float *__restrict__ part, int nsplit,
+                                                             int B, int Lk, int D, float *__restrict__ dk,
+                                                             long dk_sb, long dk_sl, float *__restrict__ dv,
+                                                             long dv_sb, long dv_sl) {
+  const long per = (long)B * Lk * D, n4 = per / 4;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * n4) return;
+  const int which = i >= n4;
+  const long e = (i - which * n4) * 4;
+  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z = 0; z < nsplit; ++z) {
+    const float4 v = *reinterpret_cast<const float4 *>(part + ((long)z * 2 + which) * per + e);
+    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+  }
+  const long row = e / D;
+  const int col = (int)(e - row * D);
+  const long b = row / Lk, l = row - b * Lk;
+  float *o = which ? dv + b * dv_sb + l * dv_sl + col : dk + b * dk_sb + l * dk_sl + col;
+  *reinterpret_cast<float4 *>(o) = t;
 }
 
 // 4 waves per workgroup share one staged tile.  A 1-wave variant (4x more workgroups for the
@@ -588,6 +621,24 @@ extern "C" int eda_mha_fwd_f32(const float *q, const float *k, const float *v, l
   return 0;
 }
 
+// Query splits for dK/dV: a short key dimension gives only B*H*ceil(Lk/64) workgroups that each
+// walk ALL Lq queries (Lk = 80/132, Lq = 1024: 128-192 workgroups x 16 tiles, 108 us); splitting
+// the query range over up to 4 workgroups fills the chip (measured: see DESIGN.md).
+static int dkv_splits(int B, int H, int Lq, int Lk) {
+  const long wgs = (long)B * H * ((Lk + TILE - 1) / TILE);
+  if (wgs >= 256 || Lq < 4 * TILE) return 1;
+  int s = (int)((512 + wgs - 1) / wgs);
+  if (s > 4) s = 4;
+  if (s > Lq / (2 * TILE)) s = Lq / (2 * TILE);      // at least two query tiles per split
+  return s < 1 ? 1 : s;
+}
+
+extern "C" size_t eda_mha_bwd_workspace_bytes(int B, int H, int Lq, int Lk) {
+  const int s = dkv_splits(B, H, Lq, Lk);
+  if (s <= 1) return 0;
+  return sizeof(float) * (size_t)s * 2 * (size_t)B * Lk * (H * HD);
+}
+
 extern "C" int eda_mha_bwd_f32(const float *q, const float *k, const float *v, long q_sb, long q_sl,
                                long k_sb, long k_sl, long v_sb, long v_sl,
                                const unsigned char *key_padding_mask, int B, int H, int Lq, int Lk,
@@ -596,7 +647,7 @@ extern "C" int eda_mha_bwd_f32(const float *q, const float *k, const float *v, l
                                const float *lse, const float *dout, long do_sb, long do_sl,
                                float *delta_ws, float *dq, float *dk, float *dv, long dq_sb,
                                long dq_sl, long dk_sb, long dk_sl, long dv_sb, long dv_sl,
-                               void *stream_) {
+                               void *ws, size_t ws_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EDA_CHECK_ARG(head_dim == HD, "only head_dim 36 (d_model 288 / 8 heads) is built");
   EDA_CHECK_ARG(B >= 0 && H > 0 && Lq >= 0 && Lk >= 0, "bad dimension");
@@ -627,13 +678,26 @@ extern "C" int eda_mha_bwd_f32(const float *q, const float *k, const float *v, l
     EDA_CHECK_LAUNCH();
   }
   if (Lk > 0) {
+    const int nsplit = dkv_splits(B, H, Lq, Lk);
+    const bool split = nsplit > 1 && ws && ws_bytes >= eda_mha_bwd_workspace_bytes(B, H, Lq, Lk);
+    if (split) {
+      a.q_split_rows = ((Lq + nsplit - 1) / nsplit + TILE - 1) / TILE * TILE;
+      a.dkv_part = reinterpret_cast<float *>(ws);
+    }
+    const unsigned gz = split ? (unsigned)((Lq + a.q_split_rows - 1) / a.q_split_rows) : 1u;
     if (pick_waves(Lk, B * H) == 1)
-      hipLaunchKernelGGL(mha_bwd_dkv_kernel<1>, dim3((unsigned)(B * H), (unsigned)((Lk + 15) / 16)), dim3(64),
+      hipLaunchKernelGGL(mha_bwd_dkv_kernel<1>, dim3((unsigned)(B * H), (unsigned)((Lk + 15) / 16), gz), dim3(64),
                          0, stream, a);
     else
-      hipLaunchKernelGGL(mha_bwd_dkv_kernel<4>, dim3((unsigned)(B * H), (unsigned)((Lk + 63) / 64)), dim3(256),
+      hipLaunchKernelGGL(mha_bwd_dkv_kernel<4>, dim3((unsigned)(B * H), (unsigned)((Lk + 63) / 64), gz), dim3(256),
                          0, stream, a);
     EDA_CHECK_LAUNCH();
+    if (split) {
+      const long items = 2L * B * Lk * (H * HD) / 4;
+      hipLaunchKernelGGL(mha_dkv_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream,
+                         a.dkv_part, (int)gz, B, Lk, H * HD, dk, dk_sb, dk_sl, dv, dv_sb, dv_sl);
+      EDA_CHECK_LAUNCH();
+    }
   }
   return 0;
 }

@@ -146,7 +146,12 @@ int eda_mha_bwd_f32(const float *q, const float *k, const float *v, long q_sb, l
                     const unsigned long long *seed_ptr, unsigned salt, const float *out,
                     const float *lse, const float *dout, long do_sb, long do_sl,
                     float *delta_ws, float *dq, float *dk, float *dv, long dq_sb, long dq_sl,
-                    long dk_sb, long dk_sl, long dv_sb, long dv_sl, void *stream);
+                    long dk_sb, long dk_sl, long dv_sb, long dv_sl, void *ws, size_t ws_bytes,
+                    void *stream);
+/* ws: optional scratch of eda_mha_bwd_workspace_bytes() (0 = none needed): with it, short key
+ * dimensions split the query range of the dK/dV kernel over more workgroups (partials summed in
+ * split order); without it (NULL) the unsplit kernel runs.                                   */
+size_t eda_mha_bwd_workspace_bytes(int B, int H, int Lq, int Lk);
 
 /* ---- set-abstraction grouped MLP, channels-last pipeline -----------------
  * Rows are positions (scene, centre j, neighbour k) of a (b*m*ns, C) matrix.
