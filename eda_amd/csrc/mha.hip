@@ -55,6 +55,9 @@ struct MhaArgs {
   // dK/dV with the query range split over gridDim.z workgroups (short Lk): partial results
   int q_split_rows;                           // queries per split (multiple of TILE); 0 = no split
   float *dkv_part;                            // [split][dk|dv][B][Lk][H*36] dense
+  // dQ with the key range split over gridDim.z workgroups (short Lq): partial results
+  int k_split_rows;                           // keys per split (multiple of TILE); 0 = no split
+  float *dq_part;                             // [split][B][Lq][H*36] dense
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -350,15 +353,18 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dq_kernel(MhaArgs a) {
   const unsigned rowbase = ((unsigned)bh * (unsigned)a.Lq + (unsigned)qi) * (unsigned)a.Lk;
 
   f32x4 dq[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-  stage_rows<NW>(Kbuf[0], kbase, a.k_sl, 0, a.Lk);
-  stage_rows<NW>(Vbuf[0], vbase, a.v_sl, 0, a.Lk);
-  stage_dead(deadbuf[0], mrow, 0, a.Lk);
+  // key range of this workgroup: everything, or split blockIdx.z of the range
+  const int kbeg = a.k_split_rows ? (int)blockIdx.z * a.k_split_rows : 0;
+  const int kend = a.k_split_rows ? min(a.Lk, kbeg + a.k_split_rows) : a.Lk;
+  stage_rows<NW>(Kbuf[0], kbase, a.k_sl, kbeg, a.Lk);
+  stage_rows<NW>(Vbuf[0], vbase, a.v_sl, kbeg, a.Lk);
+  stage_dead(deadbuf[0], mrow, kbeg, a.Lk);
   __syncthreads();
   int cur = 0;
-  for (int k0 = 0; k0 < a.Lk; k0 += TILE, cur ^= 1) {
+  for (int k0 = kbeg; k0 < kend; k0 += TILE, cur ^= 1) {
     const float *Kl = Kbuf[cur], *Vl = Vbuf[cur];
     const unsigned *deadl = deadbuf[cur];
-    const bool more = k0 + TILE < a.Lk;
+    const bool more = k0 + TILE < kend;
     RowStage<NW> ks, vs;
     if (more) {
       issue_rows<NW>(ks, kbase, a.k_sl, k0 + TILE, a.Lk);
@@ -410,6 +416,8 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dq_kernel(MhaArgs a) {
   }
   if (qvalid) {
     float *out = a.dq + (long)b * a.dq_sb + (long)qi * a.dq_sl + h * HD;
+    if (a.k_split_rows)         // partial of this key split, dense (B,Lq,H*36); summed by mha_part_reduce_kernel
+      out = a.dq_part + ((long)blockIdx.z * a.B * a.Lq + (long)b * a.Lq + qi) * (a.H * HD) + h * HD;
     const float sc = a.scale;
     *reinterpret_cast<float4 *>(out + 4 * g) = make_float4(dq[0][0] * sc, dq[0][1] * sc, dq[0][2] * sc, dq[0][3] * sc);
     *reinterpret_cast<float4 *>(out + 16 + 4 * g) = make_float4(dq[1][0] * sc, dq[1][1] * sc, dq[1][2] * sc, dq[1][3] * sc);
@@ -552,19 +560,20 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dkv_kernel(MhaArgs a) {
   }
 }
 
-// dk/dv = sum over the query splits of the dense partials, written with the outputs' strides.
-__global__ __launch_bounds__(256) void mha_dkv_reduce_kernel(const float *__restrict__ part, int nsplit,
-                                                             int B, int Lk, int D, float *__restrict__ dk,
-                                                             long dk_sb, long dk_sl, float *__restrict__ dv,
-                                                             long dv_sb, long dv_sl) {
+// out tensors (1: dq; 2: dk, dv) = sum over the splits of the dense partials [split][tensor][B][L][D],
+// written with the outputs' strides, in split order (deterministic).
+__global__ __launch_bounds__(256) void mha_part_reduce_kernel(const float *__restrict__ part, int nsplit,
+                                                              int ntens, int B, int Lk, int D,
+                                                              float *__restrict__ dk, long dk_sb, long dk_sl,
+                                                              float *__restrict__ dv, long dv_sb, long dv_sl) {
   const long per = (long)B * Lk * D, n4 = per / 4;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= 2 * n4) return;
+  if (i >= ntens * n4) return;
   const int which = i >= n4;
   const long e = (i - which * n4) * 4;
   float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int z = 0; z < nsplit; ++z) {
-    const float4 v = *reinterpret_cast<const float4 *>(part + ((long)z * 2 + which) * per + e);
+    const float4 v = *reinterpret_cast<const float4 *>(part + ((long)z * ntens + which) * per + e);
     t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
   }
   const long row = e / D;
@@ -623,7 +632,9 @@ extern "C" int eda_mha_fwd_f32(const float *q, const float *k, const float *v, l
 
 // Query splits for dK/dV: a short key dimension gives only B*H*ceil(Lk/64) workgroups that each
 // walk ALL Lq queries (Lk = 80/132, Lq = 1024: 128-192 workgroups x 16 tiles, 108 us); splitting
-// the query range over up to 4 workgroups fills the chip (measured: see DESIGN.md).
+// the query range over up to 4 workgroups fills the chip (measured: see DESIGN.md).  The dQ
+// kernel uses the same rule with the roles swapped (short Lq, e.g. 80 text tokens over 1024
+// points: the KEY range is split).
 static int dkv_splits(int B, int H, int Lq, int Lk) {
   const long wgs = (long)B * H * ((Lk + TILE - 1) / TILE);
   if (wgs >= 256 || Lq < 4 * TILE) return 1;
@@ -634,9 +645,15 @@ static int dkv_splits(int B, int H, int Lq, int Lk) {
 }
 
 extern "C" size_t eda_mha_bwd_workspace_bytes(int B, int H, int Lq, int Lk) {
-  const int s = dkv_splits(B, H, Lq, Lk);
-  if (s <= 1) return 0;
-  return sizeof(float) * (size_t)s * 2 * (size_t)B * Lk * (H * HD);
+  // one scratch area, used first by the dQ key split, then by the dK/dV query split
+  const int s = dkv_splits(B, H, Lq, Lk), sq = dkv_splits(B, H, Lk, Lq);
+  size_t need = 0;
+  if (s > 1) need = sizeof(float) * (size_t)s * 2 * (size_t)B * Lk * (H * HD);
+  if (sq > 1) {
+    const size_t nq = sizeof(float) * (size_t)sq * (size_t)B * Lq * (H * HD);
+    if (nq > need) need = nq;
+  }
+  return need;
 }
 
 extern "C" int eda_mha_bwd_f32(const float *q, const float *k, const float *v, long q_sb, long q_sl,
@@ -667,19 +684,34 @@ extern "C" int eda_mha_bwd_f32(const float *q, const float *k, const float *v, l
   a.dk = dk; a.dv = dv;
   a.dq_sb = dq_sb; a.dq_sl = dq_sl; a.dk_sb = dk_sb; a.dk_sl = dk_sl; a.dv_sb = dv_sb; a.dv_sl = dv_sl;
   a.o = const_cast<float *>(out); a.o_sb = (long)Lq * H * HD; a.o_sl = (long)H * HD;
+  const size_t ws_need = eda_mha_bwd_workspace_bytes(B, H, Lq, Lk);
+  const bool ws_ok = ws && ws_bytes >= ws_need && (reinterpret_cast<uintptr_t>(ws) & 15u) == 0;
   if (Lq > 0) {
     // (delta = rowsum(dO * O) is computed inside the dQ kernel and published for dK/dV)
+    const int nsplit = dkv_splits(B, H, Lk, Lq);          // same rule with the roles of Lq / Lk swapped
+    const bool split = nsplit > 1 && ws_ok;
+    if (split) {
+      a.k_split_rows = ((Lk + nsplit - 1) / nsplit + TILE - 1) / TILE * TILE;
+      a.dq_part = reinterpret_cast<float *>(ws);
+    }
+    const unsigned gz = split ? (unsigned)((Lk + a.k_split_rows - 1) / a.k_split_rows) : 1u;
     if (pick_waves(Lq, B * H) == 1)
-      hipLaunchKernelGGL(mha_bwd_dq_kernel<1>, dim3((unsigned)(B * H), (unsigned)((Lq + 15) / 16)), dim3(64),
+      hipLaunchKernelGGL(mha_bwd_dq_kernel<1>, dim3((unsigned)(B * H), (unsigned)((Lq + 15) / 16), gz), dim3(64),
                          0, stream, a);
     else
-      hipLaunchKernelGGL(mha_bwd_dq_kernel<4>, dim3((unsigned)(B * H), (unsigned)((Lq + 63) / 64)), dim3(256),
+      hipLaunchKernelGGL(mha_bwd_dq_kernel<4>, dim3((unsigned)(B * H), (unsigned)((Lq + 63) / 64), gz), dim3(256),
                          0, stream, a);
     EDA_CHECK_LAUNCH();
+    if (split) {
+      const long items = (long)B * Lq * (H * HD) / 4;
+      hipLaunchKernelGGL(mha_part_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream,
+                         a.dq_part, (int)gz, 1, B, Lq, H * HD, dq, dq_sb, dq_sl, dq, dq_sb, dq_sl);
+      EDA_CHECK_LAUNCH();
+    }
   }
   if (Lk > 0) {
     const int nsplit = dkv_splits(B, H, Lq, Lk);
-    const bool split = nsplit > 1 && ws && ws_bytes >= eda_mha_bwd_workspace_bytes(B, H, Lq, Lk);
+    const bool split = nsplit > 1 && ws_ok;
     if (split) {
       a.q_split_rows = ((Lq + nsplit - 1) / nsplit + TILE - 1) / TILE * TILE;
       a.dkv_part = reinterpret_cast<float *>(ws);
@@ -694,8 +726,8 @@ extern "C" int eda_mha_bwd_f32(const float *q, const float *k, const float *v, l
     EDA_CHECK_LAUNCH();
     if (split) {
       const long items = 2L * B * Lk * (H * HD) / 4;
-      hipLaunchKernelGGL(mha_dkv_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream,
-                         a.dkv_part, (int)gz, B, Lk, H * HD, dk, dk_sb, dk_sl, dv, dv_sb, dv_sl);
+      hipLaunchKernelGGL(mha_part_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream,
+                         a.dkv_part, (int)gz, 2, B, Lk, H * HD, dk, dk_sb, dk_sl, dv, dv_sb, dv_sl);
       EDA_CHECK_LAUNCH();
     }
   }
