@@ -10,7 +10,7 @@ NATIVE = [
     ("native: fused attention (fwd, dQ, dK/dV)", r"^mha_"),
     ("native: BN+ReLU(+pool) fwd/bwd", r"^bn_"),
     ("native: residual+dropout+LayerNorm", r"^add_dropout_ln|^ln_reduce"),
-    ("native: weight/bias gradients (wgrad, colsum)", r"^wgrad_|^colsum_"),
+    ("native: weight/bias gradients (grouped wgrad, colsum)", r"^wgrad_|^colsum_|^wcolsum_"),
     ("native: ball query (grid build + query)", r"^gq_|^ball_query"),
     ("native: gather/group/3-NN", r"^group_|^gather_|^three_"),
     ("native: zero-fill", r"^zero_kernel"),
