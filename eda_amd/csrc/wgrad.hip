@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
 //   task   = {target (or -1: padding), tm, tn, unused}; task id % 8 = the XCD it runs on
 //   target = {dW, db or 0, M, N, first job, job count, accumulate (0: store, 1: add to dW/db), unused}
 //   job    = {dY, ld_dy, X, ld_x, K, unused x3}
-__global__ __launch_bounds__(WG_THREADS) void wgrad_grouped_kernel(const long long *__restrict__ tasks,
+__global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) void wgrad_grouped_kernel(const long long *__restrict__ tasks,
                                                                    const long long *__restrict__ targets,
                                                                    const long long *__restrict__ jobs) {
   __shared__ float As[WG_KC][WG_STRIDE];
@@ -237,24 +237,31 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_grouped_kernel(const long lo
       __syncthreads();
       if (k0 + WG_KC < K) fetch(k0 + WG_KC);
       if (active) {
-        float av[WG_KC / 4], bv[3][WG_KC / 4];
+        // operands of 4 K steps at a time: 16 registers instead of 64, which keeps the kernel at
+        // <= 80 VGPRs = 6 waves per SIMD = TWO workgroups per CU (one hides the other's barriers,
+        // LDS latency and global fetches; with 128 VGPRs a CU held one workgroup: 32 % of peak)
 #pragma unroll
-        for (int kk = 0; kk < WG_KC / 4; ++kk) {
-          av[kk] = ap[kk * 4 * WG_STRIDE];
+        for (int half = 0; half < 4; ++half) {
+          float av[WG_KC / 16], bv[3][WG_KC / 16];
 #pragma unroll
-          for (int t = 0; t < 3; ++t) bv[t][kk] = bp[kk * 4 * WG_STRIDE + 16 * t];
-        }
-        __builtin_amdgcn_sched_barrier(0);
+          for (int kk = 0; kk < WG_KC / 16; ++kk) {
+            av[kk] = ap[(half * (WG_KC / 16) + kk) * 4 * WG_STRIDE];
 #pragma unroll
-        for (int kk = 0; kk < WG_KC / 4; ++kk) {
+            for (int t = 0; t < 3; ++t) bv[t][kk] = bp[(half * (WG_KC / 16) + kk) * 4 * WG_STRIDE + 16 * t];
+          }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int t = 0; t < 3; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv[t][kk], acc[t], 0, 0, 0);
+          for (int kk = 0; kk < WG_KC / 16; ++kk) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+              acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv[t][kk], acc[t], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       if (do_db) {
         float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-#pragma unroll
+#pragma unroll 2
         for (int r = 0; r < WG_KC; r += 4) {
           t0 += As[r][tid]; t1 += As[r + 1][tid]; t2 += As[r + 2][tid]; t3 += As[r + 3][tid];
         }
