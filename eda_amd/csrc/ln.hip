@@ -200,6 +200,33 @@ __global__ __launch_bounds__(1024) void ln_reduce_partials_kernel(const float *_
   }
 }
 
+// The same reduction for MANY LayerNorm sites in one launch (deferred by eda_amd/wgrad_queue.py:
+// the gamma / beta / bias gradients are only needed by the optimizer step).  desc[site] =
+// {partial, nblocks, C, dgamma, dbeta, dbias or 0, 0, 0}; grid = (column groups of 64 over 3*maxC, sites).
+__global__ __launch_bounds__(1024) void ln_reduce_grouped_kernel(const long long *__restrict__ desc) {
+  __shared__ float red[16][65];
+  const long long *d = desc + (long)blockIdx.y * 8;
+  const float *partial = reinterpret_cast<const float *>(d[0]);
+  const int nblocks = (int)d[1], C = (int)d[2];
+  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + col;               // over 3*C
+  if (blockIdx.x * 64 >= 3 * C) return;
+  float s = 0.f;
+  if (i < 3 * C) {
+#pragma unroll 8
+    for (int b = rl; b < nblocks; b += 16) s += partial[(long)b * 3 * C + i];
+  }
+  red[rl][col] = s;
+  __syncthreads();
+  if (rl == 0 && i < 3 * C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][col];
+    float *out = reinterpret_cast<float *>(i < C ? d[3] : (i < 2 * C ? d[4] : d[5]));
+    if (out) out[i < C ? i : (i < 2 * C ? i - C : i - 2 * C)] = t;
+  }
+}
+
 }  // namespace
 
 #define LN_DISPATCH(NI_EXPR, KERNEL, GRID, ...)                                                   \
@@ -245,8 +272,9 @@ extern "C" int eda_add_dropout_ln_bwd_f32(const float *dout, const float *x, con
                                           size_t ws_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EDA_CHECK_ARG(R >= 0 && C > 0 && C <= 64 * LN_MAXI, "bad dimension (C <= 1024)");
-  EDA_CHECK_ARG(grads3, "null pointer");
-  if (R == 0) return eda_zero_async(grads3, sizeof(float) * 3 * C, stream);
+  // grads3 == NULL: leave the per-block partial sums in `ws` (eda_add_dropout_ln_bwd_blocks(R) rows
+  // of 3*C floats) for a later eda_ln_reduce_grouped_f32 over many sites
+  if (R == 0) return grads3 ? eda_zero_async(grads3, sizeof(float) * 3 * C, stream) : 0;
   EDA_CHECK_ARG(dout && x && y && gamma && mean && rstd && dx && dy && ws, "null pointer");
   if (ws_bytes < eda_add_dropout_ln_bwd_workspace_bytes(R, C)) {
     eda_set_error("add_dropout_ln_bwd: workspace too small");
@@ -261,8 +289,28 @@ extern "C" int eda_add_dropout_ln_bwd_f32(const float *dout, const float *x, con
   LN_DISPATCH((C + 63) / 64, add_dropout_ln_bwd_kernel, grid, dout, x, y, y_bias, gamma, mean, rstd, R, C,
               p_drop, seed_ptr, salt, dx, dy, partial);
   EDA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ln_reduce_partials_kernel, dim3((3 * C + 63) / 64), dim3(1024), 0, stream, partial,
-                     (int)blocks, C, grads3);
+  if (grads3) {
+    hipLaunchKernelGGL(ln_reduce_partials_kernel, dim3((3 * C + 63) / 64), dim3(1024), 0, stream, partial,
+                       (int)blocks, C, grads3);
+    EDA_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+extern "C" int eda_add_dropout_ln_bwd_blocks(long R) {
+  long blocks = (R + 7) / 8;
+  if (blocks > LN_BWD_MAX_BLOCKS) blocks = LN_BWD_MAX_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+extern "C" int eda_ln_reduce_grouped_f32(const long long *desc, int nsites, int max_c, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(nsites >= 0 && max_c > 0 && max_c <= 64 * LN_MAXI, "bad dimension");
+  if (nsites == 0) return 0;
+  EDA_CHECK_ARG(desc, "null pointer");
+  hipLaunchKernelGGL(ln_reduce_grouped_kernel, dim3((unsigned)((3 * max_c + 63) / 64), (unsigned)nsites), dim3(1024),
+                     0, stream, desc);
   EDA_CHECK_LAUNCH();
   return 0;
 }

@@ -47,6 +47,7 @@ class _AddDropoutLN(Function):
                 torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "eda_add_dropout_ln_fwd_f32")
         ctx.save_for_backward(x2, y2, gamma, stats, y_bias)
+        ctx.beta_ref = beta                     # only its storage location matters (deferred gradients)
         ctx.cfg = (float(p_drop), int(salt), shape)
         return out.view(shape)
 
@@ -59,7 +60,10 @@ class _AddDropoutLN(Function):
         dout = dout.reshape(R, C).contiguous()
         dx = torch.empty_like(x2)
         dy = torch.empty_like(x2)
-        g3 = torch.empty((3, C), dtype=torch.float32, device=dev)
+        from . import wgrad_queue
+        q = wgrad_queue.active
+        planned = q.plan_ln(gamma, ctx.beta_ref, y_bias) if q is not None else None
+        g3 = torch.empty((3, C), dtype=torch.float32, device=dev) if planned is None else None
         L = _lib.lib()
         ws_bytes = L.eda_add_dropout_ln_bwd_workspace_bytes(R, C)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
@@ -70,8 +74,14 @@ class _AddDropoutLN(Function):
                 y_bias.data_ptr() if y_bias is not None else None, gamma.data_ptr(),
                 stats[0].data_ptr(), stats[1].data_ptr(), R, C, p_drop,
                 seed.data_ptr() if seed is not None else None, salt, dx.data_ptr(), dy.data_ptr(),
-                g3.data_ptr(), ws.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream)
+                g3.data_ptr() if g3 is not None else None, ws.data_ptr(), ws_bytes,
+                torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "eda_add_dropout_ln_bwd_f32")
+        if planned is not None:
+            # d(gamma), d(beta), d(bias): per-block partial sums stay in `ws`; the queue reduces all
+            # LayerNorm sites of the backward pass in one launch, straight into the gradient buffer
+            q.submit_ln(planned, ws, L.eda_add_dropout_ln_bwd_blocks(R), C)
+            return dx.view(shape), dy.view(shape), None, None, None, None, None, None
         return (dx.view(shape), dy.view(shape), g3[2] if y_bias is not None else None, g3[0], g3[1],
                 None, None, None)
 

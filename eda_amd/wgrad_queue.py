@@ -30,10 +30,11 @@ class WgradQueue:
         """locate(t) -> the gradient-buffer view matching parameter view `t`, or None."""
         self.locate = locate
         self._targets = {}       # dW data_ptr -> [dW, db, M, N, [(dy2, x2), ...]]
+        self._ln = {}            # dgamma data_ptr -> (partial ws, rows, C, dgamma, dbeta, dbias or None)
         self._ring = []          # descriptor staging: [pinned host words, device words, copy-done event]
         self._ring_pos = 0
 
-    _RING = 3
+    _RING = 6
     _WORDS = 1 << 17             # 1 MiB of descriptors per slot (bench step: ~15 k words)
 
     def reserve(self, device):
@@ -87,8 +88,28 @@ class WgradQueue:
         t[4].append((dy2, x2))
         return True
 
+    def plan_ln(self, gamma, beta, y_bias):
+        """Gradient views (dgamma, dbeta, dbias or None) a fused-LayerNorm site would write, or None
+        if it is not eligible (a LayerNorm applied twice in one pass keeps the immediate path)."""
+        gg, gb = self.locate(gamma), self.locate(beta)
+        if gg is None or gb is None or gg.data_ptr() in self._ln:
+            return None
+        gy = None
+        if y_bias is not None:
+            gy = self.locate(y_bias)
+            if gy is None or any(gy.data_ptr() == (t[1].data_ptr() if t[1] is not None else 0)
+                                 for t in self._targets.values()):
+                return None
+        return gg, gb, gy
+
+    def submit_ln(self, planned, ws, rows, C):
+        """Queue the reduction of a fused LayerNorm backward's per-block partial sums (`rows` rows
+        of 3*C floats in `ws`: d(gamma) | d(beta) | d(bias of the linear in front))."""
+        gg, gb, gy = planned
+        self._ln[gg.data_ptr()] = (ws, int(rows), int(C), gg, gb, gy)
+
     def __len__(self):
-        return sum(len(t[4]) for t in self._targets.values())
+        return sum(len(t[4]) for t in self._targets.values()) + len(self._ln)
 
     def touched(self):
         """data_ptr of every gradient view (weights and biases) that flush() will write."""
@@ -97,16 +118,22 @@ class WgradQueue:
             out.add(gW.data_ptr())
             if gb is not None:
                 out.add(gb.data_ptr())
+        for _, _, _, gg, gb, gy in self._ln.values():
+            out.update(t.data_ptr() for t in (gg, gb, gy) if t is not None)
         return out
 
     # ------------------------------------------------------------------- flush
     def flush(self, accumulate=False):
         """Launch the grouped kernel for everything queued (stores, or adds with accumulate=True)
         and drop the references to the queued activations."""
+        lns = list(self._ln.values())
+        self._ln = {}
         targets = list(self._targets.values())
         self._targets = {}
+        if lns:
+            self._flush_ln(lns)
         if not targets:
-            return 0
+            return len(lns)
         dev = targets[0][0].device
         # cost of a tile = rows it walks; place whole targets on one XCD (workgroup id % 8), big first
         costs = [sum(dy.shape[0] for dy, _ in t[4]) for t in targets]
@@ -142,6 +169,31 @@ class WgradQueue:
                               x2.stride(0) if K > 1 else N, K, 0, 0, 0)
                 j += 1
         words = np.concatenate([task_arr.ravel(), targ_arr.ravel(), job_arr.ravel()])
+        desc = self._stage(words, dev)
+        base = desc.data_ptr()
+        with torch.cuda.device(dev), _timed("wgrad_grouped", (len(targets), njobs, ntasks)):
+            rc = _lib.lib().eda_wgrad_grouped_f32(base, ntasks, base + 8 * task_arr.size,
+                                                  base + 8 * (task_arr.size + targ_arr.size),
+                                                  torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "eda_wgrad_grouped_f32")
+        # dY / X of the jobs and `desc` stay referenced by `targets` / this frame until here; the
+        # caching allocator only re-uses their memory for work queued later on this stream.
+        return njobs + len(lns)
+
+    def _flush_ln(self, lns):
+        dev = lns[0][3].device
+        arr = np.zeros((len(lns), 8), dtype=np.int64)
+        for i, (ws, rows, C, gg, gb, gy) in enumerate(lns):
+            arr[i] = (ws.data_ptr(), rows, C, gg.data_ptr(), gb.data_ptr(), gy.data_ptr() if gy is not None else 0,
+                      0, 0)
+        desc = self._stage(arr.ravel(), dev)
+        with torch.cuda.device(dev), _timed("ln_reduce_grouped", (len(lns),)):
+            rc = _lib.lib().eda_ln_reduce_grouped_f32(desc.data_ptr(), len(lns), max(l[2] for l in lns),
+                                                      torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "eda_ln_reduce_grouped_f32")
+
+    def _stage(self, words, dev):
+        """Copy descriptor words to the device through a pinned staging slot; returns the device view."""
         capturing = torch.cuda.is_current_stream_capturing()
         if not self._ring:
             if capturing:
@@ -171,12 +223,4 @@ class WgradQueue:
         else:
             slot[2] = torch.cuda.Event()
             slot[2].record()
-        base = desc.data_ptr()
-        with torch.cuda.device(dev), _timed("wgrad_grouped", (len(targets), njobs, ntasks)):
-            rc = _lib.lib().eda_wgrad_grouped_f32(base, ntasks, base + 8 * task_arr.size,
-                                                  base + 8 * (task_arr.size + targ_arr.size),
-                                                  torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "eda_wgrad_grouped_f32")
-        # dY / X of the jobs and `desc` stay referenced by `targets` / this frame until here; the
-        # caching allocator only re-uses their memory for work queued later on this stream.
-        return njobs
+        return desc[:words.size]

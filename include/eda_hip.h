@@ -209,6 +209,13 @@ int eda_add_dropout_ln_bwd_f32(const float *dout, const float *x, const float *y
                                const unsigned long long *seed_ptr, unsigned salt, float *dx,
                                float *dy, float *grads3, void *ws, size_t ws_bytes, void *stream);
 
+/* Deferred form: with grads3 == NULL eda_add_dropout_ln_bwd_f32 leaves its per-block partial sums
+ * in `ws` (eda_add_dropout_ln_bwd_blocks(R) rows of 3*C floats); eda_ln_reduce_grouped_f32 then
+ * reduces MANY sites in one launch: desc[site][8] = {ws pointer, rows, C, dgamma, dbeta,
+ * dbias or 0, 0, 0} (64-bit words on the device), max_c = the largest C among them.          */
+int eda_add_dropout_ln_bwd_blocks(long R);
+int eda_ln_reduce_grouped_f32(const long long *desc, int nsites, int max_c, void *stream);
+
 /* Grouped form: every queued weight gradient of a backward pass in ONE launch (no K split, one
  * writer per element).  Device arrays of 64-bit words, host-built (eda_amd/wgrad_queue.py):
  *   tasks[ntasks][4]  = {target index, tile row, tile column, 0}           (96x96 tiles)
