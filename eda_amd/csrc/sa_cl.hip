@@ -419,35 +419,43 @@ __device__ __forceinline__ float bn_keep(const BnDrop &d, unsigned idx) {
   return bn_hash32(d.seed ^ idx) >= d.thresh ? d.inv_keep : 0.f;
 }
 
+// CQ = float4 column groups per workgroup: CQ adjacent threads read 16*CQ contiguous bytes of a
+// row (CQ = 4: 64-byte segments instead of 16-byte ones), rows are strided by SM_THREADS / CQ.
+template <int CQ>
 __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_fwd_kernel(
     const float *__restrict__ z, int R, int C, const float *__restrict__ gamma,
     const float *__restrict__ beta, float eps, float momentum, int training,
     float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ mean_out,
     float *__restrict__ rstd_out, float *__restrict__ scale_out, float *__restrict__ shift_out,
     float *__restrict__ out, float p_drop, const unsigned long long *seed_ptr, unsigned salt) {
-  __shared__ float red[8][SM_WAVES];
-  __shared__ float sc_l[4], sh_l[4];
+  constexpr int RL = SM_THREADS / CQ;              // row lanes
+  __shared__ float red[8][CQ][SM_WAVES];
+  __shared__ float sc_l[4 * CQ], sh_l[4 * CQ];
   const BnDrop dr = bn_drop(p_drop, seed_ptr, salt);
-  const int c0 = blockIdx.x * 4;
+  const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ;
+  const int c0 = blockIdx.x * 4 * CQ + 4 * cq;     // this thread's four channels
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (training) {
     float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
 #pragma unroll 4
-    for (int r = threadIdx.x; r < R; r += SM_THREADS) {
+    for (int r = rl; r < R; r += RL) {
       const float4 x = *reinterpret_cast<const float4 *>(z + (long)r * C + c0);
       s[0] += x.x; s[1] += x.y; s[2] += x.z; s[3] += x.w;
       q[0] += x.x * x.x; q[1] += x.y * x.y; q[2] += x.z * x.z; q[3] += x.w * x.w;
     }
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const float a = wave_sum64(s[v]), b = wave_sum64(q[v]);
-      if (lane == 0) { red[v][wave] = a; red[4 + v][wave] = b; }
+      float a = s[v], b = q[v];
+#pragma unroll
+      for (int o = 32; o >= CQ; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }   // lanes of equal cq
+      if (lane < CQ) { red[v][lane][wave] = a; red[4 + v][lane][wave] = b; }
     }
     __syncthreads();
-    if (threadIdx.x < 4) {
-      const int c = c0 + threadIdx.x;
+    if (threadIdx.x < 4 * CQ) {
+      const int jq = threadIdx.x >> 2, v = threadIdx.x & 3;
+      const int c = blockIdx.x * 4 * CQ + threadIdx.x;
       double a = 0.0, b = 0.0;
-      for (int w = 0; w < SM_WAVES; ++w) { a += (double)red[threadIdx.x][w]; b += (double)red[4 + threadIdx.x][w]; }
+      for (int w = 0; w < SM_WAVES; ++w) { a += (double)red[v][jq][w]; b += (double)red[4 + v][jq][w]; }
       const double mean = a / (double)R;
       double var = b / (double)R - mean * mean;
       if (var < 0.0) var = 0.0;
@@ -462,18 +470,18 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_fwd_kernel(
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
       }
     }
-  } else if (threadIdx.x < 4) {
-    const int c = c0 + threadIdx.x;
+  } else if (threadIdx.x < 4 * CQ) {
+    const int c = blockIdx.x * 4 * CQ + threadIdx.x;
     const float rstd = 1.f / sqrtf(running_var[c] + eps);
     const float sc = gamma[c] * rstd, sh = beta[c] - running_mean[c] * sc;
     mean_out[c] = running_mean[c]; rstd_out[c] = rstd; scale_out[c] = sc; shift_out[c] = sh;
     sc_l[threadIdx.x] = sc; sh_l[threadIdx.x] = sh;
   }
   __syncthreads();
-  const float sc0 = sc_l[0], sc1 = sc_l[1], sc2 = sc_l[2], sc3 = sc_l[3];
-  const float sh0 = sh_l[0], sh1 = sh_l[1], sh2 = sh_l[2], sh3 = sh_l[3];
+  const float sc0 = sc_l[4 * cq], sc1 = sc_l[4 * cq + 1], sc2 = sc_l[4 * cq + 2], sc3 = sc_l[4 * cq + 3];
+  const float sh0 = sh_l[4 * cq], sh1 = sh_l[4 * cq + 1], sh2 = sh_l[4 * cq + 2], sh3 = sh_l[4 * cq + 3];
 #pragma unroll 4
-  for (int r = threadIdx.x; r < R; r += SM_THREADS) {
+  for (int r = rl; r < R; r += RL) {
     const float4 x = *reinterpret_cast<const float4 *>(z + (long)r * C + c0);
     float4 y;
     y.x = fmaxf(x.x * sc0 + sh0, 0.f); y.y = fmaxf(x.y * sc1 + sh1, 0.f);
@@ -486,6 +494,7 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_fwd_kernel(
   }
 }
 
+template <int CQ>
 __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_bwd_kernel(
     const float *__restrict__ da, const float *__restrict__ z, int R, int C,
     const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ rstd,
@@ -493,17 +502,19 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_bwd_kernel(
     double *__restrict__ s1_out, double *__restrict__ s2_out, float *__restrict__ dgamma,
     float *__restrict__ dbeta, float *__restrict__ dz, float p_drop, const unsigned long long *seed_ptr,
     unsigned salt) {
-  __shared__ float red[8][SM_WAVES];
-  __shared__ float ka_l[4], kb_l[4], kd_l[4];
+  constexpr int RL = SM_THREADS / CQ;              // row lanes (see the forward kernel)
+  __shared__ float red[8][CQ][SM_WAVES];
+  __shared__ float ka_l[4 * CQ], kb_l[4 * CQ], kd_l[4 * CQ];
   const BnDrop dr = bn_drop(p_drop, seed_ptr, salt);
-  const int c0 = blockIdx.x * 4;
+  const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ;
+  const int c0 = blockIdx.x * 4 * CQ + 4 * cq;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float sc[4], sh[4], mu[4], rs[4];
 #pragma unroll
   for (int v = 0; v < 4; ++v) { sc[v] = scale[c0 + v]; sh[v] = shift[c0 + v]; mu[v] = mean[c0 + v]; rs[v] = rstd[c0 + v]; }
   float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
 #pragma unroll 4
-  for (int r = threadIdx.x; r < R; r += SM_THREADS) {
+  for (int r = rl; r < R; r += RL) {
     const float4 x4 = *reinterpret_cast<const float4 *>(z + (long)r * C + c0);
     const float4 d4 = *reinterpret_cast<const float4 *>(da + (long)r * C + c0);
     const float x[4] = {x4.x, x4.y, x4.z, x4.w};
@@ -521,14 +532,17 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_bwd_kernel(
   }
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
-    const float a = wave_sum64(a1[v]), b = wave_sum64(a2[v]);
-    if (lane == 0) { red[v][wave] = a; red[4 + v][wave] = b; }
+    float a = a1[v], b = a2[v];
+#pragma unroll
+    for (int o = 32; o >= CQ; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }   // lanes of equal cq
+    if (lane < CQ) { red[v][lane][wave] = a; red[4 + v][lane][wave] = b; }
   }
   __syncthreads();
-  if (threadIdx.x < 4) {
-    const int c = c0 + threadIdx.x;
+  if (threadIdx.x < 4 * CQ) {
+    const int jq = threadIdx.x >> 2, v = threadIdx.x & 3;
+    const int c = blockIdx.x * 4 * CQ + threadIdx.x;
     double t1 = 0.0, t2 = 0.0;
-    for (int w = 0; w < SM_WAVES; ++w) { t1 += (double)red[threadIdx.x][w]; t2 += (double)red[4 + threadIdx.x][w]; }
+    for (int w = 0; w < SM_WAVES; ++w) { t1 += (double)red[v][jq][w]; t2 += (double)red[4 + v][jq][w]; }
     s1_out[c] = t1; s2_out[c] = t2;
     dbeta[c] = (float)t1; dgamma[c] = (float)t2;
     const float invR = 1.f / (float)R;
@@ -545,9 +559,9 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_bwd_kernel(
   __syncthreads();
   float ka[4], kb[4], kd[4];
 #pragma unroll
-  for (int v = 0; v < 4; ++v) { ka[v] = ka_l[v]; kb[v] = kb_l[v]; kd[v] = kd_l[v]; }
+  for (int v = 0; v < 4; ++v) { ka[v] = ka_l[4 * cq + v]; kb[v] = kb_l[4 * cq + v]; kd[v] = kd_l[4 * cq + v]; }
 #pragma unroll 4
-  for (int r = threadIdx.x; r < R; r += SM_THREADS) {
+  for (int r = rl; r < R; r += RL) {
     const float4 x4 = *reinterpret_cast<const float4 *>(z + (long)r * C + c0);
     const float4 d4 = *reinterpret_cast<const float4 *>(da + (long)r * C + c0);
     const float x[4] = {x4.x, x4.y, x4.z, x4.w};
@@ -564,6 +578,14 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_bwd_kernel(
     }
     *reinterpret_cast<float4 *>(dz + (long)r * C + c0) = make_float4(o[0], o[1], o[2], o[3]);
   }
+}
+
+// Column quads per workgroup of the single-launch kernels: 4 (64-byte row segments per 4 threads)
+// measured ~8 % faster than 1 at 2048 x 288 (EDA_BN_SMALL_CQ=1/2/4 to compare).
+int small_cq() {
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("EDA_BN_SMALL_CQ"); v = e ? atoi(e) : 4; }
+  return v;
 }
 
 constexpr long SMALL_ROWS = 4096;    // below this the single-launch kernels win (at 8192 rows the strided sweep loses)
@@ -635,10 +657,19 @@ extern "C" int eda_bn_relu_fwd_f32(const float *z, long R, int C, const float *g
   EDA_CHECK_ARG(z && gamma && beta && mean && rstd && scale && shift && out, "null pointer");
   if (pool == 1 && R <= SMALL_ROWS) {
     EDA_CHECK_ARG(training || (running_mean && running_var), "eval mode needs running statistics");
-    const int nb = C / 4;
-    hipLaunchKernelGGL(bn_relu_small_fwd_kernel, dim3(nb), dim3(SM_THREADS), 0, stream, z, (int)R, C,
-                       gamma, beta, eps, momentum, training, running_mean, running_var, mean, rstd, scale,
-                       shift, out, p_drop, seed_ptr, salt);
+    const int cq_env = small_cq();
+    if (cq_env == 4 && C % 16 == 0)
+      hipLaunchKernelGGL(bn_relu_small_fwd_kernel<4>, dim3(C / 16), dim3(SM_THREADS), 0, stream, z, (int)R, C,
+                         gamma, beta, eps, momentum, training, running_mean, running_var, mean, rstd, scale,
+                         shift, out, p_drop, seed_ptr, salt);
+    else if (cq_env == 2 && C % 8 == 0)
+      hipLaunchKernelGGL(bn_relu_small_fwd_kernel<2>, dim3(C / 8), dim3(SM_THREADS), 0, stream, z, (int)R, C,
+                         gamma, beta, eps, momentum, training, running_mean, running_var, mean, rstd, scale,
+                         shift, out, p_drop, seed_ptr, salt);
+    else
+      hipLaunchKernelGGL(bn_relu_small_fwd_kernel<1>, dim3(C / 4), dim3(SM_THREADS), 0, stream, z, (int)R, C,
+                         gamma, beta, eps, momentum, training, running_mean, running_var, mean, rstd, scale,
+                         shift, out, p_drop, seed_ptr, salt);
     EDA_CHECK_LAUNCH();
     return 0;
   }
@@ -698,10 +729,19 @@ extern "C" int eda_bn_relu_bwd_f32(const float *dout, const unsigned char *argma
   EDA_CHECK_ARG(dout && z && gamma && mean && rstd && scale && shift && ws && dz, "null pointer");
   EDA_CHECK_ARG(pool == 1 || argmax, "argmax required when pooling");
   if (pool == 1 && R <= SMALL_ROWS) {
-    const int nb = C / 4;
-    hipLaunchKernelGGL(bn_relu_small_bwd_kernel, dim3(nb), dim3(SM_THREADS), 0, stream, dout, z, (int)R,
-                       C, gamma, mean, rstd, scale, shift, training, ws, ws + C, dgamma, dbeta, dz, p_drop,
-                       seed_ptr, salt);
+    const int cq_env = small_cq();
+    if (cq_env == 4 && C % 16 == 0)
+      hipLaunchKernelGGL(bn_relu_small_bwd_kernel<4>, dim3(C / 16), dim3(SM_THREADS), 0, stream, dout, z, (int)R,
+                         C, gamma, mean, rstd, scale, shift, training, ws, ws + C, dgamma, dbeta, dz, p_drop,
+                         seed_ptr, salt);
+    else if (cq_env == 2 && C % 8 == 0)
+      hipLaunchKernelGGL(bn_relu_small_bwd_kernel<2>, dim3(C / 8), dim3(SM_THREADS), 0, stream, dout, z, (int)R,
+                         C, gamma, mean, rstd, scale, shift, training, ws, ws + C, dgamma, dbeta, dz, p_drop,
+                         seed_ptr, salt);
+    else
+      hipLaunchKernelGGL(bn_relu_small_bwd_kernel<1>, dim3(C / 4), dim3(SM_THREADS), 0, stream, dout, z, (int)R,
+                         C, gamma, mean, rstd, scale, shift, training, ws, ws + C, dgamma, dbeta, dz, p_drop,
+                         seed_ptr, salt);
     EDA_CHECK_LAUNCH();
     return 0;
   }
