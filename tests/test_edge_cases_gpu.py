@@ -1,0 +1,71 @@
+"""Degenerate sizes and argument checks of the C entry points added for the training path
+(column sums, weight gradients, fused LayerNorm / BatchNorm variants), through the C ABI."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def test_empty_inputs_produce_zero_gradients():
+    from eda_amd import _lib
+    from eda_amd.nn_utils import colsum, wgrad
+    L = _lib.lib()
+    out = torch.full((288,), 3.0, device="cuda")
+    colsum(torch.empty(0, 288, device="cuda"), out=out)
+    assert (out == 0).all()
+    dW = torch.full((3, 288), 3.0, device="cuda")
+    db = torch.full((3,), 3.0, device="cuda")
+    cnt = torch.zeros(64, dtype=torch.int32, device="cuda")
+    rc = L.eda_wcolsum_f32(None, 0, 288, 288, None, 3, 3, dW.data_ptr(), db.data_ptr(), None, 0, cnt.data_ptr(), _stream())
+    assert rc == 0 and (dW == 0).all() and (db == 0).all()
+    dW2 = torch.full((288, 288), 3.0, device="cuda")
+    db2 = torch.full((288,), 3.0, device="cuda")
+    rc = L.eda_wgrad_f32(None, 288, None, 288, 0, 288, 288, dW2.data_ptr(), db2.data_ptr(), None, 0, _stream())
+    assert rc == 0 and (dW2 == 0).all() and (db2 == 0).all()
+    assert L.eda_wgrad_grouped_f32(None, 0, None, None, _stream()) == 0
+    assert L.eda_ln_reduce_grouped_f32(None, 0, 288, _stream()) == 0
+    # python-level: zero-row linear goes through the stock path and still yields zero gradients
+    dWz, dbz = wgrad(torch.empty(0, 288, device="cuda"), torch.empty(0, 288, device="cuda"))
+    assert dWz.abs().sum().item() == 0 and dbz.abs().sum().item() == 0
+
+
+def test_argument_checks_report_errors():
+    from eda_amd import _lib
+    L = _lib.lib()
+    x = torch.zeros(64, 290, device="cuda")
+    out = torch.zeros(4, 290, device="cuda")
+    cnt = torch.zeros(64, dtype=torch.int32, device="cuda")
+    # C not a multiple of 4 is refused by the weighted column sums
+    rc = L.eda_wcolsum_f32(x.data_ptr(), 64, 290, 290, x.data_ptr(), 290, 2, out.data_ptr(), None, None, 0,
+                           cnt.data_ptr(), _stream())
+    assert rc != 0
+    with pytest.raises(RuntimeError):
+        _lib.check(rc, "eda_wcolsum_f32")
+    # more than 4 weight columns
+    rc = L.eda_wcolsum_f32(x.data_ptr(), 64, 288, 290, x.data_ptr(), 290, 5, out.data_ptr(), None, None, 0,
+                           cnt.data_ptr(), _stream())
+    assert rc != 0
+    # wgrad: M not a multiple of 4
+    rc = L.eda_wgrad_f32(x.data_ptr(), 290, x.data_ptr(), 290, 64, 6, 288, out.data_ptr(), None, None, 0, _stream())
+    assert rc != 0
+    # colsum: workspace too small for a split reduction
+    big = torch.zeros(100000, 64, device="cuda")
+    o = torch.zeros(64, device="cuda")
+    rc = L.eda_colsum_f32(big.data_ptr(), 100000, 64, 64, o.data_ptr(), None, 0, cnt.data_ptr(), _stream())
+    assert rc != 0
+
+
+def test_fused_ln_zero_rows():
+    from eda_amd.fused_ln import add_dropout_layer_norm
+    norm = torch.nn.LayerNorm(288).cuda()
+    bias = torch.zeros(288, device="cuda", requires_grad=True)
+    x = torch.empty(0, 288, device="cuda", requires_grad=True)
+    y = torch.empty(0, 288, device="cuda", requires_grad=True)
+    out = add_dropout_layer_norm(x, y, norm, 0.1, True, 3, y_bias=bias)
+    assert out.shape == (0, 288)
+    out.sum().backward()
+    assert norm.weight.grad.abs().sum().item() == 0 and bias.grad.abs().sum().item() == 0
