@@ -212,6 +212,10 @@ def main():
     ap.add_argument("--no-butd", action="store_true")
     ap.add_argument("--blas", choices=["default", "rocblas", "hipblaslt"], default="default",
                     help="torch.backends.cuda.preferred_blas_library for the library GEMMs")
+    ap.add_argument("--gemm-tuning", choices=["shipped", "online", "record", "off"], default="online",
+                    help="library-GEMM selection through TunableOp (eda_amd/gemm_tuning.py): shipped = the "
+                         "results in eda_amd/tuned only; online = those + tune unseen shapes during warm-up; "
+                         "record = tune everything and write gpurun_out/tunableop_<ordinal>.csv; off = library default")
     ap.add_argument("--defer-wgrad", type=int, default=1,
                     help="1: queue the pointwise layers' weight gradients during the backward and compute them "
                          "in one grouped kernel (eda_amd/wgrad_queue.py); 0: compute each where autograd reaches it")
@@ -249,6 +253,14 @@ def main():
     from eda_amd.parallel import FlatParams, reference_lr_groups
     if args.blas != "default":
         torch.backends.cuda.preferred_blas_library("cublas" if args.blas == "rocblas" else "cublaslt")
+    tuning_file, shipped_ok = None, False
+    if args.gemm_tuning != "off":
+        from eda_amd import gemm_tuning
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        tuning_file, shipped_ok = gemm_tuning.enable(
+            online=args.gemm_tuning in ("online", "record"),
+            scratch=os.path.join(ROOT, "gpurun_out", "tunableop_.csv"),
+            use_shipped=args.gemm_tuning != "record")
 
     torch.manual_seed(0)                       # same init on every rank (DDP broadcast equivalent)
     model = BeaUTyDETR(num_queries=args.queries, butd=not args.no_butd).to(device).train()
@@ -442,7 +454,10 @@ def main():
                        "launch": ("eager" if not args.graph else "hipGraph replay of the whole step" if world == 1
                                   and not args.split_graphs else
                                   "two hipGraphs (fwd+bwd | clip+AdamW) with the RCCL all-reduce between them"),
-                       "text_encoder": "RoBERTa-base random-init frozen"},
+                       "text_encoder": "RoBERTa-base random-init frozen",
+                       "library_gemm_selection": ("TunableOp (%s; shipped results %s)" % (
+                           args.gemm_tuning, "loaded" if shipped_ok else "not used"))
+                       if args.gemm_tuning != "off" else "library default"},
             "roofline": roofline,
             "roofline_hbm": roofline_hbm,
             "roofline_mfma": roofline_mfma,

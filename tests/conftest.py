@@ -11,6 +11,13 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("EDA_TUNED_GEMMS") == "1":
+        # tests/test_tuned_gemms_gpu.py re-runs the model parity tests in a child process with the
+        # TunableOp-selected library GEMMs that bench.py uses (eda_amd/gemm_tuning.py)
+        import torch
+        if torch.cuda.is_available():
+            from eda_amd import gemm_tuning
+            gemm_tuning.enable(online=False)
 
 
 def pytest_collection_modifyitems(config, items):
