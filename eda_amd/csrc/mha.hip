@@ -277,28 +277,6 @@ __global__ __launch_bounds__(NW * 64) void mha_fwd_kernel(MhaArgs a) {
   }
 }
 
-// ===================================================== backward: delta =======
-// delta[b,h,q] = sum_d dO[b,q,h*36+d] * O[b,q,h*36+d]
-__global__ __launch_bounds__(256) void mha_delta_kernel(const float *__restrict__ o,
-                                                        const float *__restrict__ dout, long o_sb,
-                                                        long o_sl, long do_sb, long do_sl, int B,
-                                                        int H, int Lq, float *__restrict__ delta) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;     // over B*H*Lq
-  if (i >= (long)B * H * Lq) return;
-  const int q = (int)(i % Lq);
-  const int bh = (int)(i / Lq);
-  const int b = bh / H, h = bh - b * H;
-  const float4 *po = reinterpret_cast<const float4 *>(o + (long)b * o_sb + (long)q * o_sl + h * HD);
-  const float4 *pd = reinterpret_cast<const float4 *>(dout + (long)b * do_sb + (long)q * do_sl + h * HD);
-  float s = 0.f;
-#pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const float4 x = po[t], y = pd[t];
-    s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
-  }
-  delta[i] = s;
-}
-
 // ======================================================== backward: dQ =======
 // lane owns query (l&15); streams K/V tiles.
 //   S^T = K Q^T, P^T = exp(S^T - lse);  dP^T = V dO^T;  dS^T = P^T o (dP^T_eff - delta)
