@@ -260,6 +260,16 @@ int eda_wcolsum_f32(const float *x, long R, int C, long ld, const float *w, long
                     float *out, float *wsum, void *ws, size_t ws_bytes, unsigned *counters,
                     void *stream);
 
+/* ---- Hungarian matching on the device -----------------------
+ * Replaces `scipy.optimize.linear_sum_assignment(C[b])` per scene in HungarianMatcher.forward
+ * (models/losses.py:319-329): cost is (B, Q, G) with element strides sb, sq, st; the first
+ * ntargets[b] target columns of scene b are real.  assign (B, G) int32: assign[b][t] = the query
+ * matched to target t (distinct per scene, minimum total cost), -1 for t >= ntargets[b].
+ * Q <= 1024, G <= 256.  The optimum is unique unless costs tie (then any optimum may differ from
+ * scipy's).                                                                           */
+int eda_lsa_f32(const float *cost, long sb, long sq, long st, int B, int Q, int G,
+                const int *ntargets, int *assign, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
