@@ -100,6 +100,14 @@ def synthetic_loss(end_points):
     return loss
 
 
+def make_targets(rank, per_gpu, device, inputs):
+    """Synthetic ground truth for the real training loss (eda_amd/losses.py), resident on the device."""
+    from eda_amd import synthetic
+    t = synthetic.grounding_targets(rank, per_gpu, inputs["point_clouds"][..., :3].cpu().numpy(),
+                                    inputs["tokenized"]["attention_mask"].cpu().numpy())
+    return {k: torch.from_numpy(v).to(device) for k, v in t.items()}
+
+
 def make_inputs(rank, per_gpu, device, n_points, max_len):
     from eda_amd import synthetic
     seeds = [rank * per_gpu + i for i in range(per_gpu)]
@@ -212,6 +220,9 @@ def main():
     ap.add_argument("--no-butd", action="store_true")
     ap.add_argument("--blas", choices=["default", "rocblas", "hipblaslt"], default="default",
                     help="torch.backends.cuda.preferred_blas_library for the library GEMMs")
+    ap.add_argument("--loss", choices=["synthetic", "hungarian"], default="synthetic",
+                    help="synthetic: the sync-free scalar of SURVEY 8d (the headline metric); hungarian: the "
+                         "reference's training loss with the matching solved on the device (eda_amd/losses.py)")
     ap.add_argument("--gemm-tuning", choices=["shipped", "online", "record", "off"], default="online",
                     help="library-GEMM selection through TunableOp (eda_amd/gemm_tuning.py): shipped = the "
                          "results in eda_amd/tuned only; online = those + tune unseen shapes during warm-up; "
@@ -274,9 +285,26 @@ def main():
 
     from eda_amd import attention
 
+    if args.loss == "hungarian":
+        from eda_amd import losses as L
+        targets = make_targets(rank, args.per_gpu, device, inputs)
+        parts = os.environ.get("EDA_LOSS_PARTS", "boxes,labels,contrastive_align,qp").split(",")   # (debug switch)
+        criterion = L.SetCriterion(L.HungarianMatcher(1, 0, 2, True),
+                                   losses=[x for x in ["boxes", "labels", "contrastive_align"] if x in parts],
+                                   eos_coef=0.1, temperature=0.07)            # main_utils.py:264-271
+
+        def loss_fn(end_points):
+            end_points.update(targets)
+            end_points["language_dataset"] = ["scanrefer"] * args.per_gpu
+            if "qp" not in parts:
+                end_points.pop("seeds_obj_cls_logits")
+            return L.compute_hungarian_loss(end_points, 6, criterion, query_points_obj_topk=4)[0]
+    else:
+        loss_fn = synthetic_loss
+
     def fwd_bwd():
         attention.advance_dropout_state(device)      # new attention-dropout masks every step
-        loss = synthetic_loss(model(inputs))
+        loss = loss_fn(model(inputs))
         if args.defer_wgrad:
             with flat.deferred_wgrad():              # weight gradients: one grouped kernel after the backward
                 loss.backward()
@@ -447,7 +475,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BeaUTyDETR train step (fwd+bwd+clip+AdamW), butd=%s" % (not args.no_butd),
+            "config": {"workload": "BeaUTyDETR train step (fwd+bwd+clip+AdamW), butd=%s, loss=%s" % (
+                           not args.no_butd, args.loss),
                        "scenes_per_gpu": args.per_gpu, "global_batch": args.per_gpu * world,
                        "points": args.points, "queries": args.queries, "tokens": args.tokens,
                        "parallelism": f"dp{world}", "batchnorm": "per-GPU statistics",

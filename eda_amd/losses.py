@@ -16,6 +16,9 @@ different organisation:
   live inside the captured training step.  The unused auxiliary matching is not computed.
 * the three losses are written against that padded assignment (gather / scatter with masks
   instead of ``tensor[src_idx] = ...`` on concatenated lists).
+* no ``torch.zeros`` / ``zeros_like`` / ``one_hot`` on the training path: they are memset nodes in
+  a captured HIP graph, which ROCm 7.2 does not order reliably against the kernels around them
+  (DESIGN.md); masks are built from comparisons and fill kernels instead.
 
 ``HungarianMatcher.forward(outputs, targets)`` keeps the reference's list-of-dicts signature and
 result format for drop-in use and for the parity tests.
@@ -85,17 +88,17 @@ def compute_points_obj_cls_loss_hard_topk(end_points, topk):
     B, K, G = centre.shape[0], seed_xyz.shape[1], centre.shape[1]
     inst = torch.gather(end_points["point_instance_label"], 1, seed_inds)            # (B,K), <0 = background
     owner = torch.where(inst < 0, torch.full_like(inst, G - 1), inst)
-    own = F.one_hot(owner, G).to(seed_xyz.dtype)                                     # (B,K,G)
+    own = (owner[..., None] == torch.arange(G, device=owner.device)).to(seed_xyz.dtype)   # one-hot (B,K,G)
     d = (seed_xyz[:, :, None, :] - centre[:, None, :, :]) / (size[:, None, :, :] + 1e-6)
     dist_ = torch.sqrt((d ** 2).sum(-1) + 1e-6)
     dist_ = (dist_ * own + 100 * (1 - own)).transpose(1, 2).contiguous()             # (B,G,K)
     near = torch.topk(dist_, topk, largest=False)[1]                                 # (B,G,topk)
     m = mask[:, :, None]
     near = (near * m + (m - 1)).long().view(B, -1)            # padded slots -> -1 == the extra column K
-    label = torch.zeros((B, K + 1), dtype=torch.long, device=seed_xyz.device)
+    label = torch.full((B, K + 1), 0, dtype=torch.long, device=seed_xyz.device)      # (fill kernel, see module doc)
     label.scatter_(1, torch.where(near < 0, torch.full_like(near, K), near), 1)
     label = label[:, :K]
-    label = torch.where(inst < 0, torch.zeros_like(label), label)
+    label = label * (inst >= 0).to(label.dtype)
     w = torch.full((B, K), 1.0 / max(K, 1), dtype=logits.dtype, device=logits.device)   # all K seeds count
     loss = SigmoidFocalClassificationLoss()(logits.reshape(B, K, 1), label.unsqueeze(-1).to(logits.dtype), w)
     return loss.sum() / B
@@ -201,6 +204,14 @@ def _per_query(tq, matched, table):
     return torch.gather(table, 1, idx) * matched[..., None].to(table.dtype)
 
 
+def count_boxes(ntargets):
+    """Number of real target boxes of the (global) batch as a float tensor (losses.py:630-636)."""
+    num_boxes = ntargets.sum().to(torch.float32).reshape(1)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(num_boxes)
+    return num_boxes
+
+
 class SetCriterion(nn.Module):
     """Position-aligned cross entropy, box L1 + GIoU and semantic-alignment contrastive losses
     (losses.py:339-647) on padded targets."""
@@ -209,7 +220,9 @@ class SetCriterion(nn.Module):
         super().__init__()
         self.matcher, self.losses, self.eos_coef, self.temperature = matcher, losses, eos_coef, temperature
 
-    # -- the three losses; tq (B,Q) = matched target slot or -1, assign (B,G), valid (B,G) -----
+    # -- the three losses; tq (B,Q) = matched target slot or -1, assign (B,G), valid (B,G).
+    #    Each returns PER-SCENE sums (B,) already divided by num_boxes: compute_hungarian_loss
+    #    stacks all prediction heads into the batch dimension and splits the result per head. -----
     def loss_pos_align(self, outputs, tgt, tq, assign, valid, num_boxes):
         logp = outputs["pred_logits"].log_softmax(-1)
         C = logp.shape[-1]
@@ -221,23 +234,22 @@ class SetCriterion(nn.Module):
         weight_pos = (tgt["positive_map"] * w[0] + tgt["modify_positive_map"] * w[1]
                       + tgt["pron_positive_map"] * w[2] + tgt["rel_positive_map"] * w[3])[..., :C]
         sim = _per_query(tq, matched, weight_pos)
-        no_obj = torch.zeros_like(sim)
-        no_obj[..., -1] = 1
+        no_obj = (torch.arange(C, device=sim.device) == C - 1).to(sim.dtype)          # one-hot on "no object"
         sim = torch.where(matched[..., None], sim, no_obj)
         ce = (torch.log(sim + 1e-6) * sim - logp * sim).sum(-1)
-        ce = ce * torch.where(matched, torch.ones_like(ce), torch.full_like(ce, self.eos_coef))
-        return {"loss_ce": ce.sum() / num_boxes}
+        ce = ce * (matched.to(ce.dtype) * (1 - self.eos_coef) + self.eos_coef)
+        return {"loss_ce": ce.sum(1) / num_boxes}
 
     def loss_boxes(self, outputs, tgt, tq, assign, valid, num_boxes):
         idx = assign.clamp(min=0).long()[..., None].expand(-1, -1, 6)
         src = torch.gather(outputs["pred_boxes"], 1, idx)
-        ref_box = torch.cat([src.new_zeros(3), src.new_ones(3)])
+        ref_box = (torch.arange(6, device=src.device) >= 3).to(src.dtype)             # (0,0,0,1,1,1)
         src = torch.where(valid[..., None], src, ref_box)             # padded slots: harmless unit boxes
         tb = torch.where(valid[..., None], tgt["boxes"], ref_box)
         l1 = (src[..., :3] - tb[..., :3]).abs() + 0.2 * (src[..., 3:] - tb[..., 3:]).abs()
         giou = 1 - _giou3d(box_cxcyczwhd_to_xyzxyz(src), box_cxcyczwhd_to_xyzxyz(tb))
         v = valid.to(l1.dtype)
-        return {"loss_bbox": (l1 * v[..., None]).sum() / num_boxes, "loss_giou": (giou * v).sum() / num_boxes}
+        return {"loss_bbox": (l1 * v[..., None]).sum((1, 2)) / num_boxes, "loss_giou": (giou * v).sum(1) / num_boxes}
 
     def loss_sem_align(self, outputs, tgt, tq, assign, valid, num_boxes):
         logits = torch.matmul(outputs["proj_queries"], outputs["proj_tokens"].transpose(-1, -2)) / self.temperature
@@ -255,19 +267,19 @@ class SetCriterion(nn.Module):
         other = _per_query(tq, matched, tgt["other_entity_map"][..., :L])
         rel = _per_query(tq, matched, tgt["rel_positive_map"][..., :L])
         modi_b, pron_b, rel_b = modi > 0, pron > 0, rel > 0
-        qmask = torch.where(matched, torch.ones_like(logits[..., 0]), torch.full_like(logits[..., 0], self.eos_coef))
-        zero = torch.zeros_like(logits)
-        pos_l = torch.where(pmap, -logits, zero)
-        modi_l, pron_l, rel_l = (torch.where(m, -logits, zero) for m in (modi_b, pron_b, rel_b))
+        qmask = matched.to(logits.dtype) * (1 - self.eos_coef) + self.eos_coef
+        neg_logits = -logits
+        pos_l = neg_logits * pmap.to(logits.dtype)
+        modi_l, pron_l, rel_l = (neg_logits * m.to(logits.dtype) for m in (modi_b, pron_b, rel_b))
         # object -> text
-        neg = (logits + torch.where(other > 0, logits, zero)).logsumexp(2)
+        neg = (logits + logits * (other > 0).to(logits.dtype)).logsumexp(2)
         b2t = (pos_l.sum(2) / (pmap.sum(2) + 1e-6) + 0.2 * modi_l.sum(2) / (modi_b.sum(2) + 1e-6)
                + 0.2 * pron_l.sum(2) / (pron_b.sum(2) + 1e-6) + 0.1 * rel_l.sum(2) / (rel_b.sum(2) + 1e-6) + neg)
-        b2t = (torch.where(pmap.any(2), b2t, torch.zeros_like(b2t)) * qmask).sum()
+        b2t = (b2t * pmap.any(2).to(b2t.dtype) * qmask).sum(1)
         # text -> object; the token weights are overwritten in this order (losses.py:550-556)
         tmask = torch.full((B, L), self.eos_coef, dtype=logits.dtype, device=logits.device)
-        tmask = torch.where(pos_tok == last[:, None], torch.ones_like(tmask), tmask)
-        tmask = torch.where(pmap.any(1), torch.ones_like(tmask), tmask)
+        tmask = torch.where(pos_tok == last[:, None], torch.full_like(tmask, 1.0), tmask)
+        tmask = torch.where(pmap.any(1), torch.full_like(tmask, 1.0), tmask)
         tmask = torch.where(modi_b.any(1), torch.full_like(tmask, 0.2), tmask)
         tmask = torch.where(pron_b.any(1), torch.full_like(tmask, 0.2), tmask)
         tmask = torch.where(rel_b.any(1), torch.full_like(tmask, 0.1), tmask)
@@ -276,14 +288,16 @@ class SetCriterion(nn.Module):
         pos_t = pos_l.sum(1) + modi_l.sum(1) + pron_l.sum(1) + rel_l.sum(1)
         nb = pmap.sum(1) + modi.sum(1) + pron.sum(1) + rel.sum(1) + 1e-6     # counts + map VALUES, as the reference
         t2b = -torch.log(nb + 1e-6) / nb + pos_t / nb + logits.logsumexp(1)
-        t2b = (torch.where(with_pos, t2b, torch.zeros_like(t2b)) * tmask).sum()
+        t2b = (t2b * with_pos.to(t2b.dtype) * tmask).sum(1)
         return {"loss_sem_align": (b2t + t2b) / 2 / num_boxes}
 
     _LOSSES = {"boxes": "loss_boxes", "labels": "loss_pos_align", "contrastive_align": "loss_sem_align"}
 
-    def forward_padded(self, outputs, tgt, ntargets, valid, assign=None):
+    def forward_padded(self, outputs, tgt, ntargets, valid, assign=None, num_boxes=None, per_scene=False):
         """tgt: compacted padded targets {"boxes" (B,G,6), "labels" (B,G), five "*_map" (B,G,256)};
-        ntargets (B,) int32, valid (B,G) bool.  assign (B,G): given, or solved on the device."""
+        ntargets (B,) int32, valid (B,G) bool.  assign (B,G): given, or solved on the device.
+        num_boxes: normaliser (default: sum of ntargets, all-reduced over ranks like the reference);
+        per_scene: return (B,) vectors instead of their sums."""
         if assign is None:
             assign = self.matcher.match_padded(outputs["pred_logits"].detach(), outputs["pred_boxes"].detach(),
                                                tgt["boxes"], ntargets, tgt["positive_map"], tgt["labels"])
@@ -293,13 +307,14 @@ class SetCriterion(nn.Module):
         slot = torch.arange(G, device=assign.device)[None, :].expand(B, -1)
         a = torch.where(valid, assign.long(), torch.full_like(assign.long(), Q))      # padded -> dummy column Q
         tq = torch.full((B, Q + 1), -1, dtype=torch.long, device=assign.device).scatter_(1, a, slot)[:, :Q]
-        num_boxes = ntargets.sum().to(torch.float32).reshape(1)
-        if dist.is_available() and dist.is_initialized():
-            dist.all_reduce(num_boxes)
+        if num_boxes is None:
+            num_boxes = count_boxes(ntargets)
         losses = {}
         for name in self.losses:
             assert name in self._LOSSES, f"do you really want to compute {name} loss?"
             losses.update(getattr(self, self._LOSSES[name])(outputs, tgt, tq, assign, valid, num_boxes))
+        if not per_scene:
+            losses = {k: v.sum() for k, v in losses.items()}
         return losses, assign
 
     def forward(self, outputs, targets):
@@ -325,28 +340,39 @@ class SetCriterion(nn.Module):
 
 def compute_hungarian_loss(end_points, num_decoder_layers, set_criterion, query_points_obj_topk=5, assign=None):
     """Total loss over the proposal head and the decoder heads (losses.py:650-738); writes the
-    same keys into end_points.  `assign`: optional {prefix: (B,G) assignment} (tests on CPU)."""
+    same keys into end_points.  The reference runs matcher + criterion once per head; here the P
+    heads are stacked into the batch dimension -- one (P*B, Q, G) cost, ONE assignment launch,
+    one pass of each loss -- and the per-head values are read off the per-scene sums.
+    `assign`: optional {prefix: (B,G) assignment} (tests on CPU)."""
     prefixes = ["proposal_", "last_"] + [f"{i}head_" for i in range(num_decoder_layers - 1)]
+    P = len(prefixes)
     gt_box = torch.cat([end_points["center_label"][:, :, 0:3], end_points["size_gts"]], dim=-1)
     keys = ["positive_map", "modify_positive_map", "pron_positive_map", "other_entity_map", "rel_positive_map"]
     nt, valid, packed = compact_targets(end_points["box_label_mask"], gt_box, end_points["sem_cls_label"],
                                         *[end_points[k] for k in keys])
-    tgt = {"boxes": packed[0], "labels": packed[1]}
-    tgt.update({k: packed[2 + i] for i, k in enumerate(keys)})
+    B = nt.shape[0]
+    rep = lambda t: t.unsqueeze(0).expand(P, *t.shape).reshape(P * t.shape[0], *t.shape[1:])    # heads x scenes
+    tgt = {"boxes": rep(packed[0]), "labels": rep(packed[1])}
+    tgt.update({k: rep(packed[2 + i]) for i, k in enumerate(keys)})
+    stack = lambda name: torch.cat([end_points[f"{p}{name}"] for p in prefixes], dim=0)
+    out = {"pred_logits": stack("sem_cls_scores"),
+           "pred_boxes": torch.cat([stack("center"), stack("pred_size")], dim=-1),
+           "language_dataset": end_points["language_dataset"]}
+    if "proj_tokens" in end_points:
+        out["proj_tokens"] = rep(end_points["proj_tokens"])
+        out["proj_queries"] = stack("proj_queries")
+        out["tokenized"] = {"attention_mask": rep(end_points["tokenized"]["attention_mask"])}
+    a_in = None if assign is None else torch.cat([assign[p] for p in prefixes], dim=0)
+    losses, a = set_criterion.forward_padded(out, tgt, rep(nt), rep(valid), a_in, num_boxes=count_boxes(nt),
+                                             per_scene=True)
     tot = {"loss_ce": 0, "loss_bbox": 0, "loss_giou": 0, "loss_sem_align": 0}
-    for prefix in prefixes:
-        out = {"pred_logits": end_points[f"{prefix}sem_cls_scores"],
-               "pred_boxes": torch.cat([end_points[f"{prefix}center"], end_points[f"{prefix}pred_size"]], dim=-1),
-               "language_dataset": end_points["language_dataset"]}
-        if "proj_tokens" in end_points:
-            out["proj_tokens"] = end_points["proj_tokens"]
-            out["proj_queries"] = end_points[f"{prefix}proj_queries"]
-            out["tokenized"] = end_points["tokenized"]
-        losses, a = set_criterion.forward_padded(out, tgt, nt, valid, None if assign is None else assign[prefix])
-        end_points[f"{prefix}assign"] = a
-        for k, v in losses.items():
-            end_points[f"{prefix}_{k}"] = v
-            tot[k] = tot[k] + v
+    for k, v in losses.items():
+        per_head = v.reshape(P, B).sum(1)
+        tot[k] = per_head.sum()
+        for i, prefix in enumerate(prefixes):
+            end_points[f"{prefix}_{k}"] = per_head[i]
+    for i, prefix in enumerate(prefixes):
+        end_points[f"{prefix}assign"] = a[i * B:(i + 1) * B]
     qp = (compute_points_obj_cls_loss_hard_topk(end_points, query_points_obj_topk)
           if "seeds_obj_cls_logits" in end_points else 0.0)
     weight = 0.5 if end_points["language_dataset"][0] == "scanrefer" else 1

@@ -98,3 +98,41 @@ def detected_boxes(seed, batch_size, max_boxes=132, n_classes=485):
         mask[i, :k] = True
         cls[i, :k] = rng.integers(0, n_classes, k)
     return boxes, mask, cls
+
+
+def grounding_targets(seed, batch_size, points_xyz, attention_mask, max_boxes=132, n_tok_classes=256):
+    """Ground truth in the layout Joint3DDataset hands to the loss (src/joint_det_dataset.py ->
+    models/losses.py:650-680): 1-3 real boxes per scene in the first slots of 132, the five token
+    maps (rows sum to 1 over the tokens they name), and the per-point instance labels (-1 =
+    background) derived from which target box contains the point.
+    points_xyz (B,N,3) float array, attention_mask (B,L) 0/1 array (1 = real token)."""
+    rng = np.random.default_rng(30_000 + seed)
+    B, N = points_xyz.shape[:2]
+    out = {
+        "box_label_mask": np.zeros((B, max_boxes), np.float32),
+        "center_label": np.zeros((B, max_boxes, 3), np.float32),
+        "size_gts": np.ones((B, max_boxes, 3), np.float32),
+        "sem_cls_label": np.zeros((B, max_boxes), np.int64),
+        "point_instance_label": np.full((B, N), -1, np.int64),
+    }
+    maps = ["positive_map", "modify_positive_map", "pron_positive_map", "other_entity_map", "rel_positive_map"]
+    for k in maps:
+        out[k] = np.zeros((B, max_boxes, n_tok_classes), np.float32)
+    for b in range(B):
+        n = int(rng.integers(1, 4))
+        ntok = int(attention_mask[b].sum())
+        out["box_label_mask"][b, :n] = 1
+        lo, hi = points_xyz[b].min(0), points_xyz[b].max(0)
+        for t in range(n):
+            c = rng.uniform(lo + 0.2 * (hi - lo), hi - 0.2 * (hi - lo))
+            s = rng.uniform(0.4, 1.6, 3)
+            out["center_label"][b, t] = c
+            out["size_gts"][b, t] = s
+            out["sem_cls_label"][b, t] = rng.integers(0, 18)
+            inside = np.all(np.abs(points_xyz[b] - c) <= 0.5 * s, axis=1)
+            out["point_instance_label"][b, inside] = t
+            for k, p_on in zip(maps, (1.0, 0.6, 0.3, 0.3, 0.5)):
+                if rng.uniform() < p_on:
+                    toks = rng.choice(np.arange(1, max(2, ntok - 1)), size=int(rng.integers(1, 4)), replace=False)
+                    out[k][b, t, toks] = 1.0 / len(toks)
+    return out

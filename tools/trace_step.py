@@ -24,9 +24,19 @@ def main():
     grads = FlatParams(model)
     opt = torch.optim.AdamW(list(grads.groups.values()), lr=1e-4, weight_decay=5e-4, fused=True)
     inputs = bench.make_inputs(0, 8, dev, 50000, 80)
+    loss_fn = bench.synthetic_loss
+    if os.environ.get("LOSS") == "hungarian":
+        from eda_amd import losses as L
+        targets = bench.make_targets(0, 8, dev, inputs)
+        crit = L.SetCriterion(L.HungarianMatcher(1, 0, 2, True), losses=["boxes", "labels", "contrastive_align"])
+
+        def loss_fn(ep):
+            ep.update(targets)
+            ep["language_dataset"] = ["scanrefer"] * 8
+            return L.compute_hungarian_loss(ep, 6, crit, query_points_obj_topk=4)[0]
 
     def step():
-        loss = bench.synthetic_loss(model(inputs))
+        loss = loss_fn(model(inputs))
         with grads.deferred_wgrad():
             loss.backward()
         grads.collect_grads()
