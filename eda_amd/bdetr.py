@@ -192,7 +192,8 @@ class BeaUTyDETR(nn.Module):
         vis, text_feats = self.cross_encoder(
             vis_feats=points_features.transpose(1, 2).contiguous(),
             pos_feats=self.pos_embed.rows(points_xyz),
-            padding_mask=torch.zeros(points_xyz.shape[:2], dtype=torch.bool, device=points_xyz.device),
+            # (torch.full = a fill kernel; torch.zeros would be a memset node in a captured graph)
+            padding_mask=torch.full(points_xyz.shape[:2], False, dtype=torch.bool, device=points_xyz.device),
             text_feats=text_feats, text_padding_mask=text_padding_mask, end_points=end_points,
             detected_feats=detected_feats, detected_mask=detected_mask)
         points_features = vis.transpose(1, 2).contiguous()       # (B, 288, 1024)

@@ -220,7 +220,7 @@ class BiDecoderLayer(nn.Module):
         if self.self_posembed is not None:
             pos = self.self_posembed.rows(query_pos)
         else:
-            pos = torch.zeros_like(query)
+            pos = torch.full_like(query, 0.0)
         qp = query + pos
         tr, sb = self.training, self._salt
         query = _attn_residual_norm(self.self_attn, query, qp, qp, query, padding_mask, self.norm1,

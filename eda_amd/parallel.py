@@ -115,7 +115,7 @@ class FlatParams:
             self._prefilled = False
             self._deferred_ptrs = set()
         elif len(have) != len(self.params):
-            self.flat_grad.zero_()
+            self.flat_grad.fill_(0.0)          # (a fill kernel rather than a memset node)
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
         for p in self.params:
