@@ -430,6 +430,12 @@ def main():
                             "tflops": round(flops / (ms * 1e-3) / 1e12, 2) if flops and ms > 0 else None})
         kernels.sort(key=lambda k: -k["ms"] * k["calls_per_step"])
         native_ms = sum(k["ms"] * k["calls_per_step"] for k in kernels)
+        # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
+        # WRITE_SIZE), measured offline for this build and shape: profiles/r01f_mha_pmc_traffic.md,
+        # profiles/r01i_bn_pmc_traffic.md.  None for shapes that were not profiled.
+        pmc_traffic = {("mha_bwd", (8, 8, 1024, 1024)): 242.8e6, ("mha_fwd", (8, 8, 1024, 1024)): 87.9e6,
+                       ("bn_relu_bwd", (1048576, 64, 1, 1)): 1311.0e6,      # profiles/r01i_bn_pmc_traffic.md
+                       ("bn_relu_fwd", (1048576, 64, 1, 1)): 786.0e6}
         # dominant HBM-priced kernel (FPS is latency-bound: reported as us/round below)
         # HBM-priced candidates: launches that move at least 32 MB (smaller ones are launch- or
         # latency-bound and are listed in `kernels` only); FPS is latency-bound and reported below.
@@ -439,14 +445,12 @@ def main():
         if dom:
             roofline_hbm = {"kernel": f"{dom['op']}{tuple(dom['dims'])}", "bound": "hbm",
                             "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(dom["gbs"] / HBM_PEAK_GBS, 5), "traffic": None,
+                            "frac": round(dom["gbs"] / HBM_PEAK_GBS, 5),
+                            "traffic": pmc_traffic.get((dom["op"], tuple(dom["dims"]))),
+                            "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE, bytes per launch, "
+                                              "profiles/r01i_bn_pmc_traffic.md",
                             "ms_per_launch": dom["ms"], "alg_bytes_per_launch": dom["alg_bytes"],
                             "ms_per_step": round(dom["ms"] * dom["calls_per_step"], 4)}
-        # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
-        # WRITE_SIZE), measured offline for this build and shape: profiles/r01f_mha_pmc_traffic.md
-        # and profiles/r01d_summary.md.  None for shapes that were not profiled.
-        pmc_traffic = {("mha_bwd", (8, 8, 1024, 1024)): 242.8e6, ("mha_fwd", (8, 8, 1024, 1024)): 87.9e6,
-                       ("bn_relu_bwd", (1048576, 64, 1, 1)): None}
         mf = [k for k in kernels if k["tflops"]]
         roofline_mfma = None
         if mf:
