@@ -93,7 +93,22 @@ __global__ __launch_bounds__(CL_THREADS) void bn_stats_kernel(const float *__res
 #pragma unroll
   for (int v = 0; v < VEC; ++v) { s[v] = 0.f; q[v] = 0.f; }
   if (trow < rpp) {
-    for (long r = r0 + trow; r < r1; r += rpp) {
+    long r = r0 + trow;
+    if (VEC == 4) {
+      // eight rows per iteration: eight independent 16-byte loads in flight per thread (one load
+      // per iteration ran at 2.9 TB/s; four at 3.6 TB/s)
+      for (; r + 7 * rpp < r1; r += 8 * rpp) {
+        float4 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4 *>(z + (r + (long)u * rpp) * C + tcol * VEC);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          s[0] += x[u].x; s[1] += x[u].y; s[2] += x[u].z; s[3] += x[u].w;
+          q[0] += x[u].x * x[u].x; q[1] += x[u].y * x[u].y; q[2] += x[u].z * x[u].z; q[3] += x[u].w * x[u].w;
+        }
+      }
+    }
+    for (; r < r1; r += rpp) {
       const float *p = z + r * C + tcol * VEC;
       if (VEC == 4) {
         const float4 x = *reinterpret_cast<const float4 *>(p);
@@ -351,7 +366,8 @@ __global__ __launch_bounds__(CL_THREADS) void bn_relu_bwd_stats_vec_kernel(
     for (int v = 0; v < 4; ++v) { sc[v] = scale[c0 + v]; sh[v] = shift[c0 + v]; mu[v] = mean[c0 + v]; rs[v] = rstd[c0 + v]; }
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
-    for (long r = r0 + trow; r < r1; r += rpp) {
+    long r = r0 + trow;
+    for (; r < r1; r += rpp) {
       const float4 x4 = *reinterpret_cast<const float4 *>(z + r * C + c0);
       const float4 d4 = *reinterpret_cast<const float4 *>(da + r * C + c0);
       const float x[4] = {x4.x, x4.y, x4.z, x4.w};
