@@ -206,28 +206,44 @@ __global__ __launch_bounds__(CL_THREADS) void bn_relu_apply_kernel(const float *
   }
 }
 
-// pooled[g, c] = max_k relu(Z[g*ns+k, c]*scale+shift); argmax[g, c] = first k attaining it
+// pooled[g, c] = max_k relu(Z[g*ns+k, c]*scale+shift); argmax[g, c] = first k attaining it.
+// Thread = four consecutive channels of one group (16-byte loads), four rows in flight.
 __global__ __launch_bounds__(CL_THREADS) void bn_relu_pool_kernel(const float *__restrict__ z,
                                                                   long G, int ns, int C,
                                                                   const float *__restrict__ scale,
                                                                   const float *__restrict__ shift,
                                                                   float *__restrict__ pooled,
                                                                   unsigned char *__restrict__ argmax) {
-  const long total = G * C;
+  const int c4n = C / 4;
+  const long total = G * c4n;
   for (long i = (long)blockIdx.x * CL_THREADS + threadIdx.x; i < total;
        i += (long)gridDim.x * CL_THREADS) {
-    const long g = i / C;
-    const int c = (int)(i - g * C);
-    const float sc = scale[c], sh = shift[c];
+    const long g = i / c4n;
+    const int c = (int)(i - g * c4n) * 4;
+    const float4 sc = *reinterpret_cast<const float4 *>(scale + c);
+    const float4 sh = *reinterpret_cast<const float4 *>(shift + c);
     const float *p = z + (g * ns) * C + c;
-    float best = -INFINITY;
-    int bi = 0;
-    for (int k = 0; k < ns; ++k) {
-      const float y = fmaxf(p[(long)k * C] * sc + sh, 0.f);
-      if (y > best) { best = y; bi = k; }
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bi[4] = {0, 0, 0, 0};
+    auto take = [&](const float4 &x, int k) {
+      const float y[4] = {fmaxf(x.x * sc.x + sh.x, 0.f), fmaxf(x.y * sc.y + sh.y, 0.f),
+                          fmaxf(x.z * sc.z + sh.z, 0.f), fmaxf(x.w * sc.w + sh.w, 0.f)};
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (y[v] > best[v]) { best[v] = y[v]; bi[v] = k; }
+    };
+    int k = 0;
+    for (; k + 3 < ns; k += 4) {
+      float4 x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const float4 *>(p + (long)(k + u) * C);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) take(x[u], k + u);
     }
-    pooled[i] = best;
-    argmax[i] = (unsigned char)bi;
+    for (; k < ns; ++k) take(*reinterpret_cast<const float4 *>(p + (long)k * C), k);
+    *reinterpret_cast<float4 *>(pooled + g * C + c) = make_float4(best[0], best[1], best[2], best[3]);
+    *reinterpret_cast<uchar4 *>(argmax + g * C + c) =
+        make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
   }
 }
 
@@ -712,7 +728,7 @@ extern "C" int eda_bn_relu_fwd_f32(const float *z, long R, int C, const float *g
   EDA_CHECK_LAUNCH();
   if (pool > 1) {
     EDA_CHECK_ARG(argmax, "argmax buffer required when pooling");
-    hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(grid_for(R / pool * C)), dim3(CL_THREADS), 0, stream,
+    hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(grid_for(R / pool * (C / 4))), dim3(CL_THREADS), 0, stream,
                        z, R / pool, pool, C, scale, shift, out, argmax);
   } else {
     hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(grid_for(R * C / 4)), dim3(CL_THREADS), 0, stream, z,
