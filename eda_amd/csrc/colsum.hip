@@ -67,12 +67,20 @@ __global__ __launch_bounds__(CS_THREADS) void colsum_kernel(const float *__restr
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k][tid];
-    if (nslab == 1) out[c0 + tid] = t;
-    else   // agent-scope (write-through) store: no L2 write-back fence needed to publish it
-      __hip_atomic_store(&partial[(long)slab * C + c0 + tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (nslab == 1) {
+      out[c0 + tid] = t;
+    } else {
+      // published with a RETURNING agent-scope exchange: the wave waits for the old value, i.e. for the
+      // write to have been performed at the memory side, before the block may take its ticket (a plain
+      // write-through store is only acknowledged by the local L2; a ticket overtaking fire-and-forget
+      // atomics was observed in the BN statistics kernel, see sa_cl.hip).  No L2 write-back fence needed.
+      const float old = __hip_atomic_exchange(&partial[(long)slab * C + c0 + tid], t, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" ::"v"(old));
+    }
   }
   if (nslab == 1) return;
-  // the barrier waits for those stores to complete (vmcnt(0)); then take a ticket.  (A
+  // the exchanges have returned, i.e. the partial row is in memory; then take a ticket.  (A
   // release FENCE at agent scope here costs a whole-L2 write-back per block: measured 3-4x
   // slower than the framework's two-pass reduction.)
   __syncthreads();
@@ -161,17 +169,26 @@ __global__ __launch_bounds__(CS_THREADS) void wcolsum_kernel(const float *__rest
       float t = 0.f;
 #pragma unroll
       for (int k = 0; k < 16; ++k) t += red[m][k][tid];
-      if (nslab == 1) out[(long)m * C + c0 + tid] = t;
-      else __hip_atomic_store(&partial[((long)slab * MW + m) * C + c0 + tid], t, __ATOMIC_RELAXED,
-                              __HIP_MEMORY_SCOPE_AGENT);
+      if (nslab == 1) {
+        out[(long)m * C + c0 + tid] = t;
+      } else {       // returning exchange: see colsum_kernel
+        const float old = __hip_atomic_exchange(&partial[((long)slab * MW + m) * C + c0 + tid], t, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(old));
+      }
     }
   }
   if (cg == 0 && tid < MW) {
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += wred[tid][k];
-    if (nslab == 1) { if (wsum) wsum[tid] = t; }
-    else __hip_atomic_store(&psum[(long)slab * MW + tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (nslab == 1) {
+      if (wsum) wsum[tid] = t;
+    } else {
+      const float old = __hip_atomic_exchange(&psum[(long)slab * MW + tid], t, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" ::"v"(old));
+    }
   }
   if (nslab == 1) return;
   __syncthreads();

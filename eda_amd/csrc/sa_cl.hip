@@ -78,12 +78,20 @@ __global__ __launch_bounds__(CL_THREADS) void group_concat_cl_grad_kernel(
 // Column sums of Z (R, C): every block owns a slab of rows, sums it in fp32
 // (<= a few hundred terms per partial), then merges into fp64 accumulators.
 // Thread t handles column (t % C4)*4.. +3 of rows (t / C4) + k * rows_per_pass.
+struct BnFinalize {          // what the last block of bn_stats_kernel needs to finish the statistics
+  const float *gamma, *beta;
+  float eps, momentum;
+  float *running_mean, *running_var, *mean_out, *rstd_out, *scale, *shift;
+  unsigned *ticket;
+};
+
 template <int VEC>
 __global__ __launch_bounds__(CL_THREADS) void bn_stats_kernel(const float *__restrict__ z, long R,
                                                               int C, long rows_per_block,
                                                               double *__restrict__ sum,
-                                                              double *__restrict__ sumsq) {
+                                                              double *__restrict__ sumsq, BnFinalize fin) {
   __shared__ float red[2][CL_THREADS * VEC];
+  __shared__ int is_last;
   const int cgroups = C / VEC;                       // threads per row
   const int rpp = CL_THREADS / cgroups;              // rows per pass (threads beyond rpp*cgroups idle)
   const int tcol = threadIdx.x % cgroups, trow = threadIdx.x / cgroups;
@@ -135,13 +143,48 @@ __global__ __launch_bounds__(CL_THREADS) void bn_stats_kernel(const float *__res
       a += (double)red[0][t * VEC + v];
       bq += (double)red[1][t * VEC + v];
     }
-    atomicAdd(sum + col, a);
-    atomicAdd(sumsq + col, bq);
+    // RETURNING atomics: the wave waits for the old values, i.e. for the read-modify-writes to have
+    // been performed at the memory side, before this block may take its ticket.  (With fire-and-forget
+    // atomics the ticket could overtake them: the last block then finalised incomplete sums -- observed
+    // as step-to-step noise in the loss.)
+    const double o1 = atomicAdd(sum + col, a);
+    const double o2 = atomicAdd(sumsq + col, bq);
+    asm volatile("" ::"v"(o1), "v"(o2));
   }
+  // The block that draws the last ticket turns the sums into mean / rstd / scale / shift and the
+  // running statistics (torch.nn.BatchNorm: biased variance normalises, unbiased variance is
+  // tracked) and leaves sums and ticket at ZERO for the next call: no zero-fill launch before and
+  // no finalize launch after this kernel.
+  __syncthreads();                           // this block's atomics have completed
+  if (threadIdx.x == 0)
+    is_last = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  __syncthreads();
+  if (!is_last) return;
+  for (int c = threadIdx.x; c < C; c += CL_THREADS) {
+    const double su = __hip_atomic_load(sum + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double sq = __hip_atomic_load(sumsq + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(sum + c, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(sumsq + c, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double mean = su / (double)R;
+    double var = sq / (double)R - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)fin.eps));
+    const float meanf = (float)mean;
+    fin.mean_out[c] = meanf;
+    fin.rstd_out[c] = rstd;
+    const float sc = fin.gamma[c] * rstd;
+    fin.scale[c] = sc;
+    fin.shift[c] = fin.beta[c] - meanf * sc;
+    if (fin.running_mean) {
+      const double unbiased = R > 1 ? var * (double)R / (double)(R - 1) : var;
+      fin.running_mean[c] = (1.f - fin.momentum) * fin.running_mean[c] + fin.momentum * meanf;
+      fin.running_var[c] = (1.f - fin.momentum) * fin.running_var[c] + fin.momentum * (float)unbiased;
+    }
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(fin.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// mean / rstd / fused scale-shift and the running-statistics update
-// (torch.nn.BatchNorm: biased variance normalises, unbiased variance is tracked).
+// (kept for reference / eval-mode callers that already hold the sums)
 __global__ void bn_finalize_kernel(const double *__restrict__ sum, const double *__restrict__ sumsq,
                                    long R, int C, const float *__restrict__ gamma,
                                    const float *__restrict__ beta, float eps, float momentum,
@@ -575,8 +618,7 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_bwd_kernel(
     const int c = blockIdx.x * 4 * CQ + threadIdx.x;
     double t1 = 0.0, t2 = 0.0;
     for (int w = 0; w < SM_WAVES; ++w) { t1 += (double)red[v][jq][w]; t2 += (double)red[4 + v][jq][w]; }
-    s1_out[c] = t1; s2_out[c] = t2;
-    dbeta[c] = (float)t1; dgamma[c] = (float)t2;
+    dbeta[c] = (float)t1; dgamma[c] = (float)t2;   // (the shared workspace stays untouched: it must remain zero)
     const float invR = 1.f / (float)R;
     const float gr = gamma[c] * rstd[c];
     ka_l[threadIdx.x] = gr;
@@ -707,19 +749,16 @@ extern "C" int eda_bn_relu_fwd_f32(const float *z, long R, int C, const float *g
   }
   if (training) {
     EDA_CHECK_ARG(ws, "workspace required");
-    { const int zrc__ = eda_zero_async(ws, sizeof(double) * 2 * C, stream); if (zrc__) return zrc__; }
-    const int cgroups = C / 4;
+    // ws (2*C + 1 doubles) is ZERO on entry and is left zero (see eda_hip.h): the statistics
+    // kernel's last block finalises and cleans up
     int nblocks = 2048;
     long rpb = (R + nblocks - 1) / nblocks;
     if (rpb < 64) rpb = 64;
     nblocks = (int)((R + rpb - 1) / rpb);
-    (void)cgroups;   // C/4 <= 256 threads per row pass (C <= 1024 checked above); idle threads allowed
+    BnFinalize fin = {gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift,
+                      reinterpret_cast<unsigned *>(ws + 2 * C)};
     hipLaunchKernelGGL(bn_stats_kernel<4>, dim3(nblocks), dim3(CL_THREADS), 0, stream, z, R, C, rpb, ws,
-                       ws + C);
-    EDA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, ws, ws + C, R,
-                       C, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale,
-                       shift);
+                       ws + C, fin);
   } else {
     EDA_CHECK_ARG(running_mean && running_var, "eval mode needs running statistics");
     hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, stream,
@@ -777,6 +816,8 @@ extern "C" int eda_bn_relu_bwd_f32(const float *dout, const unsigned char *argma
     EDA_CHECK_LAUNCH();
     return 0;
   }
+  // (backward: ws is zeroed here per call.  A self-cleaning scheme like the forward's was measured
+  // SLOWER: the apply kernel has ~8000 workgroups and their tickets serialise on one address, +16 us)
   { const int zrc__ = eda_zero_async(ws, sizeof(double) * 2 * C, stream); if (zrc__) return zrc__; }
   int nblocks = 1024;
   long rpb = (R + nblocks - 1) / nblocks;

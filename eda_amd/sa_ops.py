@@ -95,6 +95,22 @@ class PointwiseLinearCL(Function):
         return da, dw
 
 
+_bn_ws = {}
+
+
+def _bn_workspace(dev):
+    """The per-device scratch of the BN FORWARD statistics kernel (2*1024 + 1 doubles: column sums + a
+    ticket).  The kernel requires it ZERO on entry and leaves it zero (its last block finalises and
+    cleans up), so it is allocated and zeroed once; all BN launches of a device must be ordered on one
+    stream."""
+    dev = torch.device(dev)
+    if dev not in _bn_ws:
+        # zeroed by a fill KERNEL on the current stream (torch.zeros is a memset: on ROCm 7.2 the
+        # first BN launch right after it was observed to see stale data)
+        _bn_ws[dev] = torch.full((2 * 1024 + 2,), 0.0, dtype=torch.float64, device=dev)
+    return _bn_ws[dev]
+
+
 class BNReLUCL(Function):
     """relu(batch_norm(z)) on rows z (R,C), optionally max-pooled over `pool` consecutive rows."""
 
@@ -108,7 +124,7 @@ class BNReLUCL(Function):
         R, C = z.shape
         dev = z.device
         stats = torch.empty((4, C), dtype=torch.float32, device=dev)     # mean, rstd, scale, shift
-        ws = torch.empty((2 * C,), dtype=torch.float64, device=dev)
+        ws = _bn_workspace(dev)
         if pool > 1:
             out = torch.empty((R // pool, C), dtype=torch.float32, device=dev)
             argmax = torch.empty((R // pool, C), dtype=torch.uint8, device=dev)
@@ -142,7 +158,7 @@ class BNReLUCL(Function):
             seed = dropout_state(z.device)
         dout = dout.contiguous()
         dz = torch.empty_like(z)
-        ws = torch.empty((2 * C,), dtype=torch.float64, device=z.device)
+        ws = torch.empty((2 * C,), dtype=torch.float64, device=z.device)     # zeroed by the library per call
         dgb = torch.empty((2, C), dtype=torch.float32, device=z.device)
         with torch.cuda.device(z.device), _timed('bn_relu_bwd', (R, C, pool, int(training))):
             rc = _lib.lib().eda_bn_relu_bwd_f32(

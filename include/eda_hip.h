@@ -172,8 +172,12 @@ int eda_group_concat_cl_grad_f32(const float *dx, const int *idx, int b, int n, 
  * updated with `momentum`, unbiased variance) or running statistics (eval);
  * out = relu(bn(z)) (R,C), or with pool > 1 its max over each `pool` consecutive rows
  * (R/pool,C) plus the arg-max row (bytes).  mean/rstd/scale/shift (C each) are kept
- * for the backward.  ws: 2*C doubles.
- * eda_bn_relu_bwd_f32: dz (R,C), dgamma, dbeta (C floats each); ws: 2*C doubles of scratch.
+ * for the backward.
+ * eda_bn_relu_bwd_f32: dz (R,C), dgamma, dbeta (C floats each).
+ * ws of the forward: 2*C + 1 doubles that must be ZERO on entry and are left zero on return (the last
+ * workgroup of the statistics kernel finalises and clears them): a caller zeroes the buffer once and
+ * re-uses it for every call ordered on the same stream -- no zero-fill or finalize launch per call.
+ * ws of the backward: 2*C doubles of plain scratch (zeroed inside).
  * p_drop > 0: element dropout AFTER the ReLU fused into the same pass (the heads'
  * Conv-BN-ReLU-Dropout, models/modules.py:66-86), mask = the counter hash of eda_mha_* /
  * eda_add_dropout_ln_* on (seed_ptr, salt, element index); built for pool == 1 and
