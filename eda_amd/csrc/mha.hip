@@ -140,11 +140,186 @@ __device__ __forceinline__ void stage_dead(unsigned *flags, const unsigned char 
   }
 }
 
+// ---- LDS operand layouts ---------------------------------------------------------------------
+// Row operand (contracted over the 36 head dims, e.g. K in S^T = K Q^T): plain rows of 36 floats.
+// MFMA k-step s of lane group g contracts dim 8g+s for s < 8 and dim 32+g for s = 8 (any
+// permutation of the contraction index is fine as long as both operands use it: the register
+// operand is loaded as q[8g+s] / q[32+g]).  A lane's first 8 values are then CONTIGUOUS and
+// 16-byte aligned: two ds_read_b128 + one ds_read_b32 instead of nine ds_read_b32, and the row
+// stride 36 = 4*9 makes the 16 rows of a quarter-wave hit 16 different 4-bank groups.
+// Transposed operand (contracted over the tile's 64 rows, e.g. V in O^T += V^T P^T): [dim][row],
+// row stride LDT = 68; the 4 rows 16j+4g+t of k-steps t = 0..3 are one ds_read_b128.
+constexpr int LDT = 68;
+
+// the lane's 9 contraction values of one row (see above)
+__device__ __forceinline__ void load_row_operand(float (&r)[KSTEPS], const float *row, int g) {
+  const float4 x = *reinterpret_cast<const float4 *>(row + 8 * g);
+  const float4 y = *reinterpret_cast<const float4 *>(row + 8 * g + 4);
+  r[0] = x.x; r[1] = x.y; r[2] = x.z; r[3] = x.w;
+  r[4] = y.x; r[5] = y.y; r[6] = y.z; r[7] = y.w;
+  r[8] = row[32 + g];
+}
+
+// Clamped staging loads for the layouts below: rows beyond the end re-read the last valid row
+// (their scores are masked dead / their probabilities are zero, the values only have to be
+// finite), so the loads need no per-tile predicate; addresses are a uniform base plus a 32-bit
+// per-thread offset (no 64-bit address registers held across the tile).
+template <int NW>
+__device__ __forceinline__ void issue_rows_clamped(RowStage<NW> &st, const float *base, unsigned row_stride,
+                                                   int row0, int nrows) {
+#pragma unroll
+  for (int t = 0; t < (TILE * 9 + NW * 64 - 1) / (NW * 64); ++t) {
+    const int i = threadIdx.x + NW * 64 * t;
+    const int row = i / 9, c4 = i - row * 9;
+    st.r[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < TILE * 9) {
+      const unsigned r = (unsigned)min(row0 + row, nrows - 1);
+      st.r[t] = *reinterpret_cast<const float4 *>(base + (r * row_stride + 4u * (unsigned)c4));
+    }
+  }
+}
+
+template <int NW>
+__device__ __forceinline__ void commit_rows_transposed(float *lds, const RowStage<NW> &st) {
+#pragma unroll
+  for (int t = 0; t < (TILE * 9 + NW * 64 - 1) / (NW * 64); ++t) {
+    const int i = threadIdx.x + NW * 64 * t;
+    const int row = i / 9, c4 = i - row * 9;
+    if (i < TILE * 9) {
+      float *dst = lds + (4 * c4) * LDT + row;
+      dst[0] = st.r[t].x;
+      dst[LDT] = st.r[t].y;
+      dst[2 * LDT] = st.r[t].z;
+      dst[3 * LDT] = st.r[t].w;
+    }
+  }
+}
+
+struct DropCfg { bool on; unsigned seed, thresh; float inv_keep; };
+
+#ifdef EDA_MHA_PROFILE
+// Phase timing (experiments only): per-wave s_memtime stamps, forced behind the phase's last result.
+__device__ unsigned long long mha_prof[8];
+#define MHA_STAMP(slot, dep)                                                     \
+  do {                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+    const int dep__ = __builtin_amdgcn_readfirstlane(__float_as_int(dep));       \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"s"(dep__));                  \
+    const unsigned long long now__ = __builtin_amdgcn_s_memtime();               \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(now__));                           \
+    prof_acc[slot] += now__ - prof_t;                                            \
+    prof_t = now__;                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+  } while (0)
+#define MHA_PROF_ARGS , unsigned long long (&prof_acc)[8], unsigned long long &prof_t
+#define MHA_PROF_PASS , prof_acc, prof_t
+#else
+#define MHA_STAMP(slot, dep) do { } while (0)
+#define MHA_PROF_ARGS
+#define MHA_PROF_PASS
+#endif
+
+// One 64-key tile of the forward for one wave (16 queries): NSUB = live 16-key sub-tiles
+// (compile-time, so the body is branch-free: the four score chains interleave and every LDS
+// operand is requested before the first MFMA that needs it).
+template <int NSUB, class StageNext>
+__device__ __forceinline__ void fwd_tile(const float *__restrict__ Kl, const float *__restrict__ Vl,
+                                         const unsigned *__restrict__ deadl, const float (&qreg)[KSTEPS],
+                                         int c, int g, int k0, unsigned rowbase, const DropCfg &dc,
+                                         float &m, float &lsum, f32x4 (&o)[3], StageNext &&stage_next MHA_PROF_ARGS) {
+  float kreg[NSUB][KSTEPS];
+#pragma unroll
+  for (int j = 0; j < NSUB; ++j) load_row_operand(kreg[j], Kl + (16 * j + c) * HD, g);
+  f32x4 st[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j) st[j] = mfma4(kreg[j][s], qreg[s], st[j]);
+  __builtin_amdgcn_sched_barrier(0);     // (keeps the V operand's 48 registers from overlapping the K operand's 36)
+  MHA_STAMP(1, st[NSUB - 1][3]);
+  // V^T operand: dims c, 16+c, 32+(c&3) (output rows >= 36 of the third tile are never stored,
+  // so lanes c >= 4 may read any in-bounds row), keys 16j + 4g + (0..3); sub-tile 0 is requested
+  // now (it lands under the softmax arithmetic), sub-tile j+1 under the MFMAs of sub-tile j.
+  const float *vp = Vl + c * LDT + 4 * g;
+  const float *vp2 = Vl + (32 + (c & 3)) * LDT + 4 * g;
+  f32x4 va[3], vb[3];
+  va[0] = *reinterpret_cast<const f32x4 *>(vp);
+  va[1] = *reinterpret_cast<const f32x4 *>(vp + 16 * LDT);
+  va[2] = *reinterpret_cast<const f32x4 *>(vp2);
+  float tmax = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned dw = deadl[4 * j + g];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool dead = ((dw >> (8 * r)) & 0xffu) != 0u;
+      st[j][r] = dead ? -INFINITY : st[j][r];
+      tmax = fmaxf(tmax, st[j][r]);
+    }
+  }
+  tmax = xor_max(tmax);
+  const float m_new = fmaxf(m, tmax);
+  const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+  const float alpha = __expf(m - m_safe);       // m = -inf -> 0
+  float psum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float p = __expf(st[j][r] - m_safe);
+      st[j][r] = p;
+      psum += p;
+    }
+  psum = xor_sum(psum);
+  lsum = lsum * alpha + psum;
+  m = m_new;
+#pragma unroll
+  for (int nt = 0; nt < 3; ++nt) o[nt] *= alpha;
+  if (dc.on) {
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned key = (unsigned)(k0 + 16 * j + 4 * g + r);
+        const bool keep = hash32(dc.seed ^ (rowbase + key)) >= dc.thresh;
+        st[j][r] = keep ? st[j][r] * dc.inv_keep : 0.f;
+      }
+  }
+  MHA_STAMP(2, st[0][0] + lsum + va[2][3]);
+  // the next tile's global loads are issued HERE (their registers are only live across the PV
+  // MFMAs, which cover the L2 latency) rather than at the top of the tile
+  __builtin_amdgcn_sched_barrier(0);
+  stage_next();
+  __builtin_amdgcn_sched_barrier(0);
+  MHA_STAMP(0, lsum);
+  // O^T[dim][query] += V^T P^T
+#pragma unroll
+  for (int j = 0; j < NSUB; ++j) {
+    if (j + 1 < NSUB) {
+      vb[0] = *reinterpret_cast<const f32x4 *>(vp + 16 * (j + 1));
+      vb[1] = *reinterpret_cast<const f32x4 *>(vp + 16 * LDT + 16 * (j + 1));
+      vb[2] = *reinterpret_cast<const f32x4 *>(vp2 + 16 * (j + 1));
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float pb = st[j][t];
+      o[0] = mfma4(va[0][t], pb, o[0]);
+      o[1] = mfma4(va[1][t], pb, o[1]);
+      o[2] = mfma4(va[2][t], pb, o[2]);
+    }
+    if (j + 1 < NSUB) {
+      __builtin_amdgcn_sched_barrier(0);
+      va[0] = vb[0]; va[1] = vb[1]; va[2] = vb[2];
+    }
+  }
+  MHA_STAMP(3, o[0][0] + o[1][0] + o[2][0]);
+}
+
 // ============================================================== forward ======
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void mha_fwd_kernel(MhaArgs a) {
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 4))) void mha_fwd_kernel(MhaArgs a) {
   __shared__ __attribute__((aligned(16))) float Kbuf[2][TILE * HD];
-  __shared__ __attribute__((aligned(16))) float Vbuf[2][TILE * HD];
+  __shared__ __attribute__((aligned(16))) float Vbuf[2][HD * LDT];
   __shared__ unsigned deadbuf[2][TILE / 4];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -158,112 +333,74 @@ __global__ __launch_bounds__(NW * 64) void mha_fwd_kernel(MhaArgs a) {
 
   const float *qrow = a.q + (long)b * a.q_sb + (long)(qvalid ? qi : 0) * a.q_sl + h * HD;
   float qreg[KSTEPS];
+  load_row_operand(qreg, qrow, g);
 #pragma unroll
-  for (int s = 0; s < KSTEPS; ++s) qreg[s] = qvalid ? qrow[4 * s + g] * a.scale : 0.f;
+  for (int s = 0; s < KSTEPS; ++s) qreg[s] = qvalid ? qreg[s] * a.scale : 0.f;
 
   const float *kbase = a.k + (long)b * a.k_sb + h * HD;
   const float *vbase = a.v + (long)b * a.v_sb + h * HD;
   const unsigned char *mrow = a.mask ? a.mask + (long)b * a.Lk : nullptr;
 
-  const bool drop = a.p_drop > 0.f;
-  unsigned seed = 0, thresh = 0;
-  float inv_keep = 1.f;
-  if (drop) {
-    seed = hash32((unsigned)(*a.seed_ptr) * 0x9E3779B1u + a.salt);
-    thresh = (unsigned)((double)a.p_drop * 4294967296.0);
-    inv_keep = 1.f / (1.f - a.p_drop);
+  DropCfg dc = {a.p_drop > 0.f, 0u, 0u, 1.f};
+  if (dc.on) {
+    dc.seed = hash32((unsigned)(*a.seed_ptr) * 0x9E3779B1u + a.salt);
+    dc.thresh = (unsigned)((double)a.p_drop * 4294967296.0);
+    dc.inv_keep = 1.f / (1.f - a.p_drop);
   }
   const unsigned rowbase = ((unsigned)bh * (unsigned)a.Lq + (unsigned)qi) * (unsigned)a.Lk;
 
   float m = -INFINITY, lsum = 0.f;
   f32x4 o[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 
-  stage_rows<NW>(Kbuf[0], kbase, a.k_sl, 0, a.Lk);
-  stage_rows<NW>(Vbuf[0], vbase, a.v_sl, 0, a.Lk);
-  stage_dead(deadbuf[0], mrow, 0, a.Lk);
+  if (a.Lk > 0) {
+    RowStage<NW> ks, vs;
+    issue_rows_clamped<NW>(ks, kbase, (unsigned)a.k_sl, 0, a.Lk);
+    issue_rows_clamped<NW>(vs, vbase, (unsigned)a.v_sl, 0, a.Lk);
+    commit_rows<NW>(Kbuf[0], ks);
+    commit_rows_transposed<NW>(Vbuf[0], vs);
+    stage_dead(deadbuf[0], mrow, 0, a.Lk);
+  }
   __syncthreads();
+#ifdef EDA_MHA_PROFILE
+  unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long prof_t = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(prof_t));
+#endif
   int cur = 0;
   for (int k0 = 0; k0 < a.Lk; k0 += TILE, cur ^= 1) {
     const float *Kl = Kbuf[cur], *Vl = Vbuf[cur];
     const unsigned *deadl = deadbuf[cur];
     const bool more = k0 + TILE < a.Lk;
     RowStage<NW> ks, vs;
-    if (more) {                       // next tile: global -> registers, overlapped with the MFMAs below
-      issue_rows<NW>(ks, kbase, a.k_sl, k0 + TILE, a.Lk);
-      issue_rows<NW>(vs, vbase, a.v_sl, k0 + TILE, a.Lk);
-    }
-
+    auto stage_next = [&]() {
+      if (more) {
+        issue_rows_clamped<NW>(ks, kbase, (unsigned)a.k_sl, k0 + TILE, a.Lk);
+        issue_rows_clamped<NW>(vs, vbase, (unsigned)a.v_sl, k0 + TILE, a.Lk);
+      }
+    };
     // 16-key sub-tiles that lie entirely beyond Lk (e.g. 3 of 8 when Lk = 80) are skipped:
     // their probabilities are zero anyway (workgroup-uniform condition).
     const int nsub = min(4, (a.Lk - k0 + 15) / 16);
-    f32x4 st[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 acc = {0, 0, 0, 0};
-      if (j < nsub) {
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) acc = mfma4(Kl[(16 * j + c) * HD + 4 * s + g], qreg[s], acc);
-      }
-      st[j] = acc;
-    }
-    float tmax = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned dw = deadl[4 * j + g];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const bool dead = ((dw >> (8 * r)) & 0xffu) != 0u;
-        st[j][r] = dead ? -INFINITY : st[j][r];
-        tmax = fmaxf(tmax, st[j][r]);
-      }
-    }
-    tmax = xor_max(tmax);
-    const float m_new = fmaxf(m, tmax);
-    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = __expf(m - m_safe);       // m = -inf -> 0
-    float psum = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = __expf(st[j][r] - m_safe);
-        st[j][r] = p;
-        psum += p;
-      }
-    psum = xor_sum(psum);
-    lsum = lsum * alpha + psum;
-    m = m_new;
-#pragma unroll
-    for (int nt = 0; nt < 3; ++nt) o[nt] *= alpha;
-    if (drop) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const unsigned key = (unsigned)(k0 + 16 * j + 4 * g + r);
-          const bool keep = hash32(seed ^ (rowbase + key)) >= thresh;
-          st[j][r] = keep ? st[j][r] * inv_keep : 0.f;
-        }
-    }
-    // O^T[dim][query] += V^T P^T
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (j < nsub)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float *vr = Vl + (16 * j + 4 * g + t) * HD;
-        const float pb = st[j][t];
-        o[0] = mfma4(vr[c], pb, o[0]);
-        o[1] = mfma4(vr[16 + c], pb, o[1]);
-        o[2] = mfma4(c < 4 ? vr[32 + c] : 0.f, pb, o[2]);
-      }
+    if (nsub == 4) fwd_tile<4>(Kl, Vl, deadl, qreg, c, g, k0, rowbase, dc, m, lsum, o, stage_next MHA_PROF_PASS);
+    else if (nsub == 3) fwd_tile<3>(Kl, Vl, deadl, qreg, c, g, k0, rowbase, dc, m, lsum, o, stage_next MHA_PROF_PASS);
+    else if (nsub == 2) fwd_tile<2>(Kl, Vl, deadl, qreg, c, g, k0, rowbase, dc, m, lsum, o, stage_next MHA_PROF_PASS);
+    else fwd_tile<1>(Kl, Vl, deadl, qreg, c, g, k0, rowbase, dc, m, lsum, o, stage_next MHA_PROF_PASS);
     if (more) {                       // registers -> the other LDS buffer (its readers finished last iteration)
       commit_rows<NW>(Kbuf[cur ^ 1], ks);
-      commit_rows<NW>(Vbuf[cur ^ 1], vs);
+      commit_rows_transposed<NW>(Vbuf[cur ^ 1], vs);
       stage_dead(deadbuf[cur ^ 1], mrow, k0 + TILE, a.Lk);
     }
+    MHA_STAMP(4, lsum);
     __syncthreads();
+    MHA_STAMP(5, lsum);
+#ifdef EDA_MHA_PROFILE
+    prof_acc[6] += 1;
+#endif
   }
+#ifdef EDA_MHA_PROFILE
+  if (lane == 0)
+    for (int i = 0; i < 7; ++i) atomicAdd(&mha_prof[i], prof_acc[i]);
+#endif
 
   if (qvalid) {
     const float inv = 1.f / lsum;                  // all keys masked -> NaN, like the reference
@@ -564,17 +701,19 @@ __global__ __launch_bounds__(256) void mha_part_reduce_kernel(const float *__res
 // 4 waves per workgroup share one staged tile.  A 1-wave variant (4x more workgroups for the
 // short decoder / text shapes) was measured slower on every EDA shape (rocprofv3 kernel
 // durations, e.g. 256x1024 dK/dV 90 -> 152 us, 256x80 fwd 13.0 -> 16.9 us: each workgroup then
-// stages all of K/V alone), so it is only reachable through EDA_MHA_WAVES=1 for experiments.
-int pick_waves(int resident_rows, int bh) {
-  (void)resident_rows; (void)bh;
-  if (getenv("EDA_MHA_WAVES")) return atoi(getenv("EDA_MHA_WAVES")) == 1 ? 1 : 4;
-  return 4;
-}
-
+// stages all of K/V alone) and is no longer instantiated.
 bool mult4(long v) { return (v & 3) == 0; }
 bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
+
+#ifdef EDA_MHA_PROFILE
+extern "C" int eda_mha_profile_read(unsigned long long *out8) {
+  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(mha_prof), sizeof(zero)) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(mha_prof), zero, sizeof(zero)) != hipSuccess;
+}
+#endif
 
 extern "C" int eda_mha_fwd_f32(const float *q, const float *k, const float *v, long q_sb, long q_sl,
                                long k_sb, long k_sl, long v_sb, long v_sl,
@@ -597,13 +736,8 @@ extern "C" int eda_mha_fwd_f32(const float *q, const float *k, const float *v, l
   a.v_sb = v_sb; a.v_sl = v_sl; a.o = out; a.o_sb = (long)Lq * H * HD; a.o_sl = (long)H * HD;
   a.lse = lse; a.mask = key_padding_mask; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale;
   a.p_drop = p_drop; a.seed_ptr = seed_ptr; a.salt = salt;
-  if (pick_waves(Lq, B * H) == 1) {
-    hipLaunchKernelGGL(mha_fwd_kernel<1>, dim3((unsigned)(B * H), (unsigned)((Lq + 15) / 16)), dim3(64), 0,
-                       stream, a);
-  } else {
-    hipLaunchKernelGGL(mha_fwd_kernel<4>, dim3((unsigned)(B * H), (unsigned)((Lq + 63) / 64)), dim3(256), 0,
-                       stream, a);
-  }
+  hipLaunchKernelGGL(mha_fwd_kernel<4>, dim3((unsigned)(B * H), (unsigned)((Lq + 63) / 64)), dim3(256), 0,
+                     stream, a);
   EDA_CHECK_LAUNCH();
   return 0;
 }
@@ -673,11 +807,7 @@ extern "C" int eda_mha_bwd_f32(const float *q, const float *k, const float *v, l
       a.dq_part = reinterpret_cast<float *>(ws);
     }
     const unsigned gz = split ? (unsigned)((Lk + a.k_split_rows - 1) / a.k_split_rows) : 1u;
-    if (pick_waves(Lq, B * H) == 1)
-      hipLaunchKernelGGL(mha_bwd_dq_kernel<1>, dim3((unsigned)(B * H), (unsigned)((Lq + 15) / 16), gz), dim3(64),
-                         0, stream, a);
-    else
-      hipLaunchKernelGGL(mha_bwd_dq_kernel<4>, dim3((unsigned)(B * H), (unsigned)((Lq + 63) / 64), gz), dim3(256),
+    hipLaunchKernelGGL(mha_bwd_dq_kernel<4>, dim3((unsigned)(B * H), (unsigned)((Lq + 63) / 64), gz), dim3(256),
                          0, stream, a);
     EDA_CHECK_LAUNCH();
     if (split) {
@@ -695,11 +825,7 @@ extern "C" int eda_mha_bwd_f32(const float *q, const float *k, const float *v, l
       a.dkv_part = reinterpret_cast<float *>(ws);
     }
     const unsigned gz = split ? (unsigned)((Lq + a.q_split_rows - 1) / a.q_split_rows) : 1u;
-    if (pick_waves(Lk, B * H) == 1)
-      hipLaunchKernelGGL(mha_bwd_dkv_kernel<1>, dim3((unsigned)(B * H), (unsigned)((Lk + 15) / 16), gz), dim3(64),
-                         0, stream, a);
-    else
-      hipLaunchKernelGGL(mha_bwd_dkv_kernel<4>, dim3((unsigned)(B * H), (unsigned)((Lk + 63) / 64), gz), dim3(256),
+    hipLaunchKernelGGL(mha_bwd_dkv_kernel<4>, dim3((unsigned)(B * H), (unsigned)((Lk + 63) / 64), gz), dim3(256),
                          0, stream, a);
     EDA_CHECK_LAUNCH();
     if (split) {
