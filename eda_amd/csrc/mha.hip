@@ -414,12 +414,95 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 4)))
   }
 }
 
+// The lane's transposed-operand values of one 16-row sub-tile, read from a ROW-major tile:
+// element [t][n] = X[row 16j + 4g + t][dim c + 16n] (third tile: dim 32 + (c & 3); its output rows
+// >= 36 are never stored).  12 conflict-free ds_read_b32 (the 16 lanes of a group read 16
+// consecutive floats); requested one sub-tile ahead of the MFMAs that consume them.
+struct ColOperand { float v[4][3]; };
+__device__ __forceinline__ void load_col_operand(ColOperand &o, const float *tile, int j, int c, int g) {
+  const float *p = tile + (16 * j + 4 * g) * HD;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    o.v[t][0] = p[t * HD + c];
+    o.v[t][1] = p[t * HD + 16 + c];
+    o.v[t][2] = p[t * HD + 32 + (c & 3)];
+  }
+}
+
 // ======================================================== backward: dQ =======
 // lane owns query (l&15); streams K/V tiles.
 //   S^T = K Q^T, P^T = exp(S^T - lse);  dP^T = V dO^T;  dS^T = P^T o (dP^T_eff - delta)
 //   dQ^T[dim][query] += K^T dS^T    (then * scale)
+// One 64-key tile for one wave; NSUB = live 16-key sub-tiles (compile time: branch-free body).
+template <int NSUB, class StageNext>
+__device__ __forceinline__ void dq_tile(const float *__restrict__ Kl, const float *__restrict__ Vl,
+                                        const unsigned *__restrict__ deadl, const float (&qreg)[KSTEPS],
+                                        const float (&dreg)[KSTEPS], int c, int g, int k0, unsigned rowbase,
+                                        const DropCfg &dc, bool qvalid, float lse, float delta,
+                                        f32x4 (&dq)[3], StageNext &&stage_next) {
+  f32x4 ds[4];
+  // scores and dP two sub-tiles at a time: four independent accumulator chains
+#pragma unroll
+  for (int j0 = 0; j0 < NSUB; j0 += 2) {
+    float ka[2][KSTEPS], va[2][KSTEPS];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+      if (j0 + jj < NSUB) {
+        load_row_operand(ka[jj], Kl + (16 * (j0 + jj) + c) * HD, g);
+        load_row_operand(va[jj], Vl + (16 * (j0 + jj) + c) * HD, g);
+      }
+    f32x4 sacc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, pacc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+        if (j0 + jj < NSUB) {
+          sacc[jj] = mfma4(ka[jj][s], qreg[s], sacc[jj]);
+          pacc[jj] = mfma4(va[jj][s], dreg[s], pacc[jj]);
+        }
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+      if (j0 + jj < NSUB) {
+        const int j = j0 + jj;
+        const unsigned dw = deadl[4 * j + g];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = k0 + 16 * j + 4 * g + r;
+          const bool dead = (((dw >> (8 * r)) & 0xffu) != 0u) || !qvalid;
+          const float p = dead ? 0.f : __expf(sacc[jj][r] - lse);
+          float dp = pacc[jj][r];
+          if (dc.on) {
+            const bool keep = hash32(dc.seed ^ (rowbase + (unsigned)key)) >= dc.thresh;
+            dp = keep ? dp * dc.inv_keep : 0.f;
+          }
+          ds[j][r] = p * (dp - delta);
+        }
+      }
+  }
+  ColOperand ca, cb;
+  load_col_operand(ca, Kl, 0, c, g);
+  __builtin_amdgcn_sched_barrier(0);
+  stage_next();                      // next tile's global loads: live only across the MFMAs below
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < NSUB; ++j) {
+    if (j + 1 < NSUB) load_col_operand(cb, Kl, j + 1, c, g);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float sb = ds[j][t];
+      dq[0] = mfma4(ca.v[t][0], sb, dq[0]);
+      dq[1] = mfma4(ca.v[t][1], sb, dq[1]);
+      dq[2] = mfma4(ca.v[t][2], sb, dq[2]);
+    }
+    if (j + 1 < NSUB) {
+      __builtin_amdgcn_sched_barrier(0);
+      ca = cb;
+    }
+  }
+}
+
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void mha_bwd_dq_kernel(MhaArgs a) {
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 4))) void mha_bwd_dq_kernel(MhaArgs a) {
   __shared__ __attribute__((aligned(16))) float Kbuf[2][TILE * HD];
   __shared__ __attribute__((aligned(16))) float Vbuf[2][TILE * HD];
   __shared__ unsigned deadbuf[2][TILE / 4];
@@ -436,10 +519,12 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dq_kernel(MhaArgs a) {
   const float *qrow = a.q + (long)b * a.q_sb + (long)(qvalid ? qi : 0) * a.q_sl + h * HD;
   const float *drow = a.dout + (long)b * a.do_sb + (long)(qvalid ? qi : 0) * a.do_sl + h * HD;
   float qreg[KSTEPS], dreg[KSTEPS];
+  load_row_operand(qreg, qrow, g);
+  load_row_operand(dreg, drow, g);
 #pragma unroll
   for (int s = 0; s < KSTEPS; ++s) {
-    qreg[s] = qvalid ? qrow[4 * s + g] * a.scale : 0.f;
-    dreg[s] = qvalid ? drow[4 * s + g] : 0.f;
+    qreg[s] = qvalid ? qreg[s] * a.scale : 0.f;
+    dreg[s] = qvalid ? dreg[s] : 0.f;
   }
   const float lse = qvalid ? a.lse[(long)bh * a.Lq + qi] : 0.f;
   // delta = rowsum(dO * O): each of the 4 lane groups holds 9 of the 36 head dims of its query;
@@ -448,8 +533,10 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dq_kernel(MhaArgs a) {
   float delta = 0.f;
   {
     const float *orow = a.o + (long)b * a.o_sb + (long)(qvalid ? qi : 0) * a.o_sl + h * HD;
+    float oreg[KSTEPS];
+    load_row_operand(oreg, orow, g);
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) delta += qvalid ? dreg[s] * orow[4 * s + g] : 0.f;
+    for (int s = 0; s < KSTEPS; ++s) delta += dreg[s] * oreg[s];
     delta = xor_sum(delta);
     if (qvalid && g == 0) const_cast<float *>(a.delta)[(long)bh * a.Lq + qi] = delta;
   }
@@ -457,13 +544,11 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dq_kernel(MhaArgs a) {
   const float *kbase = a.k + (long)b * a.k_sb + h * HD;
   const float *vbase = a.v + (long)b * a.v_sb + h * HD;
   const unsigned char *mrow = a.mask ? a.mask + (long)b * a.Lk : nullptr;
-  const bool drop = a.p_drop > 0.f;
-  unsigned seed = 0, thresh = 0;
-  float inv_keep = 1.f;
-  if (drop) {
-    seed = hash32((unsigned)(*a.seed_ptr) * 0x9E3779B1u + a.salt);
-    thresh = (unsigned)((double)a.p_drop * 4294967296.0);
-    inv_keep = 1.f / (1.f - a.p_drop);
+  DropCfg dc = {a.p_drop > 0.f, 0u, 0u, 1.f};
+  if (dc.on) {
+    dc.seed = hash32((unsigned)(*a.seed_ptr) * 0x9E3779B1u + a.salt);
+    dc.thresh = (unsigned)((double)a.p_drop * 4294967296.0);
+    dc.inv_keep = 1.f / (1.f - a.p_drop);
   }
   const unsigned rowbase = ((unsigned)bh * (unsigned)a.Lq + (unsigned)qi) * (unsigned)a.Lk;
 
@@ -471,9 +556,14 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dq_kernel(MhaArgs a) {
   // key range of this workgroup: everything, or split blockIdx.z of the range
   const int kbeg = a.k_split_rows ? (int)blockIdx.z * a.k_split_rows : 0;
   const int kend = a.k_split_rows ? min(a.Lk, kbeg + a.k_split_rows) : a.Lk;
-  stage_rows<NW>(Kbuf[0], kbase, a.k_sl, kbeg, a.Lk);
-  stage_rows<NW>(Vbuf[0], vbase, a.v_sl, kbeg, a.Lk);
-  stage_dead(deadbuf[0], mrow, kbeg, a.Lk);
+  if (kbeg < kend) {
+    RowStage<NW> ks, vs;
+    issue_rows_clamped<NW>(ks, kbase, (unsigned)a.k_sl, kbeg, a.Lk);
+    issue_rows_clamped<NW>(vs, vbase, (unsigned)a.v_sl, kbeg, a.Lk);
+    commit_rows<NW>(Kbuf[0], ks);
+    commit_rows<NW>(Vbuf[0], vs);
+    stage_dead(deadbuf[0], mrow, kbeg, a.Lk);
+  }
   __syncthreads();
   int cur = 0;
   for (int k0 = kbeg; k0 < kend; k0 += TILE, cur ^= 1) {
@@ -481,47 +571,17 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dq_kernel(MhaArgs a) {
     const unsigned *deadl = deadbuf[cur];
     const bool more = k0 + TILE < kend;
     RowStage<NW> ks, vs;
-    if (more) {
-      issue_rows<NW>(ks, kbase, a.k_sl, k0 + TILE, a.Lk);
-      issue_rows<NW>(vs, vbase, a.v_sl, k0 + TILE, a.Lk);
-    }
+    auto stage_next = [&]() {
+      if (more) {
+        issue_rows_clamped<NW>(ks, kbase, (unsigned)a.k_sl, k0 + TILE, a.Lk);
+        issue_rows_clamped<NW>(vs, vbase, (unsigned)a.v_sl, k0 + TILE, a.Lk);
+      }
+    };
     const int nsub = min(4, (a.Lk - k0 + 15) / 16);
-    f32x4 ds[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 sacc = {0, 0, 0, 0}, pacc = {0, 0, 0, 0};
-      if (j < nsub) {
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-          sacc = mfma4(Kl[(16 * j + c) * HD + 4 * s + g], qreg[s], sacc);
-          pacc = mfma4(Vl[(16 * j + c) * HD + 4 * s + g], dreg[s], pacc);
-        }
-      }
-      const unsigned dw = deadl[4 * j + g];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = k0 + 16 * j + 4 * g + r;
-        const bool dead = (((dw >> (8 * r)) & 0xffu) != 0u) || !qvalid;
-        const float p = dead ? 0.f : __expf(sacc[r] - lse);
-        float dp = pacc[r];
-        if (drop) {
-          const bool keep = hash32(seed ^ (rowbase + (unsigned)key)) >= thresh;
-          dp = keep ? dp * inv_keep : 0.f;
-        }
-        ds[j][r] = p * (dp - delta);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (j < nsub)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float *kr = Kl + (16 * j + 4 * g + t) * HD;
-        const float sb = ds[j][t];
-        dq[0] = mfma4(kr[c], sb, dq[0]);
-        dq[1] = mfma4(kr[16 + c], sb, dq[1]);
-        dq[2] = mfma4(c < 4 ? kr[32 + c] : 0.f, sb, dq[2]);
-      }
+    if (nsub == 4) dq_tile<4>(Kl, Vl, deadl, qreg, dreg, c, g, k0, rowbase, dc, qvalid, lse, delta, dq, stage_next);
+    else if (nsub == 3) dq_tile<3>(Kl, Vl, deadl, qreg, dreg, c, g, k0, rowbase, dc, qvalid, lse, delta, dq, stage_next);
+    else if (nsub == 2) dq_tile<2>(Kl, Vl, deadl, qreg, dreg, c, g, k0, rowbase, dc, qvalid, lse, delta, dq, stage_next);
+    else dq_tile<1>(Kl, Vl, deadl, qreg, dreg, c, g, k0, rowbase, dc, qvalid, lse, delta, dq, stage_next);
     if (more) {
       commit_rows<NW>(Kbuf[cur ^ 1], ks);
       commit_rows<NW>(Vbuf[cur ^ 1], vs);
@@ -545,11 +605,106 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dq_kernel(MhaArgs a) {
 // lane owns key (l&15); streams Q/dO tiles (plus their lse/delta).
 //   S = Q K^T [query 4g+r][key l&15], P = exp(S - lse[query]);  dP = dO V^T
 //   dV^T[dim][key] += dO^T P_drop;  dS = P o (dP_eff - delta[query]);  dK^T[dim][key] += Q^T dS
+struct DkvCtx {
+  int c, g, q0, ki, Lq, Lk;
+  unsigned bh;
+  bool kdead;
+  float scale;
+};
+
+template <int NSUB, class StageNext>
+__device__ __forceinline__ void dkv_tile(const float *__restrict__ Ql, const float *__restrict__ Dl,
+                                         const float *__restrict__ lse_l, const float *__restrict__ delta_l,
+                                         const float (&kreg)[KSTEPS], const float (&vreg)[KSTEPS],
+                                         const DkvCtx &x, const DropCfg &dc, f32x4 (&dk)[3], f32x4 (&dv)[3],
+                                         StageNext &&stage_next) {
+  const int c = x.c, g = x.g;
+  f32x4 pd[4], ds[4];     // dropped P (for dV) and dS (for dK), B-operand layout
+#pragma unroll
+  for (int j0 = 0; j0 < NSUB; j0 += 2) {
+    float qa[2][KSTEPS], da[2][KSTEPS];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+      if (j0 + jj < NSUB) {
+        load_row_operand(qa[jj], Ql + (16 * (j0 + jj) + c) * HD, g);
+        load_row_operand(da[jj], Dl + (16 * (j0 + jj) + c) * HD, g);
+      }
+    f32x4 sacc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, pacc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+        if (j0 + jj < NSUB) {
+          sacc[jj] = mfma4(qa[jj][s], kreg[s], sacc[jj]);
+          pacc[jj] = mfma4(da[jj][s], vreg[s], pacc[jj]);
+        }
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+      if (j0 + jj < NSUB) {
+        const int j = j0 + jj;
+        const float4 lse4 = *reinterpret_cast<const float4 *>(lse_l + 16 * j + 4 * g);
+        const float4 del4 = *reinterpret_cast<const float4 *>(delta_l + 16 * j + 4 * g);
+        const float lse_r[4] = {lse4.x, lse4.y, lse4.z, lse4.w};
+        const float del_r[4] = {del4.x, del4.y, del4.z, del4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qq = x.q0 + 16 * j + 4 * g + r;
+          const bool dead = x.kdead || qq >= x.Lq;
+          const float p = dead ? 0.f : __expf(sacc[jj][r] * x.scale - lse_r[r]);
+          float dp = pacc[jj][r];
+          float pdrop = p;
+          if (dc.on) {
+            const unsigned idx = (x.bh * (unsigned)x.Lq + (unsigned)qq) * (unsigned)x.Lk + (unsigned)x.ki;
+            const bool keep = hash32(dc.seed ^ idx) >= dc.thresh;
+            dp = keep ? dp * dc.inv_keep : 0.f;
+            pdrop = keep ? p * dc.inv_keep : 0.f;
+          }
+          pd[j][r] = pdrop;
+          ds[j][r] = p * (dp - del_r[r]);
+        }
+      }
+  }
+  // second products as a pipeline of 2*NSUB steps (step 2j: dV += dO^T P with sub-tile j of dO,
+  // step 2j+1: dK += Q^T dS with sub-tile j of Q); three rotating operand buffers, the operand of
+  // step k+2 is requested while step k multiplies
+  ColOperand buf[3];
+  load_col_operand(buf[0], Dl, 0, c, g);
+  load_col_operand(buf[1], Ql, 0, c, g);
+  __builtin_amdgcn_sched_barrier(0);
+  stage_next();                      // next tile's global loads: live only across the MFMAs below
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < 2 * NSUB; ++k) {
+    const int j = k >> 1;
+    if (k + 2 < 2 * NSUB) load_col_operand(buf[(k + 2) % 3], (k & 1) ? Ql : Dl, j + 1, c, g);
+    const ColOperand &cur = buf[k % 3];
+    if ((k & 1) == 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float pb = pd[j][t];
+        dv[0] = mfma4(cur.v[t][0], pb, dv[0]);
+        dv[1] = mfma4(cur.v[t][1], pb, dv[1]);
+        dv[2] = mfma4(cur.v[t][2], pb, dv[2]);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float sb = ds[j][t];
+        dk[0] = mfma4(cur.v[t][0], sb, dk[0]);
+        dk[1] = mfma4(cur.v[t][1], sb, dk[1]);
+        dk[2] = mfma4(cur.v[t][2], sb, dk[2]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void mha_bwd_dkv_kernel(MhaArgs a) {
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 4))) void mha_bwd_dkv_kernel(MhaArgs a) {
   __shared__ __attribute__((aligned(16))) float Qbuf[2][TILE * HD];
   __shared__ __attribute__((aligned(16))) float Dbuf[2][TILE * HD];
-  __shared__ float lsebuf[2][TILE], deltabuf[2][TILE];
+  __shared__ __attribute__((aligned(16))) float lsebuf[2][TILE];
+  __shared__ __attribute__((aligned(16))) float deltabuf[2][TILE];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;
@@ -561,20 +716,20 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dkv_kernel(MhaArgs a) {
   const float *krow = a.k + (long)b * a.k_sb + (long)(kvalid ? ki : 0) * a.k_sl + h * HD;
   const float *vrow = a.v + (long)b * a.v_sb + (long)(kvalid ? ki : 0) * a.v_sl + h * HD;
   float kreg[KSTEPS], vreg[KSTEPS];
+  load_row_operand(kreg, krow, g);
+  load_row_operand(vreg, vrow, g);
 #pragma unroll
   for (int s = 0; s < KSTEPS; ++s) {
-    kreg[s] = kvalid ? krow[4 * s + g] : 0.f;
-    vreg[s] = kvalid ? vrow[4 * s + g] : 0.f;
+    kreg[s] = kvalid ? kreg[s] : 0.f;
+    vreg[s] = kvalid ? vreg[s] : 0.f;
   }
   const float *qbase = a.q + (long)b * a.q_sb + h * HD;
   const float *dbase = a.dout + (long)b * a.do_sb + h * HD;
-  const bool drop = a.p_drop > 0.f;
-  unsigned seed = 0, thresh = 0;
-  float inv_keep = 1.f;
-  if (drop) {
-    seed = hash32((unsigned)(*a.seed_ptr) * 0x9E3779B1u + a.salt);
-    thresh = (unsigned)((double)a.p_drop * 4294967296.0);
-    inv_keep = 1.f / (1.f - a.p_drop);
+  DropCfg dc = {a.p_drop > 0.f, 0u, 0u, 1.f};
+  if (dc.on) {
+    dc.seed = hash32((unsigned)(*a.seed_ptr) * 0x9E3779B1u + a.salt);
+    dc.thresh = (unsigned)((double)a.p_drop * 4294967296.0);
+    dc.inv_keep = 1.f / (1.f - a.p_drop);
   }
 
   f32x4 dk[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -589,65 +744,34 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dkv_kernel(MhaArgs a) {
   // query range of this workgroup: everything, or split blockIdx.z of the range
   const int qbeg = a.q_split_rows ? (int)blockIdx.z * a.q_split_rows : 0;
   const int qend = a.q_split_rows ? min(a.Lq, qbeg + a.q_split_rows) : a.Lq;
-  stage_rows<NW>(Qbuf[0], qbase, a.q_sl, qbeg, a.Lq);
-  stage_rows<NW>(Dbuf[0], dbase, a.do_sl, qbeg, a.Lq);
-  stage_stats(0, qbeg);
+  if (qbeg < qend) {
+    RowStage<NW> qs, dsg;
+    issue_rows_clamped<NW>(qs, qbase, (unsigned)a.q_sl, qbeg, a.Lq);
+    issue_rows_clamped<NW>(dsg, dbase, (unsigned)a.do_sl, qbeg, a.Lq);
+    commit_rows<NW>(Qbuf[0], qs);
+    commit_rows<NW>(Dbuf[0], dsg);
+    stage_stats(0, qbeg);
+  }
   __syncthreads();
+  DkvCtx x = {c, g, 0, ki, a.Lq, a.Lk, (unsigned)bh, kdead, a.scale};
   int cur = 0;
   for (int q0 = qbeg; q0 < qend; q0 += TILE, cur ^= 1) {
     const float *Ql = Qbuf[cur], *Dl = Dbuf[cur];
     const float *lse_l = lsebuf[cur], *delta_l = deltabuf[cur];
     const bool more = q0 + TILE < qend;
     RowStage<NW> qs, dsg;
-    if (more) {
-      issue_rows<NW>(qs, qbase, a.q_sl, q0 + TILE, a.Lq);
-      issue_rows<NW>(dsg, dbase, a.do_sl, q0 + TILE, a.Lq);
-    }
+    auto stage_next = [&]() {
+      if (more) {
+        issue_rows_clamped<NW>(qs, qbase, (unsigned)a.q_sl, q0 + TILE, a.Lq);
+        issue_rows_clamped<NW>(dsg, dbase, (unsigned)a.do_sl, q0 + TILE, a.Lq);
+      }
+    };
+    x.q0 = q0;
     const int nsub = min(4, (a.Lq - q0 + 15) / 16);
-    f32x4 pd[4], ds[4];     // dropped P (for dV) and dS (for dK), B-operand layout
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 sacc = {0, 0, 0, 0}, pacc = {0, 0, 0, 0};
-      if (j < nsub) {
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-          sacc = mfma4(Ql[(16 * j + c) * HD + 4 * s + g], kreg[s], sacc);
-          pacc = mfma4(Dl[(16 * j + c) * HD + 4 * s + g], vreg[s], pacc);
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ql = 16 * j + 4 * g + r;
-        const int qq = q0 + ql;
-        const bool dead = kdead || qq >= a.Lq;
-        const float p = dead ? 0.f : __expf(sacc[r] * a.scale - lse_l[ql]);
-        float dp = pacc[r];
-        float pdrop = p;
-        if (drop) {
-          const unsigned idx = ((unsigned)bh * (unsigned)a.Lq + (unsigned)qq) * (unsigned)a.Lk + (unsigned)ki;
-          const bool keep = hash32(seed ^ idx) >= thresh;
-          dp = keep ? dp * inv_keep : 0.f;
-          pdrop = keep ? p * inv_keep : 0.f;
-        }
-        pd[j][r] = pdrop;
-        ds[j][r] = p * (dp - delta_l[ql]);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (j < nsub)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float *qr = Ql + (16 * j + 4 * g + t) * HD;
-        const float *dr = Dl + (16 * j + 4 * g + t) * HD;
-        const float pb = pd[j][t], sb = ds[j][t];
-        dv[0] = mfma4(dr[c], pb, dv[0]);
-        dv[1] = mfma4(dr[16 + c], pb, dv[1]);
-        dv[2] = mfma4(c < 4 ? dr[32 + c] : 0.f, pb, dv[2]);
-        dk[0] = mfma4(qr[c], sb, dk[0]);
-        dk[1] = mfma4(qr[16 + c], sb, dk[1]);
-        dk[2] = mfma4(c < 4 ? qr[32 + c] : 0.f, sb, dk[2]);
-      }
+    if (nsub == 4) dkv_tile<4>(Ql, Dl, lse_l, delta_l, kreg, vreg, x, dc, dk, dv, stage_next);
+    else if (nsub == 3) dkv_tile<3>(Ql, Dl, lse_l, delta_l, kreg, vreg, x, dc, dk, dv, stage_next);
+    else if (nsub == 2) dkv_tile<2>(Ql, Dl, lse_l, delta_l, kreg, vreg, x, dc, dk, dv, stage_next);
+    else dkv_tile<1>(Ql, Dl, lse_l, delta_l, kreg, vreg, x, dc, dk, dv, stage_next);
     if (more) {
       commit_rows<NW>(Qbuf[cur ^ 1], qs);
       commit_rows<NW>(Dbuf[cur ^ 1], dsg);
