@@ -431,9 +431,9 @@ def main():
         kernels.sort(key=lambda k: -k["ms"] * k["calls_per_step"])
         native_ms = sum(k["ms"] * k["calls_per_step"] for k in kernels)
         # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
-        # WRITE_SIZE), measured offline for this build and shape: profiles/r01f_mha_pmc_traffic.md,
+        # WRITE_SIZE), measured offline for this build and shape: profiles/r01k_mha_pmc.md,
         # profiles/r01i_bn_pmc_traffic.md.  None for shapes that were not profiled.
-        pmc_traffic = {("mha_bwd", (8, 8, 1024, 1024)): 242.8e6, ("mha_fwd", (8, 8, 1024, 1024)): 87.9e6,
+        pmc_traffic = {("mha_bwd", (8, 8, 1024, 1024)): 252.7e6, ("mha_fwd", (8, 8, 1024, 1024)): 92.6e6,
                        ("bn_relu_bwd", (1048576, 64, 1, 1)): 1311.0e6,      # profiles/r01i_bn_pmc_traffic.md
                        ("bn_relu_fwd", (1048576, 64, 1, 1)): 786.0e6}
         # dominant HBM-priced kernel (FPS is latency-bound: reported as us/round below)
@@ -461,7 +461,7 @@ def main():
                              "frac": round(top["tflops"] / MFMA_F32_PEAK_TFLOPS, 4),
                              "traffic": pmc_traffic.get((top["op"], tuple(top["dims"]))),
                              "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE, bytes per launch, "
-                                               "profiles/r01f_mha_pmc_traffic.md",
+                                               "profiles/r01k_mha_pmc.md",
                              "alg_flops_per_launch": algorithmic_flops((top["op"],) + tuple(top["dims"])),
                              "ms_per_launch": top["ms"], "dtype": "f32 in / f32 accumulate MFMA",
                              "ms_per_step": round(top["ms"] * top["calls_per_step"], 4)}

@@ -23,9 +23,11 @@
 // does not care about).  O^T[dim = 4(l>>4)+r][query = l&15] makes the 1/l rescale
 // lane-local and the epilogue a 16-byte store of 4 consecutive head dims.
 //
-// Dropout: keep(b,h,q,k) = hash32(seed, linear index) -- counter-based, identical
-// in forward and backward; seed = *seed_ptr (device counter, so a replayed HIP graph
-// sees a new mask every step) mixed with a per-call-site salt.
+// Dropout: counter-based, identical in forward and backward: the two keys 2m, 2m+1 of a query share
+// one 32-bit hash of (seed, linear index of the even key); key 2m keeps iff its low 16 bits >=
+// p * 2^16, key 2m+1 uses the high 16 bits (half the integer multiplies of one hash per element;
+// p is quantised to 1/65536).  seed = *seed_ptr (device counter, so a replayed HIP graph sees a new
+// mask every step) mixed with a per-call-site salt.
 #include "eda_common.h"
 
 namespace {
@@ -279,10 +281,10 @@ __device__ __forceinline__ void fwd_tile(const float *__restrict__ Kl, const flo
 #pragma unroll
     for (int j = 0; j < NSUB; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const unsigned key = (unsigned)(k0 + 16 * j + 4 * g + r);
-        const bool keep = hash32(dc.seed ^ (rowbase + key)) >= dc.thresh;
-        st[j][r] = keep ? st[j][r] * dc.inv_keep : 0.f;
+      for (int r2 = 0; r2 < 4; r2 += 2) {
+        const unsigned h = hash32(dc.seed ^ (rowbase + (unsigned)(k0 + 16 * j + 4 * g + r2)));
+        st[j][r2] = (h & 0xffffu) >= dc.thresh ? st[j][r2] * dc.inv_keep : 0.f;
+        st[j][r2 + 1] = (h >> 16) >= dc.thresh ? st[j][r2 + 1] * dc.inv_keep : 0.f;
       }
   }
   MHA_STAMP(2, st[0][0] + lsum + va[2][3]);
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 4)))
   DropCfg dc = {a.p_drop > 0.f, 0u, 0u, 1.f};
   if (dc.on) {
     dc.seed = hash32((unsigned)(*a.seed_ptr) * 0x9E3779B1u + a.salt);
-    dc.thresh = (unsigned)((double)a.p_drop * 4294967296.0);
+    dc.thresh = (unsigned)((double)a.p_drop * 65536.0 + 0.5);
     dc.inv_keep = 1.f / (1.f - a.p_drop);
   }
   const unsigned rowbase = ((unsigned)bh * (unsigned)a.Lq + (unsigned)qi) * (unsigned)a.Lk;
@@ -465,25 +467,29 @@ __device__ __forceinline__ void dq_tile(const float *__restrict__ Kl, const floa
       if (j0 + jj < NSUB) {
         const int j = j0 + jj;
         const unsigned dw = deadl[4 * j + g];
+        unsigned hpair[2] = {0u, 0u};
+        if (dc.on) {
+          hpair[0] = hash32(dc.seed ^ (rowbase + (unsigned)(k0 + 16 * j + 4 * g)));
+          hpair[1] = hash32(dc.seed ^ (rowbase + (unsigned)(k0 + 16 * j + 4 * g + 2)));
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int key = k0 + 16 * j + 4 * g + r;
           const bool dead = (((dw >> (8 * r)) & 0xffu) != 0u) || !qvalid;
           const float p = dead ? 0.f : __expf(sacc[jj][r] - lse);
           float dp = pacc[jj][r];
           if (dc.on) {
-            const bool keep = hash32(dc.seed ^ (rowbase + (unsigned)key)) >= dc.thresh;
-            dp = keep ? dp * dc.inv_keep : 0.f;
+            const unsigned r16 = (r & 1) ? hpair[r >> 1] >> 16 : hpair[r >> 1] & 0xffffu;
+            dp = r16 >= dc.thresh ? dp * dc.inv_keep : 0.f;
           }
           ds[j][r] = p * (dp - delta);
         }
       }
   }
   ColOperand ca, cb;
-  load_col_operand(ca, Kl, 0, c, g);
   __builtin_amdgcn_sched_barrier(0);
   stage_next();                      // next tile's global loads: live only across the MFMAs below
   __builtin_amdgcn_sched_barrier(0);
+  load_col_operand(ca, Kl, 0, c, g);
 #pragma unroll
   for (int j = 0; j < NSUB; ++j) {
     if (j + 1 < NSUB) load_col_operand(cb, Kl, j + 1, c, g);
@@ -547,7 +553,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 4)))
   DropCfg dc = {a.p_drop > 0.f, 0u, 0u, 1.f};
   if (dc.on) {
     dc.seed = hash32((unsigned)(*a.seed_ptr) * 0x9E3779B1u + a.salt);
-    dc.thresh = (unsigned)((double)a.p_drop * 4294967296.0);
+    dc.thresh = (unsigned)((double)a.p_drop * 65536.0 + 0.5);
     dc.inv_keep = 1.f / (1.f - a.p_drop);
   }
   const unsigned rowbase = ((unsigned)bh * (unsigned)a.Lq + (unsigned)qi) * (unsigned)a.Lk;
@@ -646,6 +652,22 @@ __device__ __forceinline__ void dkv_tile(const float *__restrict__ Ql, const flo
         const float4 del4 = *reinterpret_cast<const float4 *>(delta_l + 16 * j + 4 * g);
         const float lse_r[4] = {lse4.x, lse4.y, lse4.z, lse4.w};
         const float del_r[4] = {del4.x, del4.y, del4.z, del4.w};
+        // dropout bits: lanes c and c^1 (keys 2m, 2m+1) need the same four pair hashes (one per
+        // query r); each computes two of them and they swap through a quad-permute DPP move
+        unsigned h16[4] = {0u, 0u, 0u, 0u};
+        if (dc.on) {
+          const int odd = c & 1;
+          const unsigned qa0 = (unsigned)(x.q0 + 16 * j + 4 * g + 2 * odd);
+          const unsigned kev = (unsigned)(x.ki & ~1);
+          const unsigned hx = hash32(dc.seed ^ ((x.bh * (unsigned)x.Lq + qa0) * (unsigned)x.Lk + kev));
+          const unsigned hy = hash32(dc.seed ^ ((x.bh * (unsigned)x.Lq + qa0 + 1u) * (unsigned)x.Lk + kev));
+          const unsigned nx = (unsigned)__builtin_amdgcn_mov_dpp((int)hx, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+          const unsigned ny = (unsigned)__builtin_amdgcn_mov_dpp((int)hy, 0xB1, 0xf, 0xf, true);
+          const unsigned h0 = odd ? nx : hx, h1 = odd ? ny : hy, h2 = odd ? hx : nx, h3 = odd ? hy : ny;
+          const int sh = 16 * odd;            // this lane's key is the odd one of its pair -> high half
+          h16[0] = (h0 >> sh) & 0xffffu; h16[1] = (h1 >> sh) & 0xffffu;
+          h16[2] = (h2 >> sh) & 0xffffu; h16[3] = (h3 >> sh) & 0xffffu;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int qq = x.q0 + 16 * j + 4 * g + r;
@@ -654,8 +676,7 @@ __device__ __forceinline__ void dkv_tile(const float *__restrict__ Ql, const flo
           float dp = pacc[jj][r];
           float pdrop = p;
           if (dc.on) {
-            const unsigned idx = (x.bh * (unsigned)x.Lq + (unsigned)qq) * (unsigned)x.Lk + (unsigned)x.ki;
-            const bool keep = hash32(dc.seed ^ idx) >= dc.thresh;
+            const bool keep = h16[r] >= dc.thresh;
             dp = keep ? dp * dc.inv_keep : 0.f;
             pdrop = keep ? p * dc.inv_keep : 0.f;
           }
@@ -728,7 +749,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 4)))
   DropCfg dc = {a.p_drop > 0.f, 0u, 0u, 1.f};
   if (dc.on) {
     dc.seed = hash32((unsigned)(*a.seed_ptr) * 0x9E3779B1u + a.salt);
-    dc.thresh = (unsigned)((double)a.p_drop * 4294967296.0);
+    dc.thresh = (unsigned)((double)a.p_drop * 65536.0 + 0.5);
     dc.inv_keep = 1.f / (1.f - a.p_drop);
   }
 
