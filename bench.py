@@ -441,11 +441,33 @@ def main():
         # latency-bound and are listed in `kernels` only); FPS is latency-bound and reported below.
         hbm = [k for k in kernels if k["alg_bytes"] >= (32 << 20) and k["op"] != "furthest_point_sampling"]
         dom = hbm[0] if hbm else None
+        # achievable HBM rate on this box: the library's copy kernel over 2 x 1 GiB (4x the 256 MB
+        # Infinity Cache), read + write bytes / HIP-event time (report both denominators)
+        copy_gbs = None
+        try:
+            from eda_amd import ext as _ext
+            n_copy = 1 << 28
+            src_c = torch.full((n_copy,), 1.0, device=device)
+            dst_c = torch.empty_like(src_c)
+            for _ in range(2):
+                _ext.device_copy(src_c, dst_c)
+            ce0, ce1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ce0.record()
+            for _ in range(5):
+                _ext.device_copy(src_c, dst_c)
+            ce1.record()
+            torch.cuda.synchronize()
+            copy_gbs = round(2.0 * 4 * n_copy * 5 / (ce0.elapsed_time(ce1) * 1e-3) / 1e9, 1)
+            del src_c, dst_c
+        except torch.OutOfMemoryError:
+            copy_gbs = None
         roofline_hbm = None
         if dom:
             roofline_hbm = {"kernel": f"{dom['op']}{tuple(dom['dims'])}", "bound": "hbm",
                             "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(dom["gbs"] / HBM_PEAK_GBS, 5),
+                            "achievable_copy_gbs": copy_gbs,
+                            "frac_of_achievable": round(dom["gbs"] / copy_gbs, 5) if copy_gbs else None,
                             "traffic": pmc_traffic.get((dom["op"], tuple(dom["dims"]))),
                             "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE, bytes per launch, "
                                               "profiles/r01i_bn_pmc_traffic.md",

@@ -56,6 +56,7 @@ SIGNATURES = {
     "eda_wcolsum_f32": (_i, [_p, _l, _i, _l, _p, _l, _i, _p, _p, _p, _sz, _p, _p]),
     "eda_colsum_workspace_bytes": (_sz, [_l, _i]),
     "eda_colsum_f32": (_i, [_p, _l, _i, _l, _p, _p, _sz, _p, _p]),
+    "eda_device_copy_f32": (_i, [_p, _p, _sz, _p]),
 }
 
 _lib = None

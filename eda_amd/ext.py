@@ -256,6 +256,20 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     return out
 
 
+def device_copy(src, dst):
+    """dst <- src with the library's copy kernel (eda_device_copy_f32): the achievable-HBM yardstick
+    of bench.py, not part of the reference's path."""
+    _require_gpu(src)
+    _require_gpu(dst)
+    if src.dtype != torch.float32 or dst.dtype != torch.float32 or src.numel() != dst.numel():
+        raise RuntimeError("device_copy: two float32 tensors of equal size")
+    if not (src.is_contiguous() and dst.is_contiguous()):
+        raise RuntimeError("device_copy: tensors must be contiguous tensor")
+    _lib.check(_lib.lib().eda_device_copy_f32(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()),
+               "eda_device_copy_f32")
+    return dst
+
+
 def set_fma_mode(mode):
     """0 = nvcc-style contracted distance arithmetic (default), 1 = strict IEEE."""
     _lib.check(_lib.lib().eda_set_fma_mode(int(mode)), "eda_set_fma_mode")

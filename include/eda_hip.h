@@ -274,6 +274,13 @@ int eda_wcolsum_f32(const float *x, long R, int C, long ld, const float *w, long
 int eda_lsa_f32(const float *cost, long sb, long sq, long st, int B, int Q, int G,
                 const int *ntargets, int *assign, void *stream);
 
+/* ---- measurement aid ---------------------------------------------------------
+ * dst[0..n) = src[0..n) with 16-byte accesses (n a multiple of 4, both pointers 16-byte aligned):
+ * the in-repo device-copy kernel SURVEY.md §8(d) asks for -- bench.py times it on a buffer far
+ * larger than the 256 MB Infinity Cache and reports read+write bytes / time as the ACHIEVABLE
+ * HBM rate next to the 8 TB/s nominal peak.  Replaces nothing in the reference.          */
+int eda_device_copy_f32(const float *src, float *dst, size_t n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

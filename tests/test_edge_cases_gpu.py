@@ -69,3 +69,16 @@ def test_fused_ln_zero_rows():
     assert out.shape == (0, 288)
     out.sum().backward()
     assert norm.weight.grad.abs().sum().item() == 0 and bias.grad.abs().sum().item() == 0
+
+
+def test_device_copy_kernel():
+    """The achievable-HBM yardstick of bench.py copies exactly (incl. a size that is not a multiple
+    of the grid stride) and rejects unaligned sizes."""
+    from eda_amd import ext
+    for n in (4, 1024 * 1024 + 4, 3 * 1024 * 1024):
+        src = torch.randn(n, device="cuda")
+        dst = torch.full((n,), -1.0, device="cuda")
+        ext.device_copy(src, dst)
+        assert torch.equal(src, dst)
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        ext.device_copy(torch.zeros(6, device="cuda"), torch.zeros(6, device="cuda"))
