@@ -16,6 +16,16 @@ One JSON line on rank 0 (contract in the task statement) carrying `roofline` and
 `cpu_baseline` objects.  N > 1: scenes shard data-parallel (8 per rank, weak
 scaling); gradients are summed with ONE RCCL all-reduce of a flat fp32 buffer.
 """
+import os
+
+# ROCm 7.2: replaying a captured HIP graph through the runtime's pre-recorded AQL packets ("graph
+# packet capture") is not equivalent to launching its nodes once a host synchronisation has happened
+# between two replays: the loss of this very step then CLIMBS (82 -> 110 in 12 un-synchronised replays
+# where node-by-node launches give 82 -> 16; rocprofv3 shows 5-7x more back-to-back kernel pairs
+# overlapping by 0.1-0.8 us).  Node-by-node launches cost nothing measurable (28.2 vs 28.1 ms/step), so
+# the optimisation is switched off before the HIP runtime initialises.  DESIGN.md §4 has the evidence.
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 import argparse
 import json
 import os
@@ -92,12 +102,24 @@ def synthetic_loss(end_points):
     loss = end_points["seeds_obj_cls_logits"].pow(2).mean()
     proj_tokens = end_points["proj_tokens"]
     prefixes = [k[:-len("center")] for k in end_points if k.endswith("center")]   # proposal_, {i}head_, last_
-    for p in prefixes:
-        loss = loss + end_points[f"{p}center"].pow(2).sum(-1).mean()
-        loss = loss + end_points[f"{p}pred_size"].pow(2).sum(-1).mean()
-        loss = loss + end_points[f"{p}sem_cls_scores"].pow(2).mean()
-        loss = loss + torch.matmul(end_points[f"{p}proj_queries"], proj_tokens.transpose(1, 2)).mean()
-    return loss
+    # sum over the prediction heads p of
+    #   mean_bq |center_p|^2 + mean_bq |pred_size_p|^2 + mean(sem_cls_scores_p^2) + mean(proj_queries_p proj_tokens^T),
+    # evaluated on the heads STACKED along a new leading dimension: ~25 launches instead of 7 x 14 (the
+    # per-head form spent ~0.5 ms/step of the graph in 5 us reductions of (8,256,3) tensors)
+    if os.environ.get("EDA_BENCH_LOSS_FORM") == "perhead":      # the original evaluation order (debugging aid)
+        for p in prefixes:
+            loss = loss + end_points[f"{p}center"].pow(2).sum(-1).mean() + end_points[f"{p}pred_size"].pow(2).sum(-1).mean()
+            loss = loss + end_points[f"{p}sem_cls_scores"].pow(2).mean()
+            loss = loss + torch.matmul(end_points[f"{p}proj_queries"], proj_tokens.transpose(1, 2)).mean()
+        return loss
+
+    def stacked(name):
+        return torch.stack([end_points[p + name] for p in prefixes])
+    centers, sizes, sem, pq = stacked("center"), stacked("pred_size"), stacked("sem_cls_scores"), stacked("proj_queries")
+    bq = float(centers.shape[1] * centers.shape[2])
+    loss = loss + centers.pow(2).sum() / bq + sizes.pow(2).sum() / bq + sem.pow(2).sum() / (bq * sem.shape[-1])
+    sim = torch.matmul(pq, proj_tokens.transpose(1, 2))              # (P, B, Q, L)
+    return loss + sim.sum() / (bq * sim.shape[-1])
 
 
 def make_targets(rank, per_gpu, device, inputs):
@@ -302,6 +324,10 @@ def main():
     else:
         loss_fn = synthetic_loss
 
+    ingraph_hist = None
+    if os.environ.get("EDA_BENCH_INGRAPH_HIST") == "1":
+        ingraph_hist = (torch.full((4096,), 0.0, device=device), torch.full((1,), 0, dtype=torch.long, device=device))
+
     def fwd_bwd():
         attention.advance_dropout_state(device)      # new attention-dropout masks every step
         loss = loss_fn(model(inputs))
@@ -311,6 +337,9 @@ def main():
         else:
             loss.backward()
         flat.collect_grads()
+        if ingraph_hist is not None:                 # debugging aid: loss history written by the graph itself
+            ingraph_hist[0].index_copy_(0, ingraph_hist[1], loss.detach().reshape(1))
+            ingraph_hist[1].add_(1)
         return loss
 
     def update():
@@ -346,10 +375,11 @@ def main():
         # thread-local capture mode: calls from other threads (RCCL's watchdog) must not
         # invalidate the capture.
         mode = dict(capture_error_mode="thread_local")
+        # (capture on the stream the eager warm-up steps ran on)
         try:
             if world == 1 and not args.split_graphs:
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, **mode):
+                with torch.cuda.graph(graph, stream=side, **mode):
                     static_loss = eager_step()
 
                 def step():
@@ -358,9 +388,9 @@ def main():
             else:
                 g_fb, g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 pool = torch.cuda.graph_pool_handle()
-                with torch.cuda.graph(g_fb, pool=pool, **mode):
+                with torch.cuda.graph(g_fb, pool=pool, stream=side, **mode):
                     static_loss = fwd_bwd()
-                with torch.cuda.graph(g_up, pool=pool, **mode):
+                with torch.cuda.graph(g_up, pool=pool, stream=side, **mode):
                     update()
 
                 def step():
@@ -375,8 +405,11 @@ def main():
             args.graph = 0
             step = eager_step
 
-    for _ in range(args.warmup):
-        step()
+    trace_loss = os.environ.get("EDA_BENCH_TRACE_LOSS") == "1"      # debugging aid: loss of every warm-up step
+    for i in range(args.warmup):
+        l_ = step()
+        if trace_loss:
+            log("warmup step %d loss %.3f" % (i, float(l_.detach())))
     torch.cuda.synchronize()
     log("warmup done")
 
@@ -397,6 +430,14 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ext.op_timer = None
+    final_loss = float(loss.detach())          # loss of the last timed step (read before the eager kernel-timing runs below)
+    if ingraph_hist is not None:
+        n_ = int(ingraph_hist[1].item())
+        log("in-graph loss history (%d steps incl. eager warm-up): " % n_ + " ".join("%.1f" % v for v in ingraph_hist[0][:n_].tolist()))
+    if os.environ.get("EDA_BENCH_TRACE_LOSS") == "1":
+        with torch.no_grad():
+            log("loss of the last timed step %.3f; eager forward with the trained parameters: %.3f"
+                % (final_loss, float(loss_fn(model(inputs)))))
     if args.graph:
         # graph replay runs no host code, so per-kernel HIP events cannot be interleaved with
         # it: time the native kernels in a few eager runs of the SAME step right after.
@@ -522,7 +563,7 @@ def main():
                               "graph-replayed timed region" % args.kernel_steps) if args.graph else
                              "HIP events on the launch stream inside the timed region",
             "kernels": kernels[:24],
-            "loss": float(loss.detach()),
+            "loss": final_loss,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = run_cpu_baseline(args)

@@ -12,3 +12,10 @@ reference's operator / module interface for this path:
     eda_amd.bdetr             <-> models/bdetr.py
 """
 __version__ = "0.1.0"
+
+# ROCm 7.2 hazard (DESIGN.md §4): replays of a captured HIP graph through the runtime's pre-recorded
+# AQL packets stop being equivalent to node-by-node launches after a host synchronisation between
+# replays; training steps replayed that way drift.  Switch the optimisation off unless the user set
+# the variable (it is read when the HIP runtime initialises, i.e. before the first device call).
+import os as _os
+_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")

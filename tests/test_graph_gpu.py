@@ -20,6 +20,29 @@ def test_graph_replay_matches_eager_training_steps():
     assert rel < 1e-3
 
 
+def test_pipelined_graph_replays_around_a_host_sync_keep_training():
+    """bench.py's pattern -- warm-up replays, host sync, timed replays issued back to back -- must train
+    like eager steps do (the synthetic loss falls from ~82 to < 30 within 17 steps).  On ROCm 7.2 it did
+    NOT with the runtime's graph packet capture enabled: after the sync the loss climbed (82 -> 110);
+    bench.py / eda_amd switch the optimisation off (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0).
+    The loss history is written by the graph itself (no host reads between replays)."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EDA_BENCH_INGRAPH_HIST="1")
+    env.pop("DEBUG_CLR_GRAPH_PACKET_CAPTURE", None)          # bench.py must set it itself
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "5",
+                        "--kernel-steps", "0", "--cpu-scenes", "0", "--gemm-tuning", "shipped"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    m = re.search(r"in-graph loss history \((\d+) steps[^:]*\): ([-0-9. ]+)", p.stderr)
+    assert m, p.stderr[-2000:]
+    hist = [float(v) for v in m.group(2).split()]
+    assert len(hist) == 17 and "HIP graph" in p.stderr
+    assert hist[-1] < 0.45 * hist[0], hist            # eager: 82 -> ~21
+    assert all(b_ < a_ * 1.05 for a_, b_ in zip(hist[6:], hist[7:])), hist     # no climb after the sync
+
+
 def test_deferred_weight_gradients_match_immediate_on_the_full_model():
     """One backward pass of BeaUTyDETR: the flat gradient with every pointwise layer's dW/db deferred
     to the grouped kernel equals the one autograd produces layer by layer (fp32 summation order aside)."""
