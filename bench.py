@@ -299,6 +299,12 @@ def main():
     model = BeaUTyDETR(num_queries=args.queries, butd=not args.no_butd).to(device).train()
     model.text_encoder.eval()                  # frozen (bdetr.py:78-80)
     model.overlap_text_encoder = args.overlap
+    if os.environ.get("EDA_BENCH_NO_DROPOUT") == "1":            # debugging aid (deterministic steps)
+        for mod_ in model.modules():
+            if isinstance(mod_, torch.nn.Dropout):
+                mod_.p = 0.0
+            if hasattr(mod_, "dropout") and isinstance(getattr(mod_, "dropout"), float):
+                mod_.dropout = 0.0
     flat = FlatParams(model, reference_lr_groups)
     lrs = {"base": 1e-4, "backbone_net": 1e-3, "text_encoder": 1e-5}     # scripts/train_scanrefer.sh
     opt = torch.optim.AdamW([{"params": [gp], "lr": lrs[k]} for k, gp in flat.groups.items()],
