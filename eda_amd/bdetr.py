@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from .backbone_module import Pointnet2Backbone
 from .encoder_decoder_layers import BiDecoderLayer, BiEncoder, BiEncoderLayer, PositionEmbeddingLearned
-from .nn_utils import Conv1dK1, Linear, deferred_bn_counters
+from .nn_utils import Conv1dK1, Linear, deferred_bn_counters, l2_normalize
 from .modules import ClsAgnosticPredictHead, GeneralSamplingModule, PointsObjClsModule
 
 
@@ -200,8 +200,7 @@ class BeaUTyDETR(nn.Module):
         end_points["text_memory"] = text_feats
         end_points["seed_features"] = points_features
         if self.contrastive_align_loss:
-            end_points["proj_tokens"] = F.normalize(
-                self.contrastive_align_projection_text(text_feats), p=2, dim=-1)
+            end_points["proj_tokens"] = l2_normalize(self.contrastive_align_projection_text(text_feats))
 
         end_points = self._generate_queries(points_xyz, points_features, end_points, features_rows=vis)
         cluster_feature = end_points["query_points_feature"]     # (B, 288, Q)
@@ -209,8 +208,7 @@ class BeaUTyDETR(nn.Module):
         cluster_rows = cluster_feature.transpose(1, 2).contiguous()             # (B, Q, 288)
         query = self.decoder_query_proj.rows(cluster_rows)
         if self.contrastive_align_loss:
-            end_points["proposal_proj_queries"] = F.normalize(
-                self.contrastive_align_projection_image(query), p=2, dim=-1)
+            end_points["proposal_proj_queries"] = l2_normalize(self.contrastive_align_projection_image(query))
         center, size = self.proposal_head(cluster_feature, base_xyz=cluster_xyz, end_points=end_points,
                                           prefix="proposal_", features_rows=cluster_rows)
         base_xyz, base_size = center.detach().clone(), size.detach().clone()
@@ -229,8 +227,7 @@ class BeaUTyDETR(nn.Module):
                                     detected_feats=detected_feats if self.butd else None,
                                     detected_mask=detected_mask if self.butd else None)
             if self.contrastive_align_loss:
-                end_points[f"{prefix}proj_queries"] = F.normalize(
-                    self.contrastive_align_projection_image(query), p=2, dim=-1)
+                end_points[f"{prefix}proj_queries"] = l2_normalize(self.contrastive_align_projection_image(query))
             center, size = self.prediction_heads[i](query.transpose(1, 2), base_xyz=cluster_xyz,
                                                     end_points=end_points, prefix=prefix,
                                                     features_rows=query)

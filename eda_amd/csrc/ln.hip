@@ -314,3 +314,97 @@ extern "C" int eda_ln_reduce_grouped_f32(const long long *desc, int nsites, int 
   EDA_CHECK_LAUNCH();
   return 0;
 }
+
+// ---- row-wise L2 normalisation (torch.nn.functional.normalize(x, p=2, dim=-1)) -----------------
+// The reference normalises the 64-channel contrastive projections of the queries (7 heads) and of the
+// text tokens (models/bdetr.py:224-226, 262-264, 316-320): unfused that is 3 launches forward and ~12
+// backward per call.  One wave per row, lane l owns columns l, l+64, ...
+namespace {
+constexpr int L2_MAXC = 1024;
+
+__device__ __forceinline__ float l2_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float *__restrict__ x, long R, int C, float eps,
+                                                         float *__restrict__ y, float *__restrict__ norm) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  for (long r = wave; r < R; r += nwaves) {
+    const float *xr = x + r * C;
+    float v[L2_MAXC / 64];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < L2_MAXC / 64; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = c < C ? xr[c] : 0.f;
+      ss += v[i] * v[i];
+    }
+    const float n = sqrtf(l2_wave_sum(ss));
+    const float inv = 1.f / fmaxf(n, eps);
+#pragma unroll
+    for (int i = 0; i < L2_MAXC / 64; ++i) {
+      const int c = lane + 64 * i;
+      if (c < C) y[r * C + c] = v[i] * inv;
+    }
+    if (lane == 0) norm[r] = n;
+  }
+}
+
+// dx = (dy - y <dy, y>) / n where n > eps (y = x / n); rows clamped at eps: dx = dy / eps
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+                                                         const float *__restrict__ norm, long R, int C, float eps,
+                                                         float *__restrict__ dx) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  for (long r = wave; r < R; r += nwaves) {
+    float g[L2_MAXC / 64], yy[L2_MAXC / 64];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < L2_MAXC / 64; ++i) {
+      const int c = lane + 64 * i;
+      g[i] = c < C ? dy[r * C + c] : 0.f;
+      yy[i] = c < C ? y[r * C + c] : 0.f;
+      dot += g[i] * yy[i];
+    }
+    dot = l2_wave_sum(dot);
+    const float n = norm[r];
+    const bool clamped = !(n > eps);
+    const float inv = 1.f / fmaxf(n, eps);
+    if (clamped) dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < L2_MAXC / 64; ++i) {
+      const int c = lane + 64 * i;
+      if (c < C) dx[r * C + c] = (g[i] - yy[i] * dot) * inv;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int eda_l2norm_rows_fwd_f32(const float *x, long R, int C, float eps, float *y, float *norm,
+                                       void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(R >= 0 && C > 0 && C <= L2_MAXC, "rows of 1..1024 floats");
+  if (R == 0) return 0;
+  EDA_CHECK_ARG(x && y && norm, "null pointer");
+  long blocks = (R + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, R, C, eps, y, norm);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int eda_l2norm_rows_bwd_f32(const float *dy, const float *y, const float *norm, long R, int C,
+                                       float eps, float *dx, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(R >= 0 && C > 0 && C <= L2_MAXC, "rows of 1..1024 floats");
+  if (R == 0) return 0;
+  EDA_CHECK_ARG(dy && y && norm && dx, "null pointer");
+  long blocks = (R + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dy, y, norm, R, C, eps, dx);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}

@@ -240,3 +240,47 @@ def bn_relu_rows(bn, z, dropout=None):
 def rows_ok(x, *channels):
     """The rows fast path needs the HIP library (GPU tensors) and channel counts % 4 == 0."""
     return x.is_cuda and all(c % 4 == 0 for c in channels)
+
+
+class _L2NormalizeRows(torch.autograd.Function):
+    """F.normalize(x, p=2, dim=-1) as one HIP launch forward and one backward (csrc/ln.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        from . import _lib
+        from .ext import _timed
+        xc = x.contiguous()
+        C = xc.shape[-1]
+        R = xc.numel() // C
+        y = torch.empty_like(xc)
+        norm = torch.empty((R,), dtype=torch.float32, device=xc.device)
+        with torch.cuda.device(xc.device), _timed("l2norm_fwd", (R, C)):
+            rc = _lib.lib().eda_l2norm_rows_fwd_f32(xc.data_ptr(), R, C, float(eps), y.data_ptr(), norm.data_ptr(),
+                                                    torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "eda_l2norm_rows_fwd_f32")
+        ctx.save_for_backward(y, norm)
+        ctx.eps = float(eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib
+        from .ext import _timed
+        y, norm = ctx.saved_tensors
+        dyc = dy.contiguous()
+        C = y.shape[-1]
+        R = y.numel() // C
+        dx = torch.empty_like(y)
+        with torch.cuda.device(y.device), _timed("l2norm_bwd", (R, C)):
+            rc = _lib.lib().eda_l2norm_rows_bwd_f32(dyc.data_ptr(), y.data_ptr(), norm.data_ptr(), R, C, ctx.eps,
+                                                    dx.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "eda_l2norm_rows_bwd_f32")
+        return dx, None
+
+
+def l2_normalize(x, eps=1e-12):
+    """torch.nn.functional.normalize(x, p=2, dim=-1): fused on the GPU (fp32, rows of <= 1024), the
+    torch composition elsewhere (CPU tensors of the host-logic tests)."""
+    if x.is_cuda and x.dtype == torch.float32 and 0 < x.shape[-1] <= 1024:
+        return _L2NormalizeRows.apply(x, eps)
+    return torch.nn.functional.normalize(x, p=2, dim=-1, eps=eps)

@@ -274,6 +274,16 @@ int eda_wcolsum_f32(const float *x, long R, int C, long ld, const float *w, long
 int eda_lsa_f32(const float *cost, long sb, long sq, long st, int B, int Q, int G,
                 const int *ntargets, int *assign, void *stream);
 
+/* ---- row-wise L2 normalisation -------------------------------------------------------------
+ * y[r,:] = x[r,:] / max(||x[r,:]||_2, eps), norm[r] = ||x[r,:]||_2 (kept for the backward):
+ * torch.nn.functional.normalize(x, p=2, dim=-1) as the reference applies it to the 64-channel
+ * contrastive projections of queries and text tokens (models/bdetr.py:224-226, 262-264, 316-320).
+ * Backward: dx = (dy - y <dy,y>) / norm where norm > eps, dy / eps on clamped rows (what autograd
+ * derives for the reference's x / norm.clamp_min(eps)).  Contiguous rows, 1 <= C <= 1024.      */
+int eda_l2norm_rows_fwd_f32(const float *x, long R, int C, float eps, float *y, float *norm, void *stream);
+int eda_l2norm_rows_bwd_f32(const float *dy, const float *y, const float *norm, long R, int C, float eps,
+                            float *dx, void *stream);
+
 /* ---- measurement aid ---------------------------------------------------------
  * dst[0..n) = src[0..n) with 16-byte accesses (n a multiple of 4, both pointers 16-byte aligned):
  * the in-repo device-copy kernel SURVEY.md §8(d) asks for -- bench.py times it on a buffer far

@@ -125,3 +125,24 @@ def test_linear_rows_matches_torch():
     torch.testing.assert_close(linear_rows(x, W, b), F.linear(x, W, b), rtol=1e-5, atol=1e-5)
     for g, e in zip(got, exp):
         torch.testing.assert_close(g, e, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("shape", [(8, 256, 64), (3, 80, 64), (5, 7, 288), (2, 3, 1000), (4, 1)])
+def test_l2_normalize_matches_torch(shape):
+    """nn_utils.l2_normalize == F.normalize(p=2, dim=-1) forward and backward, incl. all-zero rows
+    (clamped at eps) and a row length that is not a multiple of 64."""
+    import torch.nn.functional as F
+    from eda_amd.nn_utils import l2_normalize
+    torch.manual_seed(0)
+    x = torch.randn(*shape, device="cuda")
+    x.view(-1, shape[-1])[0].zero_()                      # a clamped row
+    w = torch.randn(*shape, device="cuda")
+    a = x.clone().requires_grad_(True)
+    b = x.clone().requires_grad_(True)
+    ya = l2_normalize(a)
+    yb = F.normalize(b, p=2, dim=-1)
+    torch.testing.assert_close(ya, yb, rtol=1e-6, atol=1e-7)
+    (ya * w).sum().backward()
+    (yb * w).sum().backward()
+    # the clamped row: torch gives dy / eps there as well
+    torch.testing.assert_close(a.grad, b.grad, rtol=1e-5, atol=1e-6 * float(b.grad.abs().max()))
