@@ -299,11 +299,13 @@ def main():
     model = BeaUTyDETR(num_queries=args.queries, butd=not args.no_butd).to(device).train()
     model.text_encoder.eval()                  # frozen (bdetr.py:78-80)
     model.overlap_text_encoder = args.overlap
-    if os.environ.get("EDA_BENCH_NO_DROPOUT") == "1":            # debugging aid (deterministic steps)
-        for mod_ in model.modules():
-            if isinstance(mod_, torch.nn.Dropout):
+    no_drop = os.environ.get("EDA_BENCH_NO_DROPOUT", "")          # debugging aid: "1" (all), "modules", "attention"
+    if no_drop:
+        for name_, mod_ in model.named_modules():
+            if isinstance(mod_, torch.nn.Dropout) and (no_drop in ("1", "modules") or (no_drop == "ffn") == ("ffn" in name_)
+                                                        and no_drop in ("ffn", "notffn")):
                 mod_.p = 0.0
-            if hasattr(mod_, "dropout") and isinstance(getattr(mod_, "dropout"), float):
+            if hasattr(mod_, "dropout") and isinstance(getattr(mod_, "dropout"), float) and no_drop in ("1", "attention"):
                 mod_.dropout = 0.0
     flat = FlatParams(model, reference_lr_groups)
     lrs = {"base": 1e-4, "backbone_net": 1e-3, "text_encoder": 1e-5}     # scripts/train_scanrefer.sh
