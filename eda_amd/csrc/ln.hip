@@ -42,7 +42,8 @@ __global__ __launch_bounds__(LN_THREADS) void add_dropout_ln_fwd_kernel(
     const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ ybias,
     const float *__restrict__ gamma, const float *__restrict__ beta, long R, int C, float eps, float p,
     const unsigned long long *seed_ptr, unsigned salt, float *__restrict__ out,
-    float *__restrict__ mean_out, float *__restrict__ rstd_out) {
+    float *__restrict__ mean_out, float *__restrict__ rstd_out, const float *__restrict__ pos,
+    float *__restrict__ out_pos) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * (LN_THREADS / 64) + (threadIdx.x >> 6);
   if (row >= R) return;
@@ -73,7 +74,11 @@ __global__ __launch_bounds__(LN_THREADS) void add_dropout_ln_fwd_kernel(
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int c = lane + 64 * i;
-    if (c < C) out[row * C + c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+    if (c < C) {
+      const float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
+      out[row * C + c] = o;
+      if (out_pos) out_pos[row * C + c] = o + pos[row * C + c];      // the next block's query = out + pos
+    }
   }
   if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 }
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(LN_THREADS) void add_dropout_ln_bwd_kernel(
     const float *__restrict__ ybias, const float *__restrict__ gamma,
     const float *__restrict__ mean_in, const float *__restrict__ rstd_in, long R, int C, float p,
     const unsigned long long *seed_ptr, unsigned salt, float *__restrict__ dx,
-    float *__restrict__ dy, float *__restrict__ partial) {
+    float *__restrict__ dy, float *__restrict__ partial, const float *__restrict__ dout2) {
   __shared__ float red[3][LN_THREADS / 64][64 * NI];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const LnDrop d = ln_drop(p, seed_ptr, salt);
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(LN_THREADS) void add_dropout_ln_bwd_kernel(
         const bool ok = live[u] && c < C;
         xv[u][i] = ok ? x[row * C + c] : 0.f;
         yv[u][i] = ok ? y[row * C + c] : 0.f;
-        gv[u][i] = ok ? dout[row * C + c] : 0.f;
+        gv[u][i] = ok ? dout[row * C + c] + (dout2 ? dout2[row * C + c] : 0.f) : 0.f;
       }
     }
 #pragma unroll
@@ -241,7 +246,8 @@ extern "C" int eda_add_dropout_ln_fwd_f32(const float *x, const float *y, const 
                                           const float *gamma, const float *beta, long R, int C,
                                           float eps, float p_drop,
                                           const unsigned long long *seed_ptr, unsigned salt,
-                                          float *out, float *mean, float *rstd, void *stream_) {
+                                          float *out, float *mean, float *rstd, const float *pos,
+                                          float *out_pos, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EDA_CHECK_ARG(R >= 0 && C > 0 && C <= 64 * LN_MAXI, "bad dimension (C <= 1024)");
   if (R == 0) return 0;
@@ -249,8 +255,9 @@ extern "C" int eda_add_dropout_ln_fwd_f32(const float *x, const float *y, const 
   EDA_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed_ptr), "bad dropout arguments");
   EDA_CHECK_ARG(R * C < (1ll << 32), "R*C must fit the 32-bit dropout counter");
   const dim3 grid((unsigned)((R + LN_THREADS / 64 - 1) / (LN_THREADS / 64)));
+  EDA_CHECK_ARG((pos == nullptr) == (out_pos == nullptr), "pos and out_pos go together");
   LN_DISPATCH((C + 63) / 64, add_dropout_ln_fwd_kernel, grid, x, y, y_bias, gamma, beta, R, C, eps, p_drop,
-              seed_ptr, salt, out, mean, rstd);
+              seed_ptr, salt, out, mean, rstd, pos, out_pos);
   EDA_CHECK_LAUNCH();
   return 0;
 }
@@ -269,7 +276,7 @@ extern "C" int eda_add_dropout_ln_bwd_f32(const float *dout, const float *x, con
                                           const float *rstd, long R, int C, float p_drop,
                                           const unsigned long long *seed_ptr, unsigned salt,
                                           float *dx, float *dy, float *grads3, void *ws,
-                                          size_t ws_bytes, void *stream_) {
+                                          size_t ws_bytes, const float *dout2, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EDA_CHECK_ARG(R >= 0 && C > 0 && C <= 64 * LN_MAXI, "bad dimension (C <= 1024)");
   // grads3 == NULL: leave the per-block partial sums in `ws` (eda_add_dropout_ln_bwd_blocks(R) rows
@@ -287,7 +294,7 @@ extern "C" int eda_add_dropout_ln_bwd_f32(const float *dout, const float *x, con
   const dim3 grid((unsigned)blocks);
   float *partial = reinterpret_cast<float *>(ws);
   LN_DISPATCH((C + 63) / 64, add_dropout_ln_bwd_kernel, grid, dout, x, y, y_bias, gamma, mean, rstd, R, C,
-              p_drop, seed_ptr, salt, dx, dy, partial);
+              p_drop, seed_ptr, salt, dx, dy, partial, dout2);
   EDA_CHECK_LAUNCH();
   if (grads3) {
     hipLaunchKernelGGL(ln_reduce_partials_kernel, dim3((3 * C + 63) / 64), dim3(1024), 0, stream, partial,

@@ -37,12 +37,12 @@ def _ffn_residual_norm(x, ffn, norm, training, salt):
     return add_dropout_layer_norm(x, ffn[3](h), norm, ffn[4].p, training, salt)
 
 
-def _attn_residual_norm(attn, x, q, k, v, mask, norm, p_drop, training, salt, batch_first=True):
+def _attn_residual_norm(attn, x, q, k, v, mask, norm, p_drop, training, salt, batch_first=True, pos=None):
     """norm(x + dropout(attn(q, k, v))): the out-projection bias is deferred to the fused
-    residual+LayerNorm kernel whenever that kernel runs."""
+    residual+LayerNorm kernel whenever that kernel runs.  With `pos`: (out, out + pos)."""
     y, y_bias = attn(q, k, v, key_padding_mask=mask, batch_first=batch_first,
                      defer_out_bias=fuses_bias(x, norm))
-    return add_dropout_layer_norm(x, y, norm, p_drop, training, salt, y_bias=y_bias)
+    return add_dropout_layer_norm(x, y, norm, p_drop, training, salt, y_bias=y_bias, pos=pos)
 
 
 class PositionEmbeddingLearned(nn.Module):
@@ -223,15 +223,20 @@ class BiDecoderLayer(nn.Module):
             pos = torch.full_like(query, 0.0)
         qp = query + pos
         tr, sb = self.training, self._salt
-        query = _attn_residual_norm(self.self_attn, query, qp, qp, query, padding_mask, self.norm1,
-                                    self.dropout1.p, tr, sb)
-        query = _attn_residual_norm(self.cross_l, query, query + pos, lang_feats, lang_feats,
-                                    text_key_padding_mask, self.norm_l, self.dropout_l.p, tr, sb + 1)
+        # every residual LayerNorm below also emits out + pos, the query of the block that follows it
+        query, qp = _attn_residual_norm(self.self_attn, query, qp, qp, query, padding_mask, self.norm1,
+                                        self.dropout1.p, tr, sb, pos=pos)
         if detected_feats is not None:
-            query = _attn_residual_norm(self.cross_d, query, query + pos, detected_feats,
-                                        detected_feats, detected_mask, self.norm_d, self.dropout_d.p,
-                                        tr, sb + 2)
-        query = _attn_residual_norm(self.cross_v, query, query + pos, vis_feats, vis_feats, None,
+            query, qp = _attn_residual_norm(self.cross_l, query, qp, lang_feats, lang_feats,
+                                            text_key_padding_mask, self.norm_l, self.dropout_l.p, tr, sb + 1,
+                                            pos=pos)
+            query, qp = _attn_residual_norm(self.cross_d, query, qp, detected_feats, detected_feats,
+                                            detected_mask, self.norm_d, self.dropout_d.p, tr, sb + 2, pos=pos)
+        else:
+            query, qp = _attn_residual_norm(self.cross_l, query, qp, lang_feats, lang_feats,
+                                            text_key_padding_mask, self.norm_l, self.dropout_l.p, tr, sb + 1,
+                                            pos=pos)
+        query = _attn_residual_norm(self.cross_v, query, qp, vis_feats, vis_feats, None,
                                     self.norm_v, self.dropout_v.p, tr, sb + 3)
         query = _ffn_residual_norm(query, self.ffn, self.norm2, tr, sb + 4)
         return query.contiguous()

@@ -201,17 +201,23 @@ int eda_bn_relu_bwd_f32(const float *dout, const unsigned char *argmax, const fl
  * bias y_bias (C floats, may be NULL) is added here so that its gradient comes out of the
  * backward for free).  mean/rstd (R floats each) are kept for the backward, which returns
  * dx, dy (R,C) and grads3 = [d(gamma) | d(beta) | d(y_bias)] (3*C floats) using `ws` scratch
- * for per-block partial sums.  Dropout mask: the same counter-based hash as eda_mha_*.  */
+ * for per-block partial sums.  Dropout mask: the same counter-based hash as eda_mha_*.
+ * pos / out_pos (both (R,C), or both NULL): also write out_pos = out + pos, the query of the NEXT
+ * attention block (`with_pos_embed(out, query_pos)`, encoder_decoder_layers.py:366-401), so that
+ * the separate add launch and -- through dout2, the gradient that arrives for out_pos -- the
+ * autograd accumulation of the two gradients of `out` disappear.                              */
 int eda_add_dropout_ln_fwd_f32(const float *x, const float *y, const float *y_bias,
                                const float *gamma, const float *beta, long R, int C, float eps,
                                float p_drop, const unsigned long long *seed_ptr, unsigned salt,
-                               float *out, float *mean, float *rstd, void *stream);
+                               float *out, float *mean, float *rstd, const float *pos, float *out_pos,
+                               void *stream);
 size_t eda_add_dropout_ln_bwd_workspace_bytes(long R, int C);
 int eda_add_dropout_ln_bwd_f32(const float *dout, const float *x, const float *y,
                                const float *y_bias, const float *gamma, const float *mean,
                                const float *rstd, long R, int C, float p_drop,
                                const unsigned long long *seed_ptr, unsigned salt, float *dx,
-                               float *dy, float *grads3, void *ws, size_t ws_bytes, void *stream);
+                               float *dy, float *grads3, void *ws, size_t ws_bytes,
+                               const float *dout2 /* (R,C) or NULL: added to dout */, void *stream);
 
 /* Deferred form: with grads3 == NULL eda_add_dropout_ln_bwd_f32 leaves its per-block partial sums
  * in `ws` (eda_add_dropout_ln_bwd_blocks(R) rows of 3*C floats); eda_ln_reduce_grouped_f32 then

@@ -146,3 +146,48 @@ def test_l2_normalize_matches_torch(shape):
     (yb * w).sum().backward()
     # the clamped row: torch gives dy / eps there as well
     torch.testing.assert_close(a.grad, b.grad, rtol=1e-5, atol=1e-6 * float(b.grad.abs().max()))
+
+
+@pytest.mark.parametrize("use", ["both", "only_pos", "only_out"])
+def test_add_dropout_layer_norm_with_pos_output(use):
+    """(out, out + pos) from one launch == the torch composition, forward and every input gradient,
+    whichever of the two outputs the consumer uses."""
+    from eda_amd.fused_ln import add_dropout_layer_norm
+    torch.manual_seed(0)
+    B, L, C = 3, 37, 288
+    norm = torch.nn.LayerNorm(C).cuda()
+    with torch.no_grad():
+        norm.weight.normal_(1.0, 0.2); norm.bias.normal_(0, 0.2)
+    ref = torch.nn.LayerNorm(C).cuda()
+    ref.load_state_dict(norm.state_dict())
+    base = [torch.randn(B, L, C, device="cuda") for _ in range(3)]
+    bias0 = torch.randn(C, device="cuda")
+    w1, w2 = torch.randn(B, L, C, device="cuda"), torch.randn(B, L, C, device="cuda")
+
+    def run(fused):
+        x, y, pos = (t.clone().requires_grad_(True) for t in base)
+        bias = bias0.clone().requires_grad_(True)
+        if fused:
+            out, outp = add_dropout_layer_norm(x, y, norm, 0.1, False, 7, y_bias=bias, pos=pos)
+            mod = norm
+        else:
+            out = ref(x + (y + bias))
+            outp = out + pos
+            mod = ref
+        loss = 0.0
+        if use in ("both", "only_out"):
+            loss = loss + (out * w1).sum()
+        if use in ("both", "only_pos"):
+            loss = loss + (outp * w2).sum()
+        loss.backward()
+        return out, outp, [x.grad, y.grad, pos.grad, bias.grad, mod.weight.grad, mod.bias.grad]
+
+    oa, pa, ga = run(True)
+    ob, pb, gb = run(False)
+    torch.testing.assert_close(oa, ob, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(pa, pb, rtol=1e-5, atol=1e-5)
+    for a, b in zip(ga, gb):
+        if b is None:
+            assert a is None or float(a.abs().max()) == 0.0
+        else:
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
