@@ -37,7 +37,7 @@ __device__ __forceinline__ LnDrop ln_drop(float p, const unsigned long long *see
   return d;
 }
 
-template <int NI>
+template <int NI, bool EXTRA>
 __global__ __launch_bounds__(LN_THREADS) void add_dropout_ln_fwd_kernel(
     const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ ybias,
     const float *__restrict__ gamma, const float *__restrict__ beta, long R, int C, float eps, float p,
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(LN_THREADS) void add_dropout_ln_fwd_kernel(
     if (c < C) {
       const float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
       out[row * C + c] = o;
-      if (out_pos) out_pos[row * C + c] = o + pos[row * C + c];      // the next block's query = out + pos
+      if (EXTRA) out_pos[row * C + c] = o + pos[row * C + c];        // the next block's query = out + pos
     }
   }
   if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(LN_THREADS) void add_dropout_ln_fwd_kernel(
 // d(gamma)/d(beta) are accumulated in registers over the wave's rows, merged over the block's
 // 4 waves in LDS and written as ONE partial row per block (no atomics); ln_reduce_partials
 // then adds the <= 1024 partial rows.
-template <int NI>
+template <int NI, bool EXTRA>
 __global__ __launch_bounds__(LN_THREADS) void add_dropout_ln_bwd_kernel(
     const float *__restrict__ dout, const float *__restrict__ x, const float *__restrict__ y,
     const float *__restrict__ ybias, const float *__restrict__ gamma,
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(LN_THREADS) void add_dropout_ln_bwd_kernel(
         const bool ok = live[u] && c < C;
         xv[u][i] = ok ? x[row * C + c] : 0.f;
         yv[u][i] = ok ? y[row * C + c] : 0.f;
-        gv[u][i] = ok ? dout[row * C + c] + (dout2 ? dout2[row * C + c] : 0.f) : 0.f;
+        gv[u][i] = ok ? (EXTRA ? dout[row * C + c] + dout2[row * C + c] : dout[row * C + c]) : 0.f;
       }
     }
 #pragma unroll
@@ -234,12 +234,19 @@ __global__ __launch_bounds__(1024) void ln_reduce_grouped_kernel(const long long
 
 }  // namespace
 
-#define LN_DISPATCH(NI_EXPR, KERNEL, GRID, ...)                                                   \
-  do {                                                                                             \
-    const int ni__ = (NI_EXPR);                                                                    \
-    if (ni__ <= 5) hipLaunchKernelGGL(KERNEL<5>, GRID, dim3(LN_THREADS), 0, stream, __VA_ARGS__);  \
-    else if (ni__ <= 8) hipLaunchKernelGGL(KERNEL<8>, GRID, dim3(LN_THREADS), 0, stream, __VA_ARGS__); \
-    else hipLaunchKernelGGL(KERNEL<LN_MAXI>, GRID, dim3(LN_THREADS), 0, stream, __VA_ARGS__);      \
+// (EXTRA = the variant with the second output / second gradient input: a template flag, because a
+// run-time `ptr ? ... : 0` in the load loop slowed EVERY call of the backward from 8.7 to 11.6 us)
+#define LN_DISPATCH_X(NI_EXPR, KERNEL, EXTRA, GRID, ...)                                                      \
+  do {                                                                                                        \
+    const int ni__ = (NI_EXPR);                                                                               \
+    if (ni__ <= 5) hipLaunchKernelGGL((KERNEL<5, EXTRA>), GRID, dim3(LN_THREADS), 0, stream, __VA_ARGS__);    \
+    else if (ni__ <= 8) hipLaunchKernelGGL((KERNEL<8, EXTRA>), GRID, dim3(LN_THREADS), 0, stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<LN_MAXI, EXTRA>), GRID, dim3(LN_THREADS), 0, stream, __VA_ARGS__);        \
+  } while (0)
+#define LN_DISPATCH(NI_EXPR, KERNEL, EXTRA_COND, GRID, ...)                  \
+  do {                                                                       \
+    if (EXTRA_COND) LN_DISPATCH_X(NI_EXPR, KERNEL, true, GRID, __VA_ARGS__);   \
+    else LN_DISPATCH_X(NI_EXPR, KERNEL, false, GRID, __VA_ARGS__);             \
   } while (0)
 
 extern "C" int eda_add_dropout_ln_fwd_f32(const float *x, const float *y, const float *y_bias,
@@ -256,7 +263,7 @@ extern "C" int eda_add_dropout_ln_fwd_f32(const float *x, const float *y, const 
   EDA_CHECK_ARG(R * C < (1ll << 32), "R*C must fit the 32-bit dropout counter");
   const dim3 grid((unsigned)((R + LN_THREADS / 64 - 1) / (LN_THREADS / 64)));
   EDA_CHECK_ARG((pos == nullptr) == (out_pos == nullptr), "pos and out_pos go together");
-  LN_DISPATCH((C + 63) / 64, add_dropout_ln_fwd_kernel, grid, x, y, y_bias, gamma, beta, R, C, eps, p_drop,
+  LN_DISPATCH((C + 63) / 64, add_dropout_ln_fwd_kernel, pos != nullptr, grid, x, y, y_bias, gamma, beta, R, C, eps, p_drop,
               seed_ptr, salt, out, mean, rstd, pos, out_pos);
   EDA_CHECK_LAUNCH();
   return 0;
@@ -293,7 +300,7 @@ extern "C" int eda_add_dropout_ln_bwd_f32(const float *dout, const float *x, con
   if (blocks < 1) blocks = 1;
   const dim3 grid((unsigned)blocks);
   float *partial = reinterpret_cast<float *>(ws);
-  LN_DISPATCH((C + 63) / 64, add_dropout_ln_bwd_kernel, grid, dout, x, y, y_bias, gamma, mean, rstd, R, C,
+  LN_DISPATCH((C + 63) / 64, add_dropout_ln_bwd_kernel, dout2 != nullptr, grid, dout, x, y, y_bias, gamma, mean, rstd, R, C,
               p_drop, seed_ptr, salt, dx, dy, partial, dout2);
   EDA_CHECK_LAUNCH();
   if (grads3) {
