@@ -55,6 +55,8 @@ SHAPES = [  # (B, Lq, Lk, masked)
     (2, 16, 16, False), (2, 80, 80, True), (1, 1024, 1024, False), (2, 80, 1024, False),
     (2, 1024, 80, True), (2, 1024, 132, True), (2, 256, 256, False), (2, 256, 80, True),
     (3, 37, 101, True), (1, 5, 1, False), (2, 64, 65, True),
+    # every count of live 16-row sub-tiles in the last tile (the tile bodies are templated on it): 2 and 3
+    (2, 90, 24, False), (2, 24, 90, True), (2, 110, 175, True),
     # SR3D-shaped long utterances (BASELINE.json configs[4]: 130 tokens)
     (2, 130, 130, True), (2, 130, 1024, False), (2, 1024, 130, True), (2, 256, 130, True),
 ]
