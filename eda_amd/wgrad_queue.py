@@ -14,6 +14,8 @@ summed inside the kernel's accumulators -- one writer per element, fixed order, 
 Outside such a context nothing changes: gradients are computed immediately and returned to
 autograd (that path is what the parity tests exercise against the reference goldens).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -135,6 +137,10 @@ class WgradQueue:
         if not targets:
             return len(lns)
         dev = targets[0][0].device
+        if os.environ.get("EDA_WGRAD_DUMP"):          # debugging aid: (M, N, [K per job]) of every target
+            with open(os.environ["EDA_WGRAD_DUMP"], "w") as f:
+                for _, _, M, N, jobs in targets:
+                    f.write("%d %d %s\n" % (M, N, " ".join(str(dy.shape[0]) for dy, _ in jobs)))
         # cost of a tile = rows it walks; place whole targets on one XCD (workgroup id % 8), big first
         costs = [sum(dy.shape[0] for dy, _ in t[4]) for t in targets]
         order = sorted(range(len(targets)), key=lambda i: -costs[i] * ((targets[i][2] + _TILE - 1) // _TILE)
