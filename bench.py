@@ -93,6 +93,8 @@ def algorithmic_flops(name):
     if op == "mha_bwd":
         b, h, lq, lk = d
         return 10.0 * b * h * lq * lk * 36
+    if op == "wgrad_grouped" and len(d) >= 4:
+        return 2.0e6 * d[3]                  # (targets, jobs, tiles, 10^6 multiply-adds of all dW = dY^T X)
     return 0.0
 
 
@@ -522,7 +524,7 @@ def main():
                                               "profiles/r01i_bn_pmc_traffic.md",
                             "ms_per_launch": dom["ms"], "alg_bytes_per_launch": dom["alg_bytes"],
                             "ms_per_step": round(dom["ms"] * dom["calls_per_step"], 4)}
-        mf = [k for k in kernels if k["tflops"]]
+        mf = [k for k in kernels if k["tflops"] and k["op"].startswith("mha_")]   # (wgrad_grouped is priced in `kernels`)
         roofline_mfma = None
         if mf:
             # dominant attention launch (the 1024x1024 point self-attention) against the fp32-MFMA peak

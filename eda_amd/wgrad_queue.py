@@ -177,7 +177,8 @@ class WgradQueue:
         words = np.concatenate([task_arr.ravel(), targ_arr.ravel(), job_arr.ravel()])
         desc = self._stage(words, dev)
         base = desc.data_ptr()
-        with torch.cuda.device(dev), _timed("wgrad_grouped", (len(targets), njobs, ntasks)):
+        mmacs = sum(M * N * sum(dy.shape[0] for dy, _ in jobs) for _, _, M, N, jobs in targets) // 1000000
+        with torch.cuda.device(dev), _timed("wgrad_grouped", (len(targets), njobs, ntasks, mmacs)):
             rc = _lib.lib().eda_wgrad_grouped_f32(base, ntasks, base + 8 * task_arr.size,
                                                   base + 8 * (task_arr.size + targ_arr.size),
                                                   torch.cuda.current_stream().cuda_stream)
