@@ -1,0 +1,55 @@
+// gemm.h -- internal interface of gemm.hip / wgrad.hip (not part of the C ABI).
+#pragma once
+#include "eda_common.h"
+
+constexpr int G_THREADS = 256;
+constexpr int G_KC = 32;          // contraction chunk (floats)
+constexpr int G_XS = G_KC + 8;    // LDS row stride of [row][k] tiles
+
+enum { X_PLAIN = 0, X_BNRELU = 1, X_GATHER = 2 };
+enum { W_NT = 0, W_NN = 1 };
+enum { E_PLAIN = 0, E_STATS = 1, E_MASK = 2, E_SCATTER = 3 };
+
+struct GemmArgs {
+  int xmode, epi;
+  // row operand
+  const float *x; long ldx; long R; int K;
+  const float *in_scale, *in_shift;
+  // X_GATHER / E_SCATTER geometry: rows are (scene, centre, neighbour)
+  const float *xyz, *new_xyz, *feats; const int *idx;
+  int n_pts, m, ns, c_feat; float inv_radius;
+  // weight: W_NT (N, K) row-major; W_NN (K, N) row-major.  w_elem: W_NN rows are not 16-byte
+  // addressable (set by the launcher).  X_GATHER: w is the layer's (N, 3 + c_feat) weight.
+  const float *w; long ldw; int N; int w_elem;
+  const float *bias; int relu;
+  float *y; long ldy;
+  // E_STATS
+  double *sum, *sumsq; unsigned *ticket;
+  const float *gamma, *beta; float eps, momentum;
+  float *running_mean, *running_var, *mean_out, *rstd_out, *scale_out, *shift_out;
+  // E_MASK (previous layer's pre-activation and BatchNorm constants)
+  const float *zm; long ldzm; const float *m_scale, *m_shift, *m_mean, *m_rstd; double *s1, *s2;
+  // E_SCATTER
+  float *dfeats;
+  int col_tiles; long row_blocks;
+};
+
+
+// Launch the row GEMM described by `a` (tile shape chosen from R and N).  wmode: W_NT / W_NN.
+int eda_gemm_launch(GemmArgs &a, int wmode, hipStream_t stream);
+
+// ---- weight gradient with a row-operand prologue (wgrad.hip) ------------------------------------
+// dW (M, N) = dY^T X over R rows, X = plain rows | relu(Z*scale+shift) | gathered neighbourhood rows
+// (column order [dx dy dz 0 | feats], written back to the layer's (M, 3 + c_feat) weight layout).
+struct WgradXArgs {
+  int xmode;
+  const float *dy; long ld_dy; long R; int M;
+  const float *x; long ld_x; int N;                 // X_GATHER: N = 4 + c_feat
+  const float *in_scale, *in_shift;                 // X_BNRELU
+  const float *xyz, *new_xyz, *feats; const int *idx;
+  int n_pts, m, ns, c_feat; float inv_radius;
+  float *dW;                                        // (M, N) or, X_GATHER, (M, 3 + c_feat)
+  float *ws; size_t ws_bytes;
+};
+size_t eda_wgrad_x_workspace_bytes(long R, int M, int N);
+int eda_wgrad_x_launch(const WgradXArgs &a, hipStream_t stream);

@@ -1,0 +1,584 @@
+// gemm.hip -- the row-GEMM family of the path: Y = f(X) W^T (forward of every 1x1 convolution /
+// linear layer) and dX = dY W (their input gradients), fp32 in / fp32 accumulate on
+// v_mfma_f32_16x16x4_f32, with the element-wise work of the neighbouring layers folded into the
+// operand staging (prologue) and the accumulator write-out (epilogue):
+//
+//   prologues of the ROW operand X (R rows, contraction length K)
+//     X_PLAIN    X as stored
+//     X_BNRELU   relu(X * scale[k] + shift[k])        BatchNorm+ReLU of the previous SharedMLP layer
+//                                                     (pointnet2/pytorch_utils.py:67-120): the
+//                                                     activated tensor is never written to HBM
+//     X_GATHER   [ feats[idx] | (xyz[idx]-centre)/r ] QueryAndGroup (pointnet2/pointnet2_utils.py:
+//                                                     317-376): neighbourhood rows are gathered
+//                                                     straight into LDS, the grouped tensor never
+//                                                     exists (columns are permuted: features first,
+//                                                     so that feature rows stay 16-byte aligned; the
+//                                                     weight's columns are permuted to match)
+//   epilogues
+//     E_PLAIN    + bias, optional ReLU                                  linear / conv1x1 forward, dX
+//     E_STATS    column sums  (sum y, sum y^2) in fp64 accumulators; the LAST workgroup turns them
+//                into mean / rstd / scale / shift and the running statistics (train-mode BatchNorm)
+//     E_MASK     gy = acc * (z*scale+shift > 0)  and  (sum gy, sum gy*xhat): ReLU backward of the
+//                PREVIOUS layer and the two reductions its BatchNorm backward needs
+//     E_SCATTER  atomicAdd into dfeats[b, idx[row], col]                backward of the gather
+//
+// Tiling.  MFMA operand roles are swapped with respect to the usual picture: the WEIGHT tile is the
+// A operand (m = output column) and the ROW tile the B operand (n = row), so a lane's four
+// accumulator registers are four CONSECUTIVE output columns of one row: 16-byte stores, column
+// reductions = DPP reductions over the 16 lanes of a row.  A workgroup of 4 waves owns a
+// (64*WR) x (16*WC) output tile, wave w the rows [16*WR*w, 16*WR*(w+1)) and ALL columns, i.e.
+// WR + WC ds_read_b128 per 4*WR*WC MFMAs (2+6 per 48 for the 128x96 tile).  Both operands are
+// staged K-minor exactly as they lie in memory ([row][k], 32-float chunks, row stride 40 floats:
+// the lane pattern (l&15)*40 + 4*(l>>4) is conflict-free for ds_read_b128), the four k of a lane's
+// b128 feed four consecutive MFMA steps (the contraction order inside a 16-chunk is
+// 4*(l>>4)+step for both operands).  The dX form reads the weight [c][n] row-major with
+// ds_read_b32 (stride = 4 mod 8 floats: conflict-free).  The next chunk's global loads are in
+// flight during the MFMAs (register prefetch), LDS is single-buffered: 36 KB per workgroup at
+// 128x96, 4 workgroups = 4 waves per SIMD per CU.
+//
+// Grid: block id -> (row block, column tile) with id % 8 = XCD (MI355X_MICROARCH.md: block b runs
+// on XCD b % 8): all column tiles of a row block run on ONE XCD back to back, so the row tile is
+// fetched from HBM once and re-read from that XCD's L2.
+#include "eda_common.h"
+#include "gemm.h"
+#include <string.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ float row_sum16(float v) {
+  // sum over the 16 lanes of a DPP row (result in every lane of the row)
+  int i = __float_as_int(v);
+  v += __int_as_float(eda_dpp<EDA_DPP_QUAD_XOR1>(i)); i = __float_as_int(v);
+  v += __int_as_float(eda_dpp<EDA_DPP_QUAD_XOR2>(i)); i = __float_as_int(v);
+  v += __int_as_float(eda_dpp<EDA_DPP_ROW_ROR(4)>(i)); i = __float_as_int(v);
+  v += __int_as_float(eda_dpp<EDA_DPP_ROW_ROR(8)>(i));
+  return v;
+}
+
+// VEC: every operand row is 16-byte addressable (K % 4 == 0 for the row operand, aligned strides and
+// pointers; the gather's feature rows when c_feat % 4 == 0).  The staging loads are then
+// UNCONDITIONAL: rows / columns beyond the matrix are clamped to the last valid one (their results
+// are neither stored nor counted) and the contraction tail is clamped too and zeroed when the
+// chunk is written to LDS -- no arithmetic and no select touches a loaded value before the MFMAs
+// of the current chunk have been issued, so the loads stay in flight underneath them.
+// !VEC: element-wise guarded loads (odd K / strides: the 3- and 6-channel inputs).
+//
+// X_GATHER column order: [dx dy dz 0 | feats 0..C) ], K = 4 + C; the weight (N, 3+C) is read with
+// the matching map (k < 3 -> k, k == 3 -> zero, k >= 4 -> k - 1).
+template <int WR, int WC, int WMODE, int XMODE, bool VEC>
+__global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) {
+  constexpr int BM = 64 * WR, BN = 16 * WC;
+  constexpr int WSN = BN + 4;                                    // W_NN LDS row stride
+  constexpr int WS_FLOATS = WMODE == W_NT ? BN * G_XS : G_KC * WSN;
+  constexpr int XLD = BM / 32;                                   // float4 per thread per chunk, row operand
+  constexpr int WLD = BN * 8 / G_THREADS;                        // float4 per thread per chunk, weight
+  static_assert(BN * 8 % G_THREADS == 0, "weight tile must divide evenly");
+  __shared__ __attribute__((aligned(16))) float Xs[BM * G_XS];
+  __shared__ __attribute__((aligned(16))) float Ws[WS_FLOATS];
+  __shared__ int is_last;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int xcd = blockIdx.x & 7;
+  const long q = blockIdx.x >> 3;
+  const int ct = (int)(q % a.col_tiles);
+  const long rb = (q / a.col_tiles) * 8 + xcd;
+  if (rb >= a.row_blocks) return;
+  const long row0 = rb * BM;
+  const int n0 = ct * BN;
+  const long R = a.R;
+  const int K = a.K, N = a.N;             // X_GATHER: K = 4 + c_feat
+
+  // ---- staging maps -------------------------------------------------------------------------
+  const int kq4 = 4 * (tid & 7);          // first k of this thread's float4 inside a chunk
+  const int lr = tid >> 3;                // local row 0..31 (+32*i)
+  const int rows_here = (int)(R - row0 < BM ? R - row0 : BM);
+  int xoff[XLD];                          // element offset of the row from the operand base
+  float4 gxyz[XLD];                       // X_GATHER, threads with kq4 == 0: (dx, dy, dz, 0)
+  const float *xbase = XMODE == X_GATHER ? a.feats : a.x + row0 * a.ldx;
+  if (XMODE == X_GATHER) {
+    const long rows_per_scene = (long)a.m * a.ns;
+#pragma unroll
+    for (int i = 0; i < XLD; ++i) {
+      int l = lr + 32 * i;
+      if (l >= rows_here) l = rows_here - 1;
+      const long row = row0 + l;
+      const int b = (int)(row / rows_per_scene);
+      const int gc = b * a.m + (int)((row - (long)b * rows_per_scene) / a.ns);
+      const int gp = b * a.n_pts + a.idx[row];
+      xoff[i] = gp * a.c_feat;
+      gxyz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kq4 == 0) {
+        const float *p = a.xyz + (long)gp * 3, *c = a.new_xyz + (long)gc * 3;
+        gxyz[i].x = (p[0] - c[0]) * a.inv_radius;
+        gxyz[i].y = (p[1] - c[1]) * a.inv_radius;
+        gxyz[i].z = (p[2] - c[2]) * a.inv_radius;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < XLD; ++i) {
+      int l = lr + 32 * i;
+      if (l >= rows_here) l = rows_here - 1;
+      xoff[i] = l * (int)a.ldx;
+    }
+  }
+  int woff[WLD];
+#pragma unroll
+  for (int i = 0; i < WLD; ++i) {
+    const int s = tid + G_THREADS * i;
+    if (WMODE == W_NT) {
+      int n = n0 + (s >> 3);
+      if (n >= N) n = N - 1;
+      woff[i] = n * (int)a.ldw;
+    } else {
+      int nn = n0 + 4 * (s % (BN / 4));
+      if (VEC && nn > N - 4) nn = N - 4;
+      woff[i] = nn;
+    }
+  }
+
+  float4 xr[XLD], wr[WLD], bsc, bsh;
+  auto fetch = [&](int kc) {
+    const int k = kc + kq4;
+    if (VEC) {
+      // ---- row operand: unconditional 16-byte loads
+      if (XMODE == X_GATHER) {
+        int f = k - 4;                                  // feature index of this float4
+        if (f > a.c_feat - 4) f = a.c_feat - 4;
+        if (f < 0) f = 0;
+#pragma unroll
+        for (int i = 0; i < XLD; ++i) xr[i] = *reinterpret_cast<const float4 *>(xbase + xoff[i] + f);
+      } else {
+        const int kx = k > K - 4 ? K - 4 : k;
+#pragma unroll
+        for (int i = 0; i < XLD; ++i) xr[i] = *reinterpret_cast<const float4 *>(xbase + xoff[i] + kx);
+        if (XMODE == X_BNRELU) {
+          bsc = *reinterpret_cast<const float4 *>(a.in_scale + kx);
+          bsh = *reinterpret_cast<const float4 *>(a.in_shift + kx);
+        }
+      }
+      // ---- weight
+#pragma unroll
+      for (int i = 0; i < WLD; ++i) {
+        const int s = tid + G_THREADS * i;
+        if (WMODE == W_NT) {
+          if (XMODE == X_GATHER) {
+            // (N, 3 + C) rows are not 16-byte aligned: four element loads, clamped
+            const int kmax = K - 2;                     // last source column = 3 + C - 1 = K - 2
+            float e[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              int sidx = k + u < 4 ? k + u : k + u - 1;
+              if (sidx > kmax) sidx = kmax;
+              e[u] = a.w[woff[i] + sidx];
+            }
+            wr[i] = make_float4(e[0], e[1], e[2], e[3]);
+          } else {
+            const int kx = k > K - 4 ? K - 4 : k;
+            wr[i] = *reinterpret_cast<const float4 *>(a.w + woff[i] + kx);
+          }
+        } else {
+          int c = kc + s / (BN / 4);
+          if (c > K - 1) c = K - 1;
+          if (a.w_elem) {
+            const float *p = a.w + (long)c * a.ldw + woff[i];
+            wr[i] = make_float4(p[0], p[1], p[2], p[3]);
+          } else {
+            wr[i] = *reinterpret_cast<const float4 *>(a.w + (long)c * a.ldw + woff[i]);
+          }
+        }
+      }
+    } else {
+      // ---- element-wise path
+#pragma unroll
+      for (int i = 0; i < XLD; ++i) {
+        float e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int kk = k + u;
+          e[u] = 0.f;
+          if (XMODE == X_GATHER) {
+            if (kk >= 4 && kk < K) e[u] = xbase[xoff[i] + kk - 4];
+          } else if (kk < K) {
+            e[u] = xbase[xoff[i] + kk];
+            if (XMODE == X_BNRELU) e[u] = fmaxf(e[u] * a.in_scale[kk] + a.in_shift[kk], 0.f);
+          }
+        }
+        xr[i] = make_float4(e[0], e[1], e[2], e[3]);
+      }
+#pragma unroll
+      for (int i = 0; i < WLD; ++i) {
+        const int s = tid + G_THREADS * i;
+        float e[4];
+        if (WMODE == W_NT) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int kk = k + u;
+            e[u] = 0.f;
+            if (XMODE == X_GATHER) {
+              if (kk < K && kk != 3) e[u] = a.w[woff[i] + (kk < 4 ? kk : kk - 1)];
+            } else if (kk < K) e[u] = a.w[woff[i] + kk];
+          }
+        } else {
+          const int c = kc + s / (BN / 4);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            e[u] = 0.f;
+            if (c < K && woff[i] + u < N) e[u] = a.w[(long)c * a.ldw + woff[i] + u];
+          }
+        }
+        wr[i] = make_float4(e[0], e[1], e[2], e[3]);
+      }
+    }
+  };
+  // write the fetched chunk kc to LDS (VEC: zero the contraction tail, apply the prologue here)
+  auto stage = [&](int kc) {
+    const int k = kc + kq4;
+    const bool kok = k < K;
+#pragma unroll
+    for (int i = 0; i < XLD; ++i) {
+      float4 v = xr[i];
+      if (VEC) {
+        if (XMODE == X_BNRELU) {
+          v.x = fmaxf(v.x * bsc.x + bsh.x, 0.f); v.y = fmaxf(v.y * bsc.y + bsh.y, 0.f);
+          v.z = fmaxf(v.z * bsc.z + bsh.z, 0.f); v.w = fmaxf(v.w * bsc.w + bsh.w, 0.f);
+        }
+        if (XMODE == X_GATHER && k == 0) v = gxyz[i];
+        if (!kok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else if (XMODE == X_GATHER && k == 0) {
+        v = gxyz[i];
+      }
+      *reinterpret_cast<float4 *>(&Xs[(lr + 32 * i) * G_XS + kq4]) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < WLD; ++i) {
+      const int s = tid + G_THREADS * i;
+      float4 v = wr[i];
+      if (WMODE == W_NT) {
+        if (VEC) {
+          if (XMODE == X_GATHER && k == 0) v.w = 0.f;          // the padding column between xyz and features
+          if (!kok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        *reinterpret_cast<float4 *>(&Ws[(s >> 3) * G_XS + kq4]) = v;
+      } else {
+        if (VEC && kc + s / (BN / 4) >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(&Ws[(s / (BN / 4)) * WSN + 4 * (s % (BN / 4))]) = v;
+      }
+    }
+  };
+
+  f32x4 acc[WC][WR];
+#pragma unroll
+  for (int j = 0; j < WC; ++j)
+#pragma unroll
+    for (int i = 0; i < WR; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const float *xb = Xs + (wave * 16 * WR + (lane & 15)) * G_XS + 4 * (lane >> 4);
+  const float *wb = WMODE == W_NT ? Ws + (lane & 15) * G_XS + 4 * (lane >> 4)
+                                  : Ws + (4 * (lane >> 4)) * WSN + (lane & 15);
+
+  fetch(0);
+  for (int kc = 0; kc < K; kc += G_KC) {
+    stage(kc);
+    __syncthreads();
+    if (kc + G_KC < K) fetch(kc + G_KC);
+#pragma unroll
+    for (int ks = 0; ks < G_KC; ks += 16) {
+      f32x4 bv[WR];
+#pragma unroll
+      for (int i = 0; i < WR; ++i) bv[i] = *reinterpret_cast<const f32x4 *>(xb + 16 * i * G_XS + ks);
+#pragma unroll
+      for (int j = 0; j < WC; ++j) {
+        f32x4 av;
+        if (WMODE == W_NT) av = *reinterpret_cast<const f32x4 *>(wb + 16 * j * G_XS + ks);
+        else {
+          av[0] = wb[(ks + 0) * WSN + 16 * j]; av[1] = wb[(ks + 1) * WSN + 16 * j];
+          av[2] = wb[(ks + 2) * WSN + 16 * j]; av[3] = wb[(ks + 3) * WSN + 16 * j];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < WR; ++i)
+            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[i][s], acc[j][i], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------------
+  // lane: row = row0 + 16*WR*wave + 16*i + (lane&15), columns n0 + 16*j + 4*(lane>>4) + {0..3}
+  const int cq = 4 * (lane >> 4);
+  const bool yvec = (N % 4 == 0) && (a.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15u) == 0);
+  // column partials of this wave (E_STATS / E_MASK) are parked in Xs, which is free after the main
+  // loop's last barrier: [w*BN + c] first statistic of wave w, [4*BN + w*BN + c] second
+  float *red = Xs;
+  auto park = [&](int j, int u, float s1v, float s2v) {
+    s1v = row_sum16(s1v);
+    s2v = row_sum16(s2v);
+    if ((lane & 15) == 0) {
+      red[wave * BN + 16 * j + cq + u] = s1v;
+      red[4 * BN + wave * BN + 16 * j + cq + u] = s2v;
+    }
+  };
+  if (a.epi == E_PLAIN || a.epi == E_STATS) {
+#pragma unroll
+    for (int j = 0; j < WC; ++j) {
+      const int col = n0 + 16 * j + cq;
+      float bb[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (col + u < N) bb[u] = a.bias[col + u];
+      }
+      float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < WR; ++i) {
+        const long row = row0 + 16 * WR * wave + 16 * i + (lane & 15);
+        float o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          o[u] = acc[j][i][u] + bb[u];
+          if (a.relu) o[u] = fmaxf(o[u], 0.f);
+        }
+        if (row < R && col < N) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { t1[u] += o[u]; t2[u] += o[u] * o[u]; }
+          float *p = a.y + row * a.ldy + col;
+          if (yvec) *reinterpret_cast<float4 *>(p) = make_float4(o[0], o[1], o[2], o[3]);
+          else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (col + u < N) p[u] = o[u];
+          }
+        }
+      }
+      if (a.epi == E_STATS) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) park(j, u, t1[u], t2[u]);
+      }
+    }
+  } else if (a.epi == E_MASK) {
+#pragma unroll
+    for (int j = 0; j < WC; ++j) {
+      const int col = n0 + 16 * j + cq;
+      float sc[4], sh[4], mu[4], rs[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool ok = col + u < N;
+        sc[u] = ok ? a.m_scale[col + u] : 0.f; sh[u] = ok ? a.m_shift[col + u] : 0.f;
+        mu[u] = ok ? a.m_mean[col + u] : 0.f; rs[u] = ok ? a.m_rstd[col + u] : 0.f;
+      }
+      float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < WR; ++i) {
+        const long row = row0 + 16 * WR * wave + 16 * i + (lane & 15);
+        if (row < R && col < N) {
+          const float *zp = a.zm + row * a.ldzm + col;
+          float zz[4] = {0.f, 0.f, 0.f, 0.f};
+          if (yvec && (a.ldzm % 4 == 0)) {
+            const float4 z4 = *reinterpret_cast<const float4 *>(zp);
+            zz[0] = z4.x; zz[1] = z4.y; zz[2] = z4.z; zz[3] = z4.w;
+          } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (col + u < N) zz[u] = zp[u];
+          }
+          float o[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float yv = zz[u] * sc[u] + sh[u];
+            o[u] = yv > 0.f ? acc[j][i][u] : 0.f;
+            t1[u] += o[u];
+            t2[u] += o[u] * (zz[u] - mu[u]) * rs[u];
+          }
+          float *p = a.y + row * a.ldy + col;
+          if (yvec) *reinterpret_cast<float4 *>(p) = make_float4(o[0], o[1], o[2], o[3]);
+          else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (col + u < N) p[u] = o[u];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) park(j, u, t1[u], t2[u]);
+    }
+  } else if (a.epi == E_SCATTER) {
+    const long rows_per_scene = (long)a.m * a.ns;
+    const int C = a.c_feat;
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+      const long row = row0 + 16 * WR * wave + 16 * i + (lane & 15);
+      if (row < R) {
+        const int b = (int)(row / rows_per_scene);
+        float *dst = a.dfeats + ((long)b * a.n_pts + a.idx[row]) * C;
+#pragma unroll
+        for (int j = 0; j < WC; ++j) {
+          const int col = n0 + 16 * j + cq;
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (col + u < C) atomicAdd(dst + col + u, acc[j][i][u]);
+        }
+      }
+    }
+  }
+  if (a.epi == E_STATS || a.epi == E_MASK) {
+    __syncthreads();
+    double *d1 = a.epi == E_STATS ? a.sum : a.s1;
+    double *d2 = a.epi == E_STATS ? a.sumsq : a.s2;
+    for (int c = tid; c < BN; c += G_THREADS) {
+      if (n0 + c < N) {
+        const double v1 = (double)red[c] + (double)red[BN + c] + (double)red[2 * BN + c] + (double)red[3 * BN + c];
+        const double v2 = (double)red[4 * BN + c] + (double)red[5 * BN + c] + (double)red[6 * BN + c] +
+                          (double)red[7 * BN + c];
+        // returning atomics: the ticket below must not overtake them (see sa_cl.hip bn_stats_kernel)
+        const double o1 = atomicAdd(d1 + n0 + c, v1);
+        const double o2 = atomicAdd(d2 + n0 + c, v2);
+        asm volatile("" ::"v"(o1), "v"(o2));
+      }
+    }
+    if (a.epi == E_STATS) {
+      __syncthreads();
+      if (tid == 0)
+        is_last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                  (unsigned)(a.row_blocks * a.col_tiles - 1);
+      __syncthreads();
+      if (is_last) {
+        for (int c = tid; c < N; c += G_THREADS) {
+          const double su = __hip_atomic_load(a.sum + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const double sq = __hip_atomic_load(a.sumsq + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(a.sum + c, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(a.sumsq + c, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const double mean = su / (double)R;
+          double var = sq / (double)R - mean * mean;
+          if (var < 0.0) var = 0.0;
+          const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+          const float meanf = (float)mean;
+          a.mean_out[c] = meanf;
+          a.rstd_out[c] = rstd;
+          const float scv = a.gamma[c] * rstd;
+          a.scale_out[c] = scv;
+          a.shift_out[c] = a.beta[c] - meanf * scv;
+          if (a.running_mean) {
+            const double unbiased = R > 1 ? var * (double)R / (double)(R - 1) : var;
+            a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * meanf;
+            a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+          }
+        }
+        if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
+bool gemm_vec_ok(const GemmArgs &a, int wmode) {
+  auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  if (a.xmode == X_GATHER) {
+    if (a.c_feat % 4 != 0 || a.c_feat < 4 || !al16(a.feats)) return false;
+    return wmode == W_NT;
+  }
+  if (a.K % 4 != 0 || a.K < 4 || a.ldx % 4 != 0 || !al16(a.x)) return false;
+  if (a.xmode == X_BNRELU && (!al16(a.in_scale) || !al16(a.in_shift))) return false;
+  if (wmode == W_NT) return a.ldw % 4 == 0 && al16(a.w);
+  if (a.N < 4 || a.N % 4 != 0) return false;
+  return true;
+}
+
+template <int WR, int WC, bool VEC>
+int launch_cfg(GemmArgs &a, int wmode, hipStream_t stream) {
+  constexpr int BM = 64 * WR, BN = 16 * WC;
+  a.row_blocks = (a.R + BM - 1) / BM;
+  a.col_tiles = (a.N + BN - 1) / BN;
+  const long groups = (a.row_blocks + 7) / 8;
+  const long blocks = groups * 8 * a.col_tiles;
+  if (blocks > 0x7fffffffL) { eda_set_error("gemm: grid too large"); return EDA_ERR_INVALID_ARG; }
+  const dim3 grid((unsigned)blocks), block(G_THREADS);
+  if (wmode == W_NN)
+    hipLaunchKernelGGL((gemm_rows_kernel<WR, WC, W_NN, X_PLAIN, VEC>), grid, block, 0, stream, a);
+  else if (a.xmode == X_PLAIN)
+    hipLaunchKernelGGL((gemm_rows_kernel<WR, WC, W_NT, X_PLAIN, VEC>), grid, block, 0, stream, a);
+  else if (a.xmode == X_BNRELU)
+    hipLaunchKernelGGL((gemm_rows_kernel<WR, WC, W_NT, X_BNRELU, VEC>), grid, block, 0, stream, a);
+  else
+    hipLaunchKernelGGL((gemm_rows_kernel<WR, WC, W_NT, X_GATHER, VEC>), grid, block, 0, stream, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { eda_set_error("gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+
+int g_force_cfg() {
+  static int v = -2;
+  if (v == -2) { const char *e = getenv("EDA_GEMM_CFG"); v = e ? atoi(e) : -1; }
+  return v;
+}
+
+}  // namespace
+
+// Tile selection: the column tile that pads least (96 for the 288-multiples, 128 / 64 for the
+// powers of two), 128-row blocks when that still gives >= 2 workgroups per CU, else 64-row blocks.
+// Operands that are not 16-byte addressable take the element-wise 64x64 kernel.
+// EDA_GEMM_CFG=<WR><WC> forces a tile (e.g. 26).
+int eda_gemm_launch(GemmArgs &a, int wmode, hipStream_t stream) {
+  if (a.R <= 0 || a.N <= 0) return 0;
+  if (wmode == W_NN && a.xmode != X_PLAIN) { eda_set_error("gemm: dX form takes plain rows"); return EDA_ERR_INVALID_ARG; }
+  // 32-bit element offsets: per 64/128-row tile for plain rows, from the tensor base for the gather
+  if ((long)(64 * 2) * a.ldx >= 0x7fffffffL || (long)(wmode == W_NT ? a.N : a.K) * a.ldw >= 0x7fffffffL ||
+      (a.xmode == X_GATHER && (long)a.n_pts * (a.c_feat > 3 ? a.c_feat : 3) *
+                                  ((a.R + (long)a.m * a.ns - 1) / ((long)a.m * a.ns)) >= 0x7fffffffL)) {
+    eda_set_error("gemm: operand too large for 32-bit element offsets");
+    return EDA_ERR_INVALID_ARG;
+  }
+  if (!gemm_vec_ok(a, wmode)) return launch_cfg<1, 4, false>(a, wmode, stream);
+  a.w_elem = (wmode == W_NN) && (a.ldw % 4 != 0 || (reinterpret_cast<uintptr_t>(a.w) & 15u) != 0);
+  // measured on MI355X (tools/bench_gemm.py, profiles/r02a_gemm_tiles.txt): the 64x64 tile at 5-6
+  // waves per SIMD beats the 128-row tiles at 2-4 on every shape of the path; 64x128 is a few
+  // per cent ahead for the 128-multiples with many rows
+  const int N = a.N;
+  int wr = 1, wc = 4;
+  if (N % 128 == 0 && a.R >= 32768) wc = 8;
+  const int f = g_force_cfg();
+  if (f > 0) { wr = f / 10; wc = f % 10; }
+  if (wr == 2) {
+    switch (wc) {
+      case 4: return launch_cfg<2, 4, true>(a, wmode, stream);
+      case 6: return launch_cfg<2, 6, true>(a, wmode, stream);
+      default: return launch_cfg<2, 8, true>(a, wmode, stream);
+    }
+  }
+  switch (wc) {
+    case 4: return launch_cfg<1, 4, true>(a, wmode, stream);
+    case 6: return launch_cfg<1, 6, true>(a, wmode, stream);
+    default: return launch_cfg<1, 8, true>(a, wmode, stream);
+  }
+}
+
+// ---- C ABI: plain linear layers ----------------------------------------------------------------
+static void gemm_defaults(GemmArgs &a) {
+  memset(&a, 0, sizeof(a));
+}
+
+extern "C" int eda_linear_fwd_f32(const float *x, long ldx, long R, int K, const float *w, long ldw, int N,
+                                  const float *bias, int relu, float *y, long ldy, void *stream_) {
+  EDA_CHECK_ARG(R >= 0 && K > 0 && N > 0 && ldx >= K && ldw >= K && ldy >= N, "bad dimension");
+  if (R == 0) return 0;
+  EDA_CHECK_ARG(x && w && y, "null pointer");
+  GemmArgs a;
+  gemm_defaults(a);
+  a.xmode = X_PLAIN; a.epi = E_PLAIN;
+  a.x = x; a.ldx = ldx; a.R = R; a.K = K;
+  a.w = w; a.ldw = ldw; a.N = N; a.bias = bias; a.relu = relu;
+  a.y = y; a.ldy = ldy;
+  return eda_gemm_launch(a, W_NT, (hipStream_t)stream_);
+}
+
+extern "C" int eda_linear_dgrad_f32(const float *dy, long lddy, long R, int N, const float *w, long ldw, int K,
+                                    float *dx, long lddx, void *stream_) {
+  EDA_CHECK_ARG(R >= 0 && K > 0 && N > 0 && lddy >= N && ldw >= K && lddx >= K, "bad dimension");
+  if (R == 0) return 0;
+  EDA_CHECK_ARG(dy && w && dx, "null pointer");
+  GemmArgs a;
+  gemm_defaults(a);
+  a.xmode = X_PLAIN; a.epi = E_PLAIN;
+  a.x = dy; a.ldx = lddy; a.R = R; a.K = N;      // contraction over the layer's output channels
+  a.w = w; a.ldw = ldw; a.N = K;                 // W (N, K) read as (contraction, output column)
+  a.y = dx; a.ldy = lddx;
+  return eda_gemm_launch(a, W_NN, (hipStream_t)stream_);
+}

@@ -19,6 +19,8 @@
 // Results equal the reference's to fp32 rounding (tested against goldens generated
 // by the reference's own modules, tests/golden/model_sa_*).
 #include "eda_common.h"
+#include "gemm.h"
+#include <string.h>
 
 namespace {
 
@@ -841,5 +843,255 @@ extern "C" int eda_bn_relu_bwd_f32(const float *dout, const unsigned char *argma
                        dout, argmax, z, R, C, pool, mean, rstd, scale, shift, gamma, ws, ws + C, training,
                        dgamma, dbeta, dz);
   EDA_CHECK_LAUNCH();
+  return 0;
+}
+
+
+// =================================================================================================
+// Fused SharedMLP pipeline: QueryAndGroup (or plain rows) -> L x [conv1x1 -> BatchNorm -> ReLU] ->
+// max-pool over the nsample rows of a centre (or plain rows out).  Reference chain:
+// pointnet2/pointnet2_utils.py:317-376 -> pointnet2/pytorch_utils.py:67-120 ->
+// pointnet2/pointnet2_modules.py:251-257 (SA) / :407-414 (FP).
+//
+// Per layer ONE launch of csrc/gemm.hip's row GEMM: the neighbourhood gather (layer 0) or the
+// previous layer's BatchNorm+ReLU (layers >= 1) happens while the row operand is staged into LDS,
+// the BatchNorm statistics of the layer's own output come out of the accumulators (E_STATS, last
+// workgroup finalises).  Neither the grouped tensor nor any activated tensor is written to HBM;
+// what is kept is the pre-activation z_l of every layer (the backward needs it densely: the
+// train-mode BatchNorm backward has a mean and a variance term on every row).
+// Backward per layer: weight gradient with the same prologue (wgrad.hip), input gradient with the
+// ReLU mask of the layer below and that layer's two BatchNorm reductions in the epilogue (E_MASK),
+// then one element-wise pass dz = A*gy + B*z + D; the first layer's input gradient is scattered
+// straight into d(features) (E_SCATTER).
+namespace {
+struct MlpGeom {
+  const float *x; long ldx;
+  const float *xyz, *new_xyz, *feats; const int *idx;
+  int b, n, m, ns, c_feat; float inv_radius;
+  bool gather;
+};
+
+void mlp_row_operand(GemmArgs &a, const MlpGeom &g, int l, int c_in, const float *z_prev, const float *stats_prev) {
+  if (l == 0) {
+    if (g.gather) {
+      a.xmode = X_GATHER;
+      a.xyz = g.xyz; a.new_xyz = g.new_xyz; a.feats = g.feats; a.idx = g.idx;
+      a.n_pts = g.n; a.m = g.m; a.ns = g.ns; a.c_feat = g.c_feat; a.inv_radius = g.inv_radius;
+      a.K = 4 + g.c_feat;
+    } else {
+      a.xmode = X_PLAIN; a.x = g.x; a.ldx = g.ldx; a.K = c_in;
+    }
+  } else {
+    a.xmode = X_BNRELU; a.x = z_prev; a.ldx = c_in; a.K = c_in;
+    a.in_scale = stats_prev + 2 * c_in; a.in_shift = stats_prev + 3 * c_in;
+  }
+}
+
+int check_mlp(int nlayers, const int *channels, long R, int pool, const MlpGeom &g) {
+  EDA_CHECK_ARG(nlayers >= 1 && nlayers <= 8 && channels, "1..8 layers");
+  EDA_CHECK_ARG(R >= 0 && pool >= 1 && pool <= 255 && R % pool == 0, "rows must be a multiple of the pooling width");
+  for (int l = 1; l <= nlayers; ++l)
+    EDA_CHECK_ARG(channels[l] > 0 && channels[l] % 4 == 0 && channels[l] <= 1024, "layer widths must be multiples of 4 (<= 1024)");
+  if (g.gather) {
+    EDA_CHECK_ARG(g.xyz && g.new_xyz && g.idx && (g.feats || g.c_feat == 0), "null pointer");
+    EDA_CHECK_ARG(channels[0] == 3 + g.c_feat, "channels[0] must be 3 + c_feat");
+    EDA_CHECK_ARG(R == (long)g.b * g.m * g.ns, "row count must be b*m*ns");
+    EDA_CHECK_ARG(pool == 1 || pool == g.ns, "pooling width must be nsample");
+  } else {
+    EDA_CHECK_ARG(g.x && g.ldx >= channels[0] && channels[0] > 0, "bad plain-row input");
+  }
+  return 0;
+}
+}  // namespace
+
+extern "C" int eda_sa_fused_fwd_f32(const float *x, long ldx, const float *xyz, const float *new_xyz,
+                                    const float *feats_cl, const int *idx, int b, int n, int m, int ns, int c_feat,
+                                    float radius, int normalize_xyz, long R, int nlayers, const int *channels,
+                                    const float *const *weight, const float *const *gamma, const float *const *beta,
+                                    float *const *running_mean, float *const *running_var, float eps, float momentum,
+                                    int training, int pool, float *const *z, float *const *stats, double *ws,
+                                    float *out, unsigned char *argmax, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  MlpGeom g = {x, ldx, xyz, new_xyz, feats_cl, idx, b, n, m, ns, c_feat, normalize_xyz ? 1.0f / radius : 1.0f, idx != nullptr};
+  { const int rc = check_mlp(nlayers, channels, R, pool, g); if (rc) return rc; }
+  if (R == 0) return 0;
+  EDA_CHECK_ARG(weight && gamma && beta && z && stats && out, "null pointer");
+  EDA_CHECK_ARG(!training || ws, "workspace required in training mode");
+  EDA_CHECK_ARG(pool == 1 || argmax, "argmax buffer required when pooling");
+  for (int l = 0; l < nlayers; ++l) {
+    const int cin = channels[l], cout = channels[l + 1];
+    float *st = stats[l];
+    EDA_CHECK_ARG(weight[l] && gamma[l] && beta[l] && z[l] && st, "null pointer");
+    if (!training) {
+      EDA_CHECK_ARG(running_mean && running_var && running_mean[l] && running_var[l], "eval mode needs running statistics");
+      hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((cout + 255) / 256), dim3(256), 0, stream, running_mean[l],
+                         running_var[l], gamma[l], beta[l], eps, cout, st, st + cout, st + 2 * cout, st + 3 * cout);
+      EDA_CHECK_LAUNCH();
+    }
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.R = R;
+    mlp_row_operand(a, g, l, cin, l ? z[l - 1] : nullptr, l ? stats[l - 1] : nullptr);
+    a.w = weight[l]; a.ldw = cin; a.N = cout;
+    a.y = z[l]; a.ldy = cout;
+    if (training) {
+      a.epi = E_STATS;
+      a.sum = ws; a.sumsq = ws + cout; a.ticket = reinterpret_cast<unsigned *>(ws + 2 * cout);
+      a.gamma = gamma[l]; a.beta = beta[l]; a.eps = eps; a.momentum = momentum;
+      a.running_mean = running_mean ? running_mean[l] : nullptr;
+      a.running_var = running_var ? running_var[l] : nullptr;
+      a.mean_out = st; a.rstd_out = st + cout; a.scale_out = st + 2 * cout; a.shift_out = st + 3 * cout;
+    } else {
+      a.epi = E_PLAIN;
+    }
+    const int rc = eda_gemm_launch(a, W_NT, stream);
+    if (rc) return rc;
+  }
+  const int C = channels[nlayers];
+  const float *st = stats[nlayers - 1];
+  if (pool > 1)
+    hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(grid_for(R / pool * (C / 4))), dim3(CL_THREADS), 0, stream,
+                       z[nlayers - 1], R / pool, pool, C, st + 2 * C, st + 3 * C, out, argmax);
+  else
+    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(grid_for(R * C / 4)), dim3(CL_THREADS), 0, stream, z[nlayers - 1],
+                       R * C / 4, C, st + 2 * C, st + 3 * C, out);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" size_t eda_sa_fused_bwd_workspace_bytes(long R, int nlayers, const int *channels, int gather) {
+  if (R <= 0 || nlayers < 1 || !channels) return 0;
+  size_t slabs = 0;
+  int cmax = 0;
+  for (int l = 0; l < nlayers; ++l) {
+    const int ncols = (l == 0 && gather) ? channels[0] + 1 : channels[l];
+    const size_t sbytes = eda_wgrad_x_workspace_bytes(R, channels[l + 1], ncols);
+    if (sbytes > slabs) slabs = sbytes;
+    if (channels[l + 1] > cmax) cmax = channels[l + 1];
+  }
+  return sizeof(double) * 2 * (size_t)cmax + slabs;
+}
+
+extern "C" int eda_sa_fused_bwd_f32(const float *dout, const unsigned char *argmax, const float *x, long ldx,
+                                    const float *xyz, const float *new_xyz, const float *feats_cl, const int *idx,
+                                    int b, int n, int m, int ns, int c_feat, float radius, int normalize_xyz, long R,
+                                    int nlayers, const int *channels, const float *const *weight,
+                                    const float *const *gamma, const float *const *z, const float *const *stats,
+                                    int training, int pool, float *scratch_a, float *scratch_b, void *ws_,
+                                    size_t ws_bytes, float *const *dW, float *const *dgamma, float *const *dbeta,
+                                    float *dx, long lddx, float *dfeats_cl, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  MlpGeom g = {x, ldx, xyz, new_xyz, feats_cl, idx, b, n, m, ns, c_feat, normalize_xyz ? 1.0f / radius : 1.0f, idx != nullptr};
+  { const int rc = check_mlp(nlayers, channels, R, pool, g); if (rc) return rc; }
+  EDA_CHECK_ARG(weight && gamma && z && stats && dW && dgamma && dbeta, "null pointer");
+  if (g.gather && dfeats_cl) {
+    const int zrc = eda_zero_async(dfeats_cl, sizeof(float) * (size_t)b * n * c_feat, stream);
+    if (zrc) return zrc;
+  }
+  if (R == 0) {
+    for (int l = 0; l < nlayers; ++l) {
+      int rc = eda_zero_async(dW[l], sizeof(float) * (size_t)channels[l] * channels[l + 1], stream);
+      if (!rc) rc = eda_zero_async(dgamma[l], sizeof(float) * channels[l + 1], stream);
+      if (!rc) rc = eda_zero_async(dbeta[l], sizeof(float) * channels[l + 1], stream);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  EDA_CHECK_ARG(dout && scratch_a && scratch_b && ws_, "null pointer");
+  EDA_CHECK_ARG(ws_bytes >= eda_sa_fused_bwd_workspace_bytes(R, nlayers, channels, g.gather) &&
+                    (reinterpret_cast<uintptr_t>(ws_) & 15u) == 0, "workspace too small or misaligned");
+  EDA_CHECK_ARG(pool == 1 || argmax, "argmax required when pooling");
+  int cmax = 0;
+  for (int l = 1; l <= nlayers; ++l) if (channels[l] > cmax) cmax = channels[l];
+  double *red = reinterpret_cast<double *>(ws_);
+  float *slabs = reinterpret_cast<float *>(red + 2 * cmax);
+  const size_t slab_bytes = ws_bytes - sizeof(double) * 2 * (size_t)cmax;
+
+  // ---- last layer: BatchNorm+ReLU(+pool) backward from d(out) -> dz in scratch_a
+  {
+    const int l = nlayers - 1, C = channels[nlayers];
+    const float *st = stats[l];
+    { const int zrc = eda_zero_async(red, sizeof(double) * 2 * C, stream); if (zrc) return zrc; }
+    int nblocks = 1024;
+    long rpb = (R + nblocks - 1) / nblocks;
+    if (rpb < 64) rpb = 64;
+    rpb = (rpb + pool - 1) / pool * pool;
+    nblocks = (int)((R + rpb - 1) / rpb);
+    if (pool > 1)
+      hipLaunchKernelGGL(bn_relu_bwd_stats_kernel<true>, dim3(nblocks), dim3(CL_THREADS), 0, stream, dout, argmax, z[l],
+                         R, C, pool, rpb, st, st + C, st + 2 * C, st + 3 * C, red, red + C);
+    else
+      hipLaunchKernelGGL(bn_relu_bwd_stats_vec_kernel, dim3(nblocks), dim3(CL_THREADS), 0, stream, dout, z[l], R, C, rpb,
+                         st, st + C, st + 2 * C, st + 3 * C, red, red + C);
+    EDA_CHECK_LAUNCH();
+    const int apply_grid = grid_for(R * (C / 4));
+    if (pool > 1)
+      hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<true>, dim3(apply_grid), dim3(CL_THREADS), 0, stream, dout, argmax,
+                         z[l], R, C, pool, st, st + C, st + 2 * C, st + 3 * C, gamma[l], red, red + C, training,
+                         dgamma[l], dbeta[l], scratch_a);
+    else
+      hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<false>, dim3(apply_grid), dim3(CL_THREADS), 0, stream, dout, argmax,
+                         z[l], R, C, pool, st, st + C, st + 2 * C, st + 3 * C, gamma[l], red, red + C, training,
+                         dgamma[l], dbeta[l], scratch_a);
+    EDA_CHECK_LAUNCH();
+  }
+  float *cur = scratch_a, *other = scratch_b;
+  for (int l = nlayers - 1; l >= 0; --l) {
+    const int cin = channels[l], cout = channels[l + 1];
+    // ---- weight gradient: dW_l = dz_l^T (row operand of the forward GEMM, recomputed while staging)
+    {
+      WgradXArgs wa;
+      memset(&wa, 0, sizeof(wa));
+      wa.dy = cur; wa.ld_dy = cout; wa.R = R; wa.M = cout;
+      if (l == 0 && g.gather) {
+        wa.xmode = X_GATHER;
+        wa.xyz = xyz; wa.new_xyz = new_xyz; wa.feats = feats_cl; wa.idx = idx;
+        wa.n_pts = n; wa.m = m; wa.ns = ns; wa.c_feat = c_feat; wa.inv_radius = g.inv_radius;
+        wa.N = 4 + c_feat;
+      } else if (l == 0) {
+        wa.xmode = X_PLAIN; wa.x = x; wa.ld_x = ldx; wa.N = cin;
+      } else {
+        wa.xmode = X_BNRELU; wa.x = z[l - 1]; wa.ld_x = cin; wa.N = cin;
+        wa.in_scale = stats[l - 1] + 2 * cin; wa.in_shift = stats[l - 1] + 3 * cin;
+      }
+      wa.dW = dW[l]; wa.ws = slabs; wa.ws_bytes = slab_bytes;
+      const int rc = eda_wgrad_x_launch(wa, stream);
+      if (rc) return rc;
+    }
+    // ---- input gradient
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xmode = X_PLAIN; a.x = cur; a.ldx = cout; a.R = R; a.K = cout;
+    a.w = weight[l]; a.ldw = cin;
+    if (l > 0) {
+      const float *st = stats[l - 1];
+      { const int zrc = eda_zero_async(red, sizeof(double) * 2 * cin, stream); if (zrc) return zrc; }
+      a.N = cin; a.y = other; a.ldy = cin;
+      a.epi = E_MASK;
+      a.zm = z[l - 1]; a.ldzm = cin;
+      a.m_mean = st; a.m_rstd = st + cin; a.m_scale = st + 2 * cin; a.m_shift = st + 3 * cin;
+      a.s1 = red; a.s2 = red + cin;
+      const int rc = eda_gemm_launch(a, W_NN, stream);
+      if (rc) return rc;
+      // dz_{l-1} = A*gy + B*z + D, in place (gy is already masked: the kernel's mask is idempotent)
+      hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<false>, dim3(grid_for(R * (cin / 4))), dim3(CL_THREADS), 0, stream,
+                         other, nullptr, z[l - 1], R, cin, 1, st, st + cin, st + 2 * cin, st + 3 * cin, gamma[l - 1],
+                         red, red + cin, training, dgamma[l - 1], dbeta[l - 1], other);
+      EDA_CHECK_LAUNCH();
+      float *t = cur; cur = other; other = t;
+    } else if (g.gather) {
+      if (dfeats_cl && c_feat > 0) {
+        a.w = weight[0] + 3;                                   // feature columns of the (C1, 3 + c_feat) weight
+        a.N = c_feat; a.epi = E_SCATTER;
+        a.idx = idx; a.n_pts = n; a.m = m; a.ns = ns; a.c_feat = c_feat; a.dfeats = dfeats_cl;
+        const int rc = eda_gemm_launch(a, W_NN, stream);
+        if (rc) return rc;
+      }
+    } else if (dx) {
+      a.N = cin; a.y = dx; a.ldy = lddx; a.epi = E_PLAIN;
+      const int rc = eda_gemm_launch(a, W_NN, stream);
+      if (rc) return rc;
+    }
+  }
   return 0;
 }

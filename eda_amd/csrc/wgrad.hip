@@ -16,6 +16,7 @@
 // split the first kernel writes dW directly.  Workgroups of the first column tile also sum
 // their dY chunk's columns from LDS: d(bias) costs no extra pass over dY.
 #include "eda_common.h"
+#include "gemm.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -363,5 +364,274 @@ extern "C" int eda_wgrad_f32(const float *dy, long ld_dy, const float *x, long l
                        reinterpret_cast<const float *>(ws), p.splits, (long)M * N, M, dW, db);
     EDA_CHECK_LAUNCH();
   }
+  return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The same split-K kernel with a PROLOGUE on the X operand: the fused set-abstraction / feature-
+// propagation pipeline (sa_cl.hip) never writes the activated tensor relu(BN(z)) nor the grouped
+// neighbourhood rows to HBM, so the weight gradient recomputes them while staging X into LDS --
+// exactly what csrc/gemm.hip's forward kernel does with its row operand.  The K axis here is the
+// row axis (up to 10^6 positions), always split; dY is read as stored (16-byte rows).
+template <int XMODE>
+__global__ __launch_bounds__(WG_THREADS) void wgrad_x_kernel(const WgradXArgs a, int chunks_per_split, int tiles_n,
+                                                             int ntiles, int nsplits) {
+  __shared__ float As[WG_KC][WG_STRIDE];
+  __shared__ float Bs[WG_KC][WG_STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wh = w & 1;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int s = xcd + 8 * (j / ntiles);
+  if (s >= nsplits) return;
+  const int tile = j - (j / ntiles) * ntiles;
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * WG_T, n0 = tn * WG_T;
+  const int M = a.M, N = a.N;
+  const long K = a.R;
+  const long kbeg = (long)s * chunks_per_split * WG_KC;
+  long kend = kbeg + (long)chunks_per_split * WG_KC;
+  if (kend > K) kend = K;
+  if (kbeg >= kend) return;
+
+  float4 ra[WG_LD], rb[WG_LD];
+  int lrow[WG_LD], lcol[WG_LD];
+#pragma unroll
+  for (int i = 0; i < WG_LD; ++i) {
+    const int idx = tid + WG_THREADS * i;
+    lrow[i] = idx / (WG_T / 4);
+    lcol[i] = (idx - lrow[i] * (WG_T / 4)) * 4;
+  }
+  // column constants of the prologue (the column of a thread's float4 never changes)
+  float4 bsc[WG_LD], bsh[WG_LD];
+  if (XMODE == X_BNRELU) {
+#pragma unroll
+    for (int i = 0; i < WG_LD; ++i) {
+      const int c = n0 + lcol[i] < N ? n0 + lcol[i] : N - 4;
+      bsc[i] = *reinterpret_cast<const float4 *>(a.in_scale + c);
+      bsh[i] = *reinterpret_cast<const float4 *>(a.in_shift + c);
+    }
+  }
+  const bool cvec = (a.c_feat & 3) == 0;
+  // plain rows that are not 16-byte addressable (odd channel counts): element loads
+  const bool x_elem = XMODE == X_PLAIN && ((N & 3) != 0 || (a.ld_x & 3) != 0 || (reinterpret_cast<uintptr_t>(a.x) & 15u) != 0);
+  const long rows_per_scene = (long)a.m * a.ns;
+  int gp[WG_LD];                       // X_GATHER: b*n_pts + point of the row being fetched NEXT
+  auto fetch_idx = [&](long k0) {
+#pragma unroll
+    for (int i = 0; i < WG_LD; ++i) {
+      long k = k0 + lrow[i];
+      if (k >= kend) k = kend - 1;
+      const int b = (int)(k / rows_per_scene);
+      gp[i] = b * a.n_pts + a.idx[k];
+    }
+  };
+  float gx[WG_LD][3], gc[WG_LD][3];    // raw point / centre coordinates of the xyz quad (stage-time arithmetic)
+  auto fetch = [&](long k0) {
+#pragma unroll
+    for (int i = 0; i < WG_LD; ++i) {
+      long k = k0 + lrow[i];
+      if (k >= kend) k = kend - 1;                       // clamped: zeroed when staged
+      const int mc = m0 + lcol[i] < M ? m0 + lcol[i] : M - 4;
+      ra[i] = *reinterpret_cast<const float4 *>(a.dy + k * a.ld_dy + mc);
+      const int nc = n0 + lcol[i];
+      if (XMODE == X_GATHER) {
+        const int C = a.c_feat;
+        if (nc == 0) {
+          const int b = (int)(k / rows_per_scene);
+          const int cen = b * a.m + (int)((k - (long)b * rows_per_scene) / a.ns);
+#pragma unroll
+          for (int u = 0; u < 3; ++u) { gx[i][u] = a.xyz[(long)gp[i] * 3 + u]; gc[i][u] = a.new_xyz[(long)cen * 3 + u]; }
+          rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if (C == 0) {
+          rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if (cvec) {
+          int f = nc - 4;
+          if (f > C - 4) f = C - 4;
+          rb[i] = *reinterpret_cast<const float4 *>(a.feats + (long)gp[i] * C + f);
+        } else {
+          float e[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { int f = nc - 4 + u; if (f > C - 1) f = C - 1; e[u] = a.feats[(long)gp[i] * C + f]; }
+          rb[i] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+      } else if (x_elem) {
+        float e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int c = nc + u < N ? nc + u : N - 1; e[u] = a.x[k * a.ld_x + c]; }
+        rb[i] = make_float4(e[0], e[1], e[2], e[3]);
+      } else {
+        const int c = nc < N ? nc : N - 4;
+        rb[i] = *reinterpret_cast<const float4 *>(a.x + k * a.ld_x + c);
+      }
+    }
+  };
+  auto stage = [&](long k0) {
+#pragma unroll
+    for (int i = 0; i < WG_LD; ++i) {
+      const bool rowok = k0 + lrow[i] < kend;
+      float4 va = ra[i], vb = rb[i];
+      const int nc = n0 + lcol[i];
+      if (XMODE == X_BNRELU) {
+        vb.x = fmaxf(vb.x * bsc[i].x + bsh[i].x, 0.f); vb.y = fmaxf(vb.y * bsc[i].y + bsh[i].y, 0.f);
+        vb.z = fmaxf(vb.z * bsc[i].z + bsh[i].z, 0.f); vb.w = fmaxf(vb.w * bsc[i].w + bsh[i].w, 0.f);
+      }
+      if (XMODE == X_GATHER) {
+        if (nc == 0)
+          vb = make_float4((gx[i][0] - gc[i][0]) * a.inv_radius, (gx[i][1] - gc[i][1]) * a.inv_radius,
+                           (gx[i][2] - gc[i][2]) * a.inv_radius, 0.f);
+        else if (!cvec) {
+          const int C = a.c_feat;
+          if (nc - 4 + 0 >= C) vb.x = 0.f;
+          if (nc - 4 + 1 >= C) vb.y = 0.f;
+          if (nc - 4 + 2 >= C) vb.z = 0.f;
+          if (nc - 4 + 3 >= C) vb.w = 0.f;
+        }
+      }
+      if (x_elem) {
+        if (nc + 1 >= N) vb.y = 0.f;
+        if (nc + 2 >= N) vb.z = 0.f;
+        if (nc + 3 >= N) vb.w = 0.f;
+      }
+      if (!rowok || m0 + lcol[i] >= M) va = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!rowok || nc >= N) vb = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4 *>(&As[lrow[i]][lcol[i]]) = va;
+      *reinterpret_cast<float4 *>(&Bs[lrow[i]][lcol[i]]) = vb;
+    }
+  };
+
+  f32x4 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool active = (m0 + 16 * wm < M) && (n0 + 48 * wh < N);
+  const float *ap = &As[lane >> 4][16 * wm + (lane & 15)];
+  const float *bp = &Bs[lane >> 4][48 * wh + (lane & 15)];
+
+  if (XMODE == X_GATHER) fetch_idx(kbeg);
+  fetch(kbeg);
+  if (XMODE == X_GATHER && kbeg + WG_KC < kend) fetch_idx(kbeg + WG_KC);
+  for (long k0 = kbeg; k0 < kend; k0 += WG_KC) {
+    stage(k0);
+    __syncthreads();
+    if (k0 + WG_KC < kend) {
+      fetch(k0 + WG_KC);                                 // uses the indices loaded one chunk earlier
+      if (XMODE == X_GATHER && k0 + 2 * WG_KC < kend) fetch_idx(k0 + 2 * WG_KC);
+    }
+    if (active) {
+#pragma unroll
+      for (int half = 0; half < 4; ++half) {
+        float av[WG_KC / 16], bv[3][WG_KC / 16];
+#pragma unroll
+        for (int kk = 0; kk < WG_KC / 16; ++kk) {
+          av[kk] = ap[(half * (WG_KC / 16) + kk) * 4 * WG_STRIDE];
+#pragma unroll
+          for (int t = 0; t < 3; ++t) bv[t][kk] = bp[(half * (WG_KC / 16) + kk) * 4 * WG_STRIDE + 16 * t];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < WG_KC / 16; ++kk) {
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv[t][kk], acc[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+  }
+  // partial tile of split s -> slab s of the workspace (M x N floats, kernel column order)
+  float *o = a.ws + (long)s * M * N;
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int col = n0 + 48 * wh + 16 * t + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 16 * wm + 4 * (lane >> 4) + r;
+        if (row < M && col < N) o[(long)row * N + col] = acc[t][r];
+      }
+    }
+  }
+}
+
+// dW[m][dst(n)] = sum_s slab[s][m][n].  A block owns 32 consecutive elements, 8 lanes of splits per
+// element (each sums every 8th slab, then the 8 partial sums are added in lane order: deterministic).
+// gather: kernel column n of [dx dy dz 0 | feats] goes to column n (n < 3) / n - 1 (n >= 4) of the
+// (M, 3 + c_feat) weight; column 3 is padding.
+__global__ __launch_bounds__(256) void wgrad_x_reduce_kernel(const float *__restrict__ partial, int S, int M, int N,
+                                                             int gather, float *__restrict__ dW) {
+  __shared__ float red[8][32];
+  const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const long MN = (long)M * N;
+  const long e = (long)blockIdx.x * 32 + el;
+  float t = 0.f;
+  if (e < MN) {
+#pragma unroll 4
+    for (int s = sl; s < S; s += 8) t += partial[(long)s * MN + e];
+  }
+  red[sl][el] = t;
+  __syncthreads();
+  if (sl != 0 || e >= MN) return;
+  t = ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) + ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
+  if (!gather) { dW[e] = t; return; }
+  const int m = (int)(e / N), n = (int)(e - (long)m * N);
+  if (n == 3) return;
+  dW[(long)m * (N - 1) + (n < 3 ? n : n - 1)] = t;
+}
+
+namespace {
+WgPlan wgx_plan(long R, int M, int N) {
+  WgPlan p;
+  p.tiles_m = (M + WG_T - 1) / WG_T;
+  p.tiles_n = (N + WG_T - 1) / WG_T;
+  const long nchunks = (R + WG_KC - 1) / WG_KC;
+  // ~512 workgroups (2 x 12 waves per CU on 256 CUs), at least 4 chunks per split
+  long want = (512 + p.tiles_m * p.tiles_n - 1) / (p.tiles_m * p.tiles_n);
+  if (want > nchunks / 4) want = nchunks / 4;
+  if (want < 1) want = 1;
+  if (want >= 8) want = want / 8 * 8;
+  p.cps = (int)((nchunks + want - 1) / want);
+  p.splits = (int)((nchunks + p.cps - 1) / p.cps);
+  return p;
+}
+}  // namespace
+
+size_t eda_wgrad_x_workspace_bytes(long R, int M, int N) {
+  if (R <= 0 || M <= 0 || N <= 0) return 0;
+  const WgPlan p = wgx_plan(R, M, N);
+  return sizeof(float) * (size_t)p.splits * (size_t)M * N;
+}
+
+int eda_wgrad_x_launch(const WgradXArgs &a, hipStream_t stream) {
+  if (a.R <= 0) {
+    const int ncols = a.xmode == X_GATHER ? a.N - 1 : a.N;
+    return eda_zero_async(a.dW, sizeof(float) * (size_t)a.M * ncols, stream);
+  }
+  if (a.M % 4 != 0 || a.ld_dy % 4 != 0 || (reinterpret_cast<uintptr_t>(a.dy) & 15u) != 0 || a.M < 4) {
+    eda_set_error("wgrad_x: dY rows must be 16-byte addressable");
+    return EDA_ERR_INVALID_ARG;
+  }
+  if (a.xmode == X_BNRELU && (a.N % 4 != 0 || a.N < 4 || a.ld_x % 4 != 0 || (reinterpret_cast<uintptr_t>(a.x) & 15u) != 0)) {
+    eda_set_error("wgrad_x: BN+ReLU rows must be 16-byte addressable");
+    return EDA_ERR_INVALID_ARG;
+  }
+  const WgPlan p = wgx_plan(a.R, a.M, a.N);
+  if (!a.ws || a.ws_bytes < eda_wgrad_x_workspace_bytes(a.R, a.M, a.N)) {
+    eda_set_error("wgrad_x: workspace too small");
+    return EDA_ERR_WORKSPACE;
+  }
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const dim3 grid((unsigned)(8 * ntiles * ((p.splits + 7) / 8)));
+  if (a.xmode == X_PLAIN)
+    hipLaunchKernelGGL(wgrad_x_kernel<X_PLAIN>, grid, dim3(WG_THREADS), 0, stream, a, p.cps, p.tiles_n, ntiles, p.splits);
+  else if (a.xmode == X_BNRELU)
+    hipLaunchKernelGGL(wgrad_x_kernel<X_BNRELU>, grid, dim3(WG_THREADS), 0, stream, a, p.cps, p.tiles_n, ntiles, p.splits);
+  else
+    hipLaunchKernelGGL(wgrad_x_kernel<X_GATHER>, grid, dim3(WG_THREADS), 0, stream, a, p.cps, p.tiles_n, ntiles, p.splits);
+  EDA_CHECK_LAUNCH();
+  const long MN = (long)a.M * a.N;
+  hipLaunchKernelGGL(wgrad_x_reduce_kernel, dim3((unsigned)((MN + 31) / 32)), dim3(256), 0, stream, a.ws, p.splits,
+                     a.M, a.N, a.xmode == X_GATHER ? 1 : 0, a.dW);
+  EDA_CHECK_LAUNCH();
   return 0;
 }

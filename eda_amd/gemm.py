@@ -1,0 +1,54 @@
+"""Row GEMMs of the pointwise layers on the repo's own fp32-MFMA kernels (csrc/gemm.hip).
+
+``linear_fwd`` / ``linear_dgrad`` are thin ctypes calls; shapes follow ``F.linear``:
+x (R,K), w (N,K), y (R,N).  Row-strided 2-D views are accepted (unit column stride).
+"""
+import torch
+
+from . import _lib
+from .ext import _timed
+
+
+def _rows2d(t):
+    if t.dim() != 2 or t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t
+
+
+def _ld(t):
+    return t.stride(0) if t.shape[0] > 1 else t.shape[1]
+
+
+def linear_fwd(x2, w, bias=None, relu=False, out=None):
+    """y = x2 @ w.T (+ bias) (ReLU) for fp32 GPU matrices."""
+    x2, w = _rows2d(x2), _rows2d(w)
+    R, K = x2.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    if out is None:
+        out = torch.empty((R, N), dtype=torch.float32, device=x2.device)
+    if R == 0:
+        return out
+    with torch.cuda.device(x2.device), _timed("gemm_fwd", (R, K, N)):
+        rc = _lib.lib().eda_linear_fwd_f32(x2.data_ptr(), _ld(x2), R, K, w.data_ptr(), _ld(w), N,
+                                           bias.data_ptr() if bias is not None else None, int(bool(relu)),
+                                           out.data_ptr(), _ld(out), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "eda_linear_fwd_f32")
+    return out
+
+
+def linear_dgrad(dy2, w, out=None):
+    """dx = dy2 @ w for fp32 GPU matrices dy2 (R,N), w (N,K)."""
+    dy2, w = _rows2d(dy2), _rows2d(w)
+    R, N = dy2.shape
+    K = w.shape[1]
+    assert w.shape[0] == N
+    if out is None:
+        out = torch.empty((R, K), dtype=torch.float32, device=dy2.device)
+    if R == 0:
+        return out
+    with torch.cuda.device(dy2.device), _timed("gemm_dgrad", (R, N, K)):
+        rc = _lib.lib().eda_linear_dgrad_f32(dy2.data_ptr(), _ld(dy2), R, N, w.data_ptr(), _ld(w), K,
+                                             out.data_ptr(), _ld(out), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "eda_linear_dgrad_f32")
+    return out

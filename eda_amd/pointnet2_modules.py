@@ -81,6 +81,12 @@ class PointnetSAModuleVotes(nn.Module):
         B, m = new_xyz.shape[0], new_xyz.shape[1]
         idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
         feats_cl = features.transpose(1, 2).contiguous() if features is not None else None
+        if sa_ops._fusable(self.mlp_module.layers()):
+            # ball query -> ONE fused native call: neighbourhood rows gathered into LDS, three MFMA
+            # GEMMs with BN statistics / BN+ReLU folded in, max-pool (csrc/sa_cl.hip, gemm.hip)
+            pooled = sa_ops.fused_mlp(self.mlp_module, self.nsample, xyz=xyz, new_xyz=new_xyz, feats_cl=feats_cl,
+                                      idx=idx, radius=self.radius, normalize_xyz=self.normalize_xyz)
+            return pooled.view(B, m, -1).transpose(1, 2).contiguous()
         rows = sa_ops.GroupConcatCL.apply(xyz, new_xyz, feats_cl, idx, self.radius, self.normalize_xyz)
         pooled = sa_ops.shared_mlp_rows(self.mlp_module, rows.view(B * m * self.nsample, -1), self.nsample)
         return pooled.view(B, m, -1).transpose(1, 2).contiguous()

@@ -170,10 +170,153 @@ class BNReLUCL(Function):
         return dz, dgb[0], dgb[1], None, None, None, None, None, None, None, None
 
 
+import ctypes
+import os
+
+_FUSED = os.environ.get("EDA_SA_FUSED", "1") != "0"
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() if t is not None else None for t in tensors])
+
+
+class FusedMLP(Function):
+    """QueryAndGroup (or plain rows) -> L x [conv1x1, BatchNorm, ReLU] -> max over `pool` rows, as
+    ONE native call per direction (eda_sa_fused_fwd/bwd_f32): per layer a single MFMA GEMM launch
+    whose operand staging does the neighbourhood gather / the previous layer's BN+ReLU and whose
+    epilogue produces the BatchNorm statistics.  Saved for the backward: the pre-activations z_l.
+
+    cfg = dict(gather, radius, normalize_xyz, pool, training, eps, momentum, running=[(rm, rv), ...]);
+    params = W0, gamma0, beta0, W1, gamma1, beta1, ...  (W_l may be (Cout, Cin, 1, 1))."""
+
+    @staticmethod
+    def forward(ctx, cfg, x_rows, xyz, new_xyz, feats_cl, idx, *params):
+        L = len(params) // 3
+        Ws = [params[3 * l].reshape(params[3 * l].shape[0], -1).contiguous() for l in range(L)]
+        gammas = [params[3 * l + 1] for l in range(L)]
+        betas = [params[3 * l + 2] for l in range(L)]
+        gather = bool(cfg["gather"])
+        if gather:
+            _need_gpu(xyz)
+            xyz, new_xyz, idx = xyz.contiguous(), new_xyz.contiguous(), idx.contiguous()
+            B, N, _ = xyz.shape
+            m, ns = idx.shape[1], idx.shape[2]
+            C = 0 if feats_cl is None else feats_cl.shape[2]
+            if feats_cl is not None:
+                feats_cl = feats_cl.contiguous()
+            R = B * m * ns
+            dev = xyz.device
+            c0 = 3 + C
+        else:
+            _need_gpu(x_rows)
+            if x_rows.stride(1) != 1:
+                x_rows = x_rows.contiguous()
+            R, c0 = x_rows.shape
+            B = N = m = ns = C = 0
+            dev = x_rows.device
+        chans = [c0] + [w.shape[0] for w in Ws]
+        for l in range(L):
+            assert Ws[l].shape[1] == chans[l], (Ws[l].shape, chans)
+        pool = int(cfg["pool"])
+        training = bool(cfg["training"])
+        z = [torch.empty((R, chans[l + 1]), dtype=torch.float32, device=dev) for l in range(L)]
+        stats = [torch.empty((4, chans[l + 1]), dtype=torch.float32, device=dev) for l in range(L)]
+        out = torch.empty((R // pool, chans[L]), dtype=torch.float32, device=dev)
+        argmax = torch.empty((R // pool, chans[L]), dtype=torch.uint8, device=dev) if pool > 1 else None
+        running = cfg["running"]
+        ws = _bn_workspace(dev)
+        chan_arr = (ctypes.c_int * (L + 1))(*chans)
+        with torch.cuda.device(dev), _timed('sa_fused_fwd', (R, pool, int(training)) + tuple(chans)):
+            rc = _lib.lib().eda_sa_fused_fwd_f32(
+                x_rows.data_ptr() if not gather else None, x_rows.stride(0) if not gather else 0,
+                xyz.data_ptr() if gather else None, new_xyz.data_ptr() if gather else None,
+                feats_cl.data_ptr() if gather and C else None, idx.data_ptr() if gather else None,
+                B, N, m, ns, C, float(cfg["radius"]) if gather else 1.0, int(bool(cfg["normalize_xyz"])) if gather else 0,
+                R, L, chan_arr, _ptr_array(Ws), _ptr_array(gammas), _ptr_array(betas),
+                _ptr_array([r[0] for r in running]), _ptr_array([r[1] for r in running]),
+                float(cfg["eps"]), float(cfg["momentum"]), int(training), pool, _ptr_array(z), _ptr_array(stats),
+                ws.data_ptr(), out.data_ptr(), argmax.data_ptr() if argmax is not None else None, _stream())
+        _lib.check(rc, "eda_sa_fused_fwd_f32")
+        ctx.save_for_backward(x_rows, xyz, new_xyz, feats_cl, idx, argmax, *Ws, *gammas, *z, *stats)
+        ctx.cfg = (gather, float(cfg["radius"]) if gather else 1.0, bool(cfg["normalize_xyz"]) if gather else False,
+                   pool, training, L, chans, (B, N, m, ns, C), [p.shape for p in params[0::3]])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        gather, radius, normalize, pool, training, L, chans, (B, N, m, ns, C), wshapes = ctx.cfg
+        sv = ctx.saved_tensors
+        x_rows, xyz, new_xyz, feats_cl, idx, argmax = sv[:6]
+        Ws, gammas = sv[6:6 + L], sv[6 + L:6 + 2 * L]
+        z, stats = sv[6 + 2 * L:6 + 3 * L], sv[6 + 3 * L:6 + 4 * L]
+        dev = dout.device
+        dout = dout.contiguous()
+        R = z[0].shape[0]
+        cmax = max(chans[1:])
+        sa = torch.empty((R, cmax), dtype=torch.float32, device=dev)
+        sb = torch.empty((R, cmax), dtype=torch.float32, device=dev) if L > 1 else sa
+        dW = [torch.empty((chans[l + 1], chans[l]), dtype=torch.float32, device=dev) for l in range(L)]
+        dgb = [torch.empty((2, chans[l + 1]), dtype=torch.float32, device=dev) for l in range(L)]
+        need_in = ctx.needs_input_grad[1] if not gather else (ctx.needs_input_grad[4] and C > 0)
+        dx = dfeats = None
+        if need_in and gather:
+            dfeats = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+        elif need_in:
+            dx = torch.empty((R, chans[0]), dtype=torch.float32, device=dev)
+        chan_arr = (ctypes.c_int * (L + 1))(*chans)
+        lib = _lib.lib()
+        ws_bytes = lib.eda_sa_fused_bwd_workspace_bytes(R, L, chan_arr, int(gather))
+        ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev), _timed('sa_fused_bwd', (R, pool, int(training)) + tuple(chans)):
+            rc = lib.eda_sa_fused_bwd_f32(
+                dout.data_ptr(), argmax.data_ptr() if argmax is not None else None,
+                x_rows.data_ptr() if not gather else None, x_rows.stride(0) if not gather else 0,
+                xyz.data_ptr() if gather else None, new_xyz.data_ptr() if gather else None,
+                feats_cl.data_ptr() if gather and C else None, idx.data_ptr() if gather else None,
+                B, N, m, ns, C, radius, int(normalize), R, L, chan_arr, _ptr_array(Ws), _ptr_array(gammas),
+                _ptr_array(z), _ptr_array(stats), int(training), pool, sa.data_ptr(), sb.data_ptr(),
+                ws.data_ptr(), ws_bytes, _ptr_array(dW), _ptr_array([g[0] for g in dgb]),
+                _ptr_array([g[1] for g in dgb]), dx.data_ptr() if dx is not None else None,
+                dx.stride(0) if dx is not None else 0, dfeats.data_ptr() if dfeats is not None else None, _stream())
+        _lib.check(rc, "eda_sa_fused_bwd_f32")
+        grads = []
+        for l in range(L):
+            grads += [dW[l].view(wshapes[l]), dgb[l][0], dgb[l][1]]
+        return (None, dx, None, None, dfeats, None, *grads)
+
+
+def _fusable(layers):
+    return _FUSED and all(l.bn is not None and l.conv.bias is None and l.conv.out_channels % 4 == 0 for l in layers)
+
+
+def fused_mlp(mlp, pool, x_rows=None, xyz=None, new_xyz=None, feats_cl=None, idx=None, radius=1.0,
+              normalize_xyz=False):
+    """Run SharedMLP `mlp` through FusedMLP on plain rows (x_rows) or gathered neighbourhoods."""
+    layers = mlp.layers()
+    bns = [layer.bn.bn for layer in layers]
+    training = bns[0].training
+    assert all(bn.training == training for bn in bns)
+    assert all(bn.eps == bns[0].eps and bn.momentum == bns[0].momentum for bn in bns)
+    cfg = dict(gather=idx is not None, radius=radius, normalize_xyz=normalize_xyz, pool=pool,
+               training=training or not bns[0].track_running_stats, eps=bns[0].eps, momentum=bns[0].momentum,
+               running=[(bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None) for bn in bns])
+    params = []
+    for layer, bn in zip(layers, bns):
+        params += [layer.conv.weight, bn.weight, bn.bias]
+    out = FusedMLP.apply(cfg, x_rows, xyz, new_xyz, feats_cl, idx, *params)
+    if training:
+        for bn in bns:
+            if bn.track_running_stats:
+                bump_batches_tracked(bn)
+    return out
+
+
 def shared_mlp_rows(mlp, rows, pool):
     """Run a SharedMLP (conv1x1 -> BN -> ReLU stack) on rows (R,Cin); the LAST layer's
     BN+ReLU is fused with a max over each `pool` consecutive rows.  Returns (R/pool, Cout)."""
     layers = mlp.layers()
+    if _fusable(layers) and rows.is_cuda:
+        return fused_mlp(mlp, pool, x_rows=rows)
     x = rows
     for i, layer in enumerate(layers):
         z = PointwiseLinearCL.apply(x, layer.conv.weight)

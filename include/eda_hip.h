@@ -297,6 +297,53 @@ int eda_l2norm_rows_bwd_f32(const float *dy, const float *y, const float *norm, 
  * HBM rate next to the 8 TB/s nominal peak.  Replaces nothing in the reference.          */
 int eda_device_copy_f32(const float *src, float *dst, size_t n, void *stream);
 
+/* ---- row GEMMs of the pointwise layers (csrc/gemm.hip, fp32 MFMA) ---------------------------
+ * eda_linear_fwd_f32 replaces the cuBLAS/cuDNN call behind every nn.Linear / Conv1d(k=1) /
+ * Conv2d(1x1) of the path (pointnet2/pytorch_utils.py:88-120; models/encoder_decoder_layers.py:
+ * 47-75,324-330; models/modules.py:19-178): y (R,N) = x (R,K) w(N,K)^T + bias, optional ReLU.
+ * Row strides ldx/ldw/ldy in floats; 16-byte loads/stores are used when K, N, the strides and
+ * the pointers allow, element accesses otherwise (any K, N >= 1).                             */
+int eda_linear_fwd_f32(const float *x, long ldx, long R, int K, const float *w, long ldw, int N,
+                       const float *bias, int relu, float *y, long ldy, void *stream);
+/* input gradient of the same layer: dx (R,K) = dy (R,N) w(N,K)                                 */
+int eda_linear_dgrad_f32(const float *dy, long lddy, long R, int N, const float *w, long ldw, int K,
+                         float *dx, long lddx, void *stream);
+
+/* ---- fused set-abstraction / feature-propagation MLP (csrc/sa_cl.hip + gemm.hip + wgrad.hip) ----
+ * eda_sa_fused_fwd_f32 replaces, in one call, QueryAndGroup.forward (pointnet2/pointnet2_utils.py:
+ * 317-376: group_points x2, centre subtraction, /radius, cat), SharedMLP.forward = nlayers x
+ * [Conv2d 1x1 without bias -> BatchNorm2d -> ReLU] (pointnet2/pytorch_utils.py:11-36,67-120) and
+ * F.max_pool2d over nsample (pointnet2/pointnet2_modules.py:251-257); with plain input rows it is
+ * the SharedMLP of PointnetFPModule (pointnet2_modules.py:407-414).
+ *   input : idx != NULL -> rows (scene, centre, neighbour) gathered from xyz (b,n,3), new_xyz (b,m,3),
+ *           feats_cl (b,n,c_feat) channels-last, idx (b,m,ns) (ball_query output); channels[0] = 3+c_feat
+ *           idx == NULL -> x (R, channels[0]) rows with row stride ldx
+ *   layers: weight[l] (channels[l+1], channels[l]) row-major, gamma/beta/running_* (channels[l+1]);
+ *           host arrays of device pointers; channels[1..] multiples of 4
+ *   output: out (R/pool, channels[nlayers]) and, pool > 1, argmax (same shape, uint8: row of the maximum)
+ *   kept for the backward: z[l] (R, channels[l+1]) pre-activations, stats[l] = mean|rstd|scale|shift
+ *   ws: 2*1024+2 doubles, ZERO on entry, left zero (shared with eda_bn_relu_fwd_f32).
+ * The grouped tensor and the activated tensors are never written to HBM (see csrc/gemm.hip).   */
+int eda_sa_fused_fwd_f32(const float *x, long ldx, const float *xyz, const float *new_xyz,
+                         const float *feats_cl, const int *idx, int b, int n, int m, int ns, int c_feat,
+                         float radius, int normalize_xyz, long R, int nlayers, const int *channels,
+                         const float *const *weight, const float *const *gamma, const float *const *beta,
+                         float *const *running_mean, float *const *running_var, float eps, float momentum,
+                         int training, int pool, float *const *z, float *const *stats, double *ws,
+                         float *out, unsigned char *argmax, void *stream);
+/* backward of the above: dW[l], dgamma[l], dbeta[l]; dx (R, channels[0]) for plain rows or
+ * dfeats_cl (b,n,c_feat; zeroed here, scatter-added) for gathered rows (either may be NULL).
+ * scratch_a / scratch_b: R * max(channels[1..]) floats each; ws: eda_sa_fused_bwd_workspace_bytes. */
+size_t eda_sa_fused_bwd_workspace_bytes(long R, int nlayers, const int *channels, int gather);
+int eda_sa_fused_bwd_f32(const float *dout, const unsigned char *argmax, const float *x, long ldx,
+                         const float *xyz, const float *new_xyz, const float *feats_cl, const int *idx,
+                         int b, int n, int m, int ns, int c_feat, float radius, int normalize_xyz, long R,
+                         int nlayers, const int *channels, const float *const *weight,
+                         const float *const *gamma, const float *const *z, const float *const *stats,
+                         int training, int pool, float *scratch_a, float *scratch_b, void *ws,
+                         size_t ws_bytes, float *const *dW, float *const *dgamma, float *const *dbeta,
+                         float *dx, long lddx, float *dfeats_cl, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,70 @@
+"""The repo's own fp32-MFMA row GEMMs (csrc/gemm.hip) against an fp64 torch reference.
+
+Tolerance: fp32 accumulation over K terms; the bound used is 1e-5 * sqrt(K) * |x|.|w| row/col
+norms (an fp32 dot product's forward error is ~ K*eps*sum|x_k w_k| worst case, sqrt(K)*eps typical),
+far inside the north star's 1e-4 relative for activations.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # (R, K, N)
+    (1, 4, 4), (7, 3, 5), (64, 6, 64), (100, 131, 128), (333, 259, 128), (2048, 288, 288),
+    (2048, 288, 1), (2048, 288, 3), (640, 768, 288), (2048, 288, 864), (1000, 64, 64),
+    (4096, 512, 256), (130, 288, 576), (8192, 256, 288), (20000, 128, 256), (70000, 64, 128),
+]
+
+
+def _ref(x, w, b, relu):
+    y = x.double() @ w.double().t()
+    if b is not None:
+        y = y + b.double()
+    return y.relu() if relu else y
+
+
+def _tol(x, w, K):
+    return 2e-6 * (K ** 0.5) * (x.abs().double() @ w.abs().double().t()).clamp_min(1e-30) + 1e-30
+
+
+@pytest.mark.parametrize("R,K,N", SHAPES)
+def test_linear_fwd(R, K, N):
+    from eda_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(R * 131 + K * 7 + N)
+    x = torch.randn(R, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g)
+    b = torch.randn(N, device="cuda", generator=g)
+    for bias, relu in ((None, False), (b, False), (b, True)):
+        y = gemm.linear_fwd(x, w, bias, relu)
+        ref = _ref(x, w, bias, relu)
+        err = (y.double() - ref).abs()
+        assert bool((err <= _tol(x, w, K) + 1e-6 * ref.abs()).all()), float(err.max())
+
+
+@pytest.mark.parametrize("R,K,N", SHAPES)
+def test_linear_dgrad(R, K, N):
+    from eda_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(R * 17 + K * 3 + N)
+    dy = torch.randn(R, N, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g)
+    dx = gemm.linear_dgrad(dy, w)
+    ref = dy.double() @ w.double()
+    err = (dx.double() - ref).abs()
+    tol = 2e-6 * (N ** 0.5) * (dy.abs().double() @ w.abs().double()) + 1e-30
+    assert bool((err <= tol + 1e-6 * ref.abs()).all()), float(err.max())
+
+
+def test_strided_operands_and_outputs():
+    """Column views of packed projection buffers (row stride 864) as inputs and outputs."""
+    from eda_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(5)
+    big = torch.randn(512, 864, device="cuda", generator=g)
+    x = big[:, 288:576]
+    w = torch.randn(3 * 288, 288, device="cuda", generator=g)
+    out = torch.full((512, 864), float("nan"), device="cuda")
+    gemm.linear_fwd(x, w[288:576], None, False, out=out[:, 576:])
+    ref = x.double() @ w[288:576].double().t()
+    assert torch.allclose(out[:, 576:].double(), ref, rtol=1e-5, atol=1e-3)
+    assert torch.isnan(out[:, :576]).all()
+    dx = gemm.linear_dgrad(big[:, 576:], w[576:])
+    assert torch.allclose(dx.double(), big[:, 576:].double() @ w[576:].double(), rtol=1e-5, atol=1e-3)

@@ -1,0 +1,164 @@
+"""The fused set-abstraction / feature-propagation MLP (eda_sa_fused_fwd/bwd_f32: gather or plain
+rows -> L x [conv1x1, BN, ReLU] -> max-pool) against an fp64 torch composition of the reference's
+ops (QueryAndGroup -> SharedMLP -> max_pool2d, pointnet2/pointnet2_modules.py:243-257).
+
+Tolerances: activations / outputs 1e-4 relative (the north star's bound) on the fp64 result's scale.
+Gradients: an fp32 error budget measured, not guessed -- the SAME composition evaluated by stock
+torch in fp32 on the GPU is compared with the fp64 result, and this library must stay within 4x that
+error (or 2e-4 of the tensor's max, whichever is larger): a weight gradient is a 10^4..10^5-term fp32
+sum behind a train-mode BatchNorm backward whose per-channel constants carry fp32 rounding into every
+row coherently.  Elements whose ReLU / arg-max decision sits within fp32 rounding of a tie are
+excluded by count (<= 1e-4 of the elements; whole rows for input gradients).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _mlp_ref64(rows, Ws, gammas, betas, running, training, pool, eps=1e-5):
+    x = rows
+    for W, g, b, (rm, rv) in zip(Ws, gammas, betas, running):
+        z = x @ W.reshape(W.shape[0], -1).t()
+        if training:
+            mean, var = z.mean(0), z.var(0, unbiased=False)
+        else:
+            mean, var = rm.to(z.dtype), rv.to(z.dtype)
+        x = torch.relu((z - mean) / torch.sqrt(var + eps) * g + b)
+    if pool > 1:
+        R, C = x.shape
+        x = x.view(R // pool, pool, C).max(dim=1)[0]
+    return x
+
+
+def _check(name, got, exp, rtol, frac=1e-4, ref32=None):
+    """All but a fraction `frac` of the elements within rtol * max|exp|.  Input gradients (dx,
+    dfeats) are judged per ROW: one ReLU / arg-max decision that sits on a tie in fp32 re-routes the
+    gradient of a whole input row, so a flipped row counts once (<= 0.2 % of the rows may)."""
+    exp = exp.to(got.dtype) if exp.dtype != got.dtype else exp
+    scale = exp.abs().max().item() + 1e-12
+    tol = rtol * scale
+    if ref32 is not None:
+        e32 = (ref32.to(exp.dtype) - exp).abs()
+        tol = max(tol, 4.0 * torch.quantile(e32.flatten()[:: max(1, e32.numel() // 1000000)], 0.999).item())
+    bad = (got - exp).abs() > tol
+    if name in ("dx", "dfeats"):
+        bad = bad.reshape(-1, bad.shape[-1]).any(dim=1)
+        frac = 2e-3
+    bad = bad.float().mean().item()
+    import os
+    if os.environ.get("EDA_TEST_VERBOSE"):
+        print(f"  {name}: bad {bad:.2e} maxerr {(got - exp).abs().max().item():.3e} scale {scale:.3e}")
+    assert bad <= frac, (name, bad, (got - exp).abs().max().item(), scale)
+
+
+def _build(chans, dev, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    Ws = [torch.randn(chans[l + 1], chans[l], 1, 1, generator=g).mul_((2.0 / chans[l]) ** 0.5).to(dev) for l in range(len(chans) - 1)]
+    gammas = [(torch.rand(c, generator=g) + 0.5).to(dev) for c in chans[1:]]
+    betas = [(torch.randn(c, generator=g) * 0.2).to(dev) for c in chans[1:]]
+    running = [((torch.randn(c, generator=g) * 0.1).to(dev), (torch.rand(c, generator=g) + 0.5).to(dev)) for c in chans[1:]]
+    return Ws, gammas, betas, running
+
+
+def _run_fused(cfg_kw, Ws, gammas, betas, running, training, pool, x_rows=None, xyz=None, new_xyz=None, feats_cl=None, idx=None):
+    from eda_amd import sa_ops
+    cfg = dict(gather=idx is not None, radius=cfg_kw.get("radius", 1.0), normalize_xyz=cfg_kw.get("normalize_xyz", False),
+               pool=pool, training=training, eps=1e-5, momentum=0.1, running=running)
+    params = []
+    for W, g, b in zip(Ws, gammas, betas):
+        params += [W, g, b]
+    return sa_ops.FusedMLP.apply(cfg, x_rows, xyz, new_xyz, feats_cl, idx, *params)
+
+
+@pytest.mark.parametrize("R,chans,training", [
+    (4096, [512, 256, 256], True), (8192, [512, 256, 288], True), (1000, [20, 32, 16], True),
+    (4096, [512, 256, 256], False), (333, [7, 64], True), (70000, [64, 64, 128], True),
+])
+def test_plain_rows(R, chans, training):
+    dev = "cuda"
+    torch.manual_seed(R + 7 * len(chans))
+    Ws, gammas, betas, running = _build(chans, dev, R + len(chans))
+    x = torch.randn(R, chans[0], device=dev)
+    leaves = [x] + Ws + gammas + betas
+    for t in leaves:
+        t.requires_grad_(True)
+    run_a = [(rm.clone(), rv.clone()) for rm, rv in running]
+    out = _run_fused({}, Ws, gammas, betas, run_a, training, 1, x_rows=x)
+    w = torch.randn_like(out)
+    got = torch.autograd.grad((out * w).sum(), leaves)
+    l64 = [t.detach().double().requires_grad_(True) for t in leaves]
+    L = len(chans) - 1
+    ref = _mlp_ref64(l64[0], l64[1:1 + L], l64[1 + L:1 + 2 * L], l64[1 + 2 * L:], running, training, 1)
+    exp = torch.autograd.grad((ref * w.double()).sum(), l64)
+    l32 = [t.detach().clone().requires_grad_(True) for t in leaves]
+    r32 = _mlp_ref64(l32[0], l32[1:1 + L], l32[1 + L:1 + 2 * L], l32[1 + 2 * L:], running, training, 1)
+    e32 = torch.autograd.grad((r32 * w).sum(), l32)
+    _check("out", out.double(), ref.detach(), 1e-4)
+    names = ["dx"] + [f"dW{l}" for l in range(L)] + [f"dgamma{l}" for l in range(L)] + [f"dbeta{l}" for l in range(L)]
+    for n, g_, e_, r_ in zip(names, got, exp, e32):
+        _check(n, g_.double(), e_, 2e-4, frac=2e-4, ref32=r_)
+    if training:
+        for l, ((rm, rv), (rm0, rv0)) in enumerate(zip(run_a, running)):
+            # torch semantics: running <- 0.9 running + 0.1 batch (unbiased variance)
+            with torch.no_grad():
+                xx = l64[0]
+                for k in range(l + 1):
+                    z = xx @ l64[1 + k].reshape(chans[k + 1], -1).t()
+                    mean, var = z.mean(0), z.var(0, unbiased=False)
+                    xx = torch.relu((z - mean) / torch.sqrt(var + 1e-5) * l64[1 + L + k] + l64[1 + 2 * L + k])
+                torch.testing.assert_close(rm.double(), 0.9 * rm0.double() + 0.1 * mean, rtol=1e-4, atol=1e-5)
+                torch.testing.assert_close(rv.double(), 0.9 * rv0.double() + 0.1 * z.var(0, unbiased=True), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,N,m,ns,C,chans,training", [
+    (2, 3000, 128, 16, 3, [64, 64, 128], True),
+    (2, 2048, 256, 32, 128, [128, 128, 256], True),
+    (1, 700, 33, 5, 8, [16, 32], True),
+    (2, 1024, 64, 16, 256, [128, 128, 256], False),
+    (2, 500, 40, 8, 0, [32, 32], True),
+    (1, 900, 50, 7, 6, [24], True),
+])
+def test_gathered_rows(B, N, m, ns, C, chans, training):
+    from eda_amd import pointnet2_utils as PU
+    dev = "cuda"
+    torch.manual_seed(N + 3 * C)
+    rng = np.random.default_rng(N + C)
+    xyz = torch.from_numpy(rng.uniform(-2, 2, (B, N, 3)).astype(np.float32)).to(dev)
+    new_xyz = xyz[:, :m].contiguous()
+    radius = 0.6
+    idx = PU.ball_query(radius, ns, xyz, new_xyz)
+    chans = [3 + C] + chans
+    Ws, gammas, betas, running = _build(chans, dev, N + C + 1)
+    feats_cl = torch.randn(B, N, C, device=dev) if C else None
+    leaves = ([feats_cl] if C else []) + Ws + gammas + betas
+    for t in leaves:
+        t.requires_grad_(True)
+    run_a = [(rm.clone(), rv.clone()) for rm, rv in running]
+    out = _run_fused(dict(radius=radius, normalize_xyz=True), Ws, gammas, betas, run_a, training, ns,
+                     xyz=xyz, new_xyz=new_xyz, feats_cl=feats_cl, idx=idx)
+    w = torch.randn_like(out)
+    got = torch.autograd.grad((out * w).sum(), leaves)
+    # fp64 composition of the reference ops: gather, centre, * (1/r), concat [xyz | feats]
+    l64 = [t.detach().double().requires_grad_(True) for t in leaves]
+    f64 = l64[0] if C else None
+    rest = l64[1:] if C else l64
+    L = len(chans) - 1
+    bidx = torch.arange(B, device=dev)[:, None, None].expand(B, m, ns)
+    gx = (xyz[bidx, idx.long()] - new_xyz[:, :, None, :]) * torch.tensor(1.0 / radius, dtype=torch.float32, device=dev)
+    rows = gx.double()
+    if C:
+        rows = torch.cat([rows, f64[bidx, idx.long()]], dim=-1)
+    ref = _mlp_ref64(rows.reshape(B * m * ns, 3 + C), rest[:L], rest[L:2 * L], rest[2 * L:], running, training, ns)
+    exp = torch.autograd.grad((ref * w.double()).sum(), l64)
+    l32 = [t.detach().clone().requires_grad_(True) for t in leaves]
+    rest32 = l32[1:] if C else l32
+    rows32 = gx if not C else torch.cat([gx, l32[0][bidx, idx.long()]], dim=-1)
+    r32 = _mlp_ref64(rows32.reshape(B * m * ns, 3 + C), rest32[:L], rest32[L:2 * L], rest32[2 * L:], running, training, ns)
+    e32 = torch.autograd.grad((r32 * w).sum(), l32)
+    _check("out", out.double(), ref.detach(), 1e-4)
+    names = (["dfeats"] if C else []) + [f"dW{l}" for l in range(L)] + [f"dgamma{l}" for l in range(L)] + [f"dbeta{l}" for l in range(L)]
+    for n_, g_, e_, r_ in zip(names, got, exp, e32):
+        _check(n_, g_.double(), e_, 2e-4, frac=2e-4, ref32=r_)
