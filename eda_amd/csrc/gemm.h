@@ -31,7 +31,7 @@ struct GemmArgs {
   const float *zm; long ldzm; const float *m_scale, *m_shift, *m_mean, *m_rstd; double *s1, *s2;
   // E_SCATTER
   float *dfeats;
-  int col_tiles; long row_blocks;
+  int col_tiles; long row_blocks; int row_slots; unsigned ticket_target;
 };
 
 

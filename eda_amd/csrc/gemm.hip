@@ -75,20 +75,26 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
   constexpr int XLD = BM / 32;                                   // float4 per thread per chunk, row operand
   constexpr int WLD = BN * 8 / G_THREADS;                        // float4 per thread per chunk, weight
   static_assert(BN * 8 % G_THREADS == 0, "weight tile must divide evenly");
-  __shared__ __attribute__((aligned(16))) float Xs[BM * G_XS];
-  __shared__ __attribute__((aligned(16))) float Ws[WS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[BM * G_XS + WS_FLOATS];
   __shared__ int is_last;
+  float *Xs = smem, *Ws = smem + BM * G_XS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int xcd = blockIdx.x & 7;
   const long q = blockIdx.x >> 3;
   const int ct = (int)(q % a.col_tiles);
-  const long rb = (q / a.col_tiles) * 8 + xcd;
-  if (rb >= a.row_blocks) return;
-  const long row0 = rb * BM;
+  // persistent over row blocks: this workgroup owns row blocks rb_first, rb_first + rb_step, ...
+  // (one pass unless the launcher capped the grid: the statistics epilogues do, so that a column
+  // costs one fp64 atomic per WORKGROUP, not per row block)
+  const long rb_first = (q / a.col_tiles) * 8 + xcd;
+  if (rb_first >= a.row_blocks) return;
+  const long rb_step = (long)a.row_slots * 8;
   const int n0 = ct * BN;
   const long R = a.R;
   const int K = a.K, N = a.N;             // X_GATHER: K = 4 + c_feat
+  double cs1 = 0.0, cs2 = 0.0;            // E_STATS / E_MASK: column tid's sums over this workgroup's row blocks
+  for (long rb = rb_first; rb < a.row_blocks; rb += rb_step) {
+  const long row0 = rb * BM;
 
   // ---- staging maps -------------------------------------------------------------------------
   const int kq4 = 4 * (tid & 7);          // first k of this thread's float4 inside a chunk
@@ -402,44 +408,58 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
       for (int u = 0; u < 4; ++u) park(j, u, t1[u], t2[u]);
     }
   } else if (a.epi == E_SCATTER) {
+    // d(features)[b, idx[row], col] += acc: the tile goes through LDS so that one atomic
+    // instruction covers 64 CONSECUTIVE channels of ONE row (lane = column): with the
+    // accumulator layout (lane = row) the same 33 M atomics of SA2 ran 25x slower.
     const long rows_per_scene = (long)a.m * a.ns;
     const int C = a.c_feat;
+    constexpr int SST = 68;                                 // staging row stride (64 columns + 4)
+    float *stg = smem + wave * 16 * SST;                    // 16 rows x 64 columns per wave: 17 KB in all
 #pragma unroll
     for (int i = 0; i < WR; ++i) {
       const long row = row0 + 16 * WR * wave + 16 * i + (lane & 15);
-      if (row < R) {
-        const int b = (int)(row / rows_per_scene);
-        float *dst = a.dfeats + ((long)b * a.n_pts + a.idx[row]) * C;
+      int mybase = -1;                                      // element offset of this lane's row in dfeats
+      if (row < R) mybase = ((int)(row / rows_per_scene) * a.n_pts + a.idx[row]) * C;
 #pragma unroll
-        for (int j = 0; j < WC; ++j) {
-          const int col = n0 + 16 * j + cq;
+      for (int jc = 0; jc < WC; jc += 4) {                  // 64 columns at a time
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (col + u < C) atomicAdd(dst + col + u, acc[j][i][u]);
+        for (int jj = 0; jj < 4; ++jj) {
+          if (jc + jj < WC)
+            *reinterpret_cast<float4 *>(&stg[(lane & 15) * SST + 16 * jj + cq]) =
+                make_float4(acc[jc + jj][i][0], acc[jc + jj][i][1], acc[jc + jj][i][2], acc[jc + jj][i][3]);
+        }
+        const int col = n0 + 16 * jc + lane;
+        const bool colok = col < C && 16 * jc + lane < BN;
+        for (int r = 0; r < 16; ++r) {
+          const int base = __shfl(mybase, r);               // lanes 0..15 hold rows 0..15 of this row tile
+          if (base >= 0 && colok) atomicAdd(a.dfeats + base + col, stg[r * SST + lane]);
         }
       }
     }
   }
   if (a.epi == E_STATS || a.epi == E_MASK) {
     __syncthreads();
+    if (tid < BN) {
+      cs1 += ((double)red[tid] + (double)red[BN + tid]) + ((double)red[2 * BN + tid] + (double)red[3 * BN + tid]);
+      cs2 += ((double)red[4 * BN + tid] + (double)red[5 * BN + tid]) + ((double)red[6 * BN + tid] + (double)red[7 * BN + tid]);
+    }
+  }
+  if (rb + rb_step < a.row_blocks) __syncthreads();        // the epilogue's LDS scratch vs the next block's staging
+  }  // row blocks
+
+  if (a.epi == E_STATS || a.epi == E_MASK) {
     double *d1 = a.epi == E_STATS ? a.sum : a.s1;
     double *d2 = a.epi == E_STATS ? a.sumsq : a.s2;
-    for (int c = tid; c < BN; c += G_THREADS) {
-      if (n0 + c < N) {
-        const double v1 = (double)red[c] + (double)red[BN + c] + (double)red[2 * BN + c] + (double)red[3 * BN + c];
-        const double v2 = (double)red[4 * BN + c] + (double)red[5 * BN + c] + (double)red[6 * BN + c] +
-                          (double)red[7 * BN + c];
-        // returning atomics: the ticket below must not overtake them (see sa_cl.hip bn_stats_kernel)
-        const double o1 = atomicAdd(d1 + n0 + c, v1);
-        const double o2 = atomicAdd(d2 + n0 + c, v2);
-        asm volatile("" ::"v"(o1), "v"(o2));
-      }
+    if (tid < BN && n0 + tid < N) {
+      // returning atomics: the ticket below must not overtake them (see sa_cl.hip bn_stats_kernel)
+      const double o1 = atomicAdd(d1 + n0 + tid, cs1);
+      const double o2 = atomicAdd(d2 + n0 + tid, cs2);
+      asm volatile("" ::"v"(o1), "v"(o2));
     }
     if (a.epi == E_STATS) {
       __syncthreads();
       if (tid == 0)
-        is_last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-                  (unsigned)(a.row_blocks * a.col_tiles - 1);
+        is_last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.ticket_target - 1;
       __syncthreads();
       if (is_last) {
         for (int c = tid; c < N; c += G_THREADS) {
@@ -487,7 +507,18 @@ int launch_cfg(GemmArgs &a, int wmode, hipStream_t stream) {
   constexpr int BM = 64 * WR, BN = 16 * WC;
   a.row_blocks = (a.R + BM - 1) / BM;
   a.col_tiles = (a.N + BN - 1) / BN;
-  const long groups = (a.row_blocks + 7) / 8;
+  long groups = (a.row_blocks + 7) / 8;
+  if (a.epi == E_STATS || a.epi == E_MASK) {
+    // ~2048 persistent workgroups (every CU full at 5-6 waves per SIMD, 1.5 rounds)
+    const long cap = 2048 / (8 * a.col_tiles) > 1 ? 2048 / (8 * a.col_tiles) : 1;
+    if (groups > cap) groups = cap;
+  }
+  a.row_slots = (int)groups;
+  {
+    // workgroups that own at least one row block take a ticket
+    const long owners = a.row_blocks < groups * 8 ? a.row_blocks : groups * 8;
+    a.ticket_target = (unsigned)(owners * a.col_tiles);
+  }
   const long blocks = groups * 8 * a.col_tiles;
   if (blocks > 0x7fffffffL) { eda_set_error("gemm: grid too large"); return EDA_ERR_INVALID_ARG; }
   const dim3 grid((unsigned)blocks), block(G_THREADS);
