@@ -21,7 +21,7 @@ from torch import nn
 import torch.nn.functional as F
 from torch.autograd import Function
 
-from . import _lib
+from . import _lib, gemm
 from .ext import _timed
 from .nn_utils import colsum, linear_rows, wgrad
 
@@ -118,7 +118,7 @@ class _ProjectedMHA(Function):
     F.linear + split + _FusedMHA under autograd, the backward writes dq/dk/dv straight into the
     packed gradient buffers (no cat), the weight/bias gradients straight into their row ranges
     of ONE (3d,d)/(3d) buffer (no zero-fill + copy + add per slice), and skips nothing else:
-    the GEMMs are the same library calls."""
+    the GEMMs are the repo's own MFMA row GEMMs (csrc/gemm.hip)."""
 
     @staticmethod
     def forward(ctx, W, b, mask, num_heads, p_drop, salt, groups, *xs):
@@ -128,7 +128,7 @@ class _ProjectedMHA(Function):
         x2s, Ps, cols = [], [], {}
         for x, (lo, hi) in zip(xs, groups):
             x2 = x.reshape(-1, d)
-            P = torch.addmm(b[lo:hi], x2, W[lo:hi].t()).view(B, -1, hi - lo)
+            P = gemm.linear_fwd(x2, W[lo:hi], b[lo:hi]).view(B, -1, hi - lo)
             x2s.append(x2)
             Ps.append(P)
             for j in range(lo // d, hi // d):
@@ -205,7 +205,7 @@ class _ProjectedMHA(Function):
                       want_db=db is not None)
             elif db is not None:
                 colsum(dP2, out=db[lo:hi])
-            dxs.append(torch.mm(dP2, W[lo:hi]).view(shapes[i]) if ctx.needs_input_grad[7 + i] else None)
+            dxs.append(gemm.linear_dgrad(dP2, W[lo:hi]).view(shapes[i]) if ctx.needs_input_grad[7 + i] else None)
         return (dW, db, None, None, None, None, None, *dxs)
 
 

@@ -67,19 +67,29 @@ __device__ __forceinline__ float row_sum16(float v) {
 //
 // X_GATHER column order: [dx dy dz 0 | feats 0..C) ], K = 4 + C; the weight (N, 3+C) is read with
 // the matching map (k < 3 -> k, k == 3 -> zero, k >= 4 -> k - 1).
-template <int WR, int WC, int WMODE, int XMODE, bool VEC>
+// WN = waves along the columns (1: four waves stacked along the rows; 2: a 2 x 2 arrangement, i.e.
+// 32*WR-row tiles for the small launches -- plain epilogue only).
+// PF = chunks in flight ahead of the one being multiplied (register ring of PF staging sets).
+// KC = contraction chunk (32 or 64 floats): a chunk costs two barriers and a staging pass whatever its
+// width, which is what bounds the small launches (9 chunks of 32 for K = 288).
+template <int WR, int WC, int WMODE, int XMODE, bool VEC, int WN = 1, int PF = 1, int KC = G_KC>
 __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) {
-  constexpr int BM = 64 * WR, BN = 16 * WC;
+  constexpr int BM = 64 * WR / WN, BN = 16 * WC * WN;
+  constexpr int XS = KC + 8;                                     // LDS row stride of [row][k] tiles
+  constexpr int KQ = KC / 4;                                     // float4 per tile row
+  constexpr int RPP = G_THREADS / KQ;                            // tile rows covered by one pass of the workgroup
+  static_assert(BM % 32 == 0, "row tile must be a multiple of 32");
   constexpr int WSN = BN + 4;                                    // W_NN LDS row stride
-  constexpr int WS_FLOATS = WMODE == W_NT ? BN * G_XS : G_KC * WSN;
-  constexpr int XLD = BM / 32;                                   // float4 per thread per chunk, row operand
-  constexpr int WLD = BN * 8 / G_THREADS;                        // float4 per thread per chunk, weight
-  static_assert(BN * 8 % G_THREADS == 0, "weight tile must divide evenly");
-  __shared__ __attribute__((aligned(16))) float smem[BM * G_XS + WS_FLOATS];
+  constexpr int WS_FLOATS = WMODE == W_NT ? BN * XS : KC * WSN;
+  constexpr int XLD = BM / RPP;                                  // float4 per thread per chunk, row operand
+  constexpr int WLD = BN * KQ / G_THREADS;                       // float4 per thread per chunk, weight
+  static_assert(BN * KQ % G_THREADS == 0 && BM % RPP == 0, "tiles must divide evenly");
+  __shared__ __attribute__((aligned(16))) float smem[BM * XS + WS_FLOATS];
   __shared__ int is_last;
-  float *Xs = smem, *Ws = smem + BM * G_XS;
+  float *Xs = smem, *Ws = smem + BM * XS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave / WN, wave_n = wave % WN;
   const int xcd = blockIdx.x & 7;
   const long q = blockIdx.x >> 3;
   const int ct = (int)(q % a.col_tiles);
@@ -97,8 +107,8 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
   const long row0 = rb * BM;
 
   // ---- staging maps -------------------------------------------------------------------------
-  const int kq4 = 4 * (tid & 7);          // first k of this thread's float4 inside a chunk
-  const int lr = tid >> 3;                // local row 0..31 (+32*i)
+  const int kq4 = 4 * (tid % KQ);         // first k of this thread's float4 inside a chunk
+  const int lr = tid / KQ;                // local row (+RPP*i)
   const int rows_here = (int)(R - row0 < BM ? R - row0 : BM);
   int xoff[XLD];                          // element offset of the row from the operand base
   float4 gxyz[XLD];                       // X_GATHER, threads with kq4 == 0: (dx, dy, dz, 0)
@@ -107,7 +117,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
     const long rows_per_scene = (long)a.m * a.ns;
 #pragma unroll
     for (int i = 0; i < XLD; ++i) {
-      int l = lr + 32 * i;
+      int l = lr + RPP * i;
       if (l >= rows_here) l = rows_here - 1;
       const long row = row0 + l;
       const int b = (int)(row / rows_per_scene);
@@ -125,7 +135,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
   } else {
 #pragma unroll
     for (int i = 0; i < XLD; ++i) {
-      int l = lr + 32 * i;
+      int l = lr + RPP * i;
       if (l >= rows_here) l = rows_here - 1;
       xoff[i] = l * (int)a.ldx;
     }
@@ -135,7 +145,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
   for (int i = 0; i < WLD; ++i) {
     const int s = tid + G_THREADS * i;
     if (WMODE == W_NT) {
-      int n = n0 + (s >> 3);
+      int n = n0 + s / KQ;
       if (n >= N) n = N - 1;
       woff[i] = n * (int)a.ldw;
     } else {
@@ -145,8 +155,8 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
     }
   }
 
-  float4 xr[XLD], wr[WLD], bsc, bsh;
-  auto fetch = [&](int kc) {
+  float4 xr[PF][XLD], wr[PF][WLD], bsc[PF], bsh[PF];
+  auto fetch = [&](const int set, int kc) {
     const int k = kc + kq4;
     if (VEC) {
       // ---- row operand: unconditional 16-byte loads
@@ -155,14 +165,14 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
         if (f > a.c_feat - 4) f = a.c_feat - 4;
         if (f < 0) f = 0;
 #pragma unroll
-        for (int i = 0; i < XLD; ++i) xr[i] = *reinterpret_cast<const float4 *>(xbase + xoff[i] + f);
+        for (int i = 0; i < XLD; ++i) xr[set][i] = *reinterpret_cast<const float4 *>(xbase + xoff[i] + f);
       } else {
         const int kx = k > K - 4 ? K - 4 : k;
 #pragma unroll
-        for (int i = 0; i < XLD; ++i) xr[i] = *reinterpret_cast<const float4 *>(xbase + xoff[i] + kx);
+        for (int i = 0; i < XLD; ++i) xr[set][i] = *reinterpret_cast<const float4 *>(xbase + xoff[i] + kx);
         if (XMODE == X_BNRELU) {
-          bsc = *reinterpret_cast<const float4 *>(a.in_scale + kx);
-          bsh = *reinterpret_cast<const float4 *>(a.in_shift + kx);
+          bsc[set] = *reinterpret_cast<const float4 *>(a.in_scale + kx);
+          bsh[set] = *reinterpret_cast<const float4 *>(a.in_shift + kx);
         }
       }
       // ---- weight
@@ -180,19 +190,19 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
               if (sidx > kmax) sidx = kmax;
               e[u] = a.w[woff[i] + sidx];
             }
-            wr[i] = make_float4(e[0], e[1], e[2], e[3]);
+            wr[set][i] = make_float4(e[0], e[1], e[2], e[3]);
           } else {
             const int kx = k > K - 4 ? K - 4 : k;
-            wr[i] = *reinterpret_cast<const float4 *>(a.w + woff[i] + kx);
+            wr[set][i] = *reinterpret_cast<const float4 *>(a.w + woff[i] + kx);
           }
         } else {
           int c = kc + s / (BN / 4);
           if (c > K - 1) c = K - 1;
           if (a.w_elem) {
             const float *p = a.w + (long)c * a.ldw + woff[i];
-            wr[i] = make_float4(p[0], p[1], p[2], p[3]);
+            wr[set][i] = make_float4(p[0], p[1], p[2], p[3]);
           } else {
-            wr[i] = *reinterpret_cast<const float4 *>(a.w + (long)c * a.ldw + woff[i]);
+            wr[set][i] = *reinterpret_cast<const float4 *>(a.w + (long)c * a.ldw + woff[i]);
           }
         }
       }
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
             if (XMODE == X_BNRELU) e[u] = fmaxf(e[u] * a.in_scale[kk] + a.in_shift[kk], 0.f);
           }
         }
-        xr[i] = make_float4(e[0], e[1], e[2], e[3]);
+        xr[set][i] = make_float4(e[0], e[1], e[2], e[3]);
       }
 #pragma unroll
       for (int i = 0; i < WLD; ++i) {
@@ -235,39 +245,39 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
             if (c < K && woff[i] + u < N) e[u] = a.w[(long)c * a.ldw + woff[i] + u];
           }
         }
-        wr[i] = make_float4(e[0], e[1], e[2], e[3]);
+        wr[set][i] = make_float4(e[0], e[1], e[2], e[3]);
       }
     }
   };
   // write the fetched chunk kc to LDS (VEC: zero the contraction tail, apply the prologue here)
-  auto stage = [&](int kc) {
+  auto stage = [&](const int set, int kc) {
     const int k = kc + kq4;
     const bool kok = k < K;
 #pragma unroll
     for (int i = 0; i < XLD; ++i) {
-      float4 v = xr[i];
+      float4 v = xr[set][i];
       if (VEC) {
         if (XMODE == X_BNRELU) {
-          v.x = fmaxf(v.x * bsc.x + bsh.x, 0.f); v.y = fmaxf(v.y * bsc.y + bsh.y, 0.f);
-          v.z = fmaxf(v.z * bsc.z + bsh.z, 0.f); v.w = fmaxf(v.w * bsc.w + bsh.w, 0.f);
+          v.x = fmaxf(v.x * bsc[set].x + bsh[set].x, 0.f); v.y = fmaxf(v.y * bsc[set].y + bsh[set].y, 0.f);
+          v.z = fmaxf(v.z * bsc[set].z + bsh[set].z, 0.f); v.w = fmaxf(v.w * bsc[set].w + bsh[set].w, 0.f);
         }
         if (XMODE == X_GATHER && k == 0) v = gxyz[i];
         if (!kok) v = make_float4(0.f, 0.f, 0.f, 0.f);
       } else if (XMODE == X_GATHER && k == 0) {
         v = gxyz[i];
       }
-      *reinterpret_cast<float4 *>(&Xs[(lr + 32 * i) * G_XS + kq4]) = v;
+      *reinterpret_cast<float4 *>(&Xs[(lr + RPP * i) * XS + kq4]) = v;
     }
 #pragma unroll
     for (int i = 0; i < WLD; ++i) {
       const int s = tid + G_THREADS * i;
-      float4 v = wr[i];
+      float4 v = wr[set][i];
       if (WMODE == W_NT) {
         if (VEC) {
           if (XMODE == X_GATHER && k == 0) v.w = 0.f;          // the padding column between xyz and features
           if (!kok) v = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        *reinterpret_cast<float4 *>(&Ws[(s >> 3) * G_XS + kq4]) = v;
+        *reinterpret_cast<float4 *>(&Ws[(s / KQ) * XS + kq4]) = v;
       } else {
         if (VEC && kc + s / (BN / 4) >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4 *>(&Ws[(s / (BN / 4)) * WSN + 4 * (s % (BN / 4))]) = v;
@@ -281,41 +291,52 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
 #pragma unroll
     for (int i = 0; i < WR; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const float *xb = Xs + (wave * 16 * WR + (lane & 15)) * G_XS + 4 * (lane >> 4);
-  const float *wb = WMODE == W_NT ? Ws + (lane & 15) * G_XS + 4 * (lane >> 4)
-                                  : Ws + (4 * (lane >> 4)) * WSN + (lane & 15);
+  const float *xb = Xs + (wave_m * 16 * WR + (lane & 15)) * XS + 4 * (lane >> 4);
+  const float *wb = WMODE == W_NT ? Ws + (wave_n * 16 * WC + (lane & 15)) * XS + 4 * (lane >> 4)
+                                  : Ws + (4 * (lane >> 4)) * WSN + wave_n * 16 * WC + (lane & 15);
 
-  fetch(0);
-  for (int kc = 0; kc < K; kc += G_KC) {
-    stage(kc);
-    __syncthreads();
-    if (kc + G_KC < K) fetch(kc + G_KC);
+  auto multiply = [&]() {
 #pragma unroll
-    for (int ks = 0; ks < G_KC; ks += 16) {
-      f32x4 bv[WR];
+    for (int ks = 0; ks < KC; ks += 16) {
+        f32x4 bv[WR];
 #pragma unroll
-      for (int i = 0; i < WR; ++i) bv[i] = *reinterpret_cast<const f32x4 *>(xb + 16 * i * G_XS + ks);
+        for (int i = 0; i < WR; ++i) bv[i] = *reinterpret_cast<const f32x4 *>(xb + 16 * i * XS + ks);
 #pragma unroll
-      for (int j = 0; j < WC; ++j) {
-        f32x4 av;
-        if (WMODE == W_NT) av = *reinterpret_cast<const f32x4 *>(wb + 16 * j * G_XS + ks);
-        else {
-          av[0] = wb[(ks + 0) * WSN + 16 * j]; av[1] = wb[(ks + 1) * WSN + 16 * j];
-          av[2] = wb[(ks + 2) * WSN + 16 * j]; av[3] = wb[(ks + 3) * WSN + 16 * j];
+        for (int j = 0; j < WC; ++j) {
+          f32x4 av;
+          if (WMODE == W_NT) av = *reinterpret_cast<const f32x4 *>(wb + 16 * j * XS + ks);
+          else {
+            av[0] = wb[(ks + 0) * WSN + 16 * j]; av[1] = wb[(ks + 1) * WSN + 16 * j];
+            av[2] = wb[(ks + 2) * WSN + 16 * j]; av[3] = wb[(ks + 3) * WSN + 16 * j];
+          }
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < WR; ++i)
+              acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[i][s], acc[j][i], 0, 0, 0);
         }
+      }
+  };
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+  for (int p = 0; p < PF; ++p)
+    if (p * KC < K) fetch(p, p * KC);
+  for (int kc0 = 0; kc0 < K; kc0 += PF * KC) {
 #pragma unroll
-          for (int i = 0; i < WR; ++i)
-            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[i][s], acc[j][i], 0, 0, 0);
+    for (int p = 0; p < PF; ++p) {
+      const int kc = kc0 + p * KC;
+      if (kc < K) {
+        stage(p, kc);
+        __syncthreads();
+        if (kc + PF * KC < K) fetch(p, kc + PF * KC);
+        multiply();
+        __syncthreads();
       }
     }
-    __syncthreads();
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------
-  // lane: row = row0 + 16*WR*wave + 16*i + (lane&15), columns n0 + 16*j + 4*(lane>>4) + {0..3}
-  const int cq = 4 * (lane >> 4);
+  // lane: row = row0 + 16*WR*wave_m + 16*i + (lane&15), columns n0 + 16*WC*wave_n + 16*j + 4*(lane>>4) + {0..3}
+  const int cq = 16 * WC * wave_n + 4 * (lane >> 4);
   const bool yvec = (N % 4 == 0) && (a.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15u) == 0);
   // column partials of this wave (E_STATS / E_MASK) are parked in Xs, which is free after the main
   // loop's last barrier: [w*BN + c] first statistic of wave w, [4*BN + w*BN + c] second
@@ -328,7 +349,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
       red[4 * BN + wave * BN + 16 * j + cq + u] = s2v;
     }
   };
-  if (a.epi == E_PLAIN || a.epi == E_STATS) {
+  if (a.epi == E_PLAIN || (WN == 1 && a.epi == E_STATS)) {
 #pragma unroll
     for (int j = 0; j < WC; ++j) {
       const int col = n0 + 16 * j + cq;
@@ -340,7 +361,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
       float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < WR; ++i) {
-        const long row = row0 + 16 * WR * wave + 16 * i + (lane & 15);
+        const long row = row0 + 16 * WR * wave_m + 16 * i + (lane & 15);
         float o[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -358,12 +379,12 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
           }
         }
       }
-      if (a.epi == E_STATS) {
+      if (WN == 1 && a.epi == E_STATS) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) park(j, u, t1[u], t2[u]);
       }
     }
-  } else if (a.epi == E_MASK) {
+  } else if (WN == 1 && a.epi == E_MASK) {
 #pragma unroll
     for (int j = 0; j < WC; ++j) {
       const int col = n0 + 16 * j + cq;
@@ -377,7 +398,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
       float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < WR; ++i) {
-        const long row = row0 + 16 * WR * wave + 16 * i + (lane & 15);
+        const long row = row0 + 16 * WR * wave_m + 16 * i + (lane & 15);
         if (row < R && col < N) {
           const float *zp = a.zm + row * a.ldzm + col;
           float zz[4] = {0.f, 0.f, 0.f, 0.f};
@@ -407,7 +428,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
 #pragma unroll
       for (int u = 0; u < 4; ++u) park(j, u, t1[u], t2[u]);
     }
-  } else if (a.epi == E_SCATTER) {
+  } else if (WN == 1 && a.epi == E_SCATTER) {
     // d(features)[b, idx[row], col] += acc: the tile goes through LDS so that one atomic
     // instruction covers 64 CONSECUTIVE channels of ONE row (lane = column): with the
     // accumulator layout (lane = row) the same 33 M atomics of SA2 ran 25x slower.
@@ -417,7 +438,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
     float *stg = smem + wave * 16 * SST;                    // 16 rows x 64 columns per wave: 17 KB in all
 #pragma unroll
     for (int i = 0; i < WR; ++i) {
-      const long row = row0 + 16 * WR * wave + 16 * i + (lane & 15);
+      const long row = row0 + 16 * WR * wave_m + 16 * i + (lane & 15);
       int mybase = -1;                                      // element offset of this lane's row in dfeats
       if (row < R) mybase = ((int)(row / rows_per_scene) * a.n_pts + a.idx[row]) * C;
 #pragma unroll
@@ -437,7 +458,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
       }
     }
   }
-  if (a.epi == E_STATS || a.epi == E_MASK) {
+  if (WN == 1 && (a.epi == E_STATS || a.epi == E_MASK)) {
     __syncthreads();
     if (tid < BN) {
       cs1 += ((double)red[tid] + (double)red[BN + tid]) + ((double)red[2 * BN + tid] + (double)red[3 * BN + tid]);
@@ -447,7 +468,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
   if (rb + rb_step < a.row_blocks) __syncthreads();        // the epilogue's LDS scratch vs the next block's staging
   }  // row blocks
 
-  if (a.epi == E_STATS || a.epi == E_MASK) {
+  if (WN == 1 && (a.epi == E_STATS || a.epi == E_MASK)) {
     double *d1 = a.epi == E_STATS ? a.sum : a.s1;
     double *d2 = a.epi == E_STATS ? a.sumsq : a.s2;
     if (tid < BN && n0 + tid < N) {
@@ -502,9 +523,9 @@ bool gemm_vec_ok(const GemmArgs &a, int wmode) {
   return true;
 }
 
-template <int WR, int WC, bool VEC>
+template <int WR, int WC, bool VEC, int WN = 1, int PF = 1, int KC = G_KC>
 int launch_cfg(GemmArgs &a, int wmode, hipStream_t stream) {
-  constexpr int BM = 64 * WR, BN = 16 * WC;
+  constexpr int BM = 64 * WR / WN, BN = 16 * WC * WN;
   a.row_blocks = (a.R + BM - 1) / BM;
   a.col_tiles = (a.N + BN - 1) / BN;
   long groups = (a.row_blocks + 7) / 8;
@@ -523,13 +544,13 @@ int launch_cfg(GemmArgs &a, int wmode, hipStream_t stream) {
   if (blocks > 0x7fffffffL) { eda_set_error("gemm: grid too large"); return EDA_ERR_INVALID_ARG; }
   const dim3 grid((unsigned)blocks), block(G_THREADS);
   if (wmode == W_NN)
-    hipLaunchKernelGGL((gemm_rows_kernel<WR, WC, W_NN, X_PLAIN, VEC>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((gemm_rows_kernel<WR, WC, W_NN, X_PLAIN, VEC, WN, PF, KC>), grid, block, 0, stream, a);
   else if (a.xmode == X_PLAIN)
-    hipLaunchKernelGGL((gemm_rows_kernel<WR, WC, W_NT, X_PLAIN, VEC>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((gemm_rows_kernel<WR, WC, W_NT, X_PLAIN, VEC, WN, PF, KC>), grid, block, 0, stream, a);
   else if (a.xmode == X_BNRELU)
-    hipLaunchKernelGGL((gemm_rows_kernel<WR, WC, W_NT, X_BNRELU, VEC>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((gemm_rows_kernel<WR, WC, W_NT, X_BNRELU, VEC, WN, PF, KC>), grid, block, 0, stream, a);
   else
-    hipLaunchKernelGGL((gemm_rows_kernel<WR, WC, W_NT, X_GATHER, VEC>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((gemm_rows_kernel<WR, WC, W_NT, X_GATHER, VEC, WN, PF, KC>), grid, block, 0, stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { eda_set_error("gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
   return 0;
@@ -558,15 +579,27 @@ int eda_gemm_launch(GemmArgs &a, int wmode, hipStream_t stream) {
     return EDA_ERR_INVALID_ARG;
   }
   if (!gemm_vec_ok(a, wmode)) return launch_cfg<1, 4, false>(a, wmode, stream);
-  a.w_elem = (wmode == W_NN) && (a.ldw % 4 != 0 || (reinterpret_cast<uintptr_t>(a.w) & 15u) != 0);
   // measured on MI355X (tools/bench_gemm.py, profiles/r02a_gemm_tiles.txt): the 64x64 tile at 5-6
   // waves per SIMD beats the 128-row tiles at 2-4 on every shape of the path; 64x128 is a few
   // per cent ahead for the 128-multiples with many rows
   const int N = a.N;
   int wr = 1, wc = 4;
   if (N % 128 == 0 && a.R >= 32768) wc = 8;
+  if (a.epi == E_PLAIN && a.xmode == X_PLAIN) {
+    // small launches: 32-row tiles (2 x 2 waves) so that every CU holds several workgroups
+    const int f2 = g_force_cfg();
+    const long wgs64 = ((a.R + 63) / 64) * ((N + 63) / 64);
+    if (f2 == 112 || (f2 <= 0 && wgs64 <= 384)) return launch_cfg<1, 1, true, 2, 2>(a, wmode, stream);  // 32 x 32
+    if (f2 == 122) return launch_cfg<1, 2, true, 2, 2>(a, wmode, stream); // 32 x 64
+    if (f2 == 132) return launch_cfg<1, 3, true, 2, 2>(a, wmode, stream);                                // 32 x 96
+    if (f2 == 142) return launch_cfg<1, 4, true, 1, 2>(a, wmode, stream);                                // 64 x 64, two chunks ahead
+    if (f2 == 212) return launch_cfg<1, 1, true, 2, 1, 64>(a, wmode, stream);                            // 32 x 32, 64-wide chunks
+    if (f2 == 222) return launch_cfg<1, 2, true, 2, 1, 64>(a, wmode, stream);                            // 32 x 64, 64-wide chunks
+    if (f2 == 232) return launch_cfg<1, 3, true, 2, 1, 64>(a, wmode, stream);                            // 32 x 96
+    if (f2 == 242) return launch_cfg<1, 4, true, 1, 1, 64>(a, wmode, stream);                            // 64 x 64
+  }
   const int f = g_force_cfg();
-  if (f > 0) { wr = f / 10; wc = f % 10; }
+  if (f > 0 && f < 100) { wr = f / 10; wc = f % 10; }
   if (wr == 2) {
     switch (wc) {
       case 4: return launch_cfg<2, 4, true>(a, wmode, stream);

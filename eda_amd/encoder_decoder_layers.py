@@ -30,7 +30,7 @@ def _ffn(d_model, dim_feedforward, dropout):
 def _ffn_residual_norm(x, ffn, norm, training, salt):
     """norm(x + ffn(x)) where ffn = Linear, ReLU, Dropout, Linear, Dropout: the last Dropout is
     applied inside the fused residual+LayerNorm kernel."""
-    h = ffn[2](ffn[1](ffn[0](x)))
+    h = ffn[2](linear_rows(x, ffn[0].weight, ffn[0].bias, relu=True))       # Linear+ReLU in one GEMM epilogue
     if fuses_bias(x, norm):      # second linear's bias (and its gradient) ride in the LN kernels
         return add_dropout_layer_norm(x, linear_rows(h, ffn[3].weight, None), norm, ffn[4].p, training, salt,
                                       y_bias=ffn[3].bias)

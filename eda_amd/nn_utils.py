@@ -102,42 +102,47 @@ def wgrad(dy2, x2, dW=None, db=None, want_db=True):
 
 
 class _LinearRows(Function):
-    """y = x W^T + b over the last dimension.  Forward and dX are the library GEMMs autograd
-    would use; dW (and the bias gradient, for free) come from wgrad()."""
+    """y = x W^T + b (optionally ReLU) over the last dimension on the repo's own fp32-MFMA row GEMMs
+    (csrc/gemm.hip): forward and dX are eda_linear_fwd/dgrad_f32, bias and ReLU ride in the
+    forward's epilogue; dW (and the bias gradient, for free) come from wgrad() / the deferred queue."""
 
     @staticmethod
-    def forward(ctx, x, W, b):
+    def forward(ctx, x, W, b, relu=False):
+        from . import gemm
         x2 = x.reshape(-1, x.shape[-1])
-        y = torch.mm(x2, W.t()) if b is None else torch.addmm(b, x2, W.t())
-        ctx.save_for_backward(x2, W, b)
+        y = gemm.linear_fwd(x2, W, b, relu)
+        ctx.save_for_backward(x2, W, b, y if relu else None)
         ctx.xshape = x.shape
         ctx.has_bias = b is not None
         return y.view(*x.shape[:-1], W.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        from . import wgrad_queue
-        x2, W, b = ctx.saved_tensors
+        from . import gemm, wgrad_queue
+        x2, W, b, y = ctx.saved_tensors
         dy2 = dy.reshape(-1, W.shape[0])
-        dx = torch.mm(dy2, W).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        if y is not None:
+            dy2 = torch.ops.aten.threshold_backward(dy2, y, 0.0)      # ReLU: dy where y > 0
+        dx = gemm.linear_dgrad(dy2, W).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         dW = db = None
         q = wgrad_queue.active
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if (q is not None and ctx.needs_input_grad[1] and (want_db or not ctx.has_bias)
                 and q.submit(W, b if want_db else None, dy2, x2)):
-            return dx, None, None          # written into the gradient buffer by the queue's flush
+            return dx, None, None, None    # written into the gradient buffer by the queue's flush
         if ctx.needs_input_grad[1]:
             dW, db = wgrad(dy2, x2, want_db=ctx.has_bias and ctx.needs_input_grad[2])
         elif ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy2)
-        return dx, dW, db
+        return dx, dW, db, None
 
 
-def linear_rows(x, weight, bias):
-    """F.linear(x, weight, bias); on the GPU (fp32) its backward uses wgrad() for dW and db."""
+def linear_rows(x, weight, bias, relu=False):
+    """F.linear(x, weight, bias) (+ ReLU); on the GPU (fp32) the repo's own MFMA GEMMs."""
     if x.is_cuda and x.dtype == torch.float32 and x.numel() > 0:
-        return _LinearRows.apply(x, weight, bias)
-    return F.linear(x, weight, bias)
+        return _LinearRows.apply(x, weight, bias, relu)
+    y = F.linear(x, weight, bias)
+    return F.relu(y) if relu else y
 
 
 class Linear(nn.Linear):

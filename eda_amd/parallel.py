@@ -43,14 +43,18 @@ class FlatParams:
         ordered = [(n, p) for k in keys for (n, p) in named if group_of(n) == k]
         self.params = [p for _, p in ordered]
         dev = self.params[0].device
-        total = sum(p.numel() for p in self.params)
-        self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
+        # every parameter starts on a 16-byte boundary (4 floats): the MFMA GEMMs read weight rows
+        # with 16-byte loads (csrc/gemm.hip); the <= 3 padding floats in front of a parameter stay
+        # zero in both buffers (zero gradient -> AdamW leaves a zero parameter at zero)
+        total = sum((p.numel() + 3) // 4 * 4 for p in self.params)
+        self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self._grad_views = []
         off = 0
         bounds = {}
         for n, p in ordered:
             k = group_of(n)
+            off = (off + 3) // 4 * 4
             sl = slice(off, off + p.numel())
             self.flat_param[sl].copy_(p.data.reshape(-1))
             p.data = self.flat_param[sl].view_as(p)          # the parameter now lives in the flat buffer
