@@ -37,7 +37,7 @@ namespace {
 constexpr int kRecWords = 8;          // u64 words per mailbox record (5 used, 64-byte record)
 constexpr int kMaxG = 64;             // workgroups per scene (one poll lane each)
 constexpr size_t kStatusBytes = 256;  // status words in front of the mailboxes
-constexpr unsigned kSpinLimit = 1u << 20;   // ~1 s of polling, then give up
+constexpr unsigned kSpinLimit = 1u << 20;   // ~1 s of polling, then give up (status word set, indices zero-filled)
 
 typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
@@ -227,7 +227,13 @@ __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz_al
       }
     }
     __syncthreads();
-    if (sh->fail) return;
+    if (sh->fail) {
+      // give-up (a peer workgroup never answered within the spin limit, i.e. the cluster was not
+      // co-resident): the status word is already set; leave VALID indices behind (0) so that the
+      // gathers / ball query that follow cannot read out of bounds, then leave.
+      if (w == 0) for (int i = r + (int)tid; i < m; i += T) idx[i] = 0;
+      return;
+    }
     // If the winner is the all-invalid candidate (-1, k = 0) these coordinates are
     // meaningless, but then no point of the scene is ever updated, so they are unused.
     x1 = sh->next_xyz[0]; y1 = sh->next_xyz[1]; z1 = sh->next_xyz[2];
@@ -506,7 +512,13 @@ __global__ __launch_bounds__(T) void fps_spec_kernel(const float *__restrict__ x
     FPS_MARK(5);
     __syncthreads();
     FPS_MARK(6);
-    if (sh->fail) return;
+    if (sh->fail) {
+      // give-up (a peer workgroup never answered within the spin limit, i.e. the cluster was not
+      // co-resident): the status word is already set; leave VALID indices behind (0) so that the
+      // gathers / ball query that follow cannot read out of bounds, then leave.
+      if (w == 0) for (int i = r + (int)tid; i < m; i += T) idx[i] = 0;
+      return;
+    }
     r += sh->nvalid;
     // sh->cand / nvalid are rewritten only after the next hand-off's first barrier
   }
@@ -663,7 +675,9 @@ extern "C" int eda_furthest_point_sampling_f32(const float *xyz, int b, int n, i
     return EDA_ERR_UNSUPPORTED;
   }
 
-  { const int zrc__ = eda_zero_async(ws, eda_fps_workspace_bytes(b, n, m), stream); if (zrc__) return zrc__; }
+  // ints 0..3 of the workspace are a STICKY status block (int 0 != 0: some call on this workspace gave
+  // up); everything behind them (diagnostics, mailboxes) is zeroed per call
+  { const int zrc__ = eda_zero_async(reinterpret_cast<unsigned char *>(ws) + 16, eda_fps_workspace_bytes(b, n, m) - 16, stream); if (zrc__) return zrc__; }
   int *status = reinterpret_cast<int *>(ws);
   u64 *mail = reinterpret_cast<u64 *>(reinterpret_cast<unsigned char *>(ws) + kStatusBytes);
 

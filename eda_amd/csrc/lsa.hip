@@ -39,7 +39,7 @@ __global__ __launch_bounds__(LSA_THREADS) void lsa_kernel(const float *__restric
   __shared__ unsigned char used[LSA_MAXQ + 1];
   __shared__ double wbest_v[LSA_THREADS / 64];
   __shared__ int wbest_j[LSA_THREADS / 64];
-  __shared__ int sh_j0;
+  __shared__ int sh_j0, sh_done;
   __shared__ double sh_delta;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float *c = cost + (long)b * sb;
@@ -84,17 +84,20 @@ __global__ __launch_bounds__(LSA_THREADS) void lsa_kernel(const float *__restric
         for (int w = 1; w < LSA_THREADS / 64; ++w) t = lsa_min(t, LsaBest{wbest_v[w], wbest_j[w]});
         sh_delta = t.v;
         sh_j0 = t.j;
+        sh_done = p[t.j] == 0;               // p[] is only rewritten by the augmentation below
       }
       __syncthreads();
       const double delta = sh_delta;
-      const int j1 = sh_j0;
       // dual update: visited columns (incl. the virtual column 0) move with their rows
       for (int j = tid; j <= Q; j += LSA_THREADS) {
         if (used[j] || j == j0) { u[p[j]] += delta; v[j] -= delta; }
         else minv[j] -= delta;
       }
       __syncthreads();
-      if (p[j1] == 0) break;                 // free column reached (uniform: all read the same LDS)
+      // Free column reached?  Decided by thread 0 BEFORE the barriers above and read from a flag:
+      // testing p[j1] here would race with thread 0's augmentation (its first write is p[j1] = ... != 0),
+      // a wave arriving late would stay in the loop while thread 0 moves on to the next row.
+      if (sh_done) break;
     }
     if (tid == 0) {                          // augment along the stored path
       int j0 = sh_j0;

@@ -89,6 +89,38 @@ def _require_gpu(t):
         raise RuntimeError("CPU not supported")
 
 
+_fps_ws = {}      # (device, stream) -> persistent workspace; its first int32 is the sticky give-up flag
+
+
+def _fps_workspace(device, nbytes):
+    """One FPS workspace per (device, stream), grown on demand.  The status block in front (see
+    include/eda_hip.h) is zeroed once here and never by the kernels, so a give-up of ANY call stays
+    visible until fps_status() is asked -- at a natural synchronisation point, not per call."""
+    key = (device, _stream())
+    ws = _fps_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        new = torch.full((max(nbytes, 4096),), 0, dtype=torch.uint8, device=device)
+        if ws is not None:
+            new[:16].copy_(ws[:16])
+        _fps_ws[key] = ws = new
+    return ws
+
+
+def fps_status(device=None, reset=False):
+    """Number of FPS workspaces whose sticky give-up flag is set (0 = every furthest-point-sampling call
+    so far ran to completion).  Synchronises with the device: call it where the host waits anyway
+    (end of a step / epoch).  A non-zero value means some sampled index sets are NOT the FPS result."""
+    bad = 0
+    for (dev, _), ws in _fps_ws.items():
+        if device is not None and torch.device(device) != dev:
+            continue
+        if int(ws[:4].view(torch.int32)[0].item()) != 0:
+            bad += 1
+            if reset:
+                ws[:16].zero_()
+    return bad
+
+
 def furthest_point_sampling(points, nsamples):
     """sampling.cpp:70-91 -- points (B,N,3) f32 -> (B,nsamples) i32."""
     _check_contiguous(points, "points")
@@ -101,10 +133,10 @@ def furthest_point_sampling(points, nsamples):
     if b == 0 or nsamples == 0:
         return out
     ws_bytes = L.eda_fps_workspace_bytes(b, n, nsamples)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=points.device)
+    ws = _fps_workspace(points.device, ws_bytes)
     with torch.cuda.device(points.device), _timed('furthest_point_sampling', (b, n, nsamples)):
         rc = L.eda_furthest_point_sampling_f32(points.data_ptr(), b, n, nsamples, out.data_ptr(),
-                                               ws.data_ptr(), ws_bytes, _stream())
+                                               ws.data_ptr(), ws.numel(), _stream())
     _lib.check(rc, "eda_furthest_point_sampling_f32")
     return out
 

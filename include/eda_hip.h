@@ -53,10 +53,12 @@ int eda_get_fma_mode(void);
  *          furthest_point_sampling_kernel<bs>   src/sampling_gpu.cu:74-234
  * xyz (b,n,3) f32 -> idx (b,m) i32.  The running min-distance array the
  * reference keeps in a (b,n) global `temp` tensor lives in registers here.
- * ws: eda_fps_workspace_bytes(b,n,m) bytes of device scratch (inter-workgroup
- * mailboxes + status word); it is zeroed on `stream` by the call itself.
- * After the stream has drained, ws[0] (int32) != 0 reports a give-up of the
- * bounded inter-workgroup spin (never observed).            */
+ * ws: eda_fps_workspace_bytes(b,n,m) bytes of device scratch.  Its first four int32 are a STICKY
+ * status block that the call never clears: the caller zeroes them once and may keep one workspace
+ * per stream for all calls; everything behind them (inter-workgroup mailboxes) is zeroed on `stream`
+ * by the call itself.  ws[0] != 0 after the stream has drained reports that a call gave up its
+ * bounded inter-workgroup spin (the scene's workgroups were not co-resident, e.g. another kernel
+ * held the CUs); the samples it had not yet produced are then index 0 (valid, but not FPS).      */
 size_t eda_fps_workspace_bytes(int b, int n, int m);
 int eda_furthest_point_sampling_f32(const float *xyz, int b, int n, int m,
                                     int *idx, void *ws, size_t ws_bytes,

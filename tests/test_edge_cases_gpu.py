@@ -82,3 +82,31 @@ def test_device_copy_kernel():
         assert torch.equal(src, dst)
     with pytest.raises(RuntimeError, match="multiple of 4"):
         ext.device_copy(torch.zeros(6, device="cuda"), torch.zeros(6, device="cuda"))
+
+
+def test_fps_is_exact_and_reports_status_while_another_stream_keeps_the_cus_busy(oracle):
+    """The cluster FPS kernel needs the 13 workgroups of a scene co-resident (they hand candidates to
+    each other).  With a second stream saturating the CUs with GEMMs -- the situation of an RCCL
+    kernel or a side-stream branch next to the sampler -- the indices must stay bit-identical to the
+    oracle and the sticky give-up flag (ext.fps_status) must stay clear; a give-up would be REPORTED
+    there (and leave valid zero indices), never silent garbage."""
+    import torch
+    from eda_amd import ext, synthetic
+    pc = synthetic.batch([11, 12, 13, 14], 50000)
+    xyz_c = torch.from_numpy(pc[:, :, :3].copy())
+    xyz = xyz_c.cuda()
+    want = oracle.furthest_point_sampling(xyz_c, 512)
+    ext.fps_status(reset=True)
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device="cuda")
+    b = torch.randn(4096, 4096, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(60):                      # ~100 ms of back-to-back full-chip GEMMs
+            a = torch.mm(a, b).mul_(1e-2)
+    outs = [ext.furthest_point_sampling(xyz, 512) for _ in range(6)]
+    torch.cuda.synchronize()
+    assert ext.fps_status() == 0
+    for o in outs:
+        assert (o.cpu() == want).all()
+    assert bool(((outs[0] >= 0) & (outs[0] < 50000)).all())
