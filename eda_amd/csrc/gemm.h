@@ -32,6 +32,7 @@ struct GemmArgs {
   // E_SCATTER
   float *dfeats;
   int col_tiles; long row_blocks; int row_slots; unsigned ticket_target;
+  int dbg;   // EDA_GEMM_DBG timing experiments (results are then wrong): 1 skip park, 2 no grid cap, 4 skip atomics, 8 skip z loads
 };
 
 

@@ -72,7 +72,9 @@ __device__ __forceinline__ float row_sum16(float v) {
 // PF = chunks in flight ahead of the one being multiplied (register ring of PF staging sets).
 // KC = contraction chunk (32 or 64 floats): a chunk costs two barriers and a staging pass whatever its
 // width, which is what bounds the small launches (9 chunks of 32 for K = 288).
-template <int WR, int WC, int WMODE, int XMODE, bool VEC, int WN = 1, int PF = 1, int KC = G_KC>
+// DB = LDS double buffering: chunk c+1 is written to the other half of LDS while chunk c is multiplied,
+// ONE barrier per chunk instead of two (PF must be 1: the register set holds chunk c+2 meanwhile).
+template <int WR, int WC, int WMODE, int XMODE, bool VEC, int WN = 1, int PF = 1, int KC = G_KC, bool DB = false>
 __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) {
   constexpr int BM = 64 * WR / WN, BN = 16 * WC * WN;
   constexpr int XS = KC + 8;                                     // LDS row stride of [row][k] tiles
@@ -84,7 +86,9 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
   constexpr int XLD = BM / RPP;                                  // float4 per thread per chunk, row operand
   constexpr int WLD = BN * KQ / G_THREADS;                       // float4 per thread per chunk, weight
   static_assert(BN * KQ % G_THREADS == 0 && BM % RPP == 0, "tiles must divide evenly");
-  __shared__ __attribute__((aligned(16))) float smem[BM * XS + WS_FLOATS];
+  constexpr int TILE_FLOATS = BM * XS + WS_FLOATS;
+  static_assert(!DB || PF == 1, "double buffering uses one register set");
+  __shared__ __attribute__((aligned(16))) float smem[TILE_FLOATS * (DB ? 2 : 1)];
   __shared__ int is_last;
   float *Xs = smem, *Ws = smem + BM * XS;
 
@@ -250,7 +254,8 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
     }
   };
   // write the fetched chunk kc to LDS (VEC: zero the contraction tail, apply the prologue here)
-  auto stage = [&](const int set, int kc) {
+  auto stage = [&](const int set, int kc, const int boff = 0) {
+    float *Xs = smem + boff, *Ws = smem + boff + BM * XS;
     const int k = kc + kq4;
     const bool kok = k < K;
 #pragma unroll
@@ -291,11 +296,40 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
 #pragma unroll
     for (int i = 0; i < WR; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const float *xb = Xs + (wave_m * 16 * WR + (lane & 15)) * XS + 4 * (lane >> 4);
-  const float *wb = WMODE == W_NT ? Ws + (wave_n * 16 * WC + (lane & 15)) * XS + 4 * (lane >> 4)
+  const float *xb0 = Xs + (wave_m * 16 * WR + (lane & 15)) * XS + 4 * (lane >> 4);
+  const float *wb0 = WMODE == W_NT ? Ws + (wave_n * 16 * WC + (lane & 15)) * XS + 4 * (lane >> 4)
                                   : Ws + (4 * (lane >> 4)) * WSN + wave_n * 16 * WC + (lane & 15);
 
-  auto multiply = [&]() {
+  // E_MASK: the previous layer's pre-activation tile, requested while the LAST chunk is being
+  // multiplied (the staging registers are dead by then, so this costs no registers; requested in
+  // the epilogue the loads were a fully exposed HBM round trip per row block)
+  const bool yvec = (N % 4 == 0) && (a.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15u) == 0);
+  const bool zvec = yvec && (a.ldzm % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.zm) & 15u) == 0);
+  float4 zt[WC][WR];
+  auto load_z = [&]() {
+    if (a.dbg & 8) return;
+#pragma unroll
+    for (int j = 0; j < WC; ++j) {
+      const int col = n0 + 16 * j + 16 * WC * wave_n + 4 * (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < WR; ++i) {
+        const long row = row0 + 16 * WR * wave_m + 16 * i + (lane & 15);
+        zt[j][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < R && col < N) {
+          const float *zp = a.zm + row * a.ldzm + col;
+          if (zvec) zt[j][i] = *reinterpret_cast<const float4 *>(zp);
+          else {
+            zt[j][i].x = zp[0];
+            if (col + 1 < N) zt[j][i].y = zp[1];
+            if (col + 2 < N) zt[j][i].z = zp[2];
+            if (col + 3 < N) zt[j][i].w = zp[3];
+          }
+        }
+      }
+    }
+  };
+  auto multiply = [&](const int boff = 0) {
+    const float *xb = xb0 + boff, *wb = wb0 + boff;
 #pragma unroll
     for (int ks = 0; ks < KC; ks += 16) {
         f32x4 bv[WR];
@@ -317,6 +351,24 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
         }
       }
   };
+  if (DB) {
+    // chunk 0 -> buffer 0; then per chunk: write c+1 into the other buffer, request c+2, multiply c, barrier
+    fetch(0, 0);
+    stage(0, 0, 0);
+    if (KC < K) fetch(0, KC);
+    __syncthreads();
+    int cur = 0;
+    for (int kc = 0; kc < K; kc += KC) {
+      if (kc + KC < K) {
+        stage(0, kc + KC, (cur ^ 1) * TILE_FLOATS);
+        if (kc + 2 * KC < K) fetch(0, kc + 2 * KC);
+        else if (WN == 1 && a.epi == E_MASK) load_z();
+      } else if (WN == 1 && a.epi == E_MASK && K <= KC) load_z();
+      multiply(cur * TILE_FLOATS);
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
 #pragma unroll
   for (int p = 0; p < PF; ++p)
     if (p * KC < K) fetch(p, p * KC);
@@ -328,20 +380,22 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
         stage(p, kc);
         __syncthreads();
         if (kc + PF * KC < K) fetch(p, kc + PF * KC);
+        else if (WN == 1 && a.epi == E_MASK && kc + KC >= K) load_z();
         multiply();
         __syncthreads();
       }
     }
   }
+  }
 
   // ---- epilogue ---------------------------------------------------------------------------------
   // lane: row = row0 + 16*WR*wave_m + 16*i + (lane&15), columns n0 + 16*WC*wave_n + 16*j + 4*(lane>>4) + {0..3}
   const int cq = 16 * WC * wave_n + 4 * (lane >> 4);
-  const bool yvec = (N % 4 == 0) && (a.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15u) == 0);
   // column partials of this wave (E_STATS / E_MASK) are parked in Xs, which is free after the main
   // loop's last barrier: [w*BN + c] first statistic of wave w, [4*BN + w*BN + c] second
   float *red = Xs;
   auto park = [&](int j, int u, float s1v, float s2v) {
+    if (a.dbg & 1) return;
     s1v = row_sum16(s1v);
     s2v = row_sum16(s2v);
     if ((lane & 15) == 0) {
@@ -400,15 +454,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
       for (int i = 0; i < WR; ++i) {
         const long row = row0 + 16 * WR * wave_m + 16 * i + (lane & 15);
         if (row < R && col < N) {
-          const float *zp = a.zm + row * a.ldzm + col;
-          float zz[4] = {0.f, 0.f, 0.f, 0.f};
-          if (yvec && (a.ldzm % 4 == 0)) {
-            const float4 z4 = *reinterpret_cast<const float4 *>(zp);
-            zz[0] = z4.x; zz[1] = z4.y; zz[2] = z4.z; zz[3] = z4.w;
-          } else {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) if (col + u < N) zz[u] = zp[u];
-          }
+          const float zz[4] = {zt[j][i].x, zt[j][i].y, zt[j][i].z, zt[j][i].w};
           float o[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
@@ -471,7 +517,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
   if (WN == 1 && (a.epi == E_STATS || a.epi == E_MASK)) {
     double *d1 = a.epi == E_STATS ? a.sum : a.s1;
     double *d2 = a.epi == E_STATS ? a.sumsq : a.s2;
-    if (tid < BN && n0 + tid < N) {
+    if (tid < BN && n0 + tid < N && !(a.dbg & 4)) {
       // returning atomics: the ticket below must not overtake them (see sa_cl.hip bn_stats_kernel)
       const double o1 = atomicAdd(d1 + n0 + tid, cs1);
       const double o2 = atomicAdd(d2 + n0 + tid, cs2);
@@ -523,13 +569,18 @@ bool gemm_vec_ok(const GemmArgs &a, int wmode) {
   return true;
 }
 
-template <int WR, int WC, bool VEC, int WN = 1, int PF = 1, int KC = G_KC>
+template <int WR, int WC, bool VEC, int WN = 1, int PF = 1, int KC = G_KC, bool DB = false>
 int launch_cfg(GemmArgs &a, int wmode, hipStream_t stream) {
   constexpr int BM = 64 * WR / WN, BN = 16 * WC * WN;
   a.row_blocks = (a.R + BM - 1) / BM;
   a.col_tiles = (a.N + BN - 1) / BN;
   long groups = (a.row_blocks + 7) / 8;
-  if (a.epi == E_STATS || a.epi == E_MASK) {
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char *e = getenv("EDA_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
+    a.dbg = dbg;
+  }
+  if ((a.epi == E_STATS || a.epi == E_MASK) && !(a.dbg & 2)) {
     // ~2048 persistent workgroups (every CU full at 5-6 waves per SIMD, 1.5 rounds)
     const long cap = 2048 / (8 * a.col_tiles) > 1 ? 2048 / (8 * a.col_tiles) : 1;
     if (groups > cap) groups = cap;
@@ -544,13 +595,13 @@ int launch_cfg(GemmArgs &a, int wmode, hipStream_t stream) {
   if (blocks > 0x7fffffffL) { eda_set_error("gemm: grid too large"); return EDA_ERR_INVALID_ARG; }
   const dim3 grid((unsigned)blocks), block(G_THREADS);
   if (wmode == W_NN)
-    hipLaunchKernelGGL((gemm_rows_kernel<WR, WC, W_NN, X_PLAIN, VEC, WN, PF, KC>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((gemm_rows_kernel<WR, WC, W_NN, X_PLAIN, VEC, WN, PF, KC, DB>), grid, block, 0, stream, a);
   else if (a.xmode == X_PLAIN)
-    hipLaunchKernelGGL((gemm_rows_kernel<WR, WC, W_NT, X_PLAIN, VEC, WN, PF, KC>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((gemm_rows_kernel<WR, WC, W_NT, X_PLAIN, VEC, WN, PF, KC, DB>), grid, block, 0, stream, a);
   else if (a.xmode == X_BNRELU)
-    hipLaunchKernelGGL((gemm_rows_kernel<WR, WC, W_NT, X_BNRELU, VEC, WN, PF, KC>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((gemm_rows_kernel<WR, WC, W_NT, X_BNRELU, VEC, WN, PF, KC, DB>), grid, block, 0, stream, a);
   else
-    hipLaunchKernelGGL((gemm_rows_kernel<WR, WC, W_NT, X_GATHER, VEC, WN, PF, KC>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((gemm_rows_kernel<WR, WC, W_NT, X_GATHER, VEC, WN, PF, KC, DB>), grid, block, 0, stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { eda_set_error("gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
   return 0;
@@ -591,8 +642,19 @@ int eda_gemm_launch(GemmArgs &a, int wmode, hipStream_t stream) {
     const long wgs64 = ((a.R + 63) / 64) * ((N + 63) / 64);
     if (f2 == 112 || (f2 <= 0 && wgs64 <= 384)) return launch_cfg<1, 1, true, 2, 2>(a, wmode, stream);  // 32 x 32
     if (f2 == 122) return launch_cfg<1, 2, true, 2, 2>(a, wmode, stream); // 32 x 64
+    // everything larger: 32 x 64 tiles, LDS double-buffered (profiles/r02b_gemm_cold.txt: best or within
+    // noise of the best on every shape when the operands come from HBM)
+    if (f2 <= 0) return launch_cfg<1, 2, true, 2, 1, 32, true>(a, wmode, stream);
     if (f2 == 132) return launch_cfg<1, 3, true, 2, 2>(a, wmode, stream);                                // 32 x 96
     if (f2 == 142) return launch_cfg<1, 4, true, 1, 2>(a, wmode, stream);                                // 64 x 64, two chunks ahead
+    if (f2 == 514) return launch_cfg<1, 4, true, 1, 1, 32, true>(a, wmode, stream);                      // 64 x 64, LDS double buffer
+    if (f2 == 518) return launch_cfg<1, 8, true, 1, 1, 32, true>(a, wmode, stream);                      // 64 x 128
+    if (f2 == 511) return launch_cfg<1, 1, true, 2, 1, 32, true>(a, wmode, stream);                      // 32 x 32
+    if (f2 == 512) return launch_cfg<1, 2, true, 2, 1, 32, true>(a, wmode, stream);                      // 32 x 64
+    if (f2 == 524) return launch_cfg<2, 4, true, 1, 1, 32, true>(a, wmode, stream);                      // 128 x 64
+    if (f2 == 182) return launch_cfg<1, 8, true, 1, 2>(a, wmode, stream);                                // 64 x 128, two chunks ahead
+    if (f2 == 282) return launch_cfg<1, 8, true, 1, 1, 64>(a, wmode, stream);                            // 64 x 128, 64-wide chunks
+    if (f2 == 184) return launch_cfg<2, 4, true, 1, 2>(a, wmode, stream);                                // 128 x 64, two chunks ahead
     if (f2 == 212) return launch_cfg<1, 1, true, 2, 1, 64>(a, wmode, stream);                            // 32 x 32, 64-wide chunks
     if (f2 == 222) return launch_cfg<1, 2, true, 2, 1, 64>(a, wmode, stream);                            // 32 x 64, 64-wide chunks
     if (f2 == 232) return launch_cfg<1, 3, true, 2, 1, 64>(a, wmode, stream);                            // 32 x 96

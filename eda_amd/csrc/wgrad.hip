@@ -369,16 +369,27 @@ extern "C" int eda_wgrad_f32(const float *dy, long ld_dy, const float *x, long l
 
 
 // ---------------------------------------------------------------------------------------------
-// The same split-K kernel with a PROLOGUE on the X operand: the fused set-abstraction / feature-
+// The split-K weight gradient with a PROLOGUE on the X operand: the fused set-abstraction / feature-
 // propagation pipeline (sa_cl.hip) never writes the activated tensor relu(BN(z)) nor the grouped
 // neighbourhood rows to HBM, so the weight gradient recomputes them while staging X into LDS --
 // exactly what csrc/gemm.hip's forward kernel does with its row operand.  The K axis here is the
 // row axis (up to 10^6 positions), always split; dY is read as stored (16-byte rows).
-template <int XMODE>
-__global__ __launch_bounds__(WG_THREADS) void wgrad_x_kernel(const WgradXArgs a, int chunks_per_split, int tiles_n,
-                                                             int ntiles, int nsplits) {
-  __shared__ float As[WG_KC][WG_STRIDE];
-  __shared__ float Bs[WG_KC][WG_STRIDE];
+//
+// Tile TM x TN (TM in {64, 96, 128} output rows = layer outputs, TN in {64, 128, 160} output
+// columns = layer inputs; 160 holds the gather layer's 4 + 128 columns in one tile): the 96 x 96
+// tile of the kernels above wasted 41-56 % of the MFMAs on the 64 / 128 / 256-wide SA layers.
+// TM/16 row strips x 2 column halves of waves, a wave owns 16 x TN/2 (TN/32 accumulators fed by ONE
+// A operand read each k step).
+template <int TM, int TN, int XMODE>
+__global__ __launch_bounds__(TM * 8) void wgrad_x_kernel(const WgradXArgs a, int chunks_per_split, int tiles_n,
+                                                         int ntiles, int nsplits) {
+  constexpr int THREADS = TM * 8;                  // (TM/16) x 2 waves
+  constexpr int SA = TM + 16, SB = TN + 16;        // LDS row strides (= 16 mod 32: conflict-free b32 operand reads)
+  constexpr int NA = 64 * (TM / 4), NB = 64 * (TN / 4);          // float4 slots per chunk
+  constexpr int LDA = (NA + THREADS - 1) / THREADS, LDB = (NB + THREADS - 1) / THREADS;
+  constexpr int NT = TN / 32;                      // accumulators per wave
+  __shared__ float As[WG_KC][SA];
+  __shared__ float Bs[WG_KC][SB];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wh = w & 1;
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -386,7 +397,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_x_kernel(const WgradXArgs a,
   if (s >= nsplits) return;
   const int tile = j - (j / ntiles) * ntiles;
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-  const int m0 = tm * WG_T, n0 = tn * WG_T;
+  const int m0 = tm * TM, n0 = tn * TN;
   const int M = a.M, N = a.N;
   const long K = a.R;
   const long kbeg = (long)s * chunks_per_split * WG_KC;
@@ -394,20 +405,26 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_x_kernel(const WgradXArgs a,
   if (kend > K) kend = K;
   if (kbeg >= kend) return;
 
-  float4 ra[WG_LD], rb[WG_LD];
-  int lrow[WG_LD], lcol[WG_LD];
+  float4 ra[LDA], rb[LDB];
+  int arow[LDA], acol[LDA], brow[LDB], bcol[LDB];
 #pragma unroll
-  for (int i = 0; i < WG_LD; ++i) {
-    const int idx = tid + WG_THREADS * i;
-    lrow[i] = idx / (WG_T / 4);
-    lcol[i] = (idx - lrow[i] * (WG_T / 4)) * 4;
+  for (int i = 0; i < LDA; ++i) {
+    const int idx = tid + THREADS * i;
+    arow[i] = idx / (TM / 4);
+    acol[i] = (idx - arow[i] * (TM / 4)) * 4;
+  }
+#pragma unroll
+  for (int i = 0; i < LDB; ++i) {
+    const int idx = tid + THREADS * i;
+    brow[i] = idx / (TN / 4);
+    bcol[i] = (idx - brow[i] * (TN / 4)) * 4;
   }
   // column constants of the prologue (the column of a thread's float4 never changes)
-  float4 bsc[WG_LD], bsh[WG_LD];
+  float4 bsc[LDB], bsh[LDB];
   if (XMODE == X_BNRELU) {
 #pragma unroll
-    for (int i = 0; i < WG_LD; ++i) {
-      const int c = n0 + lcol[i] < N ? n0 + lcol[i] : N - 4;
+    for (int i = 0; i < LDB; ++i) {
+      const int c = n0 + bcol[i] < N ? n0 + bcol[i] : N - 4;
       bsc[i] = *reinterpret_cast<const float4 *>(a.in_scale + c);
       bsh[i] = *reinterpret_cast<const float4 *>(a.in_shift + c);
     }
@@ -416,25 +433,31 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_x_kernel(const WgradXArgs a,
   // plain rows that are not 16-byte addressable (odd channel counts): element loads
   const bool x_elem = XMODE == X_PLAIN && ((N & 3) != 0 || (a.ld_x & 3) != 0 || (reinterpret_cast<uintptr_t>(a.x) & 15u) != 0);
   const long rows_per_scene = (long)a.m * a.ns;
-  int gp[WG_LD];                       // X_GATHER: b*n_pts + point of the row being fetched NEXT
+  int gp[LDB];                         // X_GATHER: b*n_pts + point of the row being fetched NEXT
   auto fetch_idx = [&](long k0) {
 #pragma unroll
-    for (int i = 0; i < WG_LD; ++i) {
-      long k = k0 + lrow[i];
+    for (int i = 0; i < LDB; ++i) {
+      long k = k0 + brow[i];
       if (k >= kend) k = kend - 1;
       const int b = (int)(k / rows_per_scene);
       gp[i] = b * a.n_pts + a.idx[k];
     }
   };
-  float gx[WG_LD][3], gc[WG_LD][3];    // raw point / centre coordinates of the xyz quad (stage-time arithmetic)
+  float gx[LDB][3], gc[LDB][3];        // raw point / centre coordinates of the xyz quad (stage-time arithmetic)
   auto fetch = [&](long k0) {
 #pragma unroll
-    for (int i = 0; i < WG_LD; ++i) {
-      long k = k0 + lrow[i];
+    for (int i = 0; i < LDA; ++i) {
+      long k = k0 + arow[i];
       if (k >= kend) k = kend - 1;                       // clamped: zeroed when staged
-      const int mc = m0 + lcol[i] < M ? m0 + lcol[i] : M - 4;
+      if (arow[i] >= WG_KC) k = kend - 1;
+      const int mc = m0 + acol[i] < M ? m0 + acol[i] : M - 4;
       ra[i] = *reinterpret_cast<const float4 *>(a.dy + k * a.ld_dy + mc);
-      const int nc = n0 + lcol[i];
+    }
+#pragma unroll
+    for (int i = 0; i < LDB; ++i) {
+      long k = k0 + brow[i];
+      if (k >= kend || brow[i] >= WG_KC) k = kend - 1;
+      const int nc = n0 + bcol[i];
       if (XMODE == X_GATHER) {
         const int C = a.c_feat;
         if (nc == 0) {
@@ -468,44 +491,52 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_x_kernel(const WgradXArgs a,
   };
   auto stage = [&](long k0) {
 #pragma unroll
-    for (int i = 0; i < WG_LD; ++i) {
-      const bool rowok = k0 + lrow[i] < kend;
-      float4 va = ra[i], vb = rb[i];
-      const int nc = n0 + lcol[i];
-      if (XMODE == X_BNRELU) {
-        vb.x = fmaxf(vb.x * bsc[i].x + bsh[i].x, 0.f); vb.y = fmaxf(vb.y * bsc[i].y + bsh[i].y, 0.f);
-        vb.z = fmaxf(vb.z * bsc[i].z + bsh[i].z, 0.f); vb.w = fmaxf(vb.w * bsc[i].w + bsh[i].w, 0.f);
+    for (int i = 0; i < LDA; ++i) {
+      if (arow[i] < WG_KC) {
+        float4 va = ra[i];
+        if (k0 + arow[i] >= kend || m0 + acol[i] >= M) va = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(&As[arow[i]][acol[i]]) = va;
       }
-      if (XMODE == X_GATHER) {
-        if (nc == 0)
-          vb = make_float4((gx[i][0] - gc[i][0]) * a.inv_radius, (gx[i][1] - gc[i][1]) * a.inv_radius,
-                           (gx[i][2] - gc[i][2]) * a.inv_radius, 0.f);
-        else if (!cvec) {
-          const int C = a.c_feat;
-          if (nc - 4 + 0 >= C) vb.x = 0.f;
-          if (nc - 4 + 1 >= C) vb.y = 0.f;
-          if (nc - 4 + 2 >= C) vb.z = 0.f;
-          if (nc - 4 + 3 >= C) vb.w = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < LDB; ++i) {
+      if (brow[i] < WG_KC) {
+        const bool rowok = k0 + brow[i] < kend;
+        float4 vb = rb[i];
+        const int nc = n0 + bcol[i];
+        if (XMODE == X_BNRELU) {
+          vb.x = fmaxf(vb.x * bsc[i].x + bsh[i].x, 0.f); vb.y = fmaxf(vb.y * bsc[i].y + bsh[i].y, 0.f);
+          vb.z = fmaxf(vb.z * bsc[i].z + bsh[i].z, 0.f); vb.w = fmaxf(vb.w * bsc[i].w + bsh[i].w, 0.f);
         }
+        if (XMODE == X_GATHER) {
+          if (nc == 0)
+            vb = make_float4((gx[i][0] - gc[i][0]) * a.inv_radius, (gx[i][1] - gc[i][1]) * a.inv_radius,
+                             (gx[i][2] - gc[i][2]) * a.inv_radius, 0.f);
+          else if (!cvec) {
+            const int C = a.c_feat;
+            if (nc - 4 + 0 >= C) vb.x = 0.f;
+            if (nc - 4 + 1 >= C) vb.y = 0.f;
+            if (nc - 4 + 2 >= C) vb.z = 0.f;
+            if (nc - 4 + 3 >= C) vb.w = 0.f;
+          }
+        }
+        if (x_elem) {
+          if (nc + 1 >= N) vb.y = 0.f;
+          if (nc + 2 >= N) vb.z = 0.f;
+          if (nc + 3 >= N) vb.w = 0.f;
+        }
+        if (!rowok || nc >= N) vb = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(&Bs[brow[i]][bcol[i]]) = vb;
       }
-      if (x_elem) {
-        if (nc + 1 >= N) vb.y = 0.f;
-        if (nc + 2 >= N) vb.z = 0.f;
-        if (nc + 3 >= N) vb.w = 0.f;
-      }
-      if (!rowok || m0 + lcol[i] >= M) va = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!rowok || nc >= N) vb = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4 *>(&As[lrow[i]][lcol[i]]) = va;
-      *reinterpret_cast<float4 *>(&Bs[lrow[i]][lcol[i]]) = vb;
     }
   };
 
-  f32x4 acc[3];
+  f32x4 acc[NT];
 #pragma unroll
-  for (int t = 0; t < 3; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const bool active = (m0 + 16 * wm < M) && (n0 + 48 * wh < N);
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool active = (m0 + 16 * wm < M) && (n0 + (TN / 2) * wh < N);
   const float *ap = &As[lane >> 4][16 * wm + (lane & 15)];
-  const float *bp = &Bs[lane >> 4][48 * wh + (lane & 15)];
+  const float *bp = &Bs[lane >> 4][(TN / 2) * wh + (lane & 15)];
 
   if (XMODE == X_GATHER) fetch_idx(kbeg);
   fetch(kbeg);
@@ -519,19 +550,19 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_x_kernel(const WgradXArgs a,
     }
     if (active) {
 #pragma unroll
-      for (int half = 0; half < 4; ++half) {
-        float av[WG_KC / 16], bv[3][WG_KC / 16];
+      for (int q = 0; q < 4; ++q) {                      // 4 k steps at a time (16 rows of the chunk)
+        float av[4], bv[NT][4];
 #pragma unroll
-        for (int kk = 0; kk < WG_KC / 16; ++kk) {
-          av[kk] = ap[(half * (WG_KC / 16) + kk) * 4 * WG_STRIDE];
+        for (int kk = 0; kk < 4; ++kk) {
+          av[kk] = ap[(q * 4 + kk) * 4 * SA];
 #pragma unroll
-          for (int t = 0; t < 3; ++t) bv[t][kk] = bp[(half * (WG_KC / 16) + kk) * 4 * WG_STRIDE + 16 * t];
+          for (int t = 0; t < NT; ++t) bv[t][kk] = bp[(q * 4 + kk) * 4 * SB + 16 * t];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kk = 0; kk < WG_KC / 16; ++kk) {
+        for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-          for (int t = 0; t < 3; ++t)
+          for (int t = 0; t < NT; ++t)
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv[t][kk], acc[t], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -543,8 +574,8 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_x_kernel(const WgradXArgs a,
   float *o = a.ws + (long)s * M * N;
   if (active) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const int col = n0 + 48 * wh + 16 * t + (lane & 15);
+    for (int t = 0; t < NT; ++t) {
+      const int col = n0 + (TN / 2) * wh + 16 * t + (lane & 15);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + 16 * wm + 4 * (lane >> 4) + r;
@@ -580,12 +611,24 @@ __global__ __launch_bounds__(256) void wgrad_x_reduce_kernel(const float *__rest
 }
 
 namespace {
-WgPlan wgx_plan(long R, int M, int N) {
-  WgPlan p;
-  p.tiles_m = (M + WG_T - 1) / WG_T;
-  p.tiles_n = (N + WG_T - 1) / WG_T;
+struct WgxPlan { int TM, TN, tiles_m, tiles_n, splits, cps; };
+WgxPlan wgx_plan(long R, int M, int N, bool gather) {
+  WgxPlan p;
+  // tile: the candidate with the least padded area (ties: the larger tile)
+  const int tms[3] = {128, 96, 64};
+  const int tns_plain[2] = {128, 64}, tns_gather[2] = {160, 64};
+  const int *tns = gather ? tns_gather : tns_plain;
+  long best = -1;
+  p.TM = 128; p.TN = tns[0];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 2; ++j) {
+      const long area = (long)((M + tms[i] - 1) / tms[i]) * tms[i] * ((N + tns[j] - 1) / tns[j]) * tns[j];
+      if (best < 0 || area < best) { best = area; p.TM = tms[i]; p.TN = tns[j]; }
+    }
+  p.tiles_m = (M + p.TM - 1) / p.TM;
+  p.tiles_n = (N + p.TN - 1) / p.TN;
   const long nchunks = (R + WG_KC - 1) / WG_KC;
-  // ~512 workgroups (2 x 12 waves per CU on 256 CUs), at least 4 chunks per split
+  // ~512 workgroups, at least 4 chunks per split
   long want = (512 + p.tiles_m * p.tiles_n - 1) / (p.tiles_m * p.tiles_n);
   if (want > nchunks / 4) want = nchunks / 4;
   if (want < 1) want = 1;
@@ -594,12 +637,26 @@ WgPlan wgx_plan(long R, int M, int N) {
   p.splits = (int)((nchunks + p.cps - 1) / p.cps);
   return p;
 }
+
+template <int TM, int TN>
+void wgx_launch(const WgradXArgs &a, const WgxPlan &p, hipStream_t stream) {
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const dim3 grid((unsigned)(8 * ntiles * ((p.splits + 7) / 8))), block(TM * 8);
+  if (a.xmode == X_PLAIN)
+    hipLaunchKernelGGL((wgrad_x_kernel<TM, TN, X_PLAIN>), grid, block, 0, stream, a, p.cps, p.tiles_n, ntiles, p.splits);
+  else if (a.xmode == X_BNRELU)
+    hipLaunchKernelGGL((wgrad_x_kernel<TM, TN, X_BNRELU>), grid, block, 0, stream, a, p.cps, p.tiles_n, ntiles, p.splits);
+  else
+    hipLaunchKernelGGL((wgrad_x_kernel<TM, TN, X_GATHER>), grid, block, 0, stream, a, p.cps, p.tiles_n, ntiles, p.splits);
+}
 }  // namespace
 
 size_t eda_wgrad_x_workspace_bytes(long R, int M, int N) {
   if (R <= 0 || M <= 0 || N <= 0) return 0;
-  const WgPlan p = wgx_plan(R, M, N);
-  return sizeof(float) * (size_t)p.splits * (size_t)M * N;
+  // (the split count depends on the tile; take the larger of the plain / gather plans)
+  const WgxPlan p = wgx_plan(R, M, N, false), q = wgx_plan(R, M, N, true);
+  const int sp = p.splits > q.splits ? p.splits : q.splits;
+  return sizeof(float) * (size_t)sp * (size_t)M * N;
 }
 
 int eda_wgrad_x_launch(const WgradXArgs &a, hipStream_t stream) {
@@ -615,19 +672,18 @@ int eda_wgrad_x_launch(const WgradXArgs &a, hipStream_t stream) {
     eda_set_error("wgrad_x: BN+ReLU rows must be 16-byte addressable");
     return EDA_ERR_INVALID_ARG;
   }
-  const WgPlan p = wgx_plan(a.R, a.M, a.N);
-  if (!a.ws || a.ws_bytes < eda_wgrad_x_workspace_bytes(a.R, a.M, a.N)) {
+  const WgxPlan p = wgx_plan(a.R, a.M, a.N, a.xmode == X_GATHER);
+  if (!a.ws || a.ws_bytes < sizeof(float) * (size_t)p.splits * a.M * a.N) {
     eda_set_error("wgrad_x: workspace too small");
     return EDA_ERR_WORKSPACE;
   }
-  const int ntiles = p.tiles_m * p.tiles_n;
-  const dim3 grid((unsigned)(8 * ntiles * ((p.splits + 7) / 8)));
-  if (a.xmode == X_PLAIN)
-    hipLaunchKernelGGL(wgrad_x_kernel<X_PLAIN>, grid, dim3(WG_THREADS), 0, stream, a, p.cps, p.tiles_n, ntiles, p.splits);
-  else if (a.xmode == X_BNRELU)
-    hipLaunchKernelGGL(wgrad_x_kernel<X_BNRELU>, grid, dim3(WG_THREADS), 0, stream, a, p.cps, p.tiles_n, ntiles, p.splits);
-  else
-    hipLaunchKernelGGL(wgrad_x_kernel<X_GATHER>, grid, dim3(WG_THREADS), 0, stream, a, p.cps, p.tiles_n, ntiles, p.splits);
+  if (p.TN == 64) {
+    if (p.TM == 128) wgx_launch<128, 64>(a, p, stream); else if (p.TM == 96) wgx_launch<96, 64>(a, p, stream); else wgx_launch<64, 64>(a, p, stream);
+  } else if (p.TN == 128) {
+    if (p.TM == 128) wgx_launch<128, 128>(a, p, stream); else if (p.TM == 96) wgx_launch<96, 128>(a, p, stream); else wgx_launch<64, 128>(a, p, stream);
+  } else {
+    if (p.TM == 128) wgx_launch<128, 160>(a, p, stream); else if (p.TM == 96) wgx_launch<96, 160>(a, p, stream); else wgx_launch<64, 160>(a, p, stream);
+  }
   EDA_CHECK_LAUNCH();
   const long MN = (long)a.M * a.N;
   hipLaunchKernelGGL(wgrad_x_reduce_kernel, dim3((unsigned)((MN + 31) / 32)), dim3(256), 0, stream, a.ws, p.splits,
