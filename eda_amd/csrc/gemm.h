@@ -10,6 +10,10 @@ enum { X_PLAIN = 0, X_BNRELU = 1, X_GATHER = 2 };
 enum { W_NT = 0, W_NN = 1 };
 enum { E_PLAIN = 0, E_STATS = 1, E_MASK = 2, E_SCATTER = 3 };
 
+// one problem of a grouped launch: same row count, own operands / widths (plain rows, plain epilogue)
+struct GemmGroup { const float *x; long ldx; const float *w; long ldw; const float *bias; float *y; long ldy; int K, N, ct0; };
+constexpr int G_MAXGROUPS = 4;
+
 struct GemmArgs {
   int xmode, epi;
   // row operand
@@ -32,6 +36,7 @@ struct GemmArgs {
   // E_SCATTER
   float *dfeats;
   int col_tiles; long row_blocks; int row_slots; unsigned ticket_target;
+  int ngroups; GemmGroup grp[G_MAXGROUPS];     // ngroups > 1: block column tile ct belongs to the group with ct0 <= ct
   int dbg;   // EDA_GEMM_DBG timing experiments (results are then wrong): 1 skip park, 2 no grid cap, 4 skip atomics, 8 skip z loads
 };
 

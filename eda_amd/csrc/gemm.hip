@@ -75,7 +75,7 @@ __device__ __forceinline__ float row_sum16(float v) {
 // DB = LDS double buffering: chunk c+1 is written to the other half of LDS while chunk c is multiplied,
 // ONE barrier per chunk instead of two (PF must be 1: the register set holds chunk c+2 meanwhile).
 template <int WR, int WC, int WMODE, int XMODE, bool VEC, int WN = 1, int PF = 1, int KC = G_KC, bool DB = false>
-__global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a_in) {
   constexpr int BM = 64 * WR / WN, BN = 16 * WC * WN;
   constexpr int XS = KC + 8;                                     // LDS row stride of [row][k] tiles
   constexpr int KQ = KC / 4;                                     // float4 per tile row
@@ -96,7 +96,21 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a) 
   const int wave_m = wave / WN, wave_n = wave % WN;
   const int xcd = blockIdx.x & 7;
   const long q = blockIdx.x >> 3;
-  const int ct = (int)(q % a.col_tiles);
+  GemmArgs a = a_in;                      // (uniform: scalar registers; a grouped launch patches the operands.
+                                          //  The group table is only ever indexed in the kernel-argument
+                                          //  segment: a dynamic index into the local copy would put it in scratch)
+  a.ngroups = 0;
+  int ct = (int)(q % a_in.col_tiles);
+  if (a_in.ngroups > 1) {
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < G_MAXGROUPS; ++i)
+      if (i < a_in.ngroups && ct >= a_in.grp[i].ct0) g = i;
+    const GemmGroup *gp = &a_in.grp[g];
+    a.x = gp->x; a.ldx = gp->ldx; a.w = gp->w; a.ldw = gp->ldw; a.bias = gp->bias;
+    a.y = gp->y; a.ldy = gp->ldy; a.K = gp->K; a.N = gp->N;
+    ct -= gp->ct0;
+  }
   // persistent over row blocks: this workgroup owns row blocks rb_first, rb_first + rb_step, ...
   // (one pass unless the launcher capped the grid: the statistics epilogues do, so that a column
   // costs one fp64 atomic per WORKGROUP, not per row block)
@@ -574,6 +588,11 @@ int launch_cfg(GemmArgs &a, int wmode, hipStream_t stream) {
   constexpr int BM = 64 * WR / WN, BN = 16 * WC * WN;
   a.row_blocks = (a.R + BM - 1) / BM;
   a.col_tiles = (a.N + BN - 1) / BN;
+  if (a.ngroups > 1) {
+    int ct = 0;
+    for (int g = 0; g < a.ngroups; ++g) { a.grp[g].ct0 = ct; ct += (a.grp[g].N + BN - 1) / BN; }
+    a.col_tiles = ct;
+  }
   long groups = (a.row_blocks + 7) / 8;
   {
     static int dbg = -1;
@@ -707,4 +726,69 @@ extern "C" int eda_linear_dgrad_f32(const float *dy, long lddy, long R, int N, c
   a.w = w; a.ldw = ldw; a.N = K;                 // W (N, K) read as (contraction, output column)
   a.y = dx; a.ldy = lddx;
   return eda_gemm_launch(a, W_NN, (hipStream_t)stream_);
+}
+
+
+// ---- C ABI: sibling linear layers in one launch -------------------------------------------------
+namespace {
+int launch_grouped(GemmArgs &a, int wmode, hipStream_t stream) {
+  // every group must satisfy the 16-byte conditions for the fast kernel; otherwise the element-wise one
+  bool vec = true;
+  int nmax = 0;
+  for (int g = 0; g < a.ngroups; ++g) {
+    GemmArgs t = a;
+    t.x = a.grp[g].x; t.ldx = a.grp[g].ldx; t.w = a.grp[g].w; t.ldw = a.grp[g].ldw; t.K = a.grp[g].K; t.N = a.grp[g].N;
+    vec = vec && gemm_vec_ok(t, wmode) && !(wmode == W_NN && (t.ldw % 4 != 0 || (reinterpret_cast<uintptr_t>(t.w) & 15u) != 0));
+    if (t.N > nmax) nmax = t.N;
+  }
+  a.N = nmax; a.K = a.grp[0].K; a.x = a.grp[0].x; a.w = a.grp[0].w; a.y = a.grp[0].y;
+  a.ldx = a.grp[0].ldx; a.ldw = a.grp[0].ldw; a.ldy = a.grp[0].ldy;
+  if (!vec) return launch_cfg<1, 4, false>(a, wmode, stream);
+  return launch_cfg<1, 1, true, 2, 2>(a, wmode, stream);            // 32 x 32 tiles: these are small launches
+}
+}  // namespace
+
+extern "C" int eda_linear_grouped_fwd_f32(int ngroups, const float *const *x, const long *ldx, long R, const int *K,
+                                          const float *const *w, const long *ldw, const int *N,
+                                          const float *const *bias, int relu, float *const *y, const long *ldy,
+                                          void *stream_) {
+  EDA_CHECK_ARG(ngroups >= 1 && ngroups <= G_MAXGROUPS && R >= 0, "1..4 groups");
+  if (R == 0) return 0;
+  EDA_CHECK_ARG(x && ldx && K && w && ldw && N && y && ldy, "null pointer");
+  GemmArgs a;
+  gemm_defaults(a);
+  a.xmode = X_PLAIN; a.epi = E_PLAIN; a.R = R; a.relu = relu; a.ngroups = ngroups;
+  for (int g = 0; g < ngroups; ++g) {
+    EDA_CHECK_ARG(x[g] && w[g] && y[g] && K[g] > 0 && N[g] > 0 && ldx[g] >= K[g] && ldw[g] >= K[g] && ldy[g] >= N[g], "bad group");
+    a.grp[g] = GemmGroup{x[g], ldx[g], w[g], ldw[g], bias ? bias[g] : nullptr, y[g], ldy[g], K[g], N[g], 0};
+  }
+  if (ngroups == 1) {
+    a.ngroups = 0;
+    a.x = x[0]; a.ldx = ldx[0]; a.K = K[0]; a.w = w[0]; a.ldw = ldw[0]; a.N = N[0]; a.bias = bias ? bias[0] : nullptr;
+    a.y = y[0]; a.ldy = ldy[0];
+    return eda_gemm_launch(a, W_NT, (hipStream_t)stream_);
+  }
+  return launch_grouped(a, W_NT, (hipStream_t)stream_);
+}
+
+extern "C" int eda_linear_grouped_dgrad_f32(int ngroups, const float *const *dy, const long *lddy, long R, const int *N,
+                                            const float *const *w, const long *ldw, const int *K, float *const *dx,
+                                            const long *lddx, void *stream_) {
+  EDA_CHECK_ARG(ngroups >= 1 && ngroups <= G_MAXGROUPS && R >= 0, "1..4 groups");
+  if (R == 0) return 0;
+  EDA_CHECK_ARG(dy && lddy && K && w && ldw && N && dx && lddx, "null pointer");
+  GemmArgs a;
+  gemm_defaults(a);
+  a.xmode = X_PLAIN; a.epi = E_PLAIN; a.R = R; a.ngroups = ngroups;
+  for (int g = 0; g < ngroups; ++g) {
+    EDA_CHECK_ARG(dy[g] && w[g] && dx[g] && K[g] > 0 && N[g] > 0 && lddy[g] >= N[g] && ldw[g] >= K[g] && lddx[g] >= K[g], "bad group");
+    // contraction over the layer's N outputs, K output columns
+    a.grp[g] = GemmGroup{dy[g], lddy[g], w[g], ldw[g], nullptr, dx[g], lddx[g], N[g], K[g], 0};
+  }
+  if (ngroups == 1) {
+    a.ngroups = 0;
+    a.x = dy[0]; a.ldx = lddy[0]; a.K = N[0]; a.w = w[0]; a.ldw = ldw[0]; a.N = K[0]; a.y = dx[0]; a.ldy = lddx[0];
+    return eda_gemm_launch(a, W_NN, (hipStream_t)stream_);
+  }
+  return launch_grouped(a, W_NN, (hipStream_t)stream_);
 }

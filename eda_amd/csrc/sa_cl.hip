@@ -479,6 +479,14 @@ __device__ __forceinline__ float wave_sum64(float v) {
 // Element dropout fused behind the ReLU (the heads' Conv-BN-ReLU-Dropout): the same counter-based
 // hash as csrc/ln.hip (step counter x call-site salt, element index), regenerated in the backward.
 struct BnDrop { bool on; unsigned seed, thresh; float inv_keep; };
+// per-channel-group parameters of the single-launch kernels: channel c belongs to group c / cpg (sibling
+// BatchNorm modules applied to column blocks of one row matrix, e.g. the three MLPs of a prediction head)
+struct BnGrp {
+  const float *gamma[4], *beta[4];
+  float *running_mean[4], *running_var[4];
+  unsigned salt[4];
+  int cpg;
+};
 __device__ __forceinline__ unsigned bn_hash32(unsigned x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
@@ -500,15 +508,18 @@ __device__ __forceinline__ float bn_keep(const BnDrop &d, unsigned idx) {
 // row (CQ = 4: 64-byte segments instead of 16-byte ones), rows are strided by SM_THREADS / CQ.
 template <int CQ>
 __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_fwd_kernel(
-    const float *__restrict__ z, int R, int C, const float *__restrict__ gamma,
-    const float *__restrict__ beta, float eps, float momentum, int training,
-    float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ mean_out,
+    const float *__restrict__ z, int R, int C, const BnGrp G, float eps, float momentum, int training,
+    float *__restrict__ mean_out,
     float *__restrict__ rstd_out, float *__restrict__ scale_out, float *__restrict__ shift_out,
-    float *__restrict__ out, float p_drop, const unsigned long long *seed_ptr, unsigned salt) {
+    float *__restrict__ out, float p_drop, const unsigned long long *seed_ptr) {
   constexpr int RL = SM_THREADS / CQ;              // row lanes
   __shared__ float red[8][CQ][SM_WAVES];
   __shared__ float sc_l[4 * CQ], sh_l[4 * CQ];
-  const BnDrop dr = bn_drop(p_drop, seed_ptr, salt);
+  const int grp = (blockIdx.x * 4 * CQ) / G.cpg, gc0 = grp * G.cpg;     // (a block's channels lie in one group)
+  const float *gamma = G.gamma[grp] - gc0, *beta = G.beta[grp] - gc0;
+  float *running_mean = G.running_mean[grp] ? G.running_mean[grp] - gc0 : nullptr;
+  float *running_var = G.running_var[grp] ? G.running_var[grp] - gc0 : nullptr;
+  const BnDrop dr = bn_drop(p_drop, seed_ptr, G.salt[grp]);
   const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ;
   const int c0 = blockIdx.x * 4 * CQ + 4 * cq;     // this thread's four channels
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -574,15 +585,16 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_fwd_kernel(
 template <int CQ>
 __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_bwd_kernel(
     const float *__restrict__ da, const float *__restrict__ z, int R, int C,
-    const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ rstd,
+    const BnGrp G, const float *__restrict__ mean, const float *__restrict__ rstd,
     const float *__restrict__ scale, const float *__restrict__ shift, int train,
     double *__restrict__ s1_out, double *__restrict__ s2_out, float *__restrict__ dgamma,
-    float *__restrict__ dbeta, float *__restrict__ dz, float p_drop, const unsigned long long *seed_ptr,
-    unsigned salt) {
+    float *__restrict__ dbeta, float *__restrict__ dz, float p_drop, const unsigned long long *seed_ptr) {
   constexpr int RL = SM_THREADS / CQ;              // row lanes (see the forward kernel)
   __shared__ float red[8][CQ][SM_WAVES];
   __shared__ float ka_l[4 * CQ], kb_l[4 * CQ], kd_l[4 * CQ];
-  const BnDrop dr = bn_drop(p_drop, seed_ptr, salt);
+  const int grp = (blockIdx.x * 4 * CQ) / G.cpg;
+  const float *gamma = G.gamma[grp] - grp * G.cpg;
+  const BnDrop dr = bn_drop(p_drop, seed_ptr, G.salt[grp]);
   const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ;
   const int c0 = blockIdx.x * 4 * CQ + 4 * cq;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -733,19 +745,23 @@ extern "C" int eda_bn_relu_fwd_f32(const float *z, long R, int C, const float *g
   EDA_CHECK_ARG(z && gamma && beta && mean && rstd && scale && shift && out, "null pointer");
   if (pool == 1 && R <= SMALL_ROWS) {
     EDA_CHECK_ARG(training || (running_mean && running_var), "eval mode needs running statistics");
+    BnGrp G;
+    memset(&G, 0, sizeof(G));
+    G.gamma[0] = gamma; G.beta[0] = beta; G.running_mean[0] = running_mean; G.running_var[0] = running_var;
+    G.salt[0] = salt; G.cpg = C;
     const int cq_env = small_cq();
     if (cq_env == 4 && C % 16 == 0)
       hipLaunchKernelGGL(bn_relu_small_fwd_kernel<4>, dim3(C / 16), dim3(SM_THREADS), 0, stream, z, (int)R, C,
-                         gamma, beta, eps, momentum, training, running_mean, running_var, mean, rstd, scale,
-                         shift, out, p_drop, seed_ptr, salt);
+                         G, eps, momentum, training, mean, rstd, scale,
+                         shift, out, p_drop, seed_ptr);
     else if (cq_env == 2 && C % 8 == 0)
       hipLaunchKernelGGL(bn_relu_small_fwd_kernel<2>, dim3(C / 8), dim3(SM_THREADS), 0, stream, z, (int)R, C,
-                         gamma, beta, eps, momentum, training, running_mean, running_var, mean, rstd, scale,
-                         shift, out, p_drop, seed_ptr, salt);
+                         G, eps, momentum, training, mean, rstd, scale,
+                         shift, out, p_drop, seed_ptr);
     else
       hipLaunchKernelGGL(bn_relu_small_fwd_kernel<1>, dim3(C / 4), dim3(SM_THREADS), 0, stream, z, (int)R, C,
-                         gamma, beta, eps, momentum, training, running_mean, running_var, mean, rstd, scale,
-                         shift, out, p_drop, seed_ptr, salt);
+                         G, eps, momentum, training, mean, rstd, scale,
+                         shift, out, p_drop, seed_ptr);
     EDA_CHECK_LAUNCH();
     return 0;
   }
@@ -802,19 +818,22 @@ extern "C" int eda_bn_relu_bwd_f32(const float *dout, const unsigned char *argma
   EDA_CHECK_ARG(dout && z && gamma && mean && rstd && scale && shift && ws && dz, "null pointer");
   EDA_CHECK_ARG(pool == 1 || argmax, "argmax required when pooling");
   if (pool == 1 && R <= SMALL_ROWS) {
+    BnGrp G;
+    memset(&G, 0, sizeof(G));
+    G.gamma[0] = gamma; G.salt[0] = salt; G.cpg = C;
     const int cq_env = small_cq();
     if (cq_env == 4 && C % 16 == 0)
       hipLaunchKernelGGL(bn_relu_small_bwd_kernel<4>, dim3(C / 16), dim3(SM_THREADS), 0, stream, dout, z, (int)R,
-                         C, gamma, mean, rstd, scale, shift, training, ws, ws + C, dgamma, dbeta, dz, p_drop,
-                         seed_ptr, salt);
+                         C, G, mean, rstd, scale, shift, training, ws, ws + C, dgamma, dbeta, dz, p_drop,
+                         seed_ptr);
     else if (cq_env == 2 && C % 8 == 0)
       hipLaunchKernelGGL(bn_relu_small_bwd_kernel<2>, dim3(C / 8), dim3(SM_THREADS), 0, stream, dout, z, (int)R,
-                         C, gamma, mean, rstd, scale, shift, training, ws, ws + C, dgamma, dbeta, dz, p_drop,
-                         seed_ptr, salt);
+                         C, G, mean, rstd, scale, shift, training, ws, ws + C, dgamma, dbeta, dz, p_drop,
+                         seed_ptr);
     else
       hipLaunchKernelGGL(bn_relu_small_bwd_kernel<1>, dim3(C / 4), dim3(SM_THREADS), 0, stream, dout, z, (int)R,
-                         C, gamma, mean, rstd, scale, shift, training, ws, ws + C, dgamma, dbeta, dz, p_drop,
-                         seed_ptr, salt);
+                         C, G, mean, rstd, scale, shift, training, ws, ws + C, dgamma, dbeta, dz, p_drop,
+                         seed_ptr);
     EDA_CHECK_LAUNCH();
     return 0;
   }
@@ -1093,5 +1112,65 @@ extern "C" int eda_sa_fused_bwd_f32(const float *dout, const unsigned char *argm
       if (rc) return rc;
     }
   }
+  return 0;
+}
+
+
+// ---- sibling BatchNorm+ReLU(+Dropout) modules on column blocks of one (R, ngroups*cpg) matrix ------
+// (the three ThreeLayerMLPs of a ClsAgnosticPredictHead, models/modules.py:111-178, run side by
+// side: one launch instead of one per module).  Single-launch kernels only: R <= 4096, cpg % 16 == 0.
+extern "C" int eda_bn_relu_grouped_fwd_f32(const float *z, long R, int ngroups, int cpg, const float *const *gamma,
+                                           const float *const *beta, float *const *running_mean,
+                                           float *const *running_var, float eps, float momentum, int training,
+                                           float *mean, float *rstd, float *scale, float *shift, float *out,
+                                           float p_drop, const unsigned long long *seed_ptr, const unsigned *salts,
+                                           void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(ngroups >= 1 && ngroups <= 4 && cpg > 0 && cpg % 16 == 0, "1..4 groups of a multiple of 16 channels");
+  EDA_CHECK_ARG(R >= 0 && R <= SMALL_ROWS, "row count beyond the single-launch kernels");
+  EDA_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || (seed_ptr && salts)), "bad dropout arguments");
+  if (R == 0) return 0;
+  EDA_CHECK_ARG(z && gamma && beta && mean && rstd && scale && shift && out, "null pointer");
+  BnGrp G;
+  memset(&G, 0, sizeof(G));
+  G.cpg = cpg;
+  for (int g = 0; g < ngroups; ++g) {
+    EDA_CHECK_ARG(gamma[g] && beta[g], "null pointer");
+    G.gamma[g] = gamma[g]; G.beta[g] = beta[g];
+    G.running_mean[g] = running_mean ? running_mean[g] : nullptr;
+    G.running_var[g] = running_var ? running_var[g] : nullptr;
+    EDA_CHECK_ARG(training || (G.running_mean[g] && G.running_var[g]), "eval mode needs running statistics");
+    G.salt[g] = salts ? salts[g] : 0u;
+  }
+  const int C = ngroups * cpg;
+  hipLaunchKernelGGL(bn_relu_small_fwd_kernel<4>, dim3(C / 16), dim3(SM_THREADS), 0, stream, z, (int)R, C, G, eps,
+                     momentum, training, mean, rstd, scale, shift, out, p_drop, seed_ptr);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int eda_bn_relu_grouped_bwd_f32(const float *dout, const float *z, long R, int ngroups, int cpg,
+                                           const float *const *gamma, const float *mean, const float *rstd,
+                                           const float *scale, const float *shift, int training, float *dgamma,
+                                           float *dbeta, float *dz, float p_drop, const unsigned long long *seed_ptr,
+                                           const unsigned *salts, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(ngroups >= 1 && ngroups <= 4 && cpg > 0 && cpg % 16 == 0, "1..4 groups of a multiple of 16 channels");
+  EDA_CHECK_ARG(R >= 0 && R <= SMALL_ROWS, "row count beyond the single-launch kernels");
+  EDA_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || (seed_ptr && salts)), "bad dropout arguments");
+  EDA_CHECK_ARG(dgamma && dbeta, "null pointer");
+  const int C = ngroups * cpg;
+  if (R == 0) {
+    const int z1 = eda_zero_async(dgamma, sizeof(float) * C, stream);
+    return z1 ? z1 : eda_zero_async(dbeta, sizeof(float) * C, stream);
+  }
+  EDA_CHECK_ARG(dout && z && gamma && mean && rstd && scale && shift && dz, "null pointer");
+  BnGrp G;
+  memset(&G, 0, sizeof(G));
+  G.cpg = cpg;
+  for (int g = 0; g < ngroups; ++g) { EDA_CHECK_ARG(gamma[g], "null pointer"); G.gamma[g] = gamma[g]; G.salt[g] = salts ? salts[g] : 0u; }
+  hipLaunchKernelGGL(bn_relu_small_bwd_kernel<4>, dim3(C / 16), dim3(SM_THREADS), 0, stream, dout, z, (int)R, C, G, mean,
+                     rstd, scale, shift, training, nullptr, nullptr, dgamma, dbeta, dz, p_drop, seed_ptr);
+  EDA_CHECK_LAUNCH();
   return 0;
 }

@@ -1,6 +1,8 @@
 """Small heads around the encoder/decoder: seed objectness, query sampling,
 box prediction.  Mirrors models/modules.py:19-178 (names = checkpoint contract).
 """
+import os
+
 import numpy as np
 import torch.nn as nn
 import torch.nn.functional as F
@@ -8,6 +10,9 @@ import torch.nn.functional as F
 from .nn_utils import Conv1dK1, bn_relu_rows, rows_ok
 from .pointnet2_utils import gather_operation
 from .encoder_decoder_layers import PositionEmbeddingLearned  # noqa: F401  (re-exported like the reference)
+
+
+_GROUPED_HEADS = os.environ.get("EDA_GROUPED_HEADS", "1") != "0"
 
 
 class PointsObjClsModule(nn.Module):
@@ -107,9 +112,52 @@ class ClsAgnosticPredictHead(nn.Module):
             end_points[f"{prefix}sem_cls_scores"] = self.sem_cls_scores_head(features).transpose(2, 1)
         return center, pred_size
 
+    def sibling_stacks(self):
+        """Names of the ThreeLayerMLP sub-stacks that run side by side on the same features (FlatParams
+        lays their same-named parameters out back to back, see eda_amd/parallel.py)."""
+        names = ["objectness_scores_head"] if self.objectness else []
+        names += ["center_residual_head", "size_pred_head"]
+        if self.compute_sem_scores:
+            names.append("sem_cls_scores_head")
+        return names
+
+    def _grouped_ok(self, rows):
+        from . import _lib
+        nets = [getattr(self, n).net for n in self.sibling_stacks()]
+        bn0 = nets[0][1]
+        return (_GROUPED_HEADS and rows.is_cuda and rows.shape[0] <= _lib.lib().eda_bn_relu_dropout_max_rows()
+                and self.seed_feat_dim % 16 == 0 and 2 <= len(nets) <= 4
+                and all(n[1].training == bn0.training and n[5].training == bn0.training for n in nets)
+                and all(n[3].p == nets[0][3].p and n[7].p == nets[0][3].p for n in nets))
+
+    def _sibling_mlps_rows(self, rows):
+        """All ThreeLayerMLP stacks of this head on rows (R, C): layer l of every stack in ONE launch
+        (eda_amd/grouped.py) -- 5 launches instead of 5 per stack."""
+        from . import grouped
+        nets = [getattr(self, n).net for n in self.sibling_stacks()]
+        z1 = grouped.shared_in_linear(rows, [n[0].weight.squeeze(-1) for n in nets])
+        a1 = grouped.grouped_bn_relu(z1, [n[1] for n in nets], [n[3] for n in nets])
+        z2 = grouped.block_linear(a1, [n[4].weight.squeeze(-1) for n in nets], [None] * len(nets), pack_out=True)
+        a2 = grouped.grouped_bn_relu(z2, [n[5] for n in nets], [n[7] for n in nets])
+        outs = grouped.block_linear(a2, [n[8].weight.squeeze(-1) for n in nets], [n[8].bias for n in nets],
+                                    pack_out=False)
+        return dict(zip(self.sibling_stacks(), outs))
+
     def _forward_rows(self, features, base_xyz, end_points, prefix, features_rows):
         B, C, Q = features.shape
         rows = (features_rows if features_rows is not None else features.transpose(1, 2)).reshape(B * Q, C)
+        if not self.heading and self._grouped_ok(rows):
+            o = self._sibling_mlps_rows(rows)
+            if self.objectness:
+                end_points[f"{prefix}objectness_scores"] = o["objectness_scores_head"].view(B, Q)
+            center = base_xyz + o["center_residual_head"].view(B, Q, 3)
+            pred_size = o["size_pred_head"].view(B, Q, 3)
+            end_points[f"{prefix}base_xyz"] = base_xyz
+            end_points[f"{prefix}center"] = center
+            end_points[f"{prefix}pred_size"] = pred_size
+            if self.compute_sem_scores:
+                end_points[f"{prefix}sem_cls_scores"] = o["sem_cls_scores_head"].view(B, Q, -1)
+            return center, pred_size
         if self.objectness:
             end_points[f"{prefix}objectness_scores"] = self.objectness_scores_head.rows(rows).view(B, Q)
         center = base_xyz + self.center_residual_head.rows(rows).view(B, Q, 3)

@@ -20,6 +20,33 @@ import torch
 import torch.distributed as dist
 
 
+def _siblings_adjacent(module, ordered):
+    """Re-order (name, parameter) pairs so that the same-named parameters of sibling sub-stacks (modules
+    exposing ``sibling_stacks()``: the three ThreeLayerMLPs of a prediction head) lie back to back: the
+    grouped kernels then see ONE packed weight (eda_amd/grouped.py: the shared input's gradient is a
+    single GEMM over the concatenated weights)."""
+    names = [n for n, _ in ordered]
+    pos = {n: i for i, n in enumerate(names)}
+    key = {n: (i, 0, 0) for i, n in enumerate(names)}
+    for mname, mod in module.named_modules():
+        fn = getattr(mod, "sibling_stacks", None)
+        if fn is None:
+            continue
+        stacks = fn()
+        pre = (mname + ".") if mname else ""
+        first = [n for n in names if n.startswith(pre + stacks[0] + ".")]
+        if not first:
+            continue
+        leaves = [n[len(pre + stacks[0] + "."):] for n in first]
+        anchor = min(pos[n] for n in first)
+        for li, leaf in enumerate(leaves):
+            for si, st in enumerate(stacks):
+                n = pre + st + "." + leaf
+                if n in key:
+                    key[n] = (anchor, 1 + li, si)
+    return sorted(ordered, key=lambda np_: key[np_[0]])
+
+
 class FlatParams:
     """Flat parameter / gradient storage, split into learning-rate groups.
 
@@ -41,6 +68,7 @@ class FlatParams:
             if k not in keys:
                 keys.append(k)
         ordered = [(n, p) for k in keys for (n, p) in named if group_of(n) == k]
+        ordered = _siblings_adjacent(module, ordered)
         self.params = [p for _, p in ordered]
         dev = self.params[0].device
         # every parameter starts on a 16-byte boundary (4 floats): the MFMA GEMMs read weight rows

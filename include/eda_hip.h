@@ -346,6 +346,32 @@ int eda_sa_fused_bwd_f32(const float *dout, const unsigned char *argmax, const f
                          size_t ws_bytes, float *const *dW, float *const *dgamma, float *const *dbeta,
                          float *dx, long lddx, float *dfeats_cl, void *stream);
 
+/* ---- sibling layers in one launch ---------------------------------------------------------------
+ * The three ThreeLayerMLPs of a ClsAgnosticPredictHead (models/modules.py:111-178: centre, size,
+ * semantic scores) are independent stacks of the same shape; the reference runs them one layer at
+ * a time (15 small cuDNN/cuBLAS launches per head, 7 heads).  Here layer l of all siblings is ONE
+ * launch: a grouped GEMM (up to 4 problems with the same row count, own operands and widths; host
+ * arrays of device pointers / strides / dims) and a grouped BatchNorm+ReLU+Dropout over column
+ * blocks of one (R, ngroups*cpg) matrix (single-launch kernels: R <= eda_bn_relu_dropout_max_rows()). */
+int eda_linear_grouped_fwd_f32(int ngroups, const float *const *x, const long *ldx, long R, const int *K,
+                               const float *const *w, const long *ldw, const int *N,
+                               const float *const *bias, int relu, float *const *y, const long *ldy,
+                               void *stream);
+int eda_linear_grouped_dgrad_f32(int ngroups, const float *const *dy, const long *lddy, long R, const int *N,
+                                 const float *const *w, const long *ldw, const int *K, float *const *dx,
+                                 const long *lddx, void *stream);
+int eda_bn_relu_grouped_fwd_f32(const float *z, long R, int ngroups, int cpg, const float *const *gamma,
+                                const float *const *beta, float *const *running_mean,
+                                float *const *running_var, float eps, float momentum, int training,
+                                float *mean, float *rstd, float *scale, float *shift, float *out,
+                                float p_drop, const unsigned long long *seed_ptr, const unsigned *salts,
+                                void *stream);
+int eda_bn_relu_grouped_bwd_f32(const float *dout, const float *z, long R, int ngroups, int cpg,
+                                const float *const *gamma, const float *mean, const float *rstd,
+                                const float *scale, const float *shift, int training, float *dgamma,
+                                float *dbeta, float *dz, float p_drop, const unsigned long long *seed_ptr,
+                                const unsigned *salts, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
