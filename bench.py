@@ -256,6 +256,10 @@ def main():
                          "in one grouped kernel (eda_amd/wgrad_queue.py); 0: compute each where autograd reaches it")
     ap.add_argument("--overlap", action="store_true",
                     help="run the text encoder on a side stream underneath the point backbone (measured slower)")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="N > 1: global-batch BatchNorm statistics like the reference's SyncBatchNorm "
+                         "(eda_amd/sync_bn.py: one fused statistics all-reduce per BN layer and direction; the fused "
+                         "single-launch BN paths are bypassed).  Default: per-GPU statistics (DESIGN.md §5)")
     ap.add_argument("--split-graphs", action="store_true",
                     help="use the N>1 graph structure (two graphs, eager all-reduce slot) even at N=1")
     ap.add_argument("--kernel-steps", type=int, default=3,
@@ -284,6 +288,10 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     from eda_amd import ext
+    if args.sync_bn and world > 1:
+        from eda_amd import sync_bn
+        sync_bn.enable()
+        args.graph = 0          # the statistics collectives run between kernels: eager launches
     from eda_amd.bdetr import BeaUTyDETR
     from eda_amd.parallel import FlatParams, reference_lr_groups
     if args.blas != "default":
@@ -464,6 +472,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
 
+    fps_giveups = ext.fps_status(device)
+    if fps_giveups:
+        raise SystemExit(f"furthest point sampling gave up its inter-workgroup spin in {fps_giveups} workspace(s): "
+                         "the sampled indices of this run are not the FPS result (include/eda_hip.h)")
     log(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step")
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -556,7 +568,7 @@ def main():
                            not args.no_butd, args.loss),
                        "scenes_per_gpu": args.per_gpu, "global_batch": args.per_gpu * world,
                        "points": args.points, "queries": args.queries, "tokens": args.tokens,
-                       "parallelism": f"dp{world}", "batchnorm": "per-GPU statistics",
+                       "parallelism": f"dp{world}", "batchnorm": "global-batch statistics (sync_bn)" if (args.sync_bn and world > 1) else "per-GPU statistics",
                        "launch": ("eager" if not args.graph else "hipGraph replay of the whole step" if world == 1
                                   and not args.split_graphs else
                                   "two hipGraphs (fwd+bwd | clip+AdamW) with the RCCL all-reduce between them"),

@@ -221,7 +221,12 @@ def bn_relu_rows(bn, z, dropout=None):
     training it is folded into the same kernel when the row count allows, with this repo's
     counter-based mask (deviations) instead of torch's Philox stream."""
     global _bn_drop_rows
-    from . import sa_ops
+    from . import sa_ops, sync_bn
+    if sync_bn.enabled():
+        out = sync_bn.bn_relu(bn, z)
+        if bn.training and bn.track_running_stats:
+            bump_batches_tracked(bn)
+        return dropout(out) if dropout is not None else out
     p, salt = 0.0, 0
     if dropout is not None and dropout.training and dropout.p > 0:
         if _bn_drop_rows is None:

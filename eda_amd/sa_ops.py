@@ -286,6 +286,9 @@ class FusedMLP(Function):
 
 
 def _fusable(layers):
+    from . import sync_bn
+    if sync_bn.enabled():          # global-batch statistics: a collective between GEMM and BN (eda_amd/sync_bn.py)
+        return False
     return _FUSED and all(l.bn is not None and l.conv.bias is None and l.conv.out_channels % 4 == 0 for l in layers)
 
 
@@ -318,7 +321,16 @@ def shared_mlp_rows(mlp, rows, pool):
     if _fusable(layers) and rows.is_cuda:
         return fused_mlp(mlp, pool, x_rows=rows)
     x = rows
+    from . import sync_bn
+    from .nn_utils import linear_rows
     for i, layer in enumerate(layers):
+        if sync_bn.enabled():
+            z = linear_rows(x, layer.conv.weight.reshape(layer.conv.weight.shape[0], -1), None)
+            bn = layer.bn.bn
+            x = sync_bn.bn_relu(bn, z, pool if i == len(layers) - 1 else 1)
+            if bn.training and bn.track_running_stats:
+                bump_batches_tracked(bn)
+            continue
         z = PointwiseLinearCL.apply(x, layer.conv.weight)
         bn = layer.bn.bn
         last = i == len(layers) - 1

@@ -50,3 +50,30 @@ def test_deferred_weight_gradients_match_immediate_on_the_full_model():
     rel, njobs = C.compare_grads(scenes=2, points=20000, tokens=24, num_queries=64, num_decoder_layers=2)
     assert njobs > 50
     assert rel < 2e-4, rel
+
+
+def test_split_graphs_structure_of_the_multi_gpu_step_trains_like_the_single_graph():
+    """The N > 1 step structure (graph: forward+backward | eager slot of the RCCL all-reduce | graph:
+    clip + AdamW) exercised on one GPU (`bench.py --split-graphs`): it must train like the one-graph step
+    (same in-graph loss history up to fp32-atomics noise) and report no furthest-point-sampling give-up."""
+    import json
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hists = []
+    for extra in ([], ["--split-graphs"]):
+        env = dict(os.environ, EDA_BENCH_INGRAPH_HIST="1")
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "3",
+                            "--kernel-steps", "0", "--cpu-scenes", "0", "--gemm-tuning", "shipped", "--per-gpu", "4",
+                            "--points", "20000"] + extra, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = json.loads(p.stdout.strip().splitlines()[-1])
+        assert line["value"] > 0 and "HIP graph" in p.stderr
+        m = re.search(r"in-graph loss history \((\d+) steps[^:]*\): ([-0-9. ]+)", p.stderr)
+        assert m, p.stderr[-2000:]
+        hists.append([float(v) for v in m.group(2).split()])
+    a, b = hists
+    assert len(a) == len(b) == 11
+    assert abs(a[0] - b[0]) <= 1e-3 * abs(a[0])
+    assert all(abs(x - y) <= 0.08 * max(abs(x), 1.0) for x, y in zip(a, b)), (a, b)
+    assert b[-1] < b[0]

@@ -85,3 +85,54 @@ def test_shard_scene_seeds():
     from eda_amd.parallel import shard_scene_seeds
     allseeds = sum((shard_scene_seeds(64, r, 8) for r in range(8)), [])
     assert allseeds == list(range(64))
+
+
+# ---- SyncBatchNorm-equivalent statistics (eda_amd/sync_bn.py) ----------------------------------------------
+def _sync_bn_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from eda_amd import sync_bn, nn_utils
+    sync_bn.enable()
+    g = torch.Generator().manual_seed(7)
+    C, rows = 16, [300, 212]                       # unequal shards: the count must travel with the sums
+    z_all = torch.randn(sum(rows), C, generator=g) * 1.7 + 0.3
+    w_all = torch.randn(sum(rows), C, generator=g)
+    lo = sum(rows[:rank])
+    z = z_all[lo:lo + rows[rank]].clone().requires_grad_(True)
+    bn = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5, generator=g); bn.bias.normal_(0, 0.2, generator=g)
+    bn.train()
+    y = nn_utils.bn_relu_rows(bn, z) if False else sync_bn.bn_relu(bn, z)
+    (y * w_all[lo:lo + rows[rank]]).sum().backward()
+    torch.save({"y": y.detach(), "dz": z.grad, "dgamma": bn.weight.grad, "dbeta": bn.bias.grad,
+                "rm": bn.running_mean.clone(), "rv": bn.running_var.clone()}, os.path.join(out_dir, f"sbn{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_sync_bn_two_ranks_equal_single_process_bn_over_the_concatenated_batch(tmp_path):
+    """Reference semantics at N > 1 (main_utils.py:336-338, SyncBatchNorm): two gloo ranks with unequal
+    shards must reproduce ONE BatchNorm over the concatenated rows -- outputs, input gradients, running
+    statistics; d(gamma)/d(beta) are local sums whose sum over ranks is the single-process gradient."""
+    world, port = 2, 29653
+    mp.spawn(_sync_bn_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(7)
+    C, rows = 16, [300, 212]
+    z_all = (torch.randn(sum(rows), C, generator=g) * 1.7 + 0.3).requires_grad_(True)
+    w_all = torch.randn(sum(rows), C, generator=g)
+    bn = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5, generator=g); bn.bias.normal_(0, 0.2, generator=g)
+    bn.train()
+    y = torch.relu(bn(z_all))
+    (y * w_all).sum().backward()
+    outs = [torch.load(os.path.join(str(tmp_path), f"sbn{r}.pt")) for r in range(world)]
+    torch.testing.assert_close(torch.cat([o["y"] for o in outs]), y.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(torch.cat([o["dz"] for o in outs]), z_all.grad, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(outs[0]["dgamma"] + outs[1]["dgamma"], bn.weight.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(outs[0]["dbeta"] + outs[1]["dbeta"], bn.bias.grad, rtol=1e-4, atol=1e-5)
+    for o in outs:
+        torch.testing.assert_close(o["rm"], bn.running_mean, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(o["rv"], bn.running_var, rtol=1e-5, atol=1e-6)
