@@ -77,6 +77,17 @@ def algorithmic_bytes(name):
     if op == "bn_relu_bwd":
         r, c, pool, _ = d       # read z and d(out), write dz
         return 4 * r * c * 2 + 4 * (r // pool) * c
+    if op == "sa_fused_fwd":
+        # SURVEY 8d "fused SA layer fwd": inputs once + weights + idx + pooled output; the grouped tensor and the
+        # activated tensors are never written.  (The pre-activations z_l kept for the backward are reported
+        # separately as saved_bytes by fused_saved_bytes().)
+        r, pool, _train, *ch = d
+        w = sum(ch[i] * ch[i + 1] for i in range(len(ch) - 1))
+        lvl = [v for v in SA_LEVELS if 3 + v[4] == ch[0] and 8 * v[1] * v[3] == r]
+        if lvl and pool > 1:
+            n, m, _, ns, c = lvl[0]
+            return 8 * (12 * n + 4 * c * n + 12 * m + 4 * m * ns + 4 * ch[-1] * m) + 4 * w
+        return 4 * r * ch[0] + 4 * w + 4 * (r // pool) * ch[-1]
     if op in ("three_interpolate", "three_interpolate_grad"):
         b, c, m, n = d if op == "three_interpolate" else (d[0], d[1], d[3], d[2])
         return b * (4 * c * m + 24 * n + 4 * c * n)
@@ -93,9 +104,50 @@ def algorithmic_flops(name):
     if op == "mha_bwd":
         b, h, lq, lk = d
         return 10.0 * b * h * lq * lk * 36
+    if op in ("gemm_fwd", "gemm_dgrad"):
+        r, k, n = d
+        return 2.0 * r * k * n
+    if op in ("gemm_grouped_fwd", "gemm_grouped_dgrad"):
+        _g, r, k, n = d                     # (groups, rows, K, sum of the groups' widths)
+        return 2.0 * r * k * n
+    if op in ("sa_fused_fwd", "sa_fused_bwd"):
+        r, _pool, _train, *ch = d
+        f = 2.0 * r * sum(ch[i] * ch[i + 1] for i in range(len(ch) - 1))
+        return f if op == "sa_fused_fwd" else 2.0 * f      # dX + dW (the first layer's dX only where it is needed)
     if op == "wgrad_grouped" and len(d) >= 4:
         return 2.0e6 * d[3]                  # (targets, jobs, tiles, 10^6 multiply-adds of all dW = dY^T X)
     return 0.0
+
+
+def fused_saved_bytes(name):
+    """Bytes of pre-activations a fused SA / FP forward keeps for its backward (z_l of every layer)."""
+    if name[0] != "sa_fused_fwd":
+        return 0
+    r, _pool, _train, *ch = name[1:]
+    return 4 * r * sum(ch[1:])
+
+
+def source_hash():
+    """sha256 over the HIP sources: stamps measured-offline numbers (PMC traffic) to the build they belong to."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "eda_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "eda_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc_traffic():
+    """profiles/pmc_traffic.json (written by tools/measure_traffic.py from rocprofv3 PMC passes) -> {(op, dims):
+    bytes per launch}; entries measured on a different build of the kernels are dropped (traffic: null)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return {}, "no profiles/pmc_traffic.json"
+    if d.get("source_hash") != source_hash():
+        return {}, "stale: profiles/pmc_traffic.json was measured on another build of csrc/ (%s)" % d.get("source_hash")
+    return {(e["op"], tuple(e["dims"])): e["bytes_per_launch"] for e in d.get("entries", [])}, d.get("how", "")
 
 
 def synthetic_loss(end_points):
@@ -256,6 +308,10 @@ def main():
                          "in one grouped kernel (eda_amd/wgrad_queue.py); 0: compute each where autograd reaches it")
     ap.add_argument("--overlap", action="store_true",
                     help="run the text encoder on a side stream underneath the point backbone (measured slower)")
+    ap.add_argument("--attn-dtype", choices=["f32", "bf16", "f16"], default="f32",
+                    help="arithmetic of the attention QK^T / PV contractions: f32 = the headline / parity path; bf16 / "
+                         "f16 = 16-bit MFMA with fp32 accumulation (csrc/mha16.hip, BASELINE.json configs[2] / [4]) -- "
+                         "a SEPARATE bench line, never the headline")
     ap.add_argument("--sync-bn", action="store_true",
                     help="N > 1: global-batch BatchNorm statistics like the reference's SyncBatchNorm "
                          "(eda_amd/sync_bn.py: one fused statistics all-reduce per BN layer and direction; the fused "
@@ -324,6 +380,7 @@ def main():
     inputs = make_inputs(rank, args.per_gpu, device, args.points, args.tokens)
 
     from eda_amd import attention
+    attention.set_compute_dtype(args.attn_dtype)
 
     if args.loss == "hungarian":
         from eda_amd import losses as L
@@ -488,17 +545,14 @@ def main():
             byts = algorithmic_bytes(name)
             flops = algorithmic_flops(name)
             kernels.append({"op": name[0], "dims": list(name[1:]), "calls_per_step": calls / ksteps,
-                            "ms": round(ms, 4), "alg_bytes": byts,
+                            "ms": round(ms, 4), "alg_bytes": byts, "saved_bytes": fused_saved_bytes(name),
                             "gbs": round(byts / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
                             "tflops": round(flops / (ms * 1e-3) / 1e12, 2) if flops and ms > 0 else None})
         kernels.sort(key=lambda k: -k["ms"] * k["calls_per_step"])
         native_ms = sum(k["ms"] * k["calls_per_step"] for k in kernels)
-        # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
-        # WRITE_SIZE), measured offline for this build and shape: profiles/r01k_mha_pmc.md,
-        # profiles/r01i_bn_pmc_traffic.md.  None for shapes that were not profiled.
-        pmc_traffic = {("mha_bwd", (8, 8, 1024, 1024)): 252.7e6, ("mha_fwd", (8, 8, 1024, 1024)): 92.6e6,
-                       ("bn_relu_bwd", (1048576, 64, 1, 1)): 1311.0e6,      # profiles/r01i_bn_pmc_traffic.md
-                       ("bn_relu_fwd", (1048576, 64, 1, 1)): 786.0e6}
+        # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) of
+        # THIS build of the kernels (tools/measure_traffic.py stamps them with the source hash); null otherwise
+        pmc_traffic, traffic_how = load_pmc_traffic()
         # dominant HBM-priced kernel (FPS is latency-bound: reported as us/round below)
         # HBM-priced candidates: launches that move at least 32 MB (smaller ones are launch- or
         # latency-bound and are listed in `kernels` only); FPS is latency-bound and reported below.
@@ -530,25 +584,31 @@ def main():
                             "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(dom["gbs"] / HBM_PEAK_GBS, 5),
                             "achievable_copy_gbs": copy_gbs,
+                            "guide_copy_gbs": 6290.0,       # MI355X_MICROARCH.md: measured float4 copy, 79 % of the 8 TB/s spec
                             "frac_of_achievable": round(dom["gbs"] / copy_gbs, 5) if copy_gbs else None,
                             "traffic": pmc_traffic.get((dom["op"], tuple(dom["dims"]))),
-                            "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE, bytes per launch, "
-                                              "profiles/r01i_bn_pmc_traffic.md",
+                            "traffic_source": traffic_how,
                             "ms_per_launch": dom["ms"], "alg_bytes_per_launch": dom["alg_bytes"],
                             "ms_per_step": round(dom["ms"] * dom["calls_per_step"], 4)}
-        mf = [k for k in kernels if k["tflops"] and k["op"].startswith("mha_")]   # (wgrad_grouped is priced in `kernels`)
+        # MFMA-priced single-kernel launches: attention and the own row GEMMs (multi-kernel calls such as
+        # sa_fused_* and the grouped weight gradient are priced in `kernels`)
+        mf = [k for k in kernels if k["tflops"] and (k["op"].startswith("mha_") or k["op"] in ("gemm_fwd", "gemm_dgrad"))]
+        peak16 = 2500.0                    # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA
         roofline_mfma = None
         if mf:
             # dominant attention launch (the 1024x1024 point self-attention) against the fp32-MFMA peak
             top = max(mf, key=lambda k: k["ms"] * k["calls_per_step"])
+            is16 = top["op"].startswith("mha_") and args.attn_dtype != "f32"
+            mpeak = peak16 if is16 else MFMA_F32_PEAK_TFLOPS
             roofline_mfma = {"kernel": f"{top['op']}{tuple(top['dims'])}", "bound": "mfma",
-                             "achieved": top["tflops"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(top["tflops"] / MFMA_F32_PEAK_TFLOPS, 4),
+                             "achieved": top["tflops"], "peak": mpeak, "unit": "TFLOP/s",
+                             "frac": round(top["tflops"] / mpeak, 4),
                              "traffic": pmc_traffic.get((top["op"], tuple(top["dims"]))),
-                             "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE, bytes per launch, "
-                                               "profiles/r01k_mha_pmc.md",
+                             "traffic_source": traffic_how,
                              "alg_flops_per_launch": algorithmic_flops((top["op"],) + tuple(top["dims"])),
-                             "ms_per_launch": top["ms"], "dtype": "f32 in / f32 accumulate MFMA",
+                             "ms_per_launch": top["ms"],
+                             "dtype": ("%s in / f32 accumulate MFMA (head_dim 36 padded to 48: padding not counted)" % args.attn_dtype)
+                             if is16 else "f32 in / f32 accumulate MFMA",
                              "ms_per_step": round(top["ms"] * top["calls_per_step"], 4)}
         # `roofline` = whichever of the two roofline-priced kernels takes more of the step (the
         # single largest launch, SA1's furthest point sampling, is bound by neither roof: it is
@@ -562,7 +622,8 @@ def main():
             "metric": "scenes/sec fwd+bwd (50k pts, 256 queries, 80 tok)",
             "value": round(scenes / dt, 3), "unit": "scenes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.attn_dtype == "f32" else "f32 (attention QK^T/PV contractions in %s)" % args.attn_dtype,
             "data": "synthetic",
             "config": {"workload": "BeaUTyDETR train step (fwd+bwd+clip+AdamW), butd=%s, loss=%s" % (
                            not args.no_butd, args.loss),
@@ -573,7 +634,9 @@ def main():
                                   and not args.split_graphs else
                                   "two hipGraphs (fwd+bwd | clip+AdamW) with the RCCL all-reduce between them"),
                        "text_encoder": "RoBERTa-base random-init frozen",
-                       "library_gemm_selection": ("TunableOp (%s; shipped results %s)" % (
+                       "attention_dtype": args.attn_dtype,
+                       "own_gemms": "every pointwise layer of the model (csrc/gemm.hip); hipBLASLt only inside RoBERTa",
+                       "roberta_gemm_selection": ("TunableOp (%s; shipped results %s)" % (
                            args.gemm_tuning, "loaded" if shipped_ok else "not used"))
                        if args.gemm_tuning != "off" else "library default"},
             "roofline": roofline,
@@ -584,7 +647,10 @@ def main():
             "kernel_timing": ("HIP events on the launch stream, %d eager runs of the same step after the "
                               "graph-replayed timed region" % args.kernel_steps) if args.graph else
                              "HIP events on the launch stream inside the timed region",
-            "kernels": kernels[:24],
+            "kernels": kernels[:40],
+            "gemm_family_ms_per_step": round(sum(k["ms"] * k["calls_per_step"] for k in kernels
+                                                 if k["op"].startswith(("gemm_", "sa_fused", "wgrad"))), 3),
+            "source_hash": source_hash(),
             "loss": final_loss,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -25,6 +25,21 @@ from . import _lib, gemm
 from .ext import _timed
 from .nn_utils import colsum, linear_rows, wgrad
 
+_DTYPES = {"f32": 0, "bf16": 1, "f16": 2}
+_compute_dtype = 0       # arithmetic of the QK^T / PV contractions (include/eda_hip.h EDA_DTYPE_*)
+
+
+def set_compute_dtype(name):
+    """"f32" (default: the parity path, fp32 MFMA), "bf16" or "f16" (16-bit MFMA contractions with fp32
+    accumulation and softmax, csrc/mha16.hip -- BASELINE.json configs[2] / configs[4]).  Tensors stay fp32."""
+    global _compute_dtype
+    _compute_dtype = _DTYPES[name]
+
+
+def compute_dtype():
+    return {v: k for k, v in _DTYPES.items()}[_compute_dtype]
+
+
 _dropout_state = {}      # device -> int64 counter tensor read by the kernels
 _salt_counter = itertools.count(1)
 
@@ -67,13 +82,14 @@ class _FusedMHA(Function):
             m8 = mask.contiguous().view(torch.uint8)
         seed = dropout_state(q.device) if p_drop > 0 else None
         with torch.cuda.device(q.device), _timed('mha_fwd', (B, num_heads, Lq, Lk)):
-            rc = _lib.lib().eda_mha_fwd_f32(
+            rc = _lib.lib().eda_mha_fwd(
                 q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
                 k.stride(1), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else None,
                 B, num_heads, Lq, Lk, hd, hd ** -0.5, float(p_drop),
                 seed.data_ptr() if seed is not None else None, int(salt), out.data_ptr(),
-                lse.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "eda_mha_fwd_f32")
+                lse.data_ptr(), _compute_dtype, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "eda_mha_fwd")
+        ctx.dtype_code = _compute_dtype
         ctx.save_for_backward(q, k, v, out, lse)
         ctx.mask8 = m8
         ctx.cfg = (num_heads, float(p_drop), int(salt))
@@ -96,7 +112,7 @@ class _FusedMHA(Function):
         ws_bytes = _lib.lib().eda_mha_bwd_workspace_bytes(B, num_heads, Lq, Lk)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=q.device) if ws_bytes else None
         with torch.cuda.device(q.device), _timed('mha_bwd', (B, num_heads, Lq, Lk)):
-            rc = _lib.lib().eda_mha_bwd_f32(
+            rc = _lib.lib().eda_mha_bwd(
                 q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
                 k.stride(1), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else None,
                 B, num_heads, Lq, Lk, hd, hd ** -0.5, p_drop,
@@ -104,8 +120,8 @@ class _FusedMHA(Function):
                 dout.data_ptr(), dout.stride(0), dout.stride(1), delta.data_ptr(), dq.data_ptr(),
                 dk.data_ptr(), dv.data_ptr(), dq.stride(0), dq.stride(1), dk.stride(0), dk.stride(1),
                 dv.stride(0), dv.stride(1), ws.data_ptr() if ws is not None else None, ws_bytes,
-                torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "eda_mha_bwd_f32")
+                ctx.dtype_code, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "eda_mha_bwd")
         return dq, dk, dv, None, None, None, None
 
 
@@ -141,13 +157,14 @@ class _ProjectedMHA(Function):
         m8 = mask.contiguous().view(torch.uint8) if mask is not None else None
         seed = dropout_state(dev) if p_drop > 0 else None
         with torch.cuda.device(dev), _timed('mha_fwd', (B, num_heads, Lq, Lk)):
-            rc = _lib.lib().eda_mha_fwd_f32(
+            rc = _lib.lib().eda_mha_fwd(
                 q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
                 k.stride(1), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else None,
                 B, num_heads, Lq, Lk, hd, hd ** -0.5, float(p_drop),
                 seed.data_ptr() if seed is not None else None, int(salt), out.data_ptr(),
-                lse.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "eda_mha_fwd_f32")
+                lse.data_ptr(), _compute_dtype, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "eda_mha_fwd")
+        ctx.dtype_code = _compute_dtype
         ctx.save_for_backward(W, out, lse, b, *x2s, *Ps)
         ctx.mask8 = m8
         ctx.cfg = (num_heads, float(p_drop), int(salt), groups, cols, [x.shape for x in xs])
@@ -173,7 +190,7 @@ class _ProjectedMHA(Function):
         ws_bytes = _lib.lib().eda_mha_bwd_workspace_bytes(B, num_heads, Lq, Lk)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
         with torch.cuda.device(dev), _timed('mha_bwd', (B, num_heads, Lq, Lk)):
-            rc = _lib.lib().eda_mha_bwd_f32(
+            rc = _lib.lib().eda_mha_bwd(
                 q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
                 k.stride(1), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else None,
                 B, num_heads, Lq, Lk, hd, hd ** -0.5, p_drop,
@@ -181,8 +198,8 @@ class _ProjectedMHA(Function):
                 dout.data_ptr(), dout.stride(0), dout.stride(1), delta.data_ptr(), dq.data_ptr(),
                 dk.data_ptr(), dv.data_ptr(), dq.stride(0), dq.stride(1), dk.stride(0), dk.stride(1),
                 dv.stride(0), dv.stride(1), ws.data_ptr() if ws is not None else None, ws_bytes,
-                torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "eda_mha_bwd_f32")
+                ctx.dtype_code, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "eda_mha_bwd")
         from . import wgrad_queue
         qd = wgrad_queue.active
         deferred = False

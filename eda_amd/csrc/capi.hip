@@ -63,11 +63,18 @@ __global__ __launch_bounds__(256) void copy_kernel(const uint4 *__restrict__ src
   size_t k = i;
   // four independent 16-byte loads in flight per lane (1, 4 or 8 loads in flight, 2048 .. 2^20
   // workgroups and torch's own copy_ all measure 4.4-4.8 TB/s read+write on a 2 x 1 GiB pair)
+  // non-temporal loads and stores: a streaming copy re-uses nothing, so it should not displace the
+  // other lines of L2 / the Infinity Cache (and the stores need no read-for-ownership)
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 *s4 = reinterpret_cast<const u32x4 *>(src);
+  u32x4 *d4 = reinterpret_cast<u32x4 *>(dst);
   for (; k + 3 * stride < n16; k += 4 * stride) {
-    const uint4 a = src[k], b = src[k + stride], c = src[k + 2 * stride], d = src[k + 3 * stride];
-    dst[k] = a; dst[k + stride] = b; dst[k + 2 * stride] = c; dst[k + 3 * stride] = d;
+    const u32x4 a = __builtin_nontemporal_load(s4 + k), b = __builtin_nontemporal_load(s4 + k + stride);
+    const u32x4 c = __builtin_nontemporal_load(s4 + k + 2 * stride), d = __builtin_nontemporal_load(s4 + k + 3 * stride);
+    __builtin_nontemporal_store(a, d4 + k); __builtin_nontemporal_store(b, d4 + k + stride);
+    __builtin_nontemporal_store(c, d4 + k + 2 * stride); __builtin_nontemporal_store(d, d4 + k + 3 * stride);
   }
-  for (; k < n16; k += stride) dst[k] = src[k];
+  for (; k < n16; k += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(s4 + k), d4 + k);
 }
 }  // namespace
 

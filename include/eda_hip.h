@@ -155,6 +155,26 @@ int eda_mha_bwd_f32(const float *q, const float *k, const float *v, long q_sb, l
  * split order); without it (NULL) the unsplit kernel runs.                                   */
 size_t eda_mha_bwd_workspace_bytes(int B, int H, int Lq, int Lk);
 
+/* The same two entry points with the arithmetic type of the QK^T / PV contractions as an argument
+ * (SURVEY.md 8b "dtype enum"; BASELINE.json configs[2] bf16, configs[4] fp16).  Tensors stay fp32 at
+ * the boundary; F32 forwards to the fp32 kernels above (v_mfma_f32_16x16x4_f32, the parity path);
+ * BF16 / F16 convert the operands on the fly and run v_mfma_f32_16x16x16_{bf16,f16} with fp32
+ * accumulation and fp32 softmax (csrc/mha16.hip; head_dim 36 padded to 48, padding not counted as
+ * useful FLOPs).  The 16-bit kernels ignore ws.                                                 */
+#define EDA_DTYPE_F32  0
+#define EDA_DTYPE_BF16 1
+#define EDA_DTYPE_F16  2
+int eda_mha_fwd(const float *q, const float *k, const float *v, long q_sb, long q_sl, long k_sb, long k_sl,
+                long v_sb, long v_sl, const unsigned char *key_padding_mask, int B, int H, int Lq, int Lk,
+                int head_dim, float scale, float p_drop, const unsigned long long *seed_ptr, unsigned salt,
+                float *out, float *lse, int dtype, void *stream);
+int eda_mha_bwd(const float *q, const float *k, const float *v, long q_sb, long q_sl, long k_sb, long k_sl,
+                long v_sb, long v_sl, const unsigned char *key_padding_mask, int B, int H, int Lq, int Lk,
+                int head_dim, float scale, float p_drop, const unsigned long long *seed_ptr, unsigned salt,
+                const float *out, const float *lse, const float *dout, long do_sb, long do_sl,
+                float *delta_ws, float *dq, float *dk, float *dv, long dq_sb, long dq_sl, long dk_sb,
+                long dk_sl, long dv_sb, long dv_sl, void *ws, size_t ws_bytes, int dtype, void *stream);
+
 /* ---- set-abstraction grouped MLP, channels-last pipeline -----------------
  * Rows are positions (scene, centre j, neighbour k) of a (b*m*ns, C) matrix.
  *

@@ -198,3 +198,83 @@ def test_module_on_gpu_matches_torch_multiheadattention(case, batch_first):
             continue
         scale = e.abs().max().item() + 1e-9
         assert (g - e).abs().max().item() <= 2e-4 * scale + 1e-6, (name, (g - e).abs().max().item(), scale)
+
+
+# ------------------------------------------------------------------ 16-bit MFMA variants (csrc/mha16.hip)
+# Tolerance (documented, BASELINE.json configs[2]/[4]): the contractions take bf16 / fp16 OPERANDS (8 / 11
+# significant bits: unit roundoff 3.9e-3 / 4.9e-4) and accumulate in fp32; Q, K, V, P, dS and dO are each
+# rounded once, so scores carry ~2u relative error, probabilities ~2u|s|, outputs / gradients a few u of the
+# tensor's scale.  Bound used: 6u * max|expected| in max norm (bf16 2.4e-2, fp16 3e-3); the fp32 kernels
+# (the parity path of the north star) keep the 1e-4 test above.
+SHAPES16 = [(2, 80, 1024, False), (2, 1024, 80, True), (1, 1024, 1024, False), (2, 256, 132, True),
+            (2, 130, 1024, False), (2, 256, 130, True), (3, 37, 101, True), (1, 5, 1, False), (2, 64, 65, True)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [("bf16", 2.4e-2), ("f16", 3e-3)])
+@pytest.mark.parametrize("B,Lq,Lk,masked", SHAPES16)
+def test_16bit_mfma_attention_vs_restatement(B, Lq, Lk, masked, dtype, tol):
+    from eda_amd import attention
+    torch.manual_seed(Lq * 5 + Lk)
+    dev = "cuda"
+    q = torch.randn(B, Lq, 288, device=dev, requires_grad=True)
+    k = torch.randn(B, Lk, 288, device=dev, requires_grad=True)
+    v = torch.randn(B, Lk, 288, device=dev, requires_grad=True)
+    mask = _mask(B, Lk, Lq + Lk).to(dev) if masked else None
+    w = torch.randn(B, Lq, 288, device=dev)
+    attention.set_compute_dtype(dtype)
+    try:
+        assert attention.compute_dtype() == dtype
+        out = attention.attention_core(q, k, v, mask, 8, 0.0, 0)
+        (out * w).sum().backward()
+    finally:
+        attention.set_compute_dtype("f32")
+    got = [out.detach(), q.grad.clone(), k.grad.clone(), v.grad.clone()]
+    qd, kd, vd = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+    exp_out = attention_ref.attention_core(qd, kd, vd, mask, 8)
+    (exp_out * w.double()).sum().backward()
+    exp = [exp_out.detach(), qd.grad, kd.grad, vd.grad]
+    # dq / dk are P * (dP - delta) contracted with K / Q: when the softmax is (nearly) one-hot the exact
+    # value cancels to ~0 while dP (16-bit operands) and delta (fp32) each carry u * |dO||V| -- the error
+    # is relative to the size of the cancelling terms, not of the result
+    cancel = (w.abs().max() * v.abs().max() * 6.0).item()
+    natural = {"out": 0.0, "dv": 0.0, "dq": cancel * k.abs().max().item() / 6.0, "dk": cancel * q.abs().max().item() / 6.0}
+    for name, g, e in zip(["out", "dq", "dk", "dv"], got, exp):
+        assert torch.isfinite(g).all(), name
+        err = (g.double() - e).abs().max().item()
+        scale = e.abs().max().item() + 1e-12
+        assert err <= tol * max(scale, 0.05 * natural[name]), (name, err, scale)
+        # and not trivially loose: the 16-bit result must differ from fp64 by more than fp32 rounding would
+        # (guards against the dtype switch silently running the fp32 kernels)
+        if e.numel() > 4096:
+            assert err >= 1e-6 * scale, (name, "suspiciously exact for a 16-bit contraction", err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_16bit_attention_dropout_consistency(dtype):
+    """Keep rate of the attention-probability dropout and forward/backward mask consistency (V = 1 makes
+    every output the kept probability mass / (1-p); d(loss)/dV then is the column sum of the dropped P)."""
+    from eda_amd import attention
+    dev = "cuda"
+    torch.manual_seed(9)
+    B, Lq, Lk, p = 2, 128, 192, 0.25
+    q = torch.randn(B, Lq, 288, device=dev) * 0.3
+    k = torch.randn(B, Lk, 288, device=dev) * 0.3
+    ones = torch.ones(B, Lk, 288, device=dev, requires_grad=True)
+    attention.dropout_state(dev).fill_(3)
+    attention.set_compute_dtype(dtype)
+    try:
+        o1 = attention.attention_core(q, k, ones, None, 8, p, 77)
+        o2 = attention.attention_core(q, k, ones, None, 8, p, 77)
+        o3 = attention.attention_core(q, k, ones, None, 8, p, 78)
+        o1.sum().backward()
+    finally:
+        attention.set_compute_dtype("f32")
+    assert torch.equal(o1, o2) and not torch.equal(o1, o3)
+    mass = o1.detach()[..., ::36].mean().item()          # one column per head: E[kept mass / (1-p)] = 1
+    assert abs(mass - 1.0) < 0.02, mass
+    # sum_q out[q, d] = sum_k (sum_q Pd[q, k]) * 1  and  dV[k, d] = sum_q Pd[q, k]  ->  totals agree per head
+    tot_out = o1.detach().view(B, Lq, 8, 36)[..., 0].sum(1)           # (B, 8)
+    tot_dv = ones.grad.view(B, Lk, 8, 36)[..., 0].sum(1)
+    torch.testing.assert_close(tot_out, tot_dv, rtol=2e-2, atol=1e-2)

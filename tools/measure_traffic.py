@@ -1,0 +1,72 @@
+"""HBM-side bytes per launch of the roofline-priced kernels, from rocprofv3 PMC passes, stamped with the hash
+of the kernel sources so that bench.py only quotes numbers that belong to the build it runs.
+
+    python tools/measure_traffic.py          (on the GPU box; writes profiles/pmc_traffic.json)
+
+Method (MI355X_MICROARCH.md, "HBM"): FETCH_SIZE and WRITE_SIZE in SEPARATE `--pmc` passes (TCC slot budget);
+FETCH_SIZE counts 128-byte fabric requests at 64 bytes on gfx950 -> x2; both are reported in KiB by this
+rocprofv3 -> x1024.  Per launch = counter summed over the kernel's dispatches / number of launches.
+"""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+DRIVER = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from eda_amd import attention
+B, Lq, Lk = 8, 1024, 1024
+q = torch.randn(B, Lq, 288, device="cuda", requires_grad=True); k = torch.randn(B, Lk, 288, device="cuda", requires_grad=True)
+v = torch.randn(B, Lk, 288, device="cuda", requires_grad=True); w = torch.randn(B, Lq, 288, device="cuda")
+for _ in range(4):
+    o = attention.attention_core(q, k, v, None, 8, 0.1, 3); o.backward(w)
+torch.cuda.synchronize()
+''' % ROOT
+
+
+def run_pass(counter, script):
+    d = tempfile.mkdtemp(prefix="pmc_")
+    subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, script],
+                   check=True, capture_output=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    tot, n = {}, {}
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = r["Kernel_Name"]
+        tot[k] = tot.get(k, 0.0) + float(r["Counter_Value"])
+        n[k] = n.get(k, 0) + 1
+    return {k: tot[k] / n[k] for k in tot}
+
+
+def main():
+    import bench
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(DRIVER)
+        script = f.name
+    fetch = run_pass("FETCH_SIZE", script)
+    write = run_pass("WRITE_SIZE", script)
+
+    def total(pred):
+        return sum((2.0 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024.0 for k in set(fetch) | set(write) if pred(k))
+    entries = [
+        {"op": "mha_fwd", "dims": [8, 8, 1024, 1024], "bytes_per_launch": total(lambda k: "mha_fwd_kernel" in k)},
+        {"op": "mha_bwd", "dims": [8, 8, 1024, 1024],
+         "bytes_per_launch": total(lambda k: "mha_bwd_dq_kernel" in k or "mha_bwd_dkv_kernel" in k or "mha_part_reduce" in k)},
+    ]
+    out = {"source_hash": bench.source_hash(),
+           "how": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate passes, KiB -> bytes, per launch "
+                  "(tools/measure_traffic.py)", "entries": entries}
+    json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
