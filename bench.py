@@ -544,9 +544,14 @@ def main():
         for name, (calls, ms) in summ.items():
             byts = algorithmic_bytes(name)
             flops = algorithmic_flops(name)
+            # a fused SA / FP forward in TRAINING mode must keep the pre-activations z_l (the BatchNorm backward
+            # needs them densely): HBM bytes of the formulation = SURVEY 8d's fused figure + each z_l written
+            # once and read once (by the next layer's operand staging / the pooling pass)
+            byts_design = byts + 2 * fused_saved_bytes(name)
             kernels.append({"op": name[0], "dims": list(name[1:]), "calls_per_step": calls / ksteps,
                             "ms": round(ms, 4), "alg_bytes": byts, "saved_bytes": fused_saved_bytes(name),
-                            "gbs": round(byts / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+                            "design_bytes": byts_design,
+                            "gbs": round(byts_design / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
                             "tflops": round(flops / (ms * 1e-3) / 1e12, 2) if flops and ms > 0 else None})
         kernels.sort(key=lambda k: -k["ms"] * k["calls_per_step"])
         native_ms = sum(k["ms"] * k["calls_per_step"] for k in kernels)
@@ -556,7 +561,7 @@ def main():
         # dominant HBM-priced kernel (FPS is latency-bound: reported as us/round below)
         # HBM-priced candidates: launches that move at least 32 MB (smaller ones are launch- or
         # latency-bound and are listed in `kernels` only); FPS is latency-bound and reported below.
-        hbm = [k for k in kernels if k["alg_bytes"] >= (32 << 20) and k["op"] != "furthest_point_sampling"]
+        hbm = [k for k in kernels if k["design_bytes"] >= (32 << 20) and k["op"] != "furthest_point_sampling"]
         dom = hbm[0] if hbm else None
         # achievable HBM rate on this box: the library's copy kernel over 2 x 1 GiB (4x the 256 MB
         # Infinity Cache), read + write bytes / HIP-event time (report both denominators)
@@ -589,6 +594,9 @@ def main():
                             "traffic": pmc_traffic.get((dom["op"], tuple(dom["dims"]))),
                             "traffic_source": traffic_how,
                             "ms_per_launch": dom["ms"], "alg_bytes_per_launch": dom["alg_bytes"],
+                            "saved_activation_bytes": dom["saved_bytes"], "priced_bytes_per_launch": dom["design_bytes"],
+                            "note": "achieved = (SURVEY 8d fused bytes + pre-activations kept for the backward, written "
+                                    "once and read once) / time of the whole fused call (one launch per layer + pooling)",
                             "ms_per_step": round(dom["ms"] * dom["calls_per_step"], 4)}
         # MFMA-priced single-kernel launches: attention and the own row GEMMs (multi-kernel calls such as
         # sa_fused_* and the grouped weight gradient are priced in `kernels`)
