@@ -50,7 +50,7 @@ def run_sa_module(dev):
     MF.assert_matches(g, "inds", si)
     MF.assert_matches(g, "new_xyz", sx, rtol=0, atol=0)
     MF.assert_matches(g, "features", sf)
-    MF.assert_matches(g, "grad_features", feats.grad, rtol=1e-4, atol=1e-5)
+    MF.assert_matches(g, "grad_features", feats.grad)
     return sx, sf
 
 
@@ -67,17 +67,17 @@ def run_sa_module_train(dev):
     _, tf, _ = sa(xyz, feats)
     (tf * MF.make_feats(6, *tf.shape).to(dev)).sum().backward()
     l0, l2 = sa.mlp_module.layer0, sa.mlp_module.layer2
-    MF.assert_matches(g, "features", tf, rtol=2e-4, atol=2e-5)
-    MF.assert_matches(g, "grad_features", feats.grad, rtol=1e-3, atol=1e-4)
-    MF.assert_matches(g, "grad_w0", l0.conv.weight.grad, rtol=1e-3, atol=2e-3)
-    MF.assert_matches(g, "grad_w2", l2.conv.weight.grad, rtol=1e-3, atol=2e-3)
-    MF.assert_matches(g, "grad_gamma0", l0.bn.bn.weight.grad, rtol=1e-3, atol=2e-3)
-    MF.assert_matches(g, "grad_beta0", l0.bn.bn.bias.grad, rtol=1e-3, atol=2e-3)
-    MF.assert_matches(g, "grad_gamma2", l2.bn.bn.weight.grad, rtol=1e-3, atol=2e-3)
-    MF.assert_matches(g, "grad_beta2", l2.bn.bn.bias.grad, rtol=1e-3, atol=2e-3)
+    MF.assert_matches(g, "features", tf)
+    MF.assert_matches(g, "grad_features", feats.grad)
+    MF.assert_matches(g, "grad_w0", l0.conv.weight.grad)
+    MF.assert_matches(g, "grad_w2", l2.conv.weight.grad)
+    MF.assert_matches(g, "grad_gamma0", l0.bn.bn.weight.grad)
+    MF.assert_matches(g, "grad_beta0", l0.bn.bn.bias.grad)
+    MF.assert_matches(g, "grad_gamma2", l2.bn.bn.weight.grad)
+    MF.assert_matches(g, "grad_beta2", l2.bn.bn.bias.grad)
     for k, t in [("running_mean0", l0.bn.bn.running_mean), ("running_var0", l0.bn.bn.running_var),
                  ("running_mean2", l2.bn.bn.running_mean), ("running_var2", l2.bn.bn.running_var)]:
-        MF.assert_matches(g, k, t, rtol=1e-4, atol=1e-5)
+        MF.assert_matches(g, k, t)
     MF.assert_matches(g, "nbt", l2.bn.bn.num_batches_tracked)
 
 
@@ -94,8 +94,8 @@ def run_fp_module(dev):
     fo = fp(xyz, sx, unk_f, kn_f)
     (fo * MF.make_feats(5, *fo.shape).to(dev)).sum().backward()
     MF.assert_matches(g, "out", fo)
-    MF.assert_matches(g, "grad_unknown", unk_f.grad, rtol=1e-4, atol=1e-5)
-    MF.assert_matches(g, "grad_known", kn_f.grad, rtol=1e-4, atol=1e-4)
+    MF.assert_matches(g, "grad_unknown", unk_f.grad)
+    MF.assert_matches(g, "grad_known", kn_f.grad)
 
 
 def run_backbone(dev):
@@ -107,7 +107,7 @@ def run_backbone(dev):
         ep = bb(MF.make_cloud(1, 2, 4096).to(dev), {})
     assert sorted(ep) == MF.names(g)
     for k in MF.names(g):
-        MF.assert_matches(g, k, ep[k], rtol=2e-4, atol=2e-5)
+        MF.assert_matches(g, k, ep[k])
 
 
 def run_encoder_decoder(dev, butd):
@@ -130,13 +130,13 @@ def run_encoder_decoder(dev, butd):
     vo, to = enc(vis, pos, vmask, text, tmask, {}, detected_feats=det, detected_mask=dmask)
     loss = (vo * MF.make_feats(14, *vo.shape).to(dev)).sum() + (to * MF.make_feats(15, *to.shape).to(dev)).sum()
     loss.backward()
-    MF.assert_matches(g, "vis_out", vo, rtol=1e-4, atol=2e-5)
-    MF.assert_matches(g, "text_out", to, rtol=1e-4, atol=2e-5)
-    MF.assert_matches(g, "grad_vis", vis.grad, rtol=1e-3, atol=1e-4)
-    MF.assert_matches(g, "grad_text", text.grad, rtol=1e-3, atol=1e-4)
-    MF.assert_matches(g, "grad_w", enc.layers[1].cross_layer.cross_lv.in_proj_weight.grad, rtol=1e-3, atol=1e-4)
+    MF.assert_matches(g, "vis_out", vo)
+    MF.assert_matches(g, "text_out", to)
+    MF.assert_matches(g, "grad_vis", vis.grad)
+    MF.assert_matches(g, "grad_text", text.grad)
+    MF.assert_matches(g, "grad_w", enc.layers[1].cross_layer.cross_lv.in_proj_weight.grad)
     if butd:
-        MF.assert_matches(g, "grad_det", det.grad, rtol=1e-3, atol=1e-4)
+        MF.assert_matches(g, "grad_det", det.grad)
 
     g = gold(f"bidecoder_{tag}")
     dec = EDL.BiDecoderLayer(d, n_heads=8, dim_feedforward=256, dropout=0.1, activation="relu",
@@ -149,11 +149,11 @@ def run_encoder_decoder(dev, butd):
     det2 = MF.make_feats(20, B, D, d).to(dev) if butd else None
     qo = dec(query, vis2, lang, qpos, None, tmask, detected_feats=det2, detected_mask=dmask)
     (qo * MF.make_feats(21, *qo.shape).to(dev)).sum().backward()
-    MF.assert_matches(g, "out", qo, rtol=1e-4, atol=2e-5)
-    MF.assert_matches(g, "grad_query", query.grad, rtol=1e-3, atol=1e-4)
-    MF.assert_matches(g, "grad_vis", vis2.grad, rtol=1e-3, atol=1e-4)
-    MF.assert_matches(g, "grad_lang", lang.grad, rtol=1e-3, atol=1e-4)
-    MF.assert_matches(g, "grad_w", dec.cross_v.in_proj_weight.grad, rtol=1e-3, atol=1e-4)
+    MF.assert_matches(g, "out", qo)
+    MF.assert_matches(g, "grad_query", query.grad)
+    MF.assert_matches(g, "grad_vis", vis2.grad)
+    MF.assert_matches(g, "grad_lang", lang.grad)
+    MF.assert_matches(g, "grad_w", dec.cross_v.in_proj_weight.grad)
 
 
 def run_full_model(dev, butd):
@@ -194,5 +194,6 @@ def run_full_model(dev, butd):
     for k in gnames:
         # the fixture scales the objectness head's last layer x40 (clear top-k gaps), which
         # scales its rounding noise too: logits of O(1) with ~5e-5 absolute noise
-        atol = 3e-4 if k == "seeds_obj_cls_logits" else 5e-5
-        MF.assert_matches(g, k, aligned(k, out[k]), rtol=5e-4, atol=atol)
+        # the seed objectness logits sit behind the whole encoder + two BatchNorm layers in eval mode
+        # (division by sqrt(running_var)): 1e-4 of the tensor's scale instead of 1e-5
+        MF.assert_matches(g, k, aligned(k, out[k]), atol_rel=1e-4 if k == "seeds_obj_cls_logits" else 1e-5)

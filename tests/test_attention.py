@@ -83,10 +83,17 @@ def test_fused_forward_backward_vs_restatement(B, Lq, Lk, masked):
     exp_out = attention_ref.attention_core(qd, kd, vd, mask, 8)
     (exp_out * w.double()).sum().backward()
     exp = [exp_out.detach(), qd.grad, kd.grad, vd.grad]
+    # element-wise: 1e-4 relative (the north star's bound for fp32 activations) plus an absolute term for
+    # elements that cancel to ~0: an fp32 sum of n terms carries up to n*2^-24 of sum|terms|; the bound
+    # 2e-6 * max|expected| is that for the ~30-term effective sums here with the tensor's own scale as the
+    # term size (measured use on MI355X: <= 40 % on every shape)
+    cancel = (w.abs().max() * v.abs().max()).item()      # dq / dk = P (dP - delta) K: exactly 0 for a one-hot softmax
+    natural = {"out": 0.0, "dv": 0.0, "dq": cancel * k.abs().max().item(), "dk": cancel * q.abs().max().item()}
     for name, g, e in zip(["out", "dq", "dk", "dv"], got, exp):
-        err = (g.double() - e).abs().max().item()
-        scale = e.abs().max().item() + 1e-12
-        assert err <= 1e-4 * scale + 5e-6, (name, err, scale)
+        err = (g.double() - e).abs()
+        tol = 1e-4 * e.abs() + 2e-6 * e.abs().max() + 2e-7 * natural[name] + 1e-30
+        worst = (err / tol).max().item()
+        assert worst <= 1.0, (name, worst, err.max().item(), e.abs().max().item())
 
 
 @pytest.mark.gpu
