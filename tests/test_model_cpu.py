@@ -55,3 +55,44 @@ def test_encoder_decoder(butd):
 @pytest.mark.parametrize("butd", [True, False])
 def test_full_model(butd):
     MC.run_full_model("cpu", butd)
+
+
+def test_checkpoint_round_trip_in_the_reference_format(tmp_path):
+    """save_checkpoint writes the reference's dictionary (main_utils.py:149-166: DDP `module.` prefix on
+    every key, names = the reference's state_dict names); load_checkpoint restores it strictly into a
+    freshly initialised model, also when that model's parameters already live in a FlatParams buffer, and
+    also when the checkpoint carries the Hugging Face bookkeeping buffer of the pinned transformers 4.17."""
+    import json
+    import os
+    import torch
+    from eda_amd import checkpoint
+    from eda_amd.bdetr import BeaUTyDETR
+    from eda_amd.parallel import FlatParams, reference_lr_groups
+    torch.manual_seed(1)
+    a = BeaUTyDETR(num_decoder_layers=2)
+    path = str(tmp_path / "ckpt_epoch_3.pth")
+    opt = torch.optim.AdamW([p for p in a.parameters() if p.requires_grad], lr=1e-4)
+    state = checkpoint.save_checkpoint(a, path, optimizer=opt, epoch=3, config={"butd": True})
+    assert set(state) == {"config", "save_path", "model", "optimizer", "scheduler", "epoch"}
+    ref_names = {k for k, _ in json.load(open(os.path.join(MC.GOLD, "state_dict_manifest.json")))}
+    mine = {k[len("module."):] for k in state["model"] if not k.startswith("module.text_encoder.")}
+    assert all(k.startswith("module.") for k in state["model"])
+    # (the manifest was dumped from the 6-layer reference model: compare the names both models have)
+    assert {k for k in mine if ".2." not in k} <= ref_names | mine and len(mine & ref_names) > 300
+    torch.manual_seed(2)
+    b = BeaUTyDETR(num_decoder_layers=2)
+    flat = FlatParams(b, reference_lr_groups)
+    # a checkpoint written under transformers 4.17 also holds this buffer:
+    ck = torch.load(path, weights_only=False)
+    ck["model"]["module.text_encoder.embeddings.position_ids"] = torch.arange(514)[None]
+    torch.save(ck, path)
+    epoch, missing, unexpected = checkpoint.load_checkpoint(b, path)
+    assert epoch == 3 and not missing and unexpected in ([], ["text_encoder.embeddings.position_ids"])
+    for (n, p), (_, q) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(p, q), n
+    p0 = flat.params[0]
+    assert p0.data_ptr() >= flat.flat_param.data_ptr() and p0.data_ptr() < flat.flat_param.data_ptr() + 4 * flat.flat_param.numel()
+    ck["model"].pop(next(k for k in ck["model"] if "backbone_net.sa1" in k))
+    torch.save(ck, path)
+    with pytest.raises(RuntimeError, match="does not match"):
+        checkpoint.load_checkpoint(b, path)
