@@ -21,6 +21,8 @@ SIGNATURES = {
     "eda_get_fma_mode": (_i, []),
     "eda_fps_workspace_bytes": (_sz, [_i, _i, _i]),
     "eda_furthest_point_sampling_f32": (_i, [_p, _i, _i, _i, _p, _p, _sz, _p]),
+    "eda_fps_prefix_workspace_bytes": (_sz, [_i, _i, _i]),
+    "eda_furthest_point_sampling_prefix_f32": (_i, [_p, _i, _i, _i, _p, _p, _sz, _p]),
     "eda_gather_points_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "eda_gather_points_grad_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "eda_ball_query_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -37,7 +37,10 @@ class Pointnet2Backbone(nn.Module):
         end_points = end_points if end_points else {}
         xyz, features = self._break_up_pc(pointcloud)
         for name, layer in (("sa1", self.sa1), ("sa2", self.sa2), ("sa3", self.sa3), ("sa4", self.sa4)):
-            xyz, features, inds = layer(xyz, features)
+            # SA2..SA4 sample from the previous level's samples, which are in sampling order: their FPS is the
+            # prefix 0..m-1 unless a tie intervenes (the reference notes it, backbone_module.py:122-131);
+            # the library verifies that instead of running the dependent rounds
+            xyz, features, inds = layer(xyz, features, xyz_in_sampling_order=name != "sa1")
             if name in ("sa1", "sa2"):
                 end_points[f"{name}_inds"] = inds
             end_points[f"{name}_xyz"] = xyz

@@ -83,8 +83,11 @@ struct FpsShared {
 template <int MODE, int T, int P, bool CLUSTER>
 __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz_all, int n, int m,
                                                 int *__restrict__ idx_all, int S, int G, int p_log2,
-                                                u64 *mail_all, int *status) {
+                                                u64 *mail_all, int *status, const int *__restrict__ only_if) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // only_if (single-workgroup scenes): run the scene only if only_if[scene] != 0 -- the prefix entry point
+  // below has already PROVEN the answer 0..m-1 for the other scenes and written it
+  if (!CLUSTER && only_if != nullptr && only_if[blockIdx.x % S] == 0) return;
   float *lx = reinterpret_cast<float *>(smem);
   float *ly = lx + T * P;
   float *lz = ly + T * P;
@@ -552,6 +555,8 @@ int launch_fps_spec(const float *xyz, int n, int m, int *idx, int S, int G, int 
   return 0;
 }
 
+thread_local const int *tl_fps_only_if = nullptr;     // set by eda_furthest_point_sampling_prefix_f32 around its fallback launch
+
 template <int MODE, int T, int P, bool CLUSTER>
 int launch_fps(const float *xyz, int n, int m, int *idx, int S, int G, int p_log2, u64 *mail,
                int *status, hipStream_t stream) {
@@ -566,13 +571,105 @@ int launch_fps(const float *xyz, int n, int m, int *idx, int S, int G, int p_log
     }
   }
   hipLaunchKernelGGL(kern, dim3(S * G), dim3(T), lds, stream, xyz, n, m, idx, S, G, p_log2, mail,
-                     status);
+                     status, tl_fps_only_if);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     eda_set_error("fps: launch failed: %s", hipGetErrorString(e));
     return (int)e;
   }
   return 0;
+}
+
+// ---- "is 0..m-1 the answer?" -----------------------------------------------------------------------------
+// The backbone feeds SA2..SA4 with the PREVIOUS level's samples in sampling order
+// (models/backbone_module.py:122-131 notes that FPS of such a set returns its prefix 0..m-1).  That
+// holds exactly when no tie of the reference's arg-max order interferes (duplicated points do interfere),
+// so it cannot be assumed -- but it can be CHECKED without the 1023 dependent rounds that make the sampler
+// slow: if the answer is 0..m-1 then the centre of round r is point r-1, known in advance, and every
+// point k can run its own min-distance recurrence independently (no per-round arg-max, no barrier):
+//   sel[r]  = min_{i<r} d(p_r, p_i)                                  (pass 1, thread per sample)
+//   point k, round r:  t = min_{i<r} d(p_k, p_i)  must lose against (sel[r], r) under the reference's
+//   total order (distance, then the tie key of sampling_gpu.cu's LDS tree)             (pass 2)
+// with the reference's arithmetic (eda_sumsq3<MODE>, point minus centre), the 1e10 initial distance and the
+// origin-ball rule.  Scenes that pass get idx = 0..m-1 here; the others set fail[scene] and are sampled by
+// the regular kernel (launched with only_if = fail).
+template <int MODE>
+__global__ __launch_bounds__(256) void fps_prefix_sel_kernel(const float *__restrict__ xyz_all, int n, int m,
+                                                             int *__restrict__ idx_all, float *__restrict__ sel_all,
+                                                             int *__restrict__ fail) {
+  __shared__ float cx[256], cy[256], cz[256];
+  const int scene = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
+  const float *xyz = xyz_all + (size_t)scene * n * 3;
+  const bool live = r < m && r < n;
+  float x = 0.f, y = 0.f, z = 0.f;
+  if (live) { x = xyz[3 * r]; y = xyz[3 * r + 1]; z = xyz[3 * r + 2]; }
+  if (r < m) idx_all[(size_t)scene * m + r] = r;
+  if (r < m && r >= 1) {
+    // sample r must exist and must not be a skipped (origin-ball) point
+    if (r >= n || (double)eda_sumsq3<MODE>(x, y, z) <= 1e-3) atomicOr(fail + scene, 1);
+  }
+  float t0 = 1e10f, t1 = 1e10f;
+  const int rmax = blockIdx.x * 256 + 255;                     // largest sample of this block: centres 0 .. rmax-1
+  for (int c0 = 0; c0 < rmax && c0 < n; c0 += 256) {
+    __syncthreads();
+    const int c = c0 + threadIdx.x;
+    if (c < n) { cx[threadIdx.x] = xyz[3 * c]; cy[threadIdx.x] = xyz[3 * c + 1]; cz[threadIdx.x] = xyz[3 * c + 2]; }
+    __syncthreads();
+    int cnt = r - c0;                                          // centres i < r
+    if (cnt > 256) cnt = 256;
+    if (live) {
+      int u = 0;
+      for (; u + 1 < cnt; u += 2) {                            // two independent min chains
+        t0 = fminf(t0, eda_sumsq3<MODE>(x - cx[u], y - cy[u], z - cz[u]));
+        t1 = fminf(t1, eda_sumsq3<MODE>(x - cx[u + 1], y - cy[u + 1], z - cz[u + 1]));
+      }
+      if (u < cnt) t0 = fminf(t0, eda_sumsq3<MODE>(x - cx[u], y - cy[u], z - cz[u]));
+    }
+  }
+  if (live && r >= 1) sel_all[(size_t)scene * m + r] = fminf(t0, t1);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void fps_prefix_check_kernel(const float *__restrict__ xyz_all, int n, int m,
+                                                               int p_log2, const float *__restrict__ sel_all,
+                                                               int *__restrict__ fail) {
+  __shared__ float cx[256], cy[256], cz[256], cs[256];
+  __shared__ unsigned ck[256];
+  const int scene = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+  const float *xyz = xyz_all + (size_t)scene * n * 3;
+  const float *sel = sel_all + (size_t)scene * m;
+  float x = 0.f, y = 0.f, z = 0.f;
+  bool valid = k < n;
+  if (valid) {
+    x = xyz[3 * k]; y = xyz[3 * k + 1]; z = xyz[3 * k + 2];
+    valid = !((double)eda_sumsq3<MODE>(x, y, z) <= 1e-3);
+  }
+  const unsigned tk = fps_tiekey((unsigned)(k < n ? k : 0), p_log2);
+  float t = 1e10f;
+  bool bad = false;
+  // rounds r = 1 .. m-1 in blocks of 256 centres staged through LDS (centre of round r = point r-1)
+  for (int r0 = 1; r0 < m; r0 += 256) {
+    __syncthreads();
+    const int c = r0 - 1 + threadIdx.x;                 // centre index for round r0 + threadIdx.x
+    if (c < n && r0 + (int)threadIdx.x < m) {
+      cx[threadIdx.x] = xyz[3 * c]; cy[threadIdx.x] = xyz[3 * c + 1]; cz[threadIdx.x] = xyz[3 * c + 2];
+      cs[threadIdx.x] = sel[r0 + threadIdx.x];
+      ck[threadIdx.x] = fps_tiekey((unsigned)(r0 + threadIdx.x), p_log2);
+    }
+    __syncthreads();
+    const int cnt = m - r0 < 256 ? m - r0 : 256;
+    if (valid) {
+#pragma unroll 4
+      for (int u = 0; u < cnt; ++u) {
+        t = fminf(t, eda_sumsq3<MODE>(x - cx[u], y - cy[u], z - cz[u]));
+        const float sr = cs[u];
+        // point k must lose against sample r: smaller distance, or equal distance and a larger tie key
+        // (k == r: t == sr and the keys are equal -> not flagged)
+        bad = bad || t > sr || (t == sr && tk < ck[u]);
+      }
+    }
+  }
+  if (bad) atomicOr(fail + scene, 1);
 }
 
 template <int MODE, int T, bool CLUSTER>
@@ -715,4 +812,42 @@ extern "C" int eda_furthest_point_sampling_f32(const float *xyz, int b, int n, i
     if (rc) return rc;
   }
   return 0;
+}
+
+
+extern "C" size_t eda_fps_prefix_workspace_bytes(int b, int n, int m) {
+  const size_t base = (eda_fps_workspace_bytes(b, n, m) + 15) / 16 * 16;
+  return base + (((size_t)(b > 0 ? b : 0) * 4 + 15) / 16 * 16) + (size_t)(b > 0 ? b : 0) * (size_t)(m > 0 ? m : 0) * 4;
+}
+
+extern "C" int eda_furthest_point_sampling_prefix_f32(const float *xyz, int b, int n, int m, int *idx, void *ws,
+                                                      size_t ws_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(b >= 0 && n >= 0 && m >= 0, "negative dimension");
+  if (b == 0 || m == 0) return 0;
+  EDA_CHECK_ARG(n > 0 && xyz && idx && ws, "bad arguments");
+  // the check costs n*m distance evaluations: only for the single-workgroup sizes (the SA2..SA4 levels)
+  if (n > 8192 || m > n || b > 65535) return eda_furthest_point_sampling_f32(xyz, b, n, m, idx, ws, ws_bytes, stream_);
+  if (ws_bytes < eda_fps_prefix_workspace_bytes(b, n, m)) {
+    eda_set_error("fps: workspace too small");
+    return EDA_ERR_WORKSPACE;
+  }
+  const size_t base = (eda_fps_workspace_bytes(b, n, m) + 15) / 16 * 16;
+  int *fail = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(ws) + base);
+  float *sel = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(fail) + ((size_t)b * 4 + 15) / 16 * 16);
+  { const int zrc = eda_zero_async(fail, (size_t)b * 4, stream); if (zrc) return zrc; }
+  const int p_log2 = fps_block_log2(n);
+  const dim3 g1((m + 255) / 256, b), g2((n + 255) / 256, b);
+  if (g_eda_fma_mode == 0) {
+    hipLaunchKernelGGL(fps_prefix_sel_kernel<0>, g1, dim3(256), 0, stream, xyz, n, m, idx, sel, fail);
+    hipLaunchKernelGGL(fps_prefix_check_kernel<0>, g2, dim3(256), 0, stream, xyz, n, m, p_log2, sel, fail);
+  } else {
+    hipLaunchKernelGGL(fps_prefix_sel_kernel<1>, g1, dim3(256), 0, stream, xyz, n, m, idx, sel, fail);
+    hipLaunchKernelGGL(fps_prefix_check_kernel<1>, g2, dim3(256), 0, stream, xyz, n, m, p_log2, sel, fail);
+  }
+  EDA_CHECK_LAUNCH();
+  tl_fps_only_if = fail;
+  const int rc = eda_furthest_point_sampling_f32(xyz, b, n, m, idx, ws, base, stream_);
+  tl_fps_only_if = nullptr;
+  return rc;
 }

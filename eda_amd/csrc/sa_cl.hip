@@ -883,6 +883,24 @@ extern "C" int eda_bn_relu_bwd_f32(const float *dout, const unsigned char *argma
 // then one element-wise pass dz = A*gy + B*z + D; the first layer's input gradient is scattered
 // straight into d(features) (E_SCATTER).
 namespace {
+// wt (cols, rows) = w (rows, ld) [:, c0 : c0 + cols]^T -- the layers' weights are a few hundred KB: transposing
+// them lets the input-gradient GEMMs run in the K-minor ("NT") form, 25-45 % faster than reading the
+// weight along its rows (profiles/r02d_sa_timeline.md)
+__global__ __launch_bounds__(256) void weight_transpose_kernel(const float *__restrict__ w, int rows, int ld, int c0,
+                                                               int cols, float *__restrict__ wt) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;      // bx: column block of w, by: row block
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    const int row = by + r, col = bx + threadIdx.x;
+    tile[r][threadIdx.x] = (row < rows && col < cols) ? w[(long)row * ld + c0 + col] : 0.f;
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    const int col = bx + r, row = by + threadIdx.x;
+    if (col < cols && row < rows) wt[(long)col * rows + row] = tile[threadIdx.x][r];
+  }
+}
+
 struct MlpGeom {
   const float *x; long ldx;
   const float *xyz, *new_xyz, *feats; const int *idx;
@@ -988,7 +1006,12 @@ extern "C" size_t eda_sa_fused_bwd_workspace_bytes(long R, int nlayers, const in
     if (sbytes > slabs) slabs = sbytes;
     if (channels[l + 1] > cmax) cmax = channels[l + 1];
   }
-  return sizeof(double) * 2 * (size_t)cmax + slabs;
+  size_t wt = 0;                                   // transposed weight of one layer (floats), 16-byte rounded
+  for (int l = 0; l < nlayers; ++l) {
+    const size_t n = (size_t)channels[l] * channels[l + 1];
+    if (n > wt) wt = n;
+  }
+  return sizeof(double) * 2 * (size_t)cmax + sizeof(float) * ((wt + 3) / 4 * 4) + slabs;
 }
 
 extern "C" int eda_sa_fused_bwd_f32(const float *dout, const unsigned char *argmax, const float *x, long ldx,
@@ -1023,8 +1046,15 @@ extern "C" int eda_sa_fused_bwd_f32(const float *dout, const unsigned char *argm
   int cmax = 0;
   for (int l = 1; l <= nlayers; ++l) if (channels[l] > cmax) cmax = channels[l];
   double *red = reinterpret_cast<double *>(ws_);
-  float *slabs = reinterpret_cast<float *>(red + 2 * cmax);
-  const size_t slab_bytes = ws_bytes - sizeof(double) * 2 * (size_t)cmax;
+  size_t wt_floats = 0;
+  for (int l = 0; l < nlayers; ++l) {
+    const size_t nn = (size_t)channels[l] * channels[l + 1];
+    if (nn > wt_floats) wt_floats = nn;
+  }
+  wt_floats = (wt_floats + 3) / 4 * 4;
+  float *wt = reinterpret_cast<float *>(red + 2 * cmax);
+  float *slabs = wt + wt_floats;
+  const size_t slab_bytes = ws_bytes - sizeof(double) * 2 * (size_t)cmax - sizeof(float) * wt_floats;
 
   // ---- last layer: BatchNorm+ReLU(+pool) backward from d(out) -> dz in scratch_a
   {
@@ -1081,7 +1111,15 @@ extern "C" int eda_sa_fused_bwd_f32(const float *dout, const unsigned char *argm
     GemmArgs a;
     memset(&a, 0, sizeof(a));
     a.xmode = X_PLAIN; a.x = cur; a.ldx = cout; a.R = R; a.K = cout;
-    a.w = weight[l]; a.ldw = cin;
+    // dX = dz W as an NT product with W^T (output columns x cout), transposed into the workspace
+    const int wcols = (l == 0 && g.gather) ? c_feat : cin, wc0 = (l == 0 && g.gather) ? 3 : 0;
+    const bool need_dx = l > 0 || (g.gather ? (dfeats_cl && c_feat > 0) : dx != nullptr);
+    if (need_dx) {
+      hipLaunchKernelGGL(weight_transpose_kernel, dim3((wcols + 31) / 32, (cout + 31) / 32), dim3(32, 8), 0, stream,
+                         weight[l], cout, cin, wc0, wcols, wt);
+      EDA_CHECK_LAUNCH();
+    }
+    a.w = wt; a.ldw = cout;
     if (l > 0) {
       const float *st = stats[l - 1];
       { const int zrc = eda_zero_async(red, sizeof(double) * 2 * cin, stream); if (zrc) return zrc; }
@@ -1090,7 +1128,7 @@ extern "C" int eda_sa_fused_bwd_f32(const float *dout, const unsigned char *argm
       a.zm = z[l - 1]; a.ldzm = cin;
       a.m_mean = st; a.m_rstd = st + cin; a.m_scale = st + 2 * cin; a.m_shift = st + 3 * cin;
       a.s1 = red; a.s2 = red + cin;
-      const int rc = eda_gemm_launch(a, W_NN, stream);
+      const int rc = eda_gemm_launch(a, W_NT, stream);
       if (rc) return rc;
       // dz_{l-1} = A*gy + B*z + D, in place (gy is already masked: the kernel's mask is idempotent)
       hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<false>, dim3(grid_for(R * (cin / 4))), dim3(CL_THREADS), 0, stream,
@@ -1100,15 +1138,14 @@ extern "C" int eda_sa_fused_bwd_f32(const float *dout, const unsigned char *argm
       float *t = cur; cur = other; other = t;
     } else if (g.gather) {
       if (dfeats_cl && c_feat > 0) {
-        a.w = weight[0] + 3;                                   // feature columns of the (C1, 3 + c_feat) weight
-        a.N = c_feat; a.epi = E_SCATTER;
+        a.N = c_feat; a.epi = E_SCATTER;                       // (wt holds the feature columns of the (C1, 3 + c_feat) weight)
         a.idx = idx; a.n_pts = n; a.m = m; a.ns = ns; a.c_feat = c_feat; a.dfeats = dfeats_cl;
-        const int rc = eda_gemm_launch(a, W_NN, stream);
+        const int rc = eda_gemm_launch(a, W_NT, stream);
         if (rc) return rc;
       }
     } else if (dx) {
       a.N = cin; a.y = dx; a.ldy = lddx; a.epi = E_PLAIN;
-      const int rc = eda_gemm_launch(a, W_NN, stream);
+      const int rc = eda_gemm_launch(a, W_NT, stream);
       if (rc) return rc;
     }
   }

@@ -141,6 +141,27 @@ def furthest_point_sampling(points, nsamples):
     return out
 
 
+def furthest_point_sampling_prefix(points, nsamples):
+    """furthest_point_sampling with the same result for every input, fast when `points` already is in
+    sampling order (eda_furthest_point_sampling_prefix_f32: 0..m-1 is verified, not assumed).  An extra of
+    this module, not one of the nine reference callables."""
+    _check_contiguous(points, "points")
+    _check_float(points, "points")
+    _require_gpu(points)
+    L = _lib.lib()
+    b, n = points.shape[0], points.shape[1]
+    nsamples = int(nsamples)
+    out = torch.empty((b, nsamples), dtype=torch.int32, device=points.device)
+    if b == 0 or nsamples == 0:
+        return out
+    ws = _fps_workspace(points.device, L.eda_fps_prefix_workspace_bytes(b, n, nsamples))
+    with torch.cuda.device(points.device), _timed('furthest_point_sampling', (b, n, nsamples)):
+        rc = L.eda_furthest_point_sampling_prefix_f32(points.data_ptr(), b, n, nsamples, out.data_ptr(),
+                                                      ws.data_ptr(), ws.numel(), _stream())
+    _lib.check(rc, "eda_furthest_point_sampling_prefix_f32")
+    return out
+
+
 def gather_points(points, idx):
     """sampling.cpp:20-43 -- points (B,C,N), idx (B,m) -> (B,C,m)."""
     _check_contiguous(points, "points"); _check_contiguous(idx, "idx")

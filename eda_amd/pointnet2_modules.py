@@ -42,9 +42,9 @@ class PointnetSAModuleVotes(nn.Module):
             spec[0] += 3
         self.mlp_module = SharedMLP(spec, bn=bn)
 
-    def forward(self, xyz, features=None, inds=None):
+    def forward(self, xyz, features=None, inds=None, xyz_in_sampling_order=False):
         if inds is None:
-            inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+            inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint, xyz_in_sampling_order)
         else:
             assert inds.shape[1] == self.npoint
         new_xyz = None

@@ -22,17 +22,22 @@ from . import ext as _ext
 
 class FurthestPointSampling(Function):
     @staticmethod
-    def forward(ctx, xyz, npoint):
-        inds = _ext.furthest_point_sampling(xyz, npoint)
+    def forward(ctx, xyz, npoint, sampling_order_hint=False):
+        # sampling_order_hint: the caller believes xyz already is in sampling order (the SA2..SA4 levels).  The
+        # HIP library then CHECKS whether 0..npoint-1 is the answer before running the dependent rounds;
+        # the result is the same either way (ext.furthest_point_sampling_prefix).
+        fast = getattr(_ext, "furthest_point_sampling_prefix", None) if sampling_order_hint else None
+        inds = fast(xyz, npoint) if fast is not None else _ext.furthest_point_sampling(xyz, npoint)
         ctx.mark_non_differentiable(inds)
         return inds
 
     @staticmethod
     def backward(ctx, grad=None):
-        return None, None
+        return None, None, None
 
 
-furthest_point_sample = FurthestPointSampling.apply
+def furthest_point_sample(xyz, npoint, sampling_order_hint=False):
+    return FurthestPointSampling.apply(xyz, npoint, sampling_order_hint)
 
 
 class GatherOperation(Function):

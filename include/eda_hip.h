@@ -64,6 +64,15 @@ int eda_furthest_point_sampling_f32(const float *xyz, int b, int n, int m,
                                     int *idx, void *ws, size_t ws_bytes,
                                     void *stream);
 
+/* Same result as eda_furthest_point_sampling_f32 for EVERY input, fast when xyz already is in sampling
+ * order (the SA2..SA4 levels sample from the previous level's samples, models/backbone_module.py:122-131):
+ * two barrier-free kernels check, under the reference's exact arithmetic and tie order, whether 0..m-1 is
+ * the answer; scenes that pass are done (~20 us instead of 0.1-0.6 ms of dependent rounds), the others run
+ * the regular kernel.  n > 8192 forwards to the regular entry point.                                  */
+size_t eda_fps_prefix_workspace_bytes(int b, int n, int m);
+int eda_furthest_point_sampling_prefix_f32(const float *xyz, int b, int n, int m, int *idx, void *ws,
+                                           size_t ws_bytes, void *stream);
+
 /* ---- gather -----------------------------------------------------------
  * replaces gather_points()        src/sampling.cpp:20-43, sampling_gpu.cu:13-35
  * points (b,c,n), idx (b,m) -> out (b,c,m)                                 */

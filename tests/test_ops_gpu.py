@@ -226,3 +226,41 @@ def test_grid_ball_query_vs_oracle(ext, oracle, b, n, m, r, ns, kind):
     oracle.set_threads(1)
     got = ext.ball_query(dev(ctr), dev(p), r, ns).cpu().numpy()
     assert (got == exp).all(), np.argwhere(got != exp)[:5]
+
+
+@pytest.mark.parametrize("fma_mode", [0, 1])
+def test_fps_prefix_verification_equals_oracle_on_every_kind_of_input(oracle, fma_mode):
+    """eda_furthest_point_sampling_prefix_f32 (used for SA2..SA4) must return exactly the oracle's indices
+    whether its shortcut applies (input in sampling order, no tie: 0..m-1 verified) or not (unordered
+    input; duplicated points = exact ties in the reference's arg-max order; points inside the origin ball;
+    a first point inside the ball; fewer valid points than samples)."""
+    import numpy as np
+    from eda_amd import ext, _lib, synthetic
+    L = _lib.lib()
+    L.eda_set_fma_mode(fma_mode); oracle.set_fma_mode(fma_mode)
+    try:
+        rng = np.random.default_rng(7)
+        base = torch.from_numpy(synthetic.batch([21, 22, 23], 50000)[:, :, :3].copy())
+        sa1 = oracle.furthest_point_sampling(base, 2048)
+        ordered = torch.gather(base, 1, sa1.long()[..., None].expand(-1, -1, 3)).contiguous()       # SA1 samples in sampling order
+        cases = {"ordered": (ordered, 1024), "ordered_short": (ordered[:, :1024].contiguous(), 512),
+                 "unordered": (base[:, :2048].contiguous(), 1024)}
+        dup = ordered.clone()
+        dup[0, 700] = dup[0, 3]; dup[1, 5] = dup[1, 4]; dup[2, 1500:1510] = dup[2, 100:110]       # exact duplicates
+        cases["duplicates"] = (dup, 1024)
+        ball = ordered.clone()
+        ball[0, 0] = torch.tensor([0.01, 0.0, 0.01]); ball[1, 7] = torch.tensor([0.0, 0.02, 0.0]); ball[2, 600:650] *= 1e-3
+        cases["origin_ball"] = (ball, 1024)
+        few = torch.zeros(2, 600, 3); few[:, :40] = torch.from_numpy(rng.uniform(1, 2, (2, 40, 3)).astype(np.float32))
+        cases["few_valid"] = (few, 256)
+        quant = (torch.round(ordered * 16) / 16).contiguous()                                      # many equal distances
+        cases["quantised"] = (quant, 512)
+        for name, (xyz, m) in cases.items():
+            want = oracle.furthest_point_sampling(xyz, m)
+            got = ext.furthest_point_sampling_prefix(xyz.cuda(), m).cpu()
+            assert torch.equal(got, want), (name, fma_mode, int((got != want).sum()))
+            if name in ("ordered", "ordered_short"):
+                assert torch.equal(want, torch.arange(m, dtype=torch.int32)[None].expand_as(want)), name
+        assert ext.fps_status() == 0
+    finally:
+        L.eda_set_fma_mode(0); oracle.set_fma_mode(0)
