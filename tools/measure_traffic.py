@@ -65,6 +65,8 @@ def main():
            "how": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate passes, KiB -> bytes, per launch "
                   "(tools/measure_traffic.py)", "entries": entries}
     json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)       # (gpurun only carries gpurun_out/ back)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 

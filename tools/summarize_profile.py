@@ -6,17 +6,18 @@ import re
 import sys
 
 NATIVE = [
+    ("native: own row GEMMs fwd / dX (gemm_rows: linear layers, fused SA/FP layers)", r"^gemm_rows_kernel"),
     ("native: furthest point sampling", r"^fps_"),
     ("native: fused attention (fwd, dQ, dK/dV)", r"^mha_"),
     ("native: BN+ReLU(+pool) fwd/bwd", r"^bn_"),
     ("native: residual+dropout+LayerNorm", r"^add_dropout_ln|^ln_reduce"),
-    ("native: weight/bias gradients (grouped wgrad, colsum)", r"^wgrad_|^colsum_|^wcolsum_"),
+    ("native: weight/bias gradients (grouped wgrad, wgrad_x, colsum)", r"^wgrad_|^colsum_|^wcolsum_|^weight_transpose"),
     ("native: ball query (grid build + query)", r"^gq_|^ball_query"),
     ("native: gather/group/3-NN", r"^group_|^gather_|^three_"),
     ("native: zero-fill", r"^zero_kernel"),
 ]
 TORCH = [
-    ("library GEMM (hipBLASLt/rocBLAS, fp32)", r"^Cijk_|gemm|Gemm"),
+    ("library GEMM (hipBLASLt/rocBLAS, fp32; RoBERTa only)", r"^Cijk_|gemm|Gemm"),
     ("optimizer / foreach", r"multi_tensor_apply"),
     ("torch reduce", r"reduce_kernel"),
     ("torch layernorm / softmax / attention (RoBERTa)", r"layer_norm|softmax|attn_fwd|LayerNorm"),
@@ -55,8 +56,8 @@ def main():
             native_rows.append((name, n, float(r["AverageNs"]) / 1e3, ms))
     d = json.load(open(dflt))
     u = json.load(open(under))
-    cb, rf, rm, rh = d["cpu_baseline"], d["roofline"], d.get("roofline_mfma"), d.get("roofline_hbm")
-    out = [f"# Round 1, run {tag[-1]} — B=8 x 50 000 points, 256 queries, 80 tokens, fp32", ""]
+    cb, rf, rm, rh = d.get("cpu_baseline") or {"value": None, "unit": "", "cores": None, "sample": "not run"}, d["roofline"], d.get("roofline_mfma"), d.get("roofline_hbm")
+    out = [f"# Run {tag} — B=8 x 50 000 points, 256 queries, 80 tokens, fp32", ""]
     out.append(f"`python bench.py` (whole step replayed from one HIP graph): **{d['value']} scenes/s, "
                f"{d['ms_per_step']} ms/step**; cpu_baseline {cb['value']} {cb['unit']} on {cb['cores']} cores "
                f"({cb['sample']}).  Full line: `{tag}_bench_default.json`.")
