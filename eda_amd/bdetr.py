@@ -23,13 +23,21 @@ import torch.nn.functional as F
 
 from .backbone_module import Pointnet2Backbone
 from .encoder_decoder_layers import BiDecoderLayer, BiEncoder, BiEncoderLayer, PositionEmbeddingLearned
-from .nn_utils import Conv1dK1, Linear, deferred_bn_counters, l2_normalize
+from .nn_utils import Conv1dK1, Linear, deferred_bn_counters, l2_normalize, linear_rows
 from .modules import ClsAgnosticPredictHead, GeneralSamplingModule, PointsObjClsModule
 
 
 def _mlp3(d_in, d_out):
     return nn.Sequential(Linear(d_in, d_in), nn.ReLU(), Linear(d_in, d_in), nn.ReLU(),
                          Linear(d_in, d_out))
+
+
+def _project(mlp, x):
+    """l2_normalize(mlp(x)) for an _mlp3 stack, the ReLUs folded into the GEMM epilogues (on CPU tensors
+    linear_rows is the torch composition)."""
+    x = linear_rows(x, mlp[0].weight, mlp[0].bias, relu=True)
+    x = linear_rows(x, mlp[2].weight, mlp[2].bias, relu=True)
+    return l2_normalize(linear_rows(x, mlp[4].weight, mlp[4].bias))
 
 
 def _load_text_stack(data_path):
@@ -200,15 +208,17 @@ class BeaUTyDETR(nn.Module):
         end_points["text_memory"] = text_feats
         end_points["seed_features"] = points_features
         if self.contrastive_align_loss:
-            end_points["proj_tokens"] = l2_normalize(self.contrastive_align_projection_text(text_feats))
+            end_points["proj_tokens"] = _project(self.contrastive_align_projection_text, text_feats)
 
         end_points = self._generate_queries(points_xyz, points_features, end_points, features_rows=vis)
         cluster_feature = end_points["query_points_feature"]     # (B, 288, Q)
         cluster_xyz = end_points["query_points_xyz"]             # (B, Q, 3)
         cluster_rows = cluster_feature.transpose(1, 2).contiguous()             # (B, Q, 288)
         query = self.decoder_query_proj.rows(cluster_rows)
-        if self.contrastive_align_loss:
-            end_points["proposal_proj_queries"] = l2_normalize(self.contrastive_align_projection_image(query))
+        # the contrastive projection of the proposal queries and of every decoder layer's output is the same
+        # MLP on 7 independent inputs that nothing in the forward reads: applied once on the 7 stacked
+        # (bdetr.py:262-264, 316-320 of the reference apply it layer by layer; same numbers)
+        projected = [("proposal_", query)]
         center, size = self.proposal_head(cluster_feature, base_xyz=cluster_xyz, end_points=end_points,
                                           prefix="proposal_", features_rows=cluster_rows)
         base_xyz, base_size = center.detach().clone(), size.detach().clone()
@@ -226,12 +236,15 @@ class BeaUTyDETR(nn.Module):
             query = self.decoder[i](query, vis, text_feats, query_pos, None, text_padding_mask,
                                     detected_feats=detected_feats if self.butd else None,
                                     detected_mask=detected_mask if self.butd else None)
-            if self.contrastive_align_loss:
-                end_points[f"{prefix}proj_queries"] = l2_normalize(self.contrastive_align_projection_image(query))
+            projected.append((prefix, query))
             center, size = self.prediction_heads[i](query.transpose(1, 2), base_xyz=cluster_xyz,
                                                     end_points=end_points, prefix=prefix,
                                                     features_rows=query)
             base_xyz, base_size = center.detach().clone(), size.detach().clone()
+        if self.contrastive_align_loss:
+            proj = _project(self.contrastive_align_projection_image, torch.stack([q for _, q in projected], 0))
+            for (prefix, _), p in zip(projected, proj.unbind(0)):
+                end_points[f"{prefix}proj_queries"] = p
         return end_points
 
     def init_bn_momentum(self):

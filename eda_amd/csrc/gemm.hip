@@ -57,6 +57,34 @@ __device__ __forceinline__ float row_sum16(float v) {
   return v;
 }
 
+// E_STATS, last workgroup: column sums -> mean / rstd / scale / shift and the running statistics
+// (train-mode BatchNorm, pointnet2/pytorch_utils.py:67-120); re-arms the accumulators and the ticket.
+__device__ __forceinline__ void bn_finalize(const GemmArgs &a, int tid, int nthreads) {
+  const long R = a.R;
+  for (int c = tid; c < a.N; c += nthreads) {
+    const double su = __hip_atomic_load(a.sum + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double sq = __hip_atomic_load(a.sumsq + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.sum + c, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.sumsq + c, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double mean = su / (double)R;
+    double var = sq / (double)R - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    const float meanf = (float)mean;
+    a.mean_out[c] = meanf;
+    a.rstd_out[c] = rstd;
+    const float scv = a.gamma[c] * rstd;
+    a.scale_out[c] = scv;
+    a.shift_out[c] = a.beta[c] - meanf * scv;
+    if (a.running_mean) {
+      const double unbiased = R > 1 ? var * (double)R / (double)(R - 1) : var;
+      a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * meanf;
+      a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+    }
+  }
+  if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // VEC: every operand row is 16-byte addressable (K % 4 == 0 for the row operand, aligned strides and
 // pointers; the gather's feature rows when c_feat % 4 == 0).  The staging loads are then
 // UNCONDITIONAL: rows / columns beyond the matrix are clamped to the last valid one (their results
@@ -542,32 +570,356 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a_i
       if (tid == 0)
         is_last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.ticket_target - 1;
       __syncthreads();
-      if (is_last) {
-        for (int c = tid; c < N; c += G_THREADS) {
-          const double su = __hip_atomic_load(a.sum + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const double sq = __hip_atomic_load(a.sumsq + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(a.sum + c, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(a.sumsq + c, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const double mean = su / (double)R;
-          double var = sq / (double)R - mean * mean;
-          if (var < 0.0) var = 0.0;
-          const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
-          const float meanf = (float)mean;
-          a.mean_out[c] = meanf;
-          a.rstd_out[c] = rstd;
-          const float scv = a.gamma[c] * rstd;
-          a.scale_out[c] = scv;
-          a.shift_out[c] = a.beta[c] - meanf * scv;
-          if (a.running_mean) {
-            const double unbiased = R > 1 ? var * (double)R / (double)(R - 1) : var;
-            a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * meanf;
-            a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
-          }
-        }
-        if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (is_last) bn_finalize(a, tid, G_THREADS);
+    }
+  }
+}
+
+// ---- streaming variants: the many-row layers of the set-abstraction modules ------------------------
+// 10^5..10^6 rows against a weight of 64..256 channels a side: a row costs 256-1024 bytes of HBM traffic
+// each way and 64-512 MFMA steps, and the (tiny) weight is the only thing worth keeping.  Here every WAVE
+// runs its own pipeline over 16-row tiles (persistent, tiles interleaved over all waves of the launch): the
+// weight (all of it, or a 64/128-column tile of it) sits in LDS for the lifetime of the workgroup --
+// loaded once, not once per row block --, a row tile is requested with coalesced 16-byte loads one tile
+// ahead, goes through a wave-private LDS strip into MFMA fragment order (an in-wave LDS write -> read
+// needs no barrier: the LDS pipeline is in order per wave), and after the one barrier that publishes the
+// weight no wave ever waits for another.  Column statistics stay in registers over all tiles of a wave
+// (a few dozen fp32 additions each, then fp64) and cost one fp64 atomic per column per WORKGROUP.
+// Measured (B = 8, rocprofv3): 262144 x 128 -> 128 with BatchNorm prologue + statistics 93 us = 92 TFLOP/s
+// (the tiled kernel above: 150 us, hipBLASLt's plain GEMM: 102 us); 1048576 x 64 -> 64: 126 us = 4.3 TB/s.
+//   KT  contraction length (64 / 128 / 256; X_GATHER: the feature channels, the 3 coordinates ride on one
+//       extra MFMA step whose row operand the lanes compute themselves)
+//   NT  column tile (64 / 128); block id % col_tiles selects it, the row operand is then read col_tiles
+//       times (the repeats come from L2)
+template <int KT, int NT, int XMODE, int EPI, int NW, int MINW>
+__global__ __launch_bounds__(64 * NW, MINW) void gemm_stream_kernel(const GemmArgs a) {
+  constexpr int XS = 64 + 8;                 // wave strip: 16 rows x 64 k (longer contractions go through it in 64-wide parts)
+  constexpr int WSS = KT + 8;                // weight row stride ([n][k], = 8 mod 16: conflict-free b128 fragments)
+  constexpr int KH = KT / 64, NJ = NT / 16;
+  constexpr bool mask = EPI == E_MASK, stats = EPI == E_STATS || EPI == E_MASK, gather = XMODE == X_GATHER;
+  static_assert(KT % 64 == 0 && NT % 64 == 0 && 2 * NT <= 16 * XS, "shape");
+  __shared__ __attribute__((aligned(16))) float smem[NT * WSS + NW * 16 * XS];
+  __shared__ __attribute__((aligned(16))) float mtab[mask ? 4 * NT : 4];   // E_MASK: scale | shift | mean | rstd
+  __shared__ int is_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  float *Ws = smem, *strip = smem + NT * WSS + wave * 16 * XS;
+  const long R = a.R;
+  // block id % 8 = XCD: the column tiles of a slot (they stream the same rows) run on ONE XCD, so the repeats
+  // of a row tile come from that XCD's L2 (the launcher makes the slot count a multiple of 8)
+  const unsigned xq = blockIdx.x >> 3;
+  const int ct = (int)(xq % (unsigned)a.col_tiles), n0 = ct * NT;
+  const long slot = (long)(xq / (unsigned)a.col_tiles) * 8 + (blockIdx.x & 7), nslots = gridDim.x / (unsigned)a.col_tiles;
+  {
+    if (mask && tid < NT) {
+      mtab[tid] = a.m_scale[n0 + tid]; mtab[NT + tid] = a.m_shift[n0 + tid];
+      mtab[2 * NT + tid] = a.m_mean[n0 + tid]; mtab[3 * NT + tid] = a.m_rstd[n0 + tid];
+    }
+    if (gather) {
+      // (N, 3 + C) weight: the feature columns start at element 3 of a row (not 16-byte aligned)
+      for (int e = tid; e < NT * KT; e += 64 * NW) {
+        const int n = e / KT, k = e % KT;
+        Ws[n * WSS + k] = a.w[(long)(n0 + n) * a.ldw + 3 + k];
+      }
+    } else {
+      constexpr int KQ = KT / 4;
+      for (int e = tid; e < NT * KQ; e += 64 * NW) {
+        const int n = e / KQ, kq = e % KQ;
+        *reinterpret_cast<float4 *>(&Ws[n * WSS + 4 * kq]) =
+            *reinterpret_cast<const float4 *>(a.w + (long)(n0 + n) * a.ldw + 4 * kq);
       }
     }
   }
+  __syncthreads();
+
+  const long ntiles = (R + 15) >> 4;
+  const long tstride = nslots * NW;
+  long t = slot * NW + wave;
+  // staging map of a 64-wide part: lane -> rows (lane>>4) + 4i, k = 4*(lane&15)
+  const int sk = 4 * (lane & 15), srow = lane >> 4;
+  float4 bsc[KH], bsh[KH];
+  if (XMODE == X_BNRELU) {
+#pragma unroll
+    for (int h = 0; h < KH; ++h) {
+      bsc[h] = *reinterpret_cast<const float4 *>(a.in_scale + 64 * h + sk);
+      bsh[h] = *reinterpret_cast<const float4 *>(a.in_shift + 64 * h + sk);
+    }
+  }
+  // X_GATHER: the neighbour indices of a tile's rows are requested TWO tiles ahead (the feature rows they
+  // address one tile ahead), the coordinate operand of the next tile during the current one
+  const unsigned rps = (gather || EPI == E_SCATTER) ? (unsigned)a.m * (unsigned)a.ns : 1u;
+  int gidx[4], gidx16 = 0;                   // idx of the staging rows / of row r16, tile t + tstride
+  float gp_[2] = {0.f, 0.f};                 // raw (point, centre) coordinate g of row r16, tile t (g < 3)
+  float avx[gather ? NJ : 1];                // weight fragment of the coordinate step
+  auto scene_of = [&](unsigned row) { return row / rps; };
+  auto load_idx = [&](long tile) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      long row = tile * 16 + srow + 4 * i;
+      if (row > R - 1) row = R - 1;
+      gidx[i] = a.idx[row];
+    }
+    long row = tile * 16 + r16;
+    if (row > R - 1) row = R - 1;
+    gidx16 = a.idx[row];
+  };
+  auto load_xyz = [&](long tile) {           // uses gidx16 of that tile
+    long row = tile * 16 + r16;
+    if (row > R - 1) row = R - 1;
+    const unsigned b = scene_of((unsigned)row);
+    const unsigned gc = b * (unsigned)a.m + ((unsigned)row - b * rps) / (unsigned)a.ns;
+    const long gp = (long)b * a.n_pts + gidx16;
+    if (g < 3) { gp_[0] = a.xyz[gp * 3 + g]; gp_[1] = a.new_xyz[(long)gc * 3 + g]; }
+  };
+  float4 xr[KH][4];
+  int goff[4];                               // X_GATHER: element offsets of the staging rows' feature rows
+  auto row_offsets = [&](long tile) {        // uses gidx of that tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      long row = tile * 16 + srow + 4 * i;
+      if (row > R - 1) row = R - 1;
+      goff[i] = ((int)scene_of((unsigned)row) * a.n_pts + gidx[i]) * KT;
+    }
+  };
+  auto fetch = [&](const int h, long tile) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (gather) {
+        xr[h][i] = *reinterpret_cast<const float4 *>(a.feats + goff[i] + 64 * h + sk);
+      } else {
+        long row = tile * 16 + srow + 4 * i;
+        if (row > R - 1) row = R - 1;
+        xr[h][i] = *reinterpret_cast<const float4 *>(a.x + row * a.ldx + 64 * h + sk);
+      }
+    }
+  };
+  auto stage = [&](const int h) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 v = xr[h][i];
+      if (XMODE == X_BNRELU) {
+        v.x = fmaxf(v.x * bsc[h].x + bsh[h].x, 0.f); v.y = fmaxf(v.y * bsc[h].y + bsh[h].y, 0.f);
+        v.z = fmaxf(v.z * bsc[h].z + bsh[h].z, 0.f); v.w = fmaxf(v.w * bsc[h].w + bsh[h].w, 0.f);
+      }
+      *reinterpret_cast<float4 *>(&strip[(srow + 4 * i) * XS + sk]) = v;
+    }
+  };
+  float t1[stats ? NJ : 1][4], t2[stats ? NJ : 1][4];
+  if (stats) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { t1[j][u] = 0.f; t2[j][u] = 0.f; }
+  }
+  if (gather) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) avx[j] = g < 3 ? a.w[(long)(n0 + 16 * j + r16) * a.ldw + g] : 0.f;
+  }
+
+  if (t < ntiles) {
+    if (gather) {
+      load_idx(t);
+      row_offsets(t);
+      load_xyz(t);
+      if (t + tstride < ntiles) load_idx(t + tstride);
+    }
+#pragma unroll
+    for (int h = 0; h < KH; ++h) fetch(h, t);
+  }
+  const float *xf = strip + r16 * XS + 4 * g;
+  const float *wf = Ws + r16 * WSS + 4 * g;
+  for (; t < ntiles; t += tstride) {
+    const long row = t * 16 + r16;
+    const bool rok = row < R;
+    const bool more = t + tstride < ntiles;
+    float4 zt[mask ? NJ : 1];
+    if (mask) {
+      const long zr = rok ? row : R - 1;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) zt[j] = *reinterpret_cast<const float4 *>(a.zm + zr * a.ldzm + n0 + 16 * j + 4 * g);
+    }
+    f32x4 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int mybase = -1;                         // E_SCATTER: element offset of row r16's point in dfeats
+    if (gather) {
+      const float bx = g < 3 ? (gp_[0] - gp_[1]) * a.inv_radius : 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(avx[j], bx, acc[j], 0, 0, 0);
+      if (more) { row_offsets(t + tstride); load_xyz(t + tstride); }
+    }
+    if (EPI == E_SCATTER && rok)
+      mybase = ((int)scene_of((unsigned)row) * a.n_pts + a.idx[row]) * a.c_feat;
+#pragma unroll
+    for (int h = 0; h < KH; ++h) {
+      stage(h);
+      if (more) fetch(h, t + tstride);
+#pragma unroll
+      for (int ks = 0; ks < 64; ks += 16) {
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(xf + ks);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const f32x4 av = *reinterpret_cast<const f32x4 *>(wf + 16 * j * WSS + 64 * h + ks);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc[j], 0, 0, 0);
+        }
+      }
+    }
+    if (gather && t + 2 * tstride < ntiles) load_idx(t + 2 * tstride);
+    if (EPI == E_SCATTER) {
+      // d(features)[point of the row, column] += acc: through the strip, so that one atomic instruction
+      // covers 64 consecutive channels of ONE row (lane = column)
+#pragma unroll
+      for (int jc = 0; jc < NJ; jc += 4) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          *reinterpret_cast<float4 *>(&strip[r16 * XS + 16 * jj + 4 * g]) =
+              make_float4(acc[jc + jj][0], acc[jc + jj][1], acc[jc + jj][2], acc[jc + jj][3]);
+        for (int r = 0; r < 16; ++r) {
+          const int base = __shfl(mybase, r);
+          if (base >= 0) atomicAdd(a.dfeats + base + n0 + 16 * jc + lane, strip[r * XS + lane]);
+        }
+      }
+    } else if (rok) {
+      float *yp = a.y + row * a.ldy + n0 + 4 * g;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        float o[4];
+        if (mask) {
+          const float zz[4] = {zt[j].x, zt[j].y, zt[j].z, zt[j].w};
+          const float4 c0 = *reinterpret_cast<const float4 *>(&mtab[16 * j + 4 * g]);
+          const float4 c1 = *reinterpret_cast<const float4 *>(&mtab[NT + 16 * j + 4 * g]);
+          const float4 c2 = *reinterpret_cast<const float4 *>(&mtab[2 * NT + 16 * j + 4 * g]);
+          const float4 c3 = *reinterpret_cast<const float4 *>(&mtab[3 * NT + 16 * j + 4 * g]);
+          const float sc[4] = {c0.x, c0.y, c0.z, c0.w}, sh[4] = {c1.x, c1.y, c1.z, c1.w};
+          const float mu[4] = {c2.x, c2.y, c2.z, c2.w}, rs[4] = {c3.x, c3.y, c3.z, c3.w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            o[u] = zz[u] * sc[u] + sh[u] > 0.f ? acc[j][u] : 0.f;
+            t1[j][u] += o[u];
+            t2[j][u] += o[u] * (zz[u] - mu[u]) * rs[u];
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            o[u] = acc[j][u];
+            if (stats) { t1[j][u] += o[u]; t2[j][u] += o[u] * o[u]; }
+          }
+        }
+        *reinterpret_cast<float4 *>(yp + 16 * j) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+  if (!stats) return;
+  // column sums of this wave -> its strip, then one fp64 atomic per column per workgroup
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float s1v = row_sum16(t1[j][u]), s2v = row_sum16(t2[j][u]);
+      if (r16 == 0) { strip[16 * j + 4 * g + u] = s1v; strip[NT + 16 * j + 4 * g + u] = s2v; }
+    }
+  __syncthreads();
+  double *d1 = mask ? a.s1 : a.sum, *d2 = mask ? a.s2 : a.sumsq;
+  if (tid < NT) {
+    double c1 = 0.0, c2 = 0.0;
+    const float *st = smem + NT * WSS;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { c1 += (double)st[w * 16 * XS + tid]; c2 += (double)st[w * 16 * XS + NT + tid]; }
+    const double o1 = atomicAdd(d1 + n0 + tid, c1);
+    const double o2 = atomicAdd(d2 + n0 + tid, c2);
+    asm volatile("" ::"v"(o1), "v"(o2));
+  }
+  if (EPI == E_STATS) {
+    __syncthreads();
+    if (tid == 0)
+      is_last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.ticket_target - 1;
+    __syncthreads();
+    if (is_last) bn_finalize(a, tid, 64 * NW);
+  }
+}
+
+// SA1's first layer: QueryAndGroup of 3 feature channels + the 6 -> NT convolution + BatchNorm statistics.
+// A row is [dx dy dz 0 | f0 f1 f2 0]: two MFMA steps whose B operand the lanes compute themselves (lane
+// (row, g) supplies coordinate g and feature g), the weight's two fragments per column tile live in
+// registers: no LDS, no barrier; the launch is bound by the 256 bytes written per row.
+template <int NT>
+__global__ __launch_bounds__(256) void gemm_gather3_kernel(const GemmArgs a) {
+  constexpr int NJ = NT / 16, NW = 4;
+  __shared__ float red[NW][2 * NT];
+  __shared__ int is_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const long R = a.R;
+  float av0[NJ], av1[NJ];
+  float4 bb[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const float *wp = a.w + (long)(16 * j + r16) * a.ldw;
+    av0[j] = g < 3 ? wp[g] : 0.f;
+    av1[j] = g < 3 ? wp[3 + g] : 0.f;
+    bb[j] = a.bias ? *reinterpret_cast<const float4 *>(a.bias + 16 * j + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float t1[NJ][4], t2[NJ][4];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { t1[j][u] = 0.f; t2[j][u] = 0.f; }
+  const unsigned rps = (unsigned)a.m * (unsigned)a.ns;
+  const long ntiles = (R + 15) >> 4;
+  const long tstride = (long)gridDim.x * NW;
+  for (long t = (long)blockIdx.x * NW + wave; t < ntiles; t += tstride) {
+    const long row = t * 16 + r16;
+    const bool rok = row < R;
+    const unsigned rr = (unsigned)(rok ? row : R - 1);
+    const unsigned b = rr / rps;
+    const unsigned gc = b * (unsigned)a.m + (rr - b * rps) / (unsigned)a.ns;
+    const long gp = (long)b * a.n_pts + a.idx[rr];
+    float bx = 0.f, bf = 0.f;
+    if (g < 3) {
+      bx = (a.xyz[gp * 3 + g] - a.new_xyz[(long)gc * 3 + g]) * a.inv_radius;
+      bf = a.feats[gp * 3 + g];
+    }
+    if (rok) {
+      float *yp = a.y + row * a.ldy + 4 * g;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[j], bx, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[j], bf, acc, 0, 0, 0);
+        const float b4[4] = {bb[j].x, bb[j].y, bb[j].z, bb[j].w};
+        float o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          o[u] = acc[u] + b4[u];
+          t1[j][u] += o[u];
+          t2[j][u] += o[u] * o[u];
+        }
+        *reinterpret_cast<float4 *>(yp + 16 * j) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float s1v = row_sum16(t1[j][u]), s2v = row_sum16(t2[j][u]);
+      if (r16 == 0) { red[wave][16 * j + 4 * g + u] = s1v; red[wave][NT + 16 * j + 4 * g + u] = s2v; }
+    }
+  __syncthreads();
+  if (tid < NT) {
+    double c1 = 0.0, c2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { c1 += (double)red[w][tid]; c2 += (double)red[w][NT + tid]; }
+    const double o1 = atomicAdd(a.sum + tid, c1);
+    const double o2 = atomicAdd(a.sumsq + tid, c2);
+    asm volatile("" ::"v"(o1), "v"(o2));
+  }
+  __syncthreads();
+  if (tid == 0)
+    is_last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.ticket_target - 1;
+  __syncthreads();
+  if (is_last) bn_finalize(a, tid, 256);
 }
 
 bool gemm_vec_ok(const GemmArgs &a, int wmode) {
@@ -626,6 +978,92 @@ int launch_cfg(GemmArgs &a, int wmode, hipStream_t stream) {
   return 0;
 }
 
+// ---- streaming launches (SA1) ---------------------------------------------------------------------
+template <typename KernelT>
+int stream_grid(KernelT kern, int threads, long ntiles, int nw) {
+  // every CU full once (persistent waves); cached per instantiation
+  static int per_cu = 0;
+  if (!per_cu) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, 0) != hipSuccess || nb < 1) nb = 1;
+    per_cu = nb;
+  }
+  long wgs = (long)per_cu * 256;
+  const long need = (ntiles + nw - 1) / nw;
+  if (wgs > need) wgs = need;
+  return (int)(wgs < 1 ? 1 : wgs);
+}
+
+template <int KT, int NT, int XMODE, int EPI, int NW, int MINW>
+int launch_stream1(GemmArgs &a, hipStream_t stream) {
+  const long ntiles = (a.R + 15) / 16;
+  a.col_tiles = a.N / NT;
+  int slots = stream_grid(gemm_stream_kernel<KT, NT, XMODE, EPI, NW, MINW>, 64 * NW, ntiles, NW) / a.col_tiles;
+  slots = (slots + 7) / 8 * 8;
+  const int grid = slots * a.col_tiles;
+  a.ticket_target = (unsigned)grid;
+  hipLaunchKernelGGL((gemm_stream_kernel<KT, NT, XMODE, EPI, NW, MINW>), dim3(grid), dim3(64 * NW), 0, stream, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { eda_set_error("gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+
+// NW waves per workgroup, MINW waves per SIMD the register allocation aims at (8 x 4: 128 registers, two
+// workgroups per CU; 8 x 2: one workgroup per CU with up to 256 registers.  Measured on SA1, B = 8: the
+// latter beats two 6-wave workgroups at <= 168 registers: 64 -> 128: 230 vs 269 us, 128 -> 64 with the
+// mask epilogue: 226 vs 254 us)
+template <int KT, int NT, int NW, int MINW>
+int launch_stream(GemmArgs &a, hipStream_t stream) {
+  if (a.epi == E_MASK) return launch_stream1<KT, NT, X_PLAIN, E_MASK, NW, MINW>(a, stream);     // dX of a layer: plain rows
+  if (a.epi == E_SCATTER) return launch_stream1<KT, NT, X_PLAIN, E_SCATTER, NW, MINW>(a, stream);
+  if (a.xmode == X_GATHER) return launch_stream1<KT, NT, X_GATHER, E_STATS, NW, MINW>(a, stream);
+  if (a.xmode == X_BNRELU) return launch_stream1<KT, NT, X_BNRELU, E_STATS, NW, MINW>(a, stream);
+  return launch_stream1<KT, NT, X_PLAIN, E_STATS, NW, MINW>(a, stream);
+}
+
+// the streaming kernels take: forward layers with BatchNorm statistics, dX with the mask epilogue and the
+// scatter of the gather's backward; many rows, 64/128/256 channels on both sides, 16-byte addressable
+// operands.  EDA_GEMM_STREAM=0 switches them off, EDA_GEMM_STREAM_MINR=<rows> moves the threshold (tests).
+// Returns -1 if the launch is not theirs.
+int try_stream(GemmArgs &a, int wmode, hipStream_t stream) {
+  if (wmode != W_NT || a.ngroups > 1 || a.epi == E_PLAIN) return -1;
+  const char *e = getenv("EDA_GEMM_STREAM");
+  if (e && atoi(e) == 0) return -1;
+  long minr = 32768;
+  if (const char *m = getenv("EDA_GEMM_STREAM_MINR")) minr = atol(m);
+  if (a.R < minr || a.R >= 0x7fffffffL) return -1;
+  auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  if (a.bias || a.relu) return -1;
+  if (a.epi != E_SCATTER && (a.ldy % 4 != 0 || !al16(a.y))) return -1;
+  if (a.xmode == X_GATHER && a.c_feat == 3) {
+    if (a.epi != E_STATS || a.N != 64) return -1;
+    const long ntiles = (a.R + 15) / 16;
+    const int grid = stream_grid(gemm_gather3_kernel<64>, 256, ntiles, 4);
+    a.ticket_target = (unsigned)grid;
+    hipLaunchKernelGGL((gemm_gather3_kernel<64>), dim3(grid), dim3(256), 0, stream, a);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) { eda_set_error("gemm: launch failed: %s", hipGetErrorString(err)); return (int)err; }
+    return 0;
+  }
+  int K = a.K;
+  if (a.xmode == X_GATHER) {
+    if (a.epi != E_STATS || !al16(a.feats)) return -1;
+    K = a.c_feat;
+  } else {
+    if (!gemm_vec_ok(a, wmode)) return -1;
+    if (a.epi == E_MASK && (a.xmode != X_PLAIN || a.ldzm % 4 != 0 || !al16(a.zm))) return -1;
+    if (a.epi == E_SCATTER && (a.xmode != X_PLAIN || a.N != a.c_feat)) return -1;
+  }
+  const int N = a.N;
+  if (N % 64 != 0) return -1;
+  if (K == 64 && N == 64) return launch_stream<64, 64, 8, 4>(a, stream);
+  if (K == 64 && N % 128 == 0) return launch_stream<64, 128, 8, 2>(a, stream);
+  if (K == 128 && N == 64) return launch_stream<128, 64, 8, 2>(a, stream);
+  if (K == 128 && N % 128 == 0) return launch_stream<128, 128, 8, 2>(a, stream);
+  if (K == 256) return launch_stream<256, 64, 8, 2>(a, stream);
+  return -1;
+}
+
 int g_force_cfg() {
   static int v = -2;
   if (v == -2) { const char *e = getenv("EDA_GEMM_CFG"); v = e ? atoi(e) : -1; }
@@ -647,6 +1085,10 @@ int eda_gemm_launch(GemmArgs &a, int wmode, hipStream_t stream) {
                                   ((a.R + (long)a.m * a.ns - 1) / ((long)a.m * a.ns)) >= 0x7fffffffL)) {
     eda_set_error("gemm: operand too large for 32-bit element offsets");
     return EDA_ERR_INVALID_ARG;
+  }
+  {
+    const int rc = try_stream(a, wmode, stream);
+    if (rc >= 0) return rc;
   }
   if (!gemm_vec_ok(a, wmode)) return launch_cfg<1, 4, false>(a, wmode, stream);
   // measured on MI355X (tools/bench_gemm.py, profiles/r02a_gemm_tiles.txt): the 64x64 tile at 5-6

@@ -73,11 +73,24 @@ def _run_fused(cfg_kw, Ws, gammas, betas, running, training, pool, x_rows=None, 
     return sa_ops.FusedMLP.apply(cfg, x_rows, xyz, new_xyz, feats_cl, idx, *params)
 
 
+@pytest.fixture(params=["default", "stream"])
+def stream_kernels(request, monkeypatch):
+    """'stream': the per-wave streaming GEMM kernels of SA1 (gemm.hip: gemm_stream_kernel, gemm_gather3_kernel)
+    take every eligible launch whatever its row count; 'default': only above 65536 rows."""
+    if request.param == "stream":
+        monkeypatch.setenv("EDA_GEMM_STREAM_MINR", "1")
+    return request.param
+
+
 @pytest.mark.parametrize("R,chans,training", [
     (4096, [512, 256, 256], True), (8192, [512, 256, 288], True), (1000, [20, 32, 16], True),
     (4096, [512, 256, 256], False), (333, [7, 64], True), (70000, [64, 64, 128], True),
+    (70003, [64, 64, 128], True), (5001, [128, 64, 64], True), (77, [64, 128, 64, 64], True),
+    (3000, [256, 128, 256, 64], True), (40000, [128, 128, 128, 256], True),
 ])
-def test_plain_rows(R, chans, training):
+def test_plain_rows(R, chans, training, stream_kernels):
+    if stream_kernels == "stream" and not all(c in (64, 128) for c in chans[1:]):
+        pytest.skip("no layer of this stack is a streaming shape")
     dev = "cuda"
     torch.manual_seed(R + 7 * len(chans))
     Ws, gammas, betas, running = _build(chans, dev, R + len(chans))
@@ -115,13 +128,18 @@ def test_plain_rows(R, chans, training):
 
 @pytest.mark.parametrize("B,N,m,ns,C,chans,training", [
     (2, 3000, 128, 16, 3, [64, 64, 128], True),
+    (3, 1500, 61, 7, 3, [64, 64, 128], True),
+    (2, 1024, 100, 16, 256, [128, 128, 256], True),
+    (3, 700, 50, 9, 64, [64, 128], True),
     (2, 2048, 256, 32, 128, [128, 128, 256], True),
     (1, 700, 33, 5, 8, [16, 32], True),
     (2, 1024, 64, 16, 256, [128, 128, 256], False),
     (2, 500, 40, 8, 0, [32, 32], True),
     (1, 900, 50, 7, 6, [24], True),
 ])
-def test_gathered_rows(B, N, m, ns, C, chans, training):
+def test_gathered_rows(B, N, m, ns, C, chans, training, stream_kernels):
+    if stream_kernels == "stream" and not ((C == 3 and chans[0] == 64) or C in (64, 128, 256)):
+        pytest.skip("not a streaming shape")
     from eda_amd import pointnet2_utils as PU
     dev = "cuda"
     torch.manual_seed(N + 3 * C)
