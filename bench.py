@@ -308,6 +308,10 @@ def main():
                          "in one grouped kernel (eda_amd/wgrad_queue.py); 0: compute each where autograd reaches it")
     ap.add_argument("--overlap", action="store_true",
                     help="run the text encoder on a side stream underneath the point backbone (measured slower)")
+    ap.add_argument("--text-stream", type=int, default=1,
+                    help="1 (with --graph): the frozen text encoder runs as its own HIP graph on a second stream "
+                         "underneath the point backbone's graph (whose furthest point sampling keeps ~100 of the 256 "
+                         "CUs busy for 3 ms); the rest of the step is a third graph behind an event.  0: one graph")
     ap.add_argument("--attn-dtype", choices=["f32", "bf16", "f16"], default="f32",
                     help="arithmetic of the attention QK^T / PV contractions: f32 = the headline / parity path; bf16 / "
                          "f16 = 16-bit MFMA with fp32 accumulation (csrc/mha16.hip, BASELINE.json configs[2] / [4]) -- "
@@ -452,7 +456,79 @@ def main():
         mode = dict(capture_error_mode="thread_local")
         # (capture on the stream the eager warm-up steps ran on)
         try:
-            if world == 1 and not args.split_graphs:
+            if args.text_stream and not args.overlap:
+                # three graphs on two streams: [frozen text encoder] on `tstream` underneath [point backbone];
+                # [rest of the forward, loss, backward (, clip + AdamW at N = 1)] behind the encoder's event
+                tstream = torch.cuda.Stream()
+                tok = inputs["tokenized"]
+                g_text, g_pts, g_rest = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                g_up = torch.cuda.CUDAGraph() if (world > 1 or args.split_graphs) else None
+                tstream.wait_stream(side)
+                with torch.cuda.graph(g_text, stream=tstream, **mode):
+                    text_hidden = model.encode_text_frozen(tok["input_ids"], tok["attention_mask"])
+                inputs_h = dict(inputs)
+                inputs_h["text_hidden"] = text_hidden
+                pool = torch.cuda.graph_pool_handle()
+                with torch.cuda.graph(g_pts, pool=pool, stream=side, **mode):
+                    attention.advance_dropout_state(device)
+                    ep_static = model.forward_point_backbone(inputs_h)
+                with torch.cuda.graph(g_rest, pool=pool, stream=side, **mode):
+                    static_loss = loss_fn(model.forward_rest(inputs_h, ep_static))
+                    if args.defer_wgrad:
+                        with flat.deferred_wgrad():
+                            static_loss.backward()
+                    else:
+                        static_loss.backward()
+                    flat.collect_grads()
+                    if g_up is None:
+                        update()
+                if g_up is not None:
+                    with torch.cuda.graph(g_up, pool=pool, stream=side, **mode):
+                        update()
+                ev_text, ev_done = torch.cuda.Event(), torch.cuda.Event()
+                ev_done.record()
+
+                host_t = [] if os.environ.get("EDA_BENCH_HOST_TIMES") == "1" else None
+
+                def step():
+                    if host_t is not None:
+                        return step_timed()
+                    cur = torch.cuda.current_stream()
+                    # (the point graph first: a replay call returns when its last node has been queued, which for
+                    #  the long graph is close to its end on the GPU -- whatever the host issues before the point
+                    #  graph is time the main queue sits idle: 0.6 ms for the text graph, measured)
+                    g_pts.replay()
+                    tstream.wait_event(ev_done)          # the previous step has consumed text_hidden
+                    with torch.cuda.stream(tstream):
+                        g_text.replay()
+                        ev_text.record(tstream)
+                    cur.wait_event(ev_text)
+                    g_rest.replay()
+                    ev_done.record(cur)
+                    if g_up is not None:
+                        flat.all_reduce_mean(world)
+                        g_up.replay()
+                    return static_loss
+
+                def step_timed():                        # experiment: where the host spends a step
+                    cur = torch.cuda.current_stream()
+                    t = [time.perf_counter()]
+                    g_pts.replay()
+                    t.append(time.perf_counter())
+                    tstream.wait_event(ev_done)
+                    with torch.cuda.stream(tstream):
+                        g_text.replay()
+                        ev_text.record(tstream)
+                    t.append(time.perf_counter())
+                    cur.wait_event(ev_text)
+                    g_rest.replay()
+                    t.append(time.perf_counter())
+                    ev_done.record(cur)
+                    host_t.append([round((b - a) * 1e3, 2) for a, b in zip(t, t[1:])])
+                    if len(host_t) % 8 == 0:
+                        log("host ms per step [points, text, rest]: %s" % host_t[-4:])
+                    return static_loss
+            elif world == 1 and not args.split_graphs:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=side, **mode):
                     static_loss = eager_step()
@@ -506,6 +582,9 @@ def main():
     dt = time.perf_counter() - t0
     ext.op_timer = None
     final_loss = float(loss.detach())          # loss of the last timed step (read before the eager kernel-timing runs below)
+    fps_in_step_ms = [round(v, 3) for v in ext.fps_last_duration_ms(device)]
+    log("furthest point sampling inside the timed steps, device-clock wall time of the last launch per workspace (ms): %s"
+        % fps_in_step_ms)
     if ingraph_hist is not None:
         n_ = int(ingraph_hist[1].item())
         log("in-graph loss history (%d steps incl. eager warm-up): " % n_ + " ".join("%.1f" % v for v in ingraph_hist[0][:n_].tolist()))
@@ -638,8 +717,12 @@ def main():
                        "scenes_per_gpu": args.per_gpu, "global_batch": args.per_gpu * world,
                        "points": args.points, "queries": args.queries, "tokens": args.tokens,
                        "parallelism": f"dp{world}", "batchnorm": "global-batch statistics (sync_bn)" if (args.sync_bn and world > 1) else "per-GPU statistics",
-                       "launch": ("eager" if not args.graph else "hipGraph replay of the whole step" if world == 1
-                                  and not args.split_graphs else
+                       "launch": ("eager" if not args.graph else
+                                  ("three hipGraphs on two streams (frozen text encoder underneath the point backbone | "
+                                   "rest of the step)" + ("" if world == 1 and not args.split_graphs else
+                                                          " + clip/AdamW graph behind the RCCL all-reduce"))
+                                  if (args.text_stream and not args.overlap) else
+                                  "hipGraph replay of the whole step" if world == 1 and not args.split_graphs else
                                   "two hipGraphs (fwd+bwd | clip+AdamW) with the RCCL all-reduce between them"),
                        "text_encoder": "RoBERTa-base random-init frozen",
                        "attention_dtype": args.attn_dtype,

@@ -130,9 +130,18 @@ class BeaUTyDETR(nn.Module):
             tok = self.tokenizer.batch_encode_plus(inputs["text"], padding="longest",
                                                    return_tensors="pt").to(device)
             ids, am = tok["input_ids"], tok["attention_mask"]
-        with torch.no_grad():
-            hidden = self.text_encoder(input_ids=ids, attention_mask=am).last_hidden_state
+        if "text_hidden" in inputs:
+            # the frozen encoder's output for exactly these tokens, computed by the caller (bench.py runs the
+            # encoder as its own HIP graph on a second stream underneath the point backbone)
+            hidden = inputs["text_hidden"]
+        else:
+            hidden = self.encode_text_frozen(ids, am)
         return hidden, am.ne(1).bool(), {"input_ids": ids, "attention_mask": am}
+
+    def encode_text_frozen(self, input_ids, attention_mask):
+        """last_hidden_state of the frozen RoBERTa (bdetr.py:78-80, 210-216 of the reference): no gradient."""
+        with torch.no_grad():
+            return self.text_encoder(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state
 
     def _text_branch(self, inputs, device):
         hidden, text_mask, tok = self._encode_text(inputs, device)
@@ -156,9 +165,15 @@ class BeaUTyDETR(nn.Module):
             cur.wait_stream(side)
             for t in (text_feats, text_mask):
                 t.record_stream(cur)
-        else:
-            end_points = self.backbone_net(pc, end_points={})
-            text_feats, text_mask, tok = self._text_branch(inputs, pc.device)
+            return self._join_text(end_points, text_feats, text_mask, tok)
+        return self._text_into(inputs, self.backbone_net(pc, end_points={}))
+
+    def _text_into(self, inputs, end_points):
+        text_feats, text_mask, tok = self._text_branch(inputs, inputs["point_clouds"].device)
+        return self._join_text(end_points, text_feats, text_mask, tok)
+
+    @staticmethod
+    def _join_text(end_points, text_feats, text_mask, tok):
         end_points["seed_inds"] = end_points["fp2_inds"]
         end_points["seed_xyz"] = end_points["fp2_xyz"]
         end_points["seed_features"] = end_points["fp2_features"]
@@ -180,10 +195,20 @@ class BeaUTyDETR(nn.Module):
     # ----------------------------------------------------------------- forward
     def forward(self, inputs):
         with deferred_bn_counters():
-            return self._forward(inputs)
+            return self._forward(inputs, self._run_backbones(inputs))
 
-    def _forward(self, inputs):
-        end_points = self._run_backbones(inputs)
+    # The forward in two halves, for callers that place something between them (bench.py ends one HIP graph after
+    # the point backbone and starts the next one behind an event of the text encoder's stream):
+    # forward(inputs) == forward_rest(inputs, forward_point_backbone(inputs)).
+    def forward_point_backbone(self, inputs):
+        with deferred_bn_counters():
+            return self.backbone_net(inputs["point_clouds"], end_points={})
+
+    def forward_rest(self, inputs, end_points):
+        with deferred_bn_counters():
+            return self._forward(inputs, self._text_into(inputs, end_points))
+
+    def _forward(self, inputs, end_points):
         points_xyz = end_points["fp2_xyz"]                       # (B, 1024, 3)
         points_features = end_points["fp2_features"]             # (B, 288, 1024)
         text_feats = end_points["text_feats"]

@@ -121,6 +121,17 @@ def fps_status(device=None, reset=False):
     return bad
 
 
+def fps_last_duration_ms(device=None):
+    """Wall time the multi-workgroup sampler last took on the device (its own 100 MHz clock reads, int 3 of the
+    workspace's status block), per workspace: a diagnostic for runs that replay graphs, where no host-side event can
+    bracket a single kernel.  Synchronises."""
+    out = []
+    for (dev, _), ws in _fps_ws.items():
+        if device is None or torch.device(device) == dev:
+            out.append(int(ws[:16].view(torch.int32)[3].item()) * 1e-5)
+    return out
+
+
 def furthest_point_sampling(points, nsamples):
     """sampling.cpp:70-91 -- points (B,N,3) f32 -> (B,nsamples) i32."""
     _check_contiguous(points, "points")

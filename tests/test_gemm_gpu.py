@@ -13,6 +13,9 @@ SHAPES = [  # (R, K, N)
     (1, 4, 4), (7, 3, 5), (64, 6, 64), (100, 131, 128), (333, 259, 128), (2048, 288, 288),
     (2048, 288, 1), (2048, 288, 3), (640, 768, 288), (2048, 288, 864), (1000, 64, 64),
     (4096, 512, 256), (130, 288, 576), (8192, 256, 288), (20000, 128, 256), (70000, 64, 128),
+    # the 256/288-wide family at ragged row counts
+    (2048, 288, 256), (2049, 288, 576), (8200, 288, 288), (8192, 288, 864), (300, 256, 288), (1056, 576, 288),
+    (2048, 864, 288), (5000, 288, 64), (40000, 288, 288), (257, 288, 48),
 ]
 
 

@@ -6,7 +6,8 @@ import re
 import sys
 
 NATIVE = [
-    ("native: own row GEMMs fwd / dX (gemm_rows: linear layers, fused SA/FP layers)", r"^gemm_rows_kernel"),
+    ("native: own row GEMMs fwd / dX, tiled (gemm_rows: linear layers, small SA/FP layers)", r"^gemm_rows_kernel"),
+    ("native: own row GEMMs fwd / dX, streaming (gemm_stream / gemm_gather3: many-row SA layers)", r"^gemm_stream_kernel|^gemm_gather3"),
     ("native: furthest point sampling", r"^fps_"),
     ("native: fused attention (fwd, dQ, dK/dV)", r"^mha_"),
     ("native: BN+ReLU(+pool) fwd/bwd", r"^bn_"),
