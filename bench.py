@@ -312,6 +312,12 @@ def main():
                     help="1 (with --graph): the frozen text encoder runs as its own HIP graph on a second stream "
                          "underneath the point backbone's graph (whose furthest point sampling keeps ~100 of the 256 "
                          "CUs busy for 3 ms); the rest of the step is a third graph behind an event.  0: one graph")
+    ap.add_argument("--fps-prefetch", type=int, default=1,
+                    help="1 (with --text-stream): the furthest point sampling of SA1 -- a function of the input coordinates "
+                         "only, 3 ms of dependent rounds on ~100 CUs -- runs for the NEXT step's batch on the second stream "
+                         "while the current step trains (an input pipeline has batch i+1 resident by then) and is handed to "
+                         "the model through the reference's own `inds` argument; one sampling per timed step either way.  "
+                         "0: sampled inside the step, on its critical path")
     ap.add_argument("--attn-dtype", choices=["f32", "bf16", "f16"], default="f32",
                     help="arithmetic of the attention QK^T / PV contractions: f32 = the headline / parity path; bf16 / "
                          "f16 = 16-bit MFMA with fp32 accumulation (csrc/mha16.hip, BASELINE.json configs[2] / [4]) -- "
@@ -468,8 +474,22 @@ def main():
                     text_hidden = model.encode_text_frozen(tok["input_ids"], tok["attention_mask"])
                 inputs_h = dict(inputs)
                 inputs_h["text_hidden"] = text_hidden
+                g_fps = inds_next = inds_cur = None
+                if args.fps_prefetch:
+                    from eda_amd import pointnet2_utils
+                    xyz_next = inputs["point_clouds"][..., 0:3].contiguous()     # (the next batch's coordinates)
+                    g_fps = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_fps, stream=tstream, **mode):
+                        inds_next = pointnet2_utils.furthest_point_sample(xyz_next, 2048)
+                    tstream.synchronize()
+                    g_fps.replay()
+                    torch.cuda.synchronize()
+                    inds_cur = inds_next.clone()
+                    inputs_h["sa1_inds"] = inds_cur
                 pool = torch.cuda.graph_pool_handle()
                 with torch.cuda.graph(g_pts, pool=pool, stream=side, **mode):
+                    if inds_cur is not None:
+                        inds_cur.copy_(inds_next)          # the sampling this step uses (written during the previous step)
                     attention.advance_dropout_state(device)
                     ep_static = model.forward_point_backbone(inputs_h)
                 with torch.cuda.graph(g_rest, pool=pool, stream=side, **mode):
@@ -480,28 +500,34 @@ def main():
                     else:
                         static_loss.backward()
                     flat.collect_grads()
+                    if ingraph_hist is not None:
+                        ingraph_hist[0].index_copy_(0, ingraph_hist[1], static_loss.detach().reshape(1))
+                        ingraph_hist[1].add_(1)
                     if g_up is None:
                         update()
                 if g_up is not None:
                     with torch.cuda.graph(g_up, pool=pool, stream=side, **mode):
                         update()
-                ev_text, ev_done = torch.cuda.Event(), torch.cuda.Event()
+                ev_text, ev_done, ev_pts, ev_fps = (torch.cuda.Event() for _ in range(4))
                 ev_done.record()
-
-                host_t = [] if os.environ.get("EDA_BENCH_HOST_TIMES") == "1" else None
+                ev_fps.record()
 
                 def step():
-                    if host_t is not None:
-                        return step_timed()
                     cur = torch.cuda.current_stream()
                     # (the point graph first: a replay call returns when its last node has been queued, which for
                     #  the long graph is close to its end on the GPU -- whatever the host issues before the point
                     #  graph is time the main queue sits idle: 0.6 ms for the text graph, measured)
+                    cur.wait_event(ev_fps)               # this batch's sampling (computed while the previous step ran)
                     g_pts.replay()
+                    ev_pts.record(cur)
                     tstream.wait_event(ev_done)          # the previous step has consumed text_hidden
                     with torch.cuda.stream(tstream):
                         g_text.replay()
                         ev_text.record(tstream)
+                        if g_fps is not None:            # queued BEFORE the long graph below: see the note above
+                            tstream.wait_event(ev_pts)   # g_pts has taken its copy of inds_next
+                            g_fps.replay()
+                            ev_fps.record(tstream)
                     cur.wait_event(ev_text)
                     g_rest.replay()
                     ev_done.record(cur)
@@ -510,24 +536,6 @@ def main():
                         g_up.replay()
                     return static_loss
 
-                def step_timed():                        # experiment: where the host spends a step
-                    cur = torch.cuda.current_stream()
-                    t = [time.perf_counter()]
-                    g_pts.replay()
-                    t.append(time.perf_counter())
-                    tstream.wait_event(ev_done)
-                    with torch.cuda.stream(tstream):
-                        g_text.replay()
-                        ev_text.record(tstream)
-                    t.append(time.perf_counter())
-                    cur.wait_event(ev_text)
-                    g_rest.replay()
-                    t.append(time.perf_counter())
-                    ev_done.record(cur)
-                    host_t.append([round((b - a) * 1e3, 2) for a, b in zip(t, t[1:])])
-                    if len(host_t) % 8 == 0:
-                        log("host ms per step [points, text, rest]: %s" % host_t[-4:])
-                    return static_loss
             elif world == 1 and not args.split_graphs:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=side, **mode):
@@ -725,6 +733,9 @@ def main():
                                   "hipGraph replay of the whole step" if world == 1 and not args.split_graphs else
                                   "two hipGraphs (fwd+bwd | clip+AdamW) with the RCCL all-reduce between them"),
                        "text_encoder": "RoBERTa-base random-init frozen",
+                       "sa1_sampling": ("furthest point sampling of the NEXT step's batch on the second stream during the "
+                                        "current step (one sampling per step; --fps-prefetch 0 puts it back on the critical path)")
+                       if (args.graph and args.text_stream and not args.overlap and args.fps_prefetch) else "inside the step",
                        "attention_dtype": args.attn_dtype,
                        "own_gemms": "every pointwise layer of the model (csrc/gemm.hip); hipBLASLt only inside RoBERTa",
                        "roberta_gemm_selection": ("TunableOp (%s; shipped results %s)" % (

@@ -33,14 +33,18 @@ class Pointnet2Backbone(nn.Module):
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
         return xyz, features
 
-    def forward(self, pointcloud, end_points=None):
+    def forward(self, pointcloud, end_points=None, sa1_inds=None):
+        """sa1_inds: optional (B, 2048) int32 furthest-point-sampling indices of `pointcloud` computed by the caller
+        (the `inds` argument of the reference's PointnetSAModuleVotes.forward, pointnet2_modules.py:217-235): they
+        depend on the input coordinates only, so an input pipeline can sample batch i+1 while step i trains."""
         end_points = end_points if end_points else {}
         xyz, features = self._break_up_pc(pointcloud)
         for name, layer in (("sa1", self.sa1), ("sa2", self.sa2), ("sa3", self.sa3), ("sa4", self.sa4)):
             # SA2..SA4 sample from the previous level's samples, which are in sampling order: their FPS is the
             # prefix 0..m-1 unless a tie intervenes (the reference notes it, backbone_module.py:122-131);
             # the library verifies that instead of running the dependent rounds
-            xyz, features, inds = layer(xyz, features, xyz_in_sampling_order=name != "sa1")
+            xyz, features, inds = layer(xyz, features, inds=sa1_inds if name == "sa1" else None,
+                                        xyz_in_sampling_order=name != "sa1")
             if name in ("sa1", "sa2"):
                 end_points[f"{name}_inds"] = inds
             end_points[f"{name}_xyz"] = xyz

@@ -53,15 +53,17 @@ def test_deferred_weight_gradients_match_immediate_on_the_full_model():
 
 
 def test_split_graphs_structure_of_the_multi_gpu_step_trains_like_the_single_graph():
-    """The N > 1 step structure (graph: forward+backward | eager slot of the RCCL all-reduce | graph:
-    clip + AdamW) exercised on one GPU (`bench.py --split-graphs`): it must train like the one-graph step
-    (same in-graph loss history up to fp32-atomics noise) and report no furthest-point-sampling give-up."""
+    """The step structures of bench.py on one GPU: (a) ONE graph (`--text-stream 0`); (b) the default: three graphs
+    on two streams (frozen text encoder underneath the point backbone, next batch's furthest point sampling
+    underneath the rest of the step); (c) the N > 1 structure: (b) + eager slot of the RCCL all-reduce + clip/AdamW
+    graph (`--split-graphs`).  All must train alike (same in-graph loss history up to fp32-atomics noise) and
+    report no furthest-point-sampling give-up."""
     import json
     import re
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hists = []
-    for extra in ([], ["--split-graphs"]):
+    for extra in (["--text-stream", "0"], [], ["--split-graphs"]):
         env = dict(os.environ, EDA_BENCH_INGRAPH_HIST="1")
         p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "3",
                             "--kernel-steps", "0", "--cpu-scenes", "0", "--gemm-tuning", "shipped", "--per-gpu", "4",
@@ -72,8 +74,9 @@ def test_split_graphs_structure_of_the_multi_gpu_step_trains_like_the_single_gra
         m = re.search(r"in-graph loss history \((\d+) steps[^:]*\): ([-0-9. ]+)", p.stderr)
         assert m, p.stderr[-2000:]
         hists.append([float(v) for v in m.group(2).split()])
-    a, b = hists
-    assert len(a) == len(b) == 11
-    assert abs(a[0] - b[0]) <= 1e-3 * abs(a[0])
-    assert all(abs(x - y) <= 0.08 * max(abs(x), 1.0) for x, y in zip(a, b)), (a, b)
-    assert b[-1] < b[0]
+    a = hists[0]
+    for b in hists[1:]:
+        assert len(a) == len(b) == 11
+        assert abs(a[0] - b[0]) <= 1e-3 * abs(a[0])
+        assert all(abs(x - y) <= 0.08 * max(abs(x), 1.0) for x, y in zip(a, b)), (a, b)
+        assert b[-1] < b[0]
