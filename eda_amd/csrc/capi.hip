@@ -93,3 +93,48 @@ extern "C" int eda_device_copy_f32(const float *src, float *dst, size_t n, void 
   EDA_CHECK_LAUNCH();
   return 0;
 }
+
+// ---- transposed copies of many small matrices in one launch --------------------------------------------
+// The input gradient of a linear layer, dX = dY W with W (N, K) row-major, contracts over W's ROW index; the
+// row-GEMM kernels read a weight fastest along the contraction (gemm.hip: "NT" form, 16-byte fragments).  Instead
+// of a second kernel form with 4-byte fragment reads, the host keeps W^T (K, N) of every linear weight in a
+// shadow buffer, refreshed by ONE launch right before a backward pass (eda_amd/wt_shadow.py), and every input
+// gradient is an NT product too.  desc: count x 5 int64 {src pointer, dst pointer, rows, cols, first tile}.
+namespace {
+__global__ __launch_bounds__(256) void transpose_batch_kernel(const long long *__restrict__ desc, int count) {
+  __shared__ float tile[32][33];
+  const long long t = blockIdx.x;
+  int lo = 0, hi = count - 1;                     // last matrix whose first tile is <= t
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid * 5 + 4] <= t) lo = mid; else hi = mid - 1;
+  }
+  const float *src = reinterpret_cast<const float *>(desc[lo * 5 + 0]);
+  float *dst = reinterpret_cast<float *>(desc[lo * 5 + 1]);
+  const int rows = (int)desc[lo * 5 + 2], cols = (int)desc[lo * 5 + 3];
+  const int lt = (int)(t - desc[lo * 5 + 4]);
+  const int tcols = (cols + 31) / 32;
+  const int r0 = (lt / tcols) * 32, c0 = (lt % tcols) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    if (r < rows && c < cols) tile[ty + 8 * i][tx] = src[(long long)r * cols + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (r < rows && c < cols) dst[(long long)c * rows + r] = tile[tx][ty + 8 * i];
+  }
+}
+}  // namespace
+
+extern "C" int eda_transpose_batch_f32(const long long *desc, int count, long long total_tiles, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (count <= 0 || total_tiles <= 0) return 0;
+  EDA_CHECK_ARG(desc && total_tiles < 0x7fffffffLL, "bad descriptor table");
+  hipLaunchKernelGGL(transpose_batch_kernel, dim3((unsigned)total_tiles), dim3(256), 0, stream, desc, count);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}

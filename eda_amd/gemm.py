@@ -39,6 +39,11 @@ def linear_fwd(x2, w, bias=None, relu=False, out=None):
 
 def linear_dgrad(dy2, w, out=None):
     """dx = dy2 @ w for fp32 GPU matrices dy2 (R,N), w (N,K)."""
+    from . import wt_shadow
+    if wt_shadow.active is not None:
+        wt = wt_shadow.active.lookup(w)
+        if wt is not None:                       # W^T is at hand: the forward's GEMM form on it
+            return linear_fwd(dy2, wt, out=out)
     dy2, w = _rows2d(dy2), _rows2d(w)
     R, N = dy2.shape
     K = w.shape[1]

@@ -15,6 +15,7 @@ per ~50 parameter tensors.  Batch-norm statistics stay per-GPU (8 scenes x >= 40
 positions per channel); that deviation from SyncBN is stated in DESIGN.md.
 """
 import contextlib
+import os
 
 import torch
 import torch.distributed as dist
@@ -93,6 +94,7 @@ class FlatParams:
             off += p.numel()
         from .wgrad_queue import WgradQueue
         self.queue = WgradQueue(self._locate_grad)
+        self.shadow = None                 # W^T of the linear weights (eda_amd/wt_shadow.py), built at the first deferred backward
         if dev.type == "cuda":
             self.queue.reserve(dev)              # pinned staging must exist before any stream capture
         self._prefilled = False
@@ -121,13 +123,20 @@ class FlatParams:
         pointwise linear layers are queued (eda_amd/wgrad_queue.py) and written into the flat
         gradient buffer by ONE grouped kernel when the context exits; collect_grads() then only
         gathers what autograd still produced itself."""
-        from . import wgrad_queue
+        from . import wgrad_queue, wt_shadow
         self.flat_grad.fill_(0.0)          # (a kernel, not a memset node: see DESIGN.md on graphs)
         prev, wgrad_queue.active = wgrad_queue.active, self.queue
+        prev_shadow = wt_shadow.active
+        if self.shadow is None and self.flat_grad.is_cuda and os.environ.get("EDA_WT_SHADOW", "1") != "0":
+            self.shadow = wt_shadow.TransposedShadow([p for p in self.params if p.requires_grad])
+        if self.shadow is not None and len(self.shadow):
+            self.shadow.refresh()          # W^T of every linear weight, one launch: input gradients in the forward's GEMM form
+            wt_shadow.active = self.shadow
         try:
             yield self.queue
         finally:
             wgrad_queue.active = prev
+            wt_shadow.active = prev_shadow
             self._deferred_ptrs = self.queue.touched()
             self.queue.flush()
             self._prefilled = True

@@ -401,6 +401,14 @@ int eda_bn_relu_grouped_bwd_f32(const float *dout, const float *z, long R, int n
                                 float *dbeta, float *dz, float p_drop, const unsigned long long *seed_ptr,
                                 const unsigned *salts, void *stream);
 
+/* Transposed copies of `count` row-major fp32 matrices in ONE launch.  desc: device array of count x 5 int64
+ * {source pointer, destination pointer, rows, cols, index of the matrix's first 32x32 tile}; total_tiles = sum over
+ * the matrices of ceil(rows/32)*ceil(cols/32).  The destination of matrix i is (cols, rows) row-major.  Used for the
+ * W^T shadow of the linear weights that turns autograd's input gradient dX = dY W (torch/nn/functional.linear's
+ * backward, every nn.Linear, 1x1 convolution and attention projection under models/) into the same row-GEMM form as
+ * the forward (eda_linear_fwd_f32 on W^T). */
+int eda_transpose_batch_f32(const long long *desc, int count, long long total_tiles, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

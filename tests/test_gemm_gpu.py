@@ -71,3 +71,40 @@ def test_strided_operands_and_outputs():
     assert torch.isnan(out[:, :576]).all()
     dx = gemm.linear_dgrad(big[:, 576:], w[576:])
     assert torch.allclose(dx.double(), big[:, 576:].double() @ w[576:].double(), rtol=1e-5, atol=1e-3)
+
+
+def test_transposed_shadow_input_gradients_equal_the_plain_form():
+    """eda_amd/wt_shadow.py: W^T of a list of weights by ONE launch; linear_dgrad through the shadow (the forward's
+    GEMM form on W^T) equals the plain form, for whole weights and for row ranges of a packed in-projection."""
+    from eda_amd import gemm, wt_shadow
+    g = torch.Generator(device="cuda").manual_seed(5)
+    flat = torch.randn(864 * 288 + 288 * 256 + 64 * 288 + 40 * 20 + 16, device="cuda", generator=g)
+    w_in = flat[:864 * 288].view(864, 288)
+    w_ffn = flat[864 * 288:864 * 288 + 288 * 256].view(288, 256)
+    o = 864 * 288 + 288 * 256
+    w_c = flat[o:o + 64 * 288].view(64, 288, 1)                     # a 1x1 convolution's weight
+    w_odd = flat[o + 64 * 288:o + 64 * 288 + 800].view(40, 20)
+    sh = wt_shadow.TransposedShadow([w_in, w_ffn, w_c, w_odd, None])
+    assert len(sh) == 4
+    sh.refresh()
+    for w in (w_in, w_ffn, w_c.squeeze(-1), w_odd):
+        assert torch.equal(sh.lookup(w), w.t())
+    assert sh.lookup(torch.randn(288, 288, device="cuda")) is None
+    cases = [(w_in, 0, 864), (w_in, 0, 576), (w_in, 576, 864), (w_in, 288, 576), (w_ffn, 0, 288), (w_c.squeeze(-1), 0, 64)]
+    for w, lo, hi in cases:
+        ws = w[lo:hi]
+        dy = torch.randn(2048, hi - lo, device="cuda", generator=g)
+        plain = gemm.linear_dgrad(dy, ws)
+        wt_shadow.active = sh
+        try:
+            via = gemm.linear_dgrad(dy, ws)
+        finally:
+            wt_shadow.active = None
+        ref = dy.double() @ ws.double()
+        tol = 2e-6 * (ws.shape[0] ** 0.5) * (dy.abs().double() @ ws.abs().double()) + 1e-30
+        assert bool(((via.double() - ref).abs() <= tol).all())
+        assert bool(((plain.double() - ref).abs() <= tol).all())
+    w_in.mul_(2.0)                                                  # a stale shadow is visible until refresh()
+    assert not torch.equal(sh.lookup(w_in), w_in.t())
+    sh.refresh()
+    assert torch.equal(sh.lookup(w_in), w_in.t())
