@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from .backbone_module import Pointnet2Backbone
 from .encoder_decoder_layers import BiDecoderLayer, BiEncoder, BiEncoderLayer, PositionEmbeddingLearned
-from .nn_utils import Conv1dK1, Linear, deferred_bn_counters, l2_normalize, linear_rows
+from .nn_utils import Conv1dK1, Linear, deferred_bn_counters, l2_normalize, mlp_chain
 from .modules import ClsAgnosticPredictHead, GeneralSamplingModule, PointsObjClsModule
 
 
@@ -33,11 +33,10 @@ def _mlp3(d_in, d_out):
 
 
 def _project(mlp, x):
-    """l2_normalize(mlp(x)) for an _mlp3 stack, the ReLUs folded into the GEMM epilogues (on CPU tensors
-    linear_rows is the torch composition)."""
-    x = linear_rows(x, mlp[0].weight, mlp[0].bias, relu=True)
-    x = linear_rows(x, mlp[2].weight, mlp[2].bias, relu=True)
-    return l2_normalize(linear_rows(x, mlp[4].weight, mlp[4].bias))
+    """l2_normalize(mlp(x)) for an _mlp3 stack as one autograd node, the ReLUs (and their backward) folded into the
+    GEMM epilogues (on CPU tensors the torch composition)."""
+    return l2_normalize(mlp_chain(x, [(mlp[0].weight, mlp[0].bias, True, 0.0, 0), (mlp[2].weight, mlp[2].bias, True, 0.0, 0),
+                                      (mlp[4].weight, mlp[4].bias, False, 0.0, 0)], False))
 
 
 def _load_text_stack(data_path):

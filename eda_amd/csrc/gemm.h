@@ -37,6 +37,11 @@ struct GemmArgs {
   float *dfeats;
   int col_tiles; long row_blocks; int row_slots; unsigned ticket_target;
   int ngroups; GemmGroup grp[G_MAXGROUPS];     // ngroups > 1: block column tile ct belongs to the group with ct0 <= ct
+  // E_PLAIN extras (eda_linear_ex_f32): Dropout after the bias / ReLU (counter-based hash of (seed, salt, element), the
+  // scheme of ln.hip), and a gate: y = gate > 0 ? y * gate_scale : 0 -- the ReLU (+ Dropout) backward of the layer
+  // whose activated output `gate` is, applied to the input gradient that flows into it
+  float drop_p; const unsigned long long *drop_seed; unsigned drop_salt;
+  const float *gate; long ldgate; float gate_scale;
   int dbg;   // EDA_GEMM_DBG timing experiments (results are then wrong): 1 skip park, 2 no grid cap, 4 skip atomics, 8 skip z loads
 };
 

@@ -47,6 +47,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+__device__ __forceinline__ unsigned gemm_hash32(unsigned x) {          // = ln_hash32 (ln.hip)
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+
 __device__ __forceinline__ float row_sum16(float v) {
   // sum over the 16 lanes of a DPP row (result in every lane of the row)
   int i = __float_as_int(v);
@@ -446,6 +451,16 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a_i
     }
   };
   if (a.epi == E_PLAIN || (WN == 1 && a.epi == E_STATS)) {
+    // Dropout of the plain epilogue: same counter-based hash as the LayerNorm / attention kernels
+    unsigned dseed = 0, dthresh = 0;
+    float dinv = 1.f;
+    const bool drop = a.epi == E_PLAIN && a.drop_p > 0.f;
+    if (drop) {
+      dseed = gemm_hash32((unsigned)(*a.drop_seed) * 0x9E3779B1u + a.drop_salt);
+      dthresh = (unsigned)((double)a.drop_p * 4294967296.0);
+      dinv = 1.f / (1.f - a.drop_p);
+    }
+    const bool gated = a.epi == E_PLAIN && a.gate != nullptr;
 #pragma unroll
     for (int j = 0; j < WC; ++j) {
       const int col = n0 + 16 * j + cq;
@@ -465,6 +480,17 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a_i
           if (a.relu) o[u] = fmaxf(o[u], 0.f);
         }
         if (row < R && col < N) {
+          if (drop) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              o[u] = gemm_hash32(dseed ^ (unsigned)(row * N + col + u)) >= dthresh ? o[u] * dinv : 0.f;
+          }
+          if (gated) {
+            const float *gp = a.gate + row * a.ldgate + col;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (col + u < N) o[u] = gp[u] > 0.f ? o[u] * a.gate_scale : 0.f;
+          }
 #pragma unroll
           for (int u = 0; u < 4; ++u) { t1[u] += o[u]; t2[u] += o[u] * o[u]; }
           float *p = a.y + row * a.ldy + col;
@@ -1152,6 +1178,27 @@ extern "C" int eda_linear_fwd_f32(const float *x, long ldx, long R, int K, const
   a.xmode = X_PLAIN; a.epi = E_PLAIN;
   a.x = x; a.ldx = ldx; a.R = R; a.K = K;
   a.w = w; a.ldw = ldw; a.N = N; a.bias = bias; a.relu = relu;
+  a.y = y; a.ldy = ldy;
+  return eda_gemm_launch(a, W_NT, (hipStream_t)stream_);
+}
+
+extern "C" int eda_linear_ex_f32(const float *x, long ldx, long R, int K, const float *w, long ldw, int N,
+                                 const float *bias, int relu, float drop_p, const unsigned long long *drop_seed,
+                                 unsigned drop_salt, const float *gate, long ldgate, float gate_scale, float *y,
+                                 long ldy, void *stream_) {
+  EDA_CHECK_ARG(R >= 0 && K > 0 && N > 0 && ldx >= K && ldw >= K && ldy >= N, "bad dimension");
+  EDA_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || drop_seed), "dropout needs 0 <= p < 1 and a seed");
+  EDA_CHECK_ARG(!gate || ldgate >= N, "bad gate stride");
+  if (R == 0) return 0;
+  EDA_CHECK_ARG(x && w && y, "null pointer");
+  EDA_CHECK_ARG((long long)R * N < 0x100000000LL || drop_p == 0.f, "dropout: more than 2^32 elements");
+  GemmArgs a;
+  gemm_defaults(a);
+  a.xmode = X_PLAIN; a.epi = E_PLAIN;
+  a.x = x; a.ldx = ldx; a.R = R; a.K = K;
+  a.w = w; a.ldw = ldw; a.N = N; a.bias = bias; a.relu = relu;
+  a.drop_p = drop_p; a.drop_seed = drop_seed; a.drop_salt = drop_salt;
+  a.gate = gate; a.ldgate = ldgate; a.gate_scale = gate_scale;
   a.y = y; a.ldy = ldy;
   return eda_gemm_launch(a, W_NT, (hipStream_t)stream_);
 }

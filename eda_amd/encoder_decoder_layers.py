@@ -15,7 +15,7 @@ from torch import nn
 
 from .attention import MultiheadAttention
 from .fused_ln import add_dropout_layer_norm, fuses_bias, new_salt_base
-from .nn_utils import Conv1dK1, Linear, bn_relu_rows, linear_rows, rows_ok
+from .nn_utils import Conv1dK1, Linear, bn_relu_rows, linear_rows, mlp_chain, rows_ok
 
 
 def _get_clones(module, n):
@@ -30,11 +30,11 @@ def _ffn(d_model, dim_feedforward, dropout):
 def _ffn_residual_norm(x, ffn, norm, training, salt):
     """norm(x + ffn(x)) where ffn = Linear, ReLU, Dropout, Linear, Dropout: the last Dropout is
     applied inside the fused residual+LayerNorm kernel."""
-    h = ffn[2](linear_rows(x, ffn[0].weight, ffn[0].bias, relu=True))       # Linear+ReLU in one GEMM epilogue
-    if fuses_bias(x, norm):      # second linear's bias (and its gradient) ride in the LN kernels
-        return add_dropout_layer_norm(x, linear_rows(h, ffn[3].weight, None), norm, ffn[4].p, training, salt,
-                                      y_bias=ffn[3].bias)
-    return add_dropout_layer_norm(x, ffn[3](h), norm, ffn[4].p, training, salt)
+    fused = fuses_bias(x, norm)  # second linear's bias (and its gradient) ride in the LN kernels
+    # Linear + ReLU + Dropout + Linear as one autograd node, the activations in the GEMM epilogues
+    y = mlp_chain(x, [(ffn[0].weight, ffn[0].bias, True, ffn[2].p, salt + 0x5BD1E995),
+                      (ffn[3].weight, None if fused else ffn[3].bias, False, 0.0, 0)], training)
+    return add_dropout_layer_norm(x, y, norm, ffn[4].p, training, salt, y_bias=ffn[3].bias if fused else None)
 
 
 def _attn_residual_norm(attn, x, q, k, v, mask, norm, p_drop, training, salt, batch_first=True, pos=None):

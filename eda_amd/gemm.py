@@ -37,6 +37,46 @@ def linear_fwd(x2, w, bias=None, relu=False, out=None):
     return out
 
 
+def linear_ex(x2, w, bias=None, relu=False, drop=None, gate=None, out=None):
+    """linear_fwd with Dropout and / or a ReLU-backward gate in the epilogue (include/eda_hip.h: eda_linear_ex_f32).
+    drop = (p, seed tensor (1,) int64 on the device, salt); gate = (activated output (R,N) of the layer the result
+    flows into, scale)."""
+    x2, w = _rows2d(x2), _rows2d(w)
+    R, K = x2.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    if out is None:
+        out = torch.empty((R, N), dtype=torch.float32, device=x2.device)
+    if R == 0:
+        return out
+    p, seed, salt = drop if drop is not None else (0.0, None, 0)
+    g, gscale = gate if gate is not None else (None, 1.0)
+    if g is not None:
+        g = _rows2d(g)
+        assert g.shape == (R, N)
+    with torch.cuda.device(x2.device), _timed("gemm_fwd", (R, K, N)):
+        rc = _lib.lib().eda_linear_ex_f32(x2.data_ptr(), _ld(x2), R, K, w.data_ptr(), _ld(w), N,
+                                          bias.data_ptr() if bias is not None else None, int(bool(relu)),
+                                          float(p), seed.data_ptr() if (seed is not None and p > 0) else None,
+                                          int(salt) & 0xFFFFFFFF, g.data_ptr() if g is not None else None,
+                                          _ld(g) if g is not None else 0, float(gscale),
+                                          out.data_ptr(), _ld(out), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "eda_linear_ex_f32")
+    return out
+
+
+def linear_dgrad_gated(dy2, w, gate, scale, out=None):
+    """dx = (dy2 @ w) * (gate > 0) * scale: the input gradient of a linear layer whose INPUT was relu(.) (* dropout
+    mask / keep probability) = `gate`.  One launch when W^T is at hand (wt_shadow), two otherwise."""
+    from . import wt_shadow
+    if wt_shadow.active is not None:
+        wt = wt_shadow.active.lookup(w)
+        if wt is not None:
+            return linear_ex(dy2, wt, gate=(gate, scale), out=out)
+    dx = linear_dgrad(dy2, w, out=out)
+    return dx.mul_(scale).mul_(gate > 0) if scale != 1.0 else dx.mul_(gate > 0)
+
+
 def linear_dgrad(dy2, w, out=None):
     """dx = dy2 @ w for fp32 GPU matrices dy2 (R,N), w (N,K)."""
     from . import wt_shadow

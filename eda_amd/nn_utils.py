@@ -137,6 +137,87 @@ class _LinearRows(Function):
         return dx, dW, db, None
 
 
+class _MLPChain(Function):
+    """Linear (-> ReLU -> Dropout) -> ... -> Linear as ONE autograd node on the repo's GEMMs: the activations ride in
+    the GEMM epilogues forward (bias, ReLU, Dropout: csrc/gemm.hip eda_linear_ex_f32) and backward (the ReLU / Dropout
+    backward of layer l is the gate of layer l+1's input-gradient GEMM), so a two-layer FFN costs 2 + 2 launches plus
+    its queued weight gradients, where Linear / ReLU / Dropout modules under autograd cost 3 + 4 (+ two gradient
+    kernels).  cfg: per layer (relu, p, salt, has_bias); tensors: x, then W_l, b_l (b_l may be None) per layer.
+    The LAST layer may leave its bias to the caller (has_bias False with b None)."""
+
+    @staticmethod
+    def forward(ctx, cfg, seed, x, *wb):
+        from . import gemm
+        x2 = x.reshape(-1, x.shape[-1])
+        acts = [x2]
+        for l, (relu, p, salt, _) in enumerate(cfg):
+            W, b = wb[2 * l], wb[2 * l + 1]
+            acts.append(gemm.linear_ex(acts[-1], W, b, relu, drop=(p, seed, salt) if p > 0 else None))
+        ctx.cfg, ctx.xshape = cfg, x.shape
+        ctx.save_for_backward(*acts[:-1], *[t for t in wb if t is not None])
+        ctx.none_b = [wb[2 * l + 1] is None for l in range(len(cfg))]
+        return acts[-1].view(*x.shape[:-1], wb[2 * (len(cfg) - 1)].shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import gemm, wgrad_queue
+        cfg = ctx.cfg
+        n = len(cfg)
+        acts = ctx.saved_tensors[:n]
+        rest = list(ctx.saved_tensors[n:])
+        Ws, bs = [], []
+        for l in range(n):
+            Ws.append(rest.pop(0))
+            bs.append(None if ctx.none_b[l] else rest.pop(0))
+        grads = [None] * (2 * n)
+        q = wgrad_queue.active
+        dz = dy.reshape(-1, Ws[-1].shape[0])
+        if not (dz.stride(1) == 1 and (dz.shape[0] <= 1 or dz.stride(0) >= dz.shape[1])):
+            dz = dz.contiguous()
+        dx = None
+        for l in range(n - 1, -1, -1):
+            W, b, inp = Ws[l], bs[l], acts[l]
+            need_w, need_b = ctx.needs_input_grad[3 + 2 * l], b is not None and ctx.needs_input_grad[4 + 2 * l]
+            if not (q is not None and need_w and (need_b or b is None) and q.submit(W, b if need_b else None, dz, inp)):
+                if need_w:
+                    grads[2 * l], db = wgrad(dz, inp, want_db=need_b)
+                    if need_b:
+                        grads[2 * l + 1] = db
+                elif need_b:
+                    grads[2 * l + 1] = colsum(dz)
+            if l > 0:
+                relu, p, _, _ = cfg[l - 1]
+                if relu:          # inp = dropout(relu(.)): positive exactly where the gradient passes
+                    dz = gemm.linear_dgrad_gated(dz, W, inp, 1.0 / (1.0 - p) if p > 0 else 1.0)
+                else:
+                    assert p == 0, "Dropout without ReLU in front of it is not a case of the model"
+                    dz = gemm.linear_dgrad(dz, W)
+            elif ctx.needs_input_grad[2]:
+                dx = gemm.linear_dgrad(dz, W).view(ctx.xshape)
+        return (None, None, dx, *grads)
+
+
+def mlp_chain(x, layers, training, seed=None):
+    """layers: [(weight, bias or None, relu, p, salt)], applied in order (Dropout only in training).  GPU fp32: one
+    autograd node (_MLPChain); otherwise the torch composition (same mathematics, torch's RNG)."""
+    if x.is_cuda and x.dtype == torch.float32 and x.numel() > 0:
+        cfg = tuple((bool(r), float(p) if training else 0.0, int(s), b is not None) for _, b, r, p, s in layers)
+        wb = []
+        for W, b, *_ in layers:
+            wb += [W, b]
+        if seed is None and any(c[1] > 0 for c in cfg):
+            from .attention import dropout_state
+            seed = dropout_state(x.device)
+        return _MLPChain.apply(cfg, seed, x, *wb)
+    for W, b, relu, p, _ in layers:
+        x = F.linear(x, W, b)
+        if relu:
+            x = F.relu(x)
+        if p > 0:
+            x = F.dropout(x, p, training)
+    return x
+
+
 def linear_rows(x, weight, bias, relu=False):
     """F.linear(x, weight, bias) (+ ReLU); on the GPU (fp32) the repo's own MFMA GEMMs."""
     if x.is_cuda and x.dtype == torch.float32 and x.numel() > 0:

@@ -401,6 +401,17 @@ int eda_bn_relu_grouped_bwd_f32(const float *dout, const float *z, long R, int n
                                 float *dbeta, float *dz, float p_drop, const unsigned long long *seed_ptr,
                                 const unsigned *salts, void *stream);
 
+/* eda_linear_fwd_f32 with two more things in its epilogue, for chains Linear -> ReLU -> Dropout -> Linear (the FFNs of
+ * models/encoder_decoder_layers.py:88-96,120-122,403-405 and the contrastive projection MLPs of models/bdetr.py:127-139):
+ *   drop_p > 0: nn.Dropout(drop_p) in training mode after the bias / ReLU; element (row, col) is kept iff
+ *               hash(seed, drop_salt, row * N + col) >= drop_p * 2^32 (*drop_seed is read on the device);
+ *   gate != NULL (R x N, row stride ldgate): y = gate > 0 ? y * gate_scale : 0, i.e. the backward of ReLU (+ Dropout,
+ *               gate_scale = 1 / (1 - p)) of the layer whose ACTIVATED output `gate` is, applied to the gradient
+ *               that flows into it (x = dY of the next layer, w = that layer's W^T). */
+int eda_linear_ex_f32(const float *x, long ldx, long R, int K, const float *w, long ldw, int N, const float *bias,
+                      int relu, float drop_p, const unsigned long long *drop_seed, unsigned drop_salt,
+                      const float *gate, long ldgate, float gate_scale, float *y, long ldy, void *stream);
+
 /* Transposed copies of `count` row-major fp32 matrices in ONE launch.  desc: device array of count x 5 int64
  * {source pointer, destination pointer, rows, cols, index of the matrix's first 32x32 tile}; total_tiles = sum over
  * the matrices of ceil(rows/32)*ceil(cols/32).  The destination of matrix i is (cols, rows) row-major.  Used for the

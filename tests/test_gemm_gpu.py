@@ -108,3 +108,58 @@ def test_transposed_shadow_input_gradients_equal_the_plain_form():
     assert not torch.equal(sh.lookup(w_in), w_in.t())
     sh.refresh()
     assert torch.equal(sh.lookup(w_in), w_in.t())
+
+
+@pytest.mark.parametrize("shadow", [False, True])
+@pytest.mark.parametrize("R,dims,p", [(2048, (288, 256, 288), 0.0), (640, (288, 256, 288), 0.1), (777, (288, 288, 288, 64), 0.0),
+                                      (2048, (288, 256, 288), 0.3)])
+def test_mlp_chain_node_matches_the_torch_composition(R, dims, p, shadow):
+    """nn_utils._MLPChain (Linear -> ReLU -> Dropout -> ... -> Linear as one node, activations in the GEMM epilogues)
+    against torch: outputs and all gradients.  With p > 0 the node's own keep mask is read back from its hidden
+    activation (h != 0 <=> kept and positive) and imposed on the torch composition; the kept fraction is checked."""
+    from eda_amd import nn_utils, wt_shadow
+    g = torch.Generator(device="cuda").manual_seed(R + len(dims))
+    n = len(dims) - 1
+    Ws = [(torch.randn(dims[l + 1], dims[l], device="cuda", generator=g) * dims[l] ** -0.5).requires_grad_(True) for l in range(n)]
+    bs = [(torch.randn(dims[l + 1], device="cuda", generator=g) * 0.1).requires_grad_(True) for l in range(n)]
+    x = torch.randn(R, dims[0], device="cuda", generator=g, requires_grad=True)
+    seed = torch.full((1,), 1234567, dtype=torch.int64, device="cuda")
+    layers = [(Ws[l], bs[l], l < n - 1, p if l < n - 1 else 0.0, 17 + l) for l in range(n)]
+    dy = torch.randn(R, dims[-1], device="cuda", generator=g)
+    sh = wt_shadow.TransposedShadow(Ws) if shadow else None
+    if sh is not None:
+        sh.refresh()
+    y = nn_utils.mlp_chain(x, layers, True, seed=seed)
+    wt_shadow.active = sh
+    try:
+        y.backward(dy)
+    finally:
+        wt_shadow.active = None
+    got = [y.detach(), x.grad] + [w.grad for w in Ws] + [b.grad for b in bs]
+    # torch composition in fp64 with the node's masks
+    xd = x.detach().double().requires_grad_(True)
+    Wd = [w.detach().double().requires_grad_(True) for w in Ws]
+    bd = [b.detach().double().requires_grad_(True) for b in bs]
+    h, h32 = xd, x.detach()
+    for l in range(n):
+        z = h @ Wd[l].t() + bd[l]
+        if l < n - 1:
+            # the node's own decisions (ReLU sign in ITS fp32 arithmetic, Dropout keep mask): its hidden activation
+            # after layer l is non-zero exactly where the element is positive and kept
+            hl = nn_utils.mlp_chain(x.detach(), layers[:l + 1], True, seed=seed)
+            z32 = h32 @ Ws[l].detach().t() + bs[l].detach()
+            live = hl != 0
+            if p > 0:
+                pos = (z32 > 1e-4)
+                dropped = (pos & ~live).float().sum().item() / max(pos.float().sum().item(), 1.0)
+                assert abs(dropped - p) < 0.02, dropped
+            else:
+                assert ((z32 > 1e-4) & ~live).sum().item() == 0 and ((z32 < -1e-4) & live).sum().item() == 0
+            z = z * live.double() / (1.0 - p)
+            h32 = hl
+        h = z
+    h.backward(dy.double())
+    exp = [h.detach(), xd.grad] + [w.grad for w in Wd] + [b.grad for b in bd]
+    for a, e in zip(got, exp):
+        scale = e.abs().max().item() + 1e-12
+        assert (a.double() - e).abs().max().item() <= 2e-4 * scale, ((a.double() - e).abs().max().item(), scale)
