@@ -31,6 +31,31 @@ torch.cuda.synchronize()
 ''' % ROOT
 
 
+DRIVER_SA1 = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from eda_amd import sa_ops, pointnet2_utils as PU
+B, N, m, ns, C, chans, radius = 8, 50000, 2048, 64, 3, [64, 64, 128], 0.2
+rng = np.random.default_rng(0)
+xyz = torch.from_numpy(rng.uniform(-3, 3, (B, N, 3)).astype(np.float32)).cuda()
+new_xyz = xyz[:, :m].contiguous()
+idx = PU.ball_query(radius, ns, xyz, new_xyz)
+chans = [3 + C] + chans
+Ws = [torch.randn(chans[l + 1], chans[l], 1, 1, device="cuda").mul_(0.1).requires_grad_(True) for l in range(3)]
+gs = [torch.ones(c, device="cuda", requires_grad=True) for c in chans[1:]]
+bs = [torch.zeros(c, device="cuda", requires_grad=True) for c in chans[1:]]
+running = [(torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")) for c in chans[1:]]
+feats = torch.randn(B, N, C, device="cuda")
+cfg = dict(gather=True, radius=radius, normalize_xyz=True, pool=ns, training=True, eps=1e-5, momentum=0.1, running=running)
+params = []
+for W, g, b in zip(Ws, gs, bs):
+    params += [W, g, b]
+for _ in range(4):
+    out = sa_ops.FusedMLP.apply(cfg, None, xyz, new_xyz, feats, idx, *params)      # forward only
+torch.cuda.synchronize()
+''' % ROOT
+
+
 def run_pass(counter, script):
     d = tempfile.mkdtemp(prefix="pmc_")
     subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, script],
@@ -53,6 +78,13 @@ def main():
         script = f.name
     fetch = run_pass("FETCH_SIZE", script)
     write = run_pass("WRITE_SIZE", script)
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(DRIVER_SA1)
+        script_sa1 = f.name
+    fetch_sa, write_sa = run_pass("FETCH_SIZE", script_sa1), run_pass("WRITE_SIZE", script_sa1)
+    sa_kernels = ("gemm_gather3_kernel", "gemm_stream_kernel", "gemm_rows_kernel", "bn_relu_pool_kernel")
+    sa_parts = {k: (2.0 * fetch_sa.get(k, 0.0) + write_sa.get(k, 0.0)) * 1024.0
+                for k in set(fetch_sa) | set(write_sa) if any(t in k for t in sa_kernels)}
 
     def total(pred):
         return sum((2.0 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024.0 for k in set(fetch) | set(write) if pred(k))
@@ -60,6 +92,9 @@ def main():
         {"op": "mha_fwd", "dims": [8, 8, 1024, 1024], "bytes_per_launch": total(lambda k: "mha_fwd_kernel" in k)},
         {"op": "mha_bwd", "dims": [8, 8, 1024, 1024],
          "bytes_per_launch": total(lambda k: "mha_bwd_dq_kernel" in k or "mha_bwd_dkv_kernel" in k or "mha_part_reduce" in k)},
+        # the fused SA1 forward = one launch per layer + pooling: sum of its kernels' per-launch bytes
+        {"op": "sa_fused_fwd", "dims": [1048576, 64, 1, 6, 64, 64, 128], "bytes_per_launch": sum(sa_parts.values()),
+         "kernels": {k[:90]: v for k, v in sorted(sa_parts.items())}},
     ]
     out = {"source_hash": bench.source_hash(),
            "how": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate passes, KiB -> bytes, per launch "
