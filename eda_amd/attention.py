@@ -44,12 +44,28 @@ _dropout_state = {}      # device -> int64 counter tensor read by the kernels
 _salt_counter = itertools.count(1)
 
 
+def _initial_dropout_counter():
+    """torch.initial_seed() mixed with the data-parallel rank (splitmix64 finaliser), kept below 2^62: ranks draw
+    different masks, torch.manual_seed() selects the stream, and a run is reproducible for a given seed."""
+    import os
+    import torch.distributed as dist
+    rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else int(os.environ.get("RANK", "0"))
+    x = (torch.initial_seed() + 0x9E3779B97F4A7C15 * (rank + 1)) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return (x ^ (x >> 31)) & ((1 << 62) - 1)
+
+
 def dropout_state(device):
+    """The device-side counter every dropout kernel of the library hashes (attention, residual LayerNorm, BN+ReLU
+    heads, FFN epilogues) together with a per-call-site salt.  Created on first use from torch's seed and the rank;
+    advance_dropout_state() bumps it once per step; get/set_dropout_counter() make it checkpointable
+    (eda_amd/checkpoint.py stores it)."""
     device = torch.device(device)
     if device.type == "cuda" and device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
     if device not in _dropout_state:
-        _dropout_state[device] = torch.zeros(1, dtype=torch.int64, device=device)
+        _dropout_state[device] = torch.full((1,), _initial_dropout_counter(), dtype=torch.int64, device=device)
     return _dropout_state[device]
 
 
@@ -57,6 +73,16 @@ def advance_dropout_state(device):
     """Bump the device-side dropout counter (once per training step; capturable in a
     HIP graph, so every replay draws new masks)."""
     dropout_state(device).add_(1)
+
+
+def get_dropout_counter(device):
+    """Current value of the dropout counter (host int; synchronises)."""
+    return int(dropout_state(device).item())
+
+
+def set_dropout_counter(device, value):
+    """Continue a saved dropout stream (in place: graphs that captured the counter tensor keep working)."""
+    dropout_state(device).fill_(int(value) & ((1 << 62) - 1))
 
 
 def _rows(t):

@@ -41,6 +41,11 @@ def load_checkpoint(model, path, optimizer=None, scheduler=None, map_location="c
         optimizer.load_state_dict(ckpt["optimizer"])
     if scheduler is not None and "scheduler" in ckpt:
         scheduler.load_state_dict(ckpt["scheduler"])
+    if "eda_dropout_counter" in ckpt:            # (absent in checkpoints written by the reference)
+        p0 = next(model.parameters(), None)
+        if p0 is not None and p0.is_cuda:
+            from . import attention
+            attention.set_dropout_counter(p0.device, ckpt["eda_dropout_counter"])
     return int(ckpt.get("epoch", 0)), list(res.missing_keys), list(res.unexpected_keys)
 
 
@@ -51,6 +56,12 @@ def save_checkpoint(model, path, optimizer=None, scheduler=None, epoch=0, config
              "optimizer": optimizer.state_dict() if optimizer is not None else {},
              "scheduler": scheduler.state_dict() if scheduler is not None else {},
              "epoch": int(epoch)}
+    p0 = next(model.parameters(), None)
+    if p0 is not None and p0.is_cuda:
+        # one extra key (ignored by the reference's loader): the library's dropout counter, so that a resumed run
+        # continues the mask stream instead of replaying it
+        from . import attention
+        state["eda_dropout_counter"] = attention.get_dropout_counter(p0.device)
     os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
     torch.save(state, path)
     return state

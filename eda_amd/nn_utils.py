@@ -16,17 +16,19 @@ _colsum_counters = {}
 
 
 def _ticket_counters(dev, n):
-    """The per-device array of self-resetting ticket counters of csrc/colsum.hip / wgrad.hip."""
-    cnt = _colsum_counters.get(dev)
+    """The array of self-resetting ticket counters of csrc/colsum.hip / wgrad.hip, one per (device, stream): two
+    streams of a device may run these kernels concurrently (a side-stream branch's backward next to the main one)."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    cnt = _colsum_counters.get(key)
     if cnt is None or cnt.numel() < n:
-        cnt = _colsum_counters[dev] = torch.zeros((max(4096, n),), dtype=torch.int32, device=dev)
+        # (a fill kernel, not torch.zeros: a memset node inside a captured HIP graph is a hazard on ROCm 7.2, DESIGN.md)
+        cnt = _colsum_counters[key] = torch.full((max(4096, n),), 0, dtype=torch.int32, device=dev)
     return cnt
 
 
 def colsum(x2, out=None):
     """out[c] = sum_r x2[r, c] for a 2-D fp32 GPU matrix: ONE launch of csrc/colsum.hip (the
-    bias gradient of a pointwise linear layer).  All calls on a device share one ticket-counter
-    array and therefore must be issued on one stream at a time (autograd's backward is)."""
+    bias gradient of a pointwise linear layer).  The ticket-counter array is per (device, stream)."""
     from . import _lib
     from .ext import _timed
     assert x2.dim() == 2 and x2.is_cuda and x2.dtype == torch.float32

@@ -56,6 +56,12 @@ class FlatParams:
     ``self.groups`` maps key -> nn.Parameter over that group's slice of the flat
     buffer, whose ``.grad`` is the matching slice of the flat gradient buffer: hand
     these to the optimizer.
+
+    Difference from per-parameter optimisation that a caller must know: a parameter that received NO gradient in a
+    step has a ZERO slice here, where the reference leaves ``p.grad = None`` and its AdamW skips the parameter
+    (no weight decay, no moment decay for that step).  In BeaUTyDETR every trainable parameter receives a gradient in
+    every step (the frozen text encoder is excluded from the buffer), so the two coincide; a model with
+    conditionally unused branches would see weight decay applied to them.
     """
 
     def __init__(self, module, group_of=None):
@@ -163,16 +169,25 @@ class FlatParams:
             p.grad = None
 
     def all_reduce_mean(self, world=None, async_op=False):
-        """Sum the flat gradient over ranks, divide by the world size (DDP semantics)."""
+        """Mean of the flat gradient over the ranks (DDP semantics): one all-reduce of the whole buffer, then 1/world.
+        async_op=True returns a handle whose wait() completes the collective AND applies the 1/world scaling (the
+        gradient is not a mean before wait() returns)."""
         if world is None:
             world = dist.get_world_size() if dist.is_initialized() else 1
         if world <= 1:
             return None
         work = dist.all_reduce(self.flat_grad, async_op=async_op)
-        if async_op:
-            return work
-        self.flat_grad.mul_(1.0 / world)
-        return None
+        if not async_op:
+            self.flat_grad.mul_(1.0 / world)
+            return None
+        flat = self.flat_grad
+
+        class _MeanWork:
+            def wait(self_inner):
+                work.wait()
+                flat.mul_(1.0 / world)
+                return True
+        return _MeanWork()
 
     def clip_grad_norm_(self, max_norm):
         """torch.nn.utils.clip_grad_norm_ over all parameters (main_utils.py:483-486) on the flat buffer."""

@@ -99,16 +99,19 @@ _bn_ws = {}
 
 
 def _bn_workspace(dev):
-    """The per-device scratch of the BN FORWARD statistics kernel (2*1024 + 1 doubles: column sums + a
-    ticket).  The kernel requires it ZERO on entry and leaves it zero (its last block finalises and
-    cleans up), so it is allocated and zeroed once; all BN launches of a device must be ordered on one
-    stream."""
+    """The scratch of the BN FORWARD statistics kernels (2*1024 + 1 doubles: column sums + a ticket), one per
+    (device, stream).  The kernels require it ZERO on entry and leave it zero (the last block finalises and cleans up),
+    so it is allocated and zeroed once; launches on ONE stream are ordered, launches on different streams use different
+    workspaces."""
     dev = torch.device(dev)
-    if dev not in _bn_ws:
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    if key not in _bn_ws:
         # zeroed by a fill KERNEL on the current stream (torch.zeros is a memset: on ROCm 7.2 the
         # first BN launch right after it was observed to see stale data)
-        _bn_ws[dev] = torch.full((2 * 1024 + 2,), 0.0, dtype=torch.float64, device=dev)
-    return _bn_ws[dev]
+        _bn_ws[key] = torch.full((2 * 1024 + 2,), 0.0, dtype=torch.float64, device=dev)
+    return _bn_ws[key]
 
 
 class BNReLUCL(Function):

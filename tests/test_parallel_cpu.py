@@ -57,7 +57,10 @@ def _worker(rank, world, port, out_dir):
         local = grads.flat_grad.clone()
         gathered = [torch.zeros_like(local) for _ in range(world)]
         dist.all_gather(gathered, local)
-        grads.all_reduce_mean(world)
+        if it == 0:
+            grads.all_reduce_mean(world)
+        else:                                           # the asynchronous form: a mean only after wait()
+            grads.all_reduce_mean(world, async_op=True).wait()
         expect = sum(gathered) / world
         assert torch.allclose(grads.flat_grad, expect, rtol=1e-6, atol=1e-7), "all-reduce != mean of rank grads"
         assert not torch.equal(gathered[0], gathered[1]), "ranks saw the same scenes"
@@ -136,3 +139,18 @@ def test_sync_bn_two_ranks_equal_single_process_bn_over_the_concatenated_batch(t
     for o in outs:
         torch.testing.assert_close(o["rm"], bn.running_mean, rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(o["rv"], bn.running_var, rtol=1e-5, atol=1e-6)
+
+
+def test_dropout_counter_is_seeded_by_torch_and_the_rank(monkeypatch):
+    """the dropout counter must follow torch.manual_seed and differ between data-parallel ranks."""
+    from eda_amd import attention
+    torch.manual_seed(1234)
+    monkeypatch.setenv("RANK", "0")
+    a0 = attention._initial_dropout_counter()
+    monkeypatch.setenv("RANK", "1")
+    a1 = attention._initial_dropout_counter()
+    torch.manual_seed(1235)
+    b1 = attention._initial_dropout_counter()
+    torch.manual_seed(1234)
+    assert attention._initial_dropout_counter() == a1
+    assert len({a0, a1, b1}) == 3 and all(0 <= v < (1 << 62) for v in (a0, a1, b1))
