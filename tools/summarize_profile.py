@@ -59,7 +59,7 @@ def main():
     u = json.load(open(under))
     cb, rf, rm, rh = d.get("cpu_baseline") or {"value": None, "unit": "", "cores": None, "sample": "not run"}, d["roofline"], d.get("roofline_mfma"), d.get("roofline_hbm")
     out = [f"# Run {tag} — B=8 x 50 000 points, 256 queries, 80 tokens, fp32", ""]
-    out.append(f"`python bench.py` (whole step replayed from one HIP graph): **{d['value']} scenes/s, "
+    out.append(f"`python bench.py` (launch: {d['config'].get('launch')}; SA1 sampling: {d['config'].get('sa1_sampling', 'inside the step')}): **{d['value']} scenes/s, "
                f"{d['ms_per_step']} ms/step**; cpu_baseline {cb['value']} {cb['unit']} on {cb['cores']} cores "
                f"({cb['sample']}).  Full line: `{tag}_bench_default.json`.")
     out.append("")
@@ -78,7 +78,11 @@ def main():
     out.append(f"`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps {steps - 3} --warmup 3 "
                f"--graph 0 --cpu-scenes 0` (eager, {steps} steps; under the profiler {u['ms_per_step']} ms/step): "
                f"{tot_ms:.1f} ms of kernels per step over {tot_n:.0f} launches (`{tag}_bench_eager_kernel_stats_rocprofv3.csv`).")
-    out += ["", "## Where the step goes", "", "| family | ms/step | launches/step |", "|---|---|---|"]
+    out += ["", "## Where the step goes",
+            "", "(kernel time of ALL streams; with the default launch structure the frozen text encoder -- the library GEMM and "
+            "`torch layernorm / softmax / attention` rows plus ~0.4 ms of the element-wise row -- and SA1's sampling "
+            "(`fps_spec_kernel`) run on the second stream, off the critical path)",
+            "", "| family | ms/step | launches/step |", "|---|---|---|"]
     for label, (ms, n) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
         out.append(f"| {label} | {ms:.2f} | {n:.0f} |")
     out += ["", "## Native kernels (avg duration agrees with bench.py's HIP-event numbers in `kernels`)", "",
