@@ -312,12 +312,14 @@ def main():
                     help="1 (with --graph): the frozen text encoder runs as its own HIP graph on a second stream "
                          "underneath the point backbone's graph (whose furthest point sampling keeps ~100 of the 256 "
                          "CUs busy for 3 ms); the rest of the step is a third graph behind an event.  0: one graph")
-    ap.add_argument("--fps-prefetch", type=int, default=1,
+    ap.add_argument("--fps-prefetch", type=int, default=1, choices=[0, 1, 2],
                     help="1 (with --text-stream): the furthest point sampling of SA1 -- a function of the input coordinates "
                          "only, 3 ms of dependent rounds on ~100 CUs -- runs for the NEXT step's batch on the second stream "
                          "while the current step trains (an input pipeline has batch i+1 resident by then) and is handed to "
                          "the model through the reference's own `inds` argument; one sampling per timed step either way.  "
-                         "0: sampled inside the step, on its critical path")
+                         "2: everything the backbone derives from the coordinates alone (the four samplings, four ball "
+                         "queries, two 3-NN searches: Pointnet2Backbone.geometry) for the next batch on the second stream.  "
+                         "0: all of it inside the step, on its critical path")
     ap.add_argument("--attn-dtype", choices=["f32", "bf16", "f16"], default="f32",
                     help="arithmetic of the attention QK^T / PV contractions: f32 = the headline / parity path; bf16 / "
                          "f16 = 16-bit MFMA with fp32 accumulation (csrc/mha16.hip, BASELINE.json configs[2] / [4]) -- "
@@ -480,16 +482,23 @@ def main():
                     xyz_next = inputs["point_clouds"][..., 0:3].contiguous()     # (the next batch's coordinates)
                     g_fps = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g_fps, stream=tstream, **mode):
-                        inds_next = pointnet2_utils.furthest_point_sample(xyz_next, 2048)
+                        if args.fps_prefetch == 2:
+                            geo_next = model.backbone_net.geometry(xyz_next)
+                            inds_next = list(geo_next.values())
+                        else:
+                            inds_next = [pointnet2_utils.furthest_point_sample(xyz_next, 2048)]
                     tstream.synchronize()
                     g_fps.replay()
                     torch.cuda.synchronize()
-                    inds_cur = inds_next.clone()
-                    inputs_h["sa1_inds"] = inds_cur
+                    inds_cur = [t.clone() for t in inds_next]
+                    if args.fps_prefetch == 2:
+                        inputs_h["backbone_geometry"] = dict(zip(geo_next.keys(), inds_cur))
+                    else:
+                        inputs_h["sa1_inds"] = inds_cur[0]
                 pool = torch.cuda.graph_pool_handle()
                 with torch.cuda.graph(g_pts, pool=pool, stream=side, **mode):
                     if inds_cur is not None:
-                        inds_cur.copy_(inds_next)          # the sampling this step uses (written during the previous step)
+                        torch._foreach_copy_(inds_cur, inds_next)   # the geometry this step uses (written during the previous step)
                     attention.advance_dropout_state(device)
                     ep_static = model.forward_point_backbone(inputs_h)
                 with torch.cuda.graph(g_rest, pool=pool, stream=side, **mode):
@@ -746,8 +755,10 @@ def main():
                                   "hipGraph replay of the whole step" if world == 1 and not args.split_graphs else
                                   "two hipGraphs (fwd+bwd | clip+AdamW) with the RCCL all-reduce between them"),
                        "text_encoder": "RoBERTa-base random-init frozen",
-                       "sa1_sampling": ("furthest point sampling of the NEXT step's batch on the second stream during the "
-                                        "current step (one sampling per step; --fps-prefetch 0 puts it back on the critical path)")
+                       "sa1_sampling": (("furthest point sampling" if args.fps_prefetch == 1 else
+                                         "coordinate-only geometry (4 samplings, 4 ball queries, 2 3-NN searches)") +
+                                        " of the NEXT step's batch on the second stream during the "
+                                        "current step (once per step; --fps-prefetch 0 puts it back on the critical path)")
                        if (args.graph and args.text_stream and not args.overlap and args.fps_prefetch) else "inside the step",
                        "attention_dtype": args.attn_dtype,
                        "own_gemms": "every pointwise layer of the model (csrc/gemm.hip); hipBLASLt only inside RoBERTa",

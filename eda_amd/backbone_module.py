@@ -33,7 +33,21 @@ class Pointnet2Backbone(nn.Module):
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
         return xyz, features
 
-    def forward(self, pointcloud, end_points=None, sa1_inds=None):
+    def geometry(self, xyz, sa1_inds=None):
+        """Everything the backbone derives from the coordinates (B, N, 3) alone: per SA level (inds, new_xyz, ball-query
+        idx), per FP level (3-NN idx, weights) -- four samplings, four ball queries, two 3-NN searches, none of which
+        any gradient flows through.  Returns a flat dict of tensors; `forward(..., geometry=)` takes it back."""
+        g, cur = {}, xyz
+        for name, layer in (("sa1", self.sa1), ("sa2", self.sa2), ("sa3", self.sa3), ("sa4", self.sa4)):
+            inds, new_xyz, idx = layer.geometry(cur, inds=sa1_inds if name == "sa1" else None,
+                                                xyz_in_sampling_order=name != "sa1")
+            g[f"{name}_inds"], g[f"{name}_xyz"], g[f"{name}_idx"] = inds, new_xyz, idx
+            cur = new_xyz
+        g["fp1_idx"], g["fp1_weight"] = self.fp1.geometry(g["sa3_xyz"], g["sa4_xyz"])
+        g["fp2_idx"], g["fp2_weight"] = self.fp2.geometry(g["sa2_xyz"], g["sa3_xyz"])
+        return g
+
+    def forward(self, pointcloud, end_points=None, sa1_inds=None, geometry=None):
         """sa1_inds: optional (B, 2048) int32 furthest-point-sampling indices of `pointcloud` computed by the caller
         (the `inds` argument of the reference's PointnetSAModuleVotes.forward, pointnet2_modules.py:217-235): they
         depend on the input coordinates only, so an input pipeline can sample batch i+1 while step i trains."""
@@ -43,15 +57,18 @@ class Pointnet2Backbone(nn.Module):
             # SA2..SA4 sample from the previous level's samples, which are in sampling order: their FPS is the
             # prefix 0..m-1 unless a tie intervenes (the reference notes it, backbone_module.py:122-131);
             # the library verifies that instead of running the dependent rounds
+            geo = (geometry[f"{name}_inds"], geometry[f"{name}_xyz"], geometry[f"{name}_idx"]) if geometry else None
             xyz, features, inds = layer(xyz, features, inds=sa1_inds if name == "sa1" else None,
-                                        xyz_in_sampling_order=name != "sa1")
+                                        xyz_in_sampling_order=name != "sa1", geometry=geo)
             if name in ("sa1", "sa2"):
                 end_points[f"{name}_inds"] = inds
             end_points[f"{name}_xyz"] = xyz
             end_points[f"{name}_features"] = features
         f = self.fp1(end_points["sa3_xyz"], end_points["sa4_xyz"], end_points["sa3_features"],
-                     end_points["sa4_features"])
-        f = self.fp2(end_points["sa2_xyz"], end_points["sa3_xyz"], end_points["sa2_features"], f)
+                     end_points["sa4_features"],
+                     geometry=(geometry["fp1_idx"], geometry["fp1_weight"]) if geometry else None)
+        f = self.fp2(end_points["sa2_xyz"], end_points["sa3_xyz"], end_points["sa2_features"], f,
+                     geometry=(geometry["fp2_idx"], geometry["fp2_weight"]) if geometry else None)
         end_points["fp2_features"] = f
         end_points["fp2_xyz"] = end_points["sa2_xyz"]
         num_seed = end_points["fp2_xyz"].shape[1]

@@ -160,12 +160,12 @@ class BeaUTyDETR(nn.Module):
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 text_feats, text_mask, tok = self._text_branch(inputs, pc.device)
-            end_points = self.backbone_net(pc, end_points={}, sa1_inds=inputs.get("sa1_inds"))
+            end_points = self.backbone_net(pc, end_points={}, sa1_inds=inputs.get("sa1_inds"), geometry=inputs.get("backbone_geometry"))
             cur.wait_stream(side)
             for t in (text_feats, text_mask):
                 t.record_stream(cur)
             return self._join_text(end_points, text_feats, text_mask, tok)
-        return self._text_into(inputs, self.backbone_net(pc, end_points={}, sa1_inds=inputs.get("sa1_inds")))
+        return self._text_into(inputs, self.backbone_net(pc, end_points={}, sa1_inds=inputs.get("sa1_inds"), geometry=inputs.get("backbone_geometry")))
 
     def _text_into(self, inputs, end_points):
         text_feats, text_mask, tok = self._text_branch(inputs, inputs["point_clouds"].device)
@@ -201,7 +201,8 @@ class BeaUTyDETR(nn.Module):
     # forward(inputs) == forward_rest(inputs, forward_point_backbone(inputs)).
     def forward_point_backbone(self, inputs):
         with deferred_bn_counters():
-            return self.backbone_net(inputs["point_clouds"], end_points={}, sa1_inds=inputs.get("sa1_inds"))
+            return self.backbone_net(inputs["point_clouds"], end_points={}, sa1_inds=inputs.get("sa1_inds"),
+                                     geometry=inputs.get("backbone_geometry"))
 
     def forward_rest(self, inputs, end_points):
         with deferred_bn_counters():

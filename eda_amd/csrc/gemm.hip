@@ -42,6 +42,9 @@
 #include "eda_common.h"
 #include "gemm.h"
 #include <string.h>
+#include <stdio.h>
+#include <map>
+#include <mutex>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -1007,14 +1010,23 @@ int launch_cfg(GemmArgs &a, int wmode, hipStream_t stream) {
 // ---- streaming launches (SA1) ---------------------------------------------------------------------
 template <typename KernelT>
 int stream_grid(KernelT kern, int threads, long ntiles, int nw) {
-  // every CU full once (persistent waves); cached per instantiation
-  static int per_cu = 0;
-  if (!per_cu) {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, 0) != hipSuccess || nb < 1) nb = 1;
-    per_cu = nb;
+  // every CU full once (persistent waves).  The occupancy is cached PER KERNEL (all instantiations share this
+  // function's type, so a function-local static would be one value for all of them)
+  static std::map<const void *, int> cache;
+  static std::mutex mu;
+  int per_cu;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    int &slot = cache[reinterpret_cast<const void *>(kern)];
+    if (!slot) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, 0) != hipSuccess || nb < 1) nb = 1;
+      slot = nb;
+    }
+    per_cu = slot;
   }
   long wgs = (long)per_cu * 256;
+  if (const char *g = getenv("EDA_GEMM_STREAM_GRID")) { const long v = atol(g); if (v > 0) wgs = v; }   // (tests: any grid must work)
   const long need = (ntiles + nw - 1) / nw;
   if (wgs > need) wgs = need;
   return (int)(wgs < 1 ? 1 : wgs);
@@ -1082,6 +1094,10 @@ int try_stream(GemmArgs &a, int wmode, hipStream_t stream) {
   }
   const int N = a.N;
   if (N % 64 != 0) return -1;
+  if (const char *sk = getenv("EDA_GEMM_STREAM_SKIP")) {       // debugging aid: "K,N,epi" leaves one shape to the tiled kernel
+    int sK = 0, sN = 0, sE = -1;
+    if (sscanf(sk, "%d,%d,%d", &sK, &sN, &sE) >= 2 && (sK == 0 || sK == K) && (sN == 0 || sN == N) && (sE < 0 || sE == a.epi)) return -1;
+  }
   if (K == 64 && N == 64) return launch_stream<64, 64, 8, 4>(a, stream);
   if (K == 64 && N % 128 == 0) return launch_stream<64, 128, 8, 2>(a, stream);
   if (K == 128 && N == 64) return launch_stream<128, 64, 8, 2>(a, stream);

@@ -42,7 +42,23 @@ class PointnetSAModuleVotes(nn.Module):
             spec[0] += 3
         self.mlp_module = SharedMLP(spec, bn=bn)
 
-    def forward(self, xyz, features=None, inds=None, xyz_in_sampling_order=False):
+    def geometry(self, xyz, inds=None, xyz_in_sampling_order=False):
+        """(inds, new_xyz, ball-query idx): everything this module derives from the coordinates alone (no gradient
+        flows through any of it).  A caller may compute it ahead of the forward -- for the NEXT batch on a second
+        stream -- and pass it back through `forward(..., geometry=)`."""
+        with torch.no_grad():
+            if inds is None:
+                inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint, xyz_in_sampling_order)
+            new_xyz = pointnet2_utils.gather_operation(
+                xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+            idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
+        return inds, new_xyz, idx
+
+    def forward(self, xyz, features=None, inds=None, xyz_in_sampling_order=False, geometry=None):
+        if geometry is not None and self._fast_path(xyz):
+            inds, new_xyz, idx = geometry
+            assert inds.shape[1] == self.npoint and idx.shape[1:] == (self.npoint, self.nsample)
+            return new_xyz, self._forward_rows(xyz, new_xyz, features, idx=idx), inds
         if inds is None:
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint, xyz_in_sampling_order)
         else:
@@ -75,11 +91,12 @@ class PointnetSAModuleVotes(nn.Module):
                 and self.nsample <= 255 and all(l.bn is not None for l in layers)
                 and all(l.conv.out_channels % 4 == 0 for l in layers))
 
-    def _forward_rows(self, xyz, new_xyz, features):
+    def _forward_rows(self, xyz, new_xyz, features, idx=None):
         """ball query -> [centred xyz | gathered features] rows -> 3 x (GEMM, fused BN+ReLU)
         -> max over the nsample rows of each centre.  Same math as the generic path."""
         B, m = new_xyz.shape[0], new_xyz.shape[1]
-        idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
+        if idx is None:
+            idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
         feats_cl = features.transpose(1, 2).contiguous() if features is not None else None
         if sa_ops._fusable(self.mlp_module.layers()):
             # ball query -> ONE fused native call: neighbourhood rows gathered into LDS, three MFMA
@@ -99,11 +116,23 @@ class PointnetFPModule(nn.Module):
         super().__init__()
         self.mlp = SharedMLP(list(mlp), bn=bn)
 
-    def forward(self, unknown, known, unknow_feats, known_feats):
-        if known is not None:
+    @staticmethod
+    def geometry(unknown, known):
+        """(idx, weight) of the 3-NN inverse-distance interpolation: a function of the coordinates alone."""
+        with torch.no_grad():
             dist, idx = pointnet2_utils.three_nn(unknown, known)
             dist_recip = 1.0 / (dist + 1e-8)
             weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+        return idx, weight
+
+    def forward(self, unknown, known, unknow_feats, known_feats, geometry=None):
+        if known is not None:
+            if geometry is not None:
+                idx, weight = geometry
+            else:
+                dist, idx = pointnet2_utils.three_nn(unknown, known)
+                dist_recip = 1.0 / (dist + 1e-8)
+                weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
             interpolated = pointnet2_utils.three_interpolate(known_feats, idx, weight)
         else:
             interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
