@@ -320,6 +320,9 @@ def main():
                          "2: everything the backbone derives from the coordinates alone (the four samplings, four ball "
                          "queries, two 3-NN searches: Pointnet2Backbone.geometry) for the next batch on the second stream.  "
                          "0: all of it inside the step, on its critical path")
+    ap.add_argument("--text-prefetch", type=int, default=1,
+                    help="1 (with --fps-prefetch): the frozen text encoder runs for the NEXT step's tokens, behind the sampling on "
+                         "the second stream (once per step either way); 0: for the current step, underneath the point backbone")
     ap.add_argument("--attn-dtype", choices=["f32", "bf16", "f16"], default="f32",
                     help="arithmetic of the attention QK^T / PV contractions: f32 = the headline / parity path; bf16 / "
                          "f16 = 16-bit MFMA with fp32 accumulation (csrc/mha16.hip, BASELINE.json configs[2] / [4]) -- "
@@ -476,6 +479,16 @@ def main():
                     text_hidden = model.encode_text_frozen(tok["input_ids"], tok["attention_mask"])
                 inputs_h = dict(inputs)
                 inputs_h["text_hidden"] = text_hidden
+                # --text-prefetch: the text encoder, too, works for the NEXT step's tokens (double-buffered hidden states),
+                # behind the sampling on the second stream: nothing runs next to the SA layers and the rest graph waits
+                # for nothing of its own step (23.2 vs 23.35 ms/step)
+                text_prefetch = bool(args.fps_prefetch) and bool(args.text_prefetch)
+                if text_prefetch:
+                    tstream.synchronize()
+                    g_text.replay()
+                    torch.cuda.synchronize()
+                    text_cur = text_hidden.clone()
+                    inputs_h["text_hidden"] = text_cur
                 g_fps = inds_next = inds_cur = None
                 if args.fps_prefetch:
                     from eda_amd import pointnet2_utils
@@ -499,6 +512,8 @@ def main():
                 with torch.cuda.graph(g_pts, pool=pool, stream=side, **mode):
                     if inds_cur is not None:
                         torch._foreach_copy_(inds_cur, inds_next)   # the geometry this step uses (written during the previous step)
+                    if text_prefetch:
+                        text_cur.copy_(text_hidden)
                     attention.advance_dropout_state(device)
                     ep_static = model.forward_point_backbone(inputs_h)
                 with torch.cuda.graph(g_rest, pool=pool, stream=side, **mode):
@@ -529,15 +544,22 @@ def main():
                     cur.wait_event(ev_fps)               # this batch's sampling (computed while the previous step ran)
                     g_pts.replay()
                     ev_pts.record(cur)
-                    tstream.wait_event(ev_done)          # the previous step has consumed text_hidden
-                    with torch.cuda.stream(tstream):
-                        g_text.replay()
-                        ev_text.record(tstream)
-                        if g_fps is not None:            # queued BEFORE the long graph below: see the note above
-                            tstream.wait_event(ev_pts)   # g_pts has taken its copy of inds_next
+                    if text_prefetch:
+                        with torch.cuda.stream(tstream):
+                            tstream.wait_event(ev_pts)   # g_pts has taken its copies of inds_next / text_hidden
                             g_fps.replay()
-                            ev_fps.record(tstream)
-                    cur.wait_event(ev_text)
+                            g_text.replay()
+                            ev_fps.record(tstream)       # (one event for both: the next point graph waits for it)
+                    else:
+                        tstream.wait_event(ev_done)          # the previous step has consumed text_hidden
+                        with torch.cuda.stream(tstream):
+                            g_text.replay()
+                            ev_text.record(tstream)
+                            if g_fps is not None:            # queued BEFORE the long graph below: see the note above
+                                tstream.wait_event(ev_pts)   # g_pts has taken its copy of inds_next
+                                g_fps.replay()
+                                ev_fps.record(tstream)
+                        cur.wait_event(ev_text)
                     g_rest.replay()
                     ev_done.record(cur)
                     if g_up is not None:
@@ -754,7 +776,9 @@ def main():
                                   if (args.text_stream and not args.overlap) else
                                   "hipGraph replay of the whole step" if world == 1 and not args.split_graphs else
                                   "two hipGraphs (fwd+bwd | clip+AdamW) with the RCCL all-reduce between them"),
-                       "text_encoder": "RoBERTa-base random-init frozen",
+                       "text_encoder": "RoBERTa-base random-init frozen" + (
+                           "; runs for the NEXT step's tokens on the second stream" if (args.graph and args.text_stream and not args.overlap
+                                                                                      and args.fps_prefetch and args.text_prefetch) else ""),
                        "sa1_sampling": (("furthest point sampling" if args.fps_prefetch == 1 else
                                          "coordinate-only geometry (4 samplings, 4 ball queries, 2 3-NN searches)") +
                                         " of the NEXT step's batch on the second stream during the "

@@ -63,7 +63,7 @@ def test_split_graphs_structure_of_the_multi_gpu_step_trains_like_the_single_gra
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hists = []
-    for extra in (["--text-stream", "0"], [], ["--split-graphs"]):
+    for extra in (["--text-stream", "0"], [], ["--split-graphs"], ["--text-prefetch", "0", "--fps-prefetch", "2"]):
         env = dict(os.environ, EDA_BENCH_INGRAPH_HIST="1")
         p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "3",
                             "--kernel-steps", "0", "--cpu-scenes", "0", "--gemm-tuning", "shipped", "--per-gpu", "4",
