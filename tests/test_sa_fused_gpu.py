@@ -73,13 +73,17 @@ def _run_fused(cfg_kw, Ws, gammas, betas, running, training, pool, x_rows=None, 
     return sa_ops.FusedMLP.apply(cfg, x_rows, xyz, new_xyz, feats_cl, idx, *params)
 
 
-@pytest.fixture(params=["default", "stream"])
+@pytest.fixture(params=["default", "stream", "stream-few-workgroups"])
 def stream_kernels(request, monkeypatch):
-    """'stream': the per-wave streaming GEMM kernels of SA1 (gemm.hip: gemm_stream_kernel, gemm_gather3_kernel)
-    take every eligible launch whatever its row count; 'default': only above 65536 rows."""
-    if request.param == "stream":
+    """'stream': the per-wave streaming GEMM kernels (gemm.hip: gemm_stream_kernel, gemm_gather3_kernel) take every
+    eligible launch whatever its row count; 'default': only above 32768 rows; 'stream-few-workgroups': additionally
+    launched with 8 workgroups, so that every wave runs MANY tiles through its pipeline (row-tile prefetch one tile
+    ahead, neighbour indices two tiles ahead) as it does at the bench sizes."""
+    if request.param != "default":
         monkeypatch.setenv("EDA_GEMM_STREAM_MINR", "1")
-    return request.param
+    if request.param == "stream-few-workgroups":
+        monkeypatch.setenv("EDA_GEMM_STREAM_GRID", "8")
+    return "stream" if request.param != "default" else "default"
 
 
 @pytest.mark.parametrize("R,chans,training", [
