@@ -163,3 +163,21 @@ def test_mlp_chain_node_matches_the_torch_composition(R, dims, p, shadow):
     for a, e in zip(got, exp):
         scale = e.abs().max().item() + 1e-12
         assert (a.double() - e).abs().max().item() <= 2e-4 * scale, ((a.double() - e).abs().max().item(), scale)
+
+
+def test_transpose_batch_c_entry_handles_ragged_matrices():
+    """eda_transpose_batch_f32 straight through the C ABI: matrices whose sides are not multiples of the 32x32 tile."""
+    from eda_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(11)
+    shapes = [(37, 53), (1, 1), (288, 864), (33, 32), (5, 260)]
+    srcs = [torch.randn(r, c, device="cuda", generator=g) for r, c in shapes]
+    dsts = [torch.full((c, r), float("nan"), device="cuda") for r, c in shapes]
+    desc, tiles = [], 0
+    for s_, d_, (r, c) in zip(srcs, dsts, shapes):
+        desc.append([s_.data_ptr(), d_.data_ptr(), r, c, tiles])
+        tiles += ((r + 31) // 32) * ((c + 31) // 32)
+    dt = torch.tensor(desc, dtype=torch.int64, device="cuda")
+    rc = _lib.lib().eda_transpose_batch_f32(dt.data_ptr(), len(shapes), tiles, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "eda_transpose_batch_f32")
+    for s_, d_ in zip(srcs, dsts):
+        assert torch.equal(d_, s_.t())
