@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from .backbone_module import Pointnet2Backbone
 from .encoder_decoder_layers import BiDecoderLayer, BiEncoder, BiEncoderLayer, PositionEmbeddingLearned
-from .nn_utils import Conv1dK1, Linear, deferred_bn_counters, l2_normalize, mlp_chain
+from .nn_utils import Conv1dK1, Linear, deferred_bn_counters, embedding_rows, l2_normalize, mlp_chain
 from .modules import ClsAgnosticPredictHead, GeneralSamplingModule, PointsObjClsModule
 
 
@@ -217,7 +217,7 @@ class BeaUTyDETR(nn.Module):
         if self.butd:
             detected_mask = ~inputs["det_bbox_label_mask"]
             box_emb = self.box_embeddings.rows(inputs["det_boxes"])                     # (B,D,128)
-            cls_emb = self.class_embeddings(self.butd_class_embeddings(inputs["det_class_ids"]))
+            cls_emb = self.class_embeddings(embedding_rows(self.butd_class_embeddings, inputs["det_class_ids"]))
             detected_feats = torch.cat([box_emb, cls_emb], 2)                           # (B,D,288)
         else:
             detected_mask, detected_feats = None, None

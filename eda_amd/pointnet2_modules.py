@@ -103,10 +103,11 @@ class PointnetSAModuleVotes(nn.Module):
             # GEMMs with BN statistics / BN+ReLU folded in, max-pool (csrc/sa_cl.hip, gemm.hip)
             pooled = sa_ops.fused_mlp(self.mlp_module, self.nsample, xyz=xyz, new_xyz=new_xyz, feats_cl=feats_cl,
                                       idx=idx, radius=self.radius, normalize_xyz=self.normalize_xyz)
-            return pooled.view(B, m, -1).transpose(1, 2).contiguous()
+            return pooled.view(B, m, -1).transpose(1, 2)       # (B, C, m) VIEW of the channels-last result: the next
+            #                                                    module's transpose(1, 2).contiguous() is then free
         rows = sa_ops.GroupConcatCL.apply(xyz, new_xyz, feats_cl, idx, self.radius, self.normalize_xyz)
         pooled = sa_ops.shared_mlp_rows(self.mlp_module, rows.view(B * m * self.nsample, -1), self.nsample)
-        return pooled.view(B, m, -1).transpose(1, 2).contiguous()
+        return pooled.view(B, m, -1).transpose(1, 2)
 
 
 class PointnetFPModule(nn.Module):
@@ -133,14 +134,18 @@ class PointnetFPModule(nn.Module):
                 dist, idx = pointnet2_utils.three_nn(unknown, known)
                 dist_recip = 1.0 / (dist + 1e-8)
                 weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
-            interpolated = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+            interpolated = pointnet2_utils.three_interpolate(known_feats.contiguous(), idx, weight)
         else:
             interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
-        x = torch.cat([interpolated, unknow_feats], dim=1) if unknow_feats is not None else interpolated
         layers = self.mlp.layers()
-        if (x.is_cuda and all(l.bn is not None for l in layers)
+        if (interpolated.is_cuda and all(l.bn is not None for l in layers)
                 and all(l.conv.out_channels % 4 == 0 for l in layers)):
-            B, C, n = x.shape                                   # channels-last rows, fused BN+ReLU
-            rows = sa_ops.shared_mlp_rows(self.mlp, x.transpose(1, 2).reshape(B * n, C), 1)
-            return rows.view(B, n, -1).transpose(1, 2).contiguous()
+            # channels-last rows, fused BN+ReLU.  The concatenation is written in rows layout directly (the skip
+            # features usually ARE a transposed view of channels-last rows: no copy on that side)
+            parts = [interpolated.transpose(1, 2)] + ([unknow_feats.transpose(1, 2)] if unknow_feats is not None else [])
+            x_rows = torch.cat(parts, dim=2) if len(parts) > 1 else parts[0].contiguous()
+            B, n, C = x_rows.shape
+            rows = sa_ops.shared_mlp_rows(self.mlp, x_rows.view(B * n, C), 1)
+            return rows.view(B, n, -1).transpose(1, 2)
+        x = torch.cat([interpolated, unknow_feats], dim=1) if unknow_feats is not None else interpolated
         return self.mlp(x.unsqueeze(-1)).squeeze(-1)
