@@ -185,7 +185,7 @@ class BeaUTyDETR(nn.Module):
         logits = self.points_obj_cls(features, seed_rows=features_rows)
         end_points["seeds_obj_cls_logits"] = logits
         sample_inds = torch.topk(torch.sigmoid(logits).squeeze(1), self.num_queries)[1].int()
-        xyz, features, sample_inds = self.gsample_module(xyz, features, sample_inds)
+        xyz, features, sample_inds = self.gsample_module(xyz, features, sample_inds, features_rows=features_rows)
         end_points["query_points_xyz"] = xyz
         end_points["query_points_feature"] = features
         end_points["query_points_sample_inds"] = sample_inds
@@ -229,7 +229,7 @@ class BeaUTyDETR(nn.Module):
             padding_mask=torch.full(points_xyz.shape[:2], False, dtype=torch.bool, device=points_xyz.device),
             text_feats=text_feats, text_padding_mask=text_padding_mask, end_points=end_points,
             detected_feats=detected_feats, detected_mask=detected_mask)
-        points_features = vis.transpose(1, 2).contiguous()       # (B, 288, 1024)
+        points_features = vis.transpose(1, 2)                    # (B, 288, 1024) as a view of the channels-last rows
         end_points["text_memory"] = text_feats
         end_points["seed_features"] = points_features
         if self.contrastive_align_loss:

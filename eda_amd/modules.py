@@ -4,6 +4,7 @@ box prediction.  Mirrors models/modules.py:19-178 (names = checkpoint contract).
 import os
 
 import numpy as np
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -44,9 +45,15 @@ class PointsObjClsModule(nn.Module):
 class GeneralSamplingModule(nn.Module):
     """Gather xyz (B,K,3) and features (B,C,K) at sample_inds (B,Q) int32."""
 
-    def forward(self, xyz, features, sample_inds):
+    def forward(self, xyz, features, sample_inds, features_rows=None):
+        """features_rows: the same features channels-last (B,K,C), when the caller has them: the sampled rows are then
+        gathered there and `new_features` is a (B,C,Q) view of them (no channels-first copy on either side)."""
         new_xyz = gather_operation(xyz.transpose(1, 2).contiguous(), sample_inds).transpose(1, 2).contiguous()
-        new_features = gather_operation(features, sample_inds).contiguous()
+        if features_rows is not None and features_rows.is_cuda:
+            C = features_rows.shape[-1]
+            rows = torch.gather(features_rows, 1, sample_inds.long().unsqueeze(-1).expand(-1, -1, C))
+            return new_xyz, rows.transpose(1, 2), sample_inds
+        new_features = gather_operation(features.contiguous(), sample_inds).contiguous()
         return new_xyz, new_features, sample_inds
 
 
