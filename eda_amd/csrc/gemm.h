@@ -6,7 +6,7 @@ constexpr int G_THREADS = 256;
 constexpr int G_KC = 32;          // contraction chunk (floats)
 constexpr int G_XS = G_KC + 8;    // LDS row stride of [row][k] tiles
 
-enum { X_PLAIN = 0, X_BNRELU = 1, X_GATHER = 2 };
+enum { X_PLAIN = 0, X_BNRELU = 1, X_GATHER = 2, X_BNBWDPOOL = 3 };
 enum { W_NT = 0, W_NN = 1 };
 enum { E_PLAIN = 0, E_STATS = 1, E_MASK = 2, E_SCATTER = 3 };
 
@@ -37,6 +37,11 @@ struct GemmArgs {
   float *dfeats;
   int col_tiles; long row_blocks; int row_slots; unsigned ticket_target;
   int ngroups; GemmGroup grp[G_MAXGROUPS];     // ngroups > 1: block column tile ct belongs to the group with ct0 <= ct
+  // X_BNBWDPOOL (streaming kernels only): the row operand is dz of a POOLED last SharedMLP layer, formed while staging
+  // from the layer's pre-activation x = z (R x K): with y = z*sc+sh, d = (y > 0 and argmax[row/pool][k] == row%pool) ?
+  // dout[row/pool][k] : 0, dz = ka*d + kb*z + kd (train-mode BatchNorm backward; bn_relu_bwd_apply_kernel<true> writes
+  // the same values to HBM when this prologue is not used).  bb_consts: 5 x K floats {sc, sh, ka, kb, kd}; pool % 16 == 0
+  const unsigned char *bb_argmax; const float *bb_dout; const float *bb_consts; int bb_pool;
   // E_PLAIN extras (eda_linear_ex_f32): Dropout after the bias / ReLU (counter-based hash of (seed, salt, element), the
   // scheme of ln.hip), and a gate: y = gate > 0 ? y * gate_scale : 0 -- the ReLU (+ Dropout) backward of the layer
   // whose activated output `gate` is, applied to the input gradient that flows into it
@@ -48,6 +53,8 @@ struct GemmArgs {
 
 // Launch the row GEMM described by `a` (tile shape chosen from R and N).  wmode: W_NT / W_NN.
 int eda_gemm_launch(GemmArgs &a, int wmode, hipStream_t stream);
+// would the streaming kernels take this launch (same checks as eda_gemm_launch, nothing is launched)?
+bool eda_gemm_stream_takes(const GemmArgs &a, int wmode);
 
 // ---- weight gradient with a row-operand prologue (wgrad.hip) ------------------------------------
 // dW (M, N) = dY^T X over R rows, X = plain rows | relu(Z*scale+shift) | gathered neighbourhood rows
@@ -61,6 +68,9 @@ struct WgradXArgs {
   int n_pts, m, ns, c_feat; float inv_radius;
   float *dW;                                        // (M, N) or, X_GATHER, (M, 3 + c_feat)
   float *ws; size_t ws_bytes;
+  // dy_pool > 0: dy is not stored; it is the dz of GemmArgs::X_BNBWDPOOL, formed from dyz (= z, R x M), dy_argmax,
+  // dy_dout (R/pool x M) and dy_consts (5 x M) while staging (xmode must be X_BNRELU)
+  const float *dyz; const unsigned char *dy_argmax; const float *dy_dout; const float *dy_consts; int dy_pool;
 };
 size_t eda_wgrad_x_workspace_bytes(long R, int M, int N);
 int eda_wgrad_x_launch(const WgradXArgs &a, hipStream_t stream);

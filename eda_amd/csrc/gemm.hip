@@ -674,6 +674,24 @@ __global__ __launch_bounds__(64 * NW, MINW) void gemm_stream_kernel(const GemmAr
       bsh[h] = *reinterpret_cast<const float4 *>(a.in_shift + 64 * h + sk);
     }
   }
+  // X_BNBWDPOOL: five column constants per part; per tile (16 rows of ONE pooling group: pool % 16 == 0) the group's
+  // arg-max bytes and pooled gradient of the lane's four columns
+  constexpr bool bnbwd = XMODE == X_BNBWDPOOL;
+  float4 qsc[bnbwd ? KH : 1], qsh[bnbwd ? KH : 1], qka[bnbwd ? KH : 1], qkb[bnbwd ? KH : 1], qkd[bnbwd ? KH : 1];
+  if (bnbwd) {
+#pragma unroll
+    for (int h = 0; h < KH; ++h) {
+      const float *c = a.bb_consts + 64 * h + sk;
+      qsc[h] = *reinterpret_cast<const float4 *>(c);
+      qsh[h] = *reinterpret_cast<const float4 *>(c + KT);
+      qka[h] = *reinterpret_cast<const float4 *>(c + 2 * KT);
+      qkb[h] = *reinterpret_cast<const float4 *>(c + 3 * KT);
+      qkd[h] = *reinterpret_cast<const float4 *>(c + 4 * KT);
+    }
+  }
+  unsigned pam[bnbwd ? KH : 1];
+  float4 pdo[bnbwd ? KH : 1];
+  int prp = 0;
   // X_GATHER: the neighbour indices of a tile's rows are requested TWO tiles ahead (the feature rows they
   // address one tile ahead), the coordinate operand of the next tile during the current one
   const unsigned rps = (gather || EPI == E_SCATTER) ? (unsigned)a.m * (unsigned)a.ns : 1u;
@@ -730,6 +748,16 @@ __global__ __launch_bounds__(64 * NW, MINW) void gemm_stream_kernel(const GemmAr
         v.x = fmaxf(v.x * bsc[h].x + bsh[h].x, 0.f); v.y = fmaxf(v.y * bsc[h].y + bsh[h].y, 0.f);
         v.z = fmaxf(v.z * bsc[h].z + bsh[h].z, 0.f); v.w = fmaxf(v.w * bsc[h].w + bsh[h].w, 0.f);
       }
+      if (bnbwd) {
+        const unsigned rp = (unsigned)(prp + srow + 4 * i);       // position of this row inside its pooling group
+        const unsigned am = pam[h];
+        const float dx_ = (am & 0xffu) == rp && v.x * qsc[h].x + qsh[h].x > 0.f ? pdo[h].x : 0.f;
+        const float dy_ = ((am >> 8) & 0xffu) == rp && v.y * qsc[h].y + qsh[h].y > 0.f ? pdo[h].y : 0.f;
+        const float dz_ = ((am >> 16) & 0xffu) == rp && v.z * qsc[h].z + qsh[h].z > 0.f ? pdo[h].z : 0.f;
+        const float dw_ = (am >> 24) == rp && v.w * qsc[h].w + qsh[h].w > 0.f ? pdo[h].w : 0.f;
+        v.x = qka[h].x * dx_ + qkb[h].x * v.x + qkd[h].x; v.y = qka[h].y * dy_ + qkb[h].y * v.y + qkd[h].y;
+        v.z = qka[h].z * dz_ + qkb[h].z * v.z + qkd[h].z; v.w = qka[h].w * dw_ + qkb[h].w * v.w + qkd[h].w;
+      }
       *reinterpret_cast<float4 *>(&strip[(srow + 4 * i) * XS + sk]) = v;
     }
   };
@@ -766,6 +794,16 @@ __global__ __launch_bounds__(64 * NW, MINW) void gemm_stream_kernel(const GemmAr
       const long zr = rok ? row : R - 1;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) zt[j] = *reinterpret_cast<const float4 *>(a.zm + zr * a.ldzm + n0 + 16 * j + 4 * g);
+    }
+    if (bnbwd) {
+      const long r0t = t * 16;
+      const long grp = r0t / a.bb_pool;
+      prp = (int)(r0t - grp * a.bb_pool);
+#pragma unroll
+      for (int h = 0; h < KH; ++h) {
+        pam[h] = *reinterpret_cast<const unsigned *>(a.bb_argmax + grp * KT + 64 * h + sk);
+        pdo[h] = *reinterpret_cast<const float4 *>(a.bb_dout + grp * KT + 64 * h + sk);
+      }
     }
     f32x4 acc[NJ];
 #pragma unroll
@@ -1052,6 +1090,7 @@ int launch_stream1(GemmArgs &a, hipStream_t stream) {
 // mask epilogue: 226 vs 254 us)
 template <int KT, int NT, int NW, int MINW>
 int launch_stream(GemmArgs &a, hipStream_t stream) {
+  if (a.epi == E_MASK && a.xmode == X_BNBWDPOOL) return launch_stream1<KT, NT, X_BNBWDPOOL, E_MASK, NW, MINW>(a, stream);
   if (a.epi == E_MASK) return launch_stream1<KT, NT, X_PLAIN, E_MASK, NW, MINW>(a, stream);     // dX of a layer: plain rows
   if (a.epi == E_SCATTER) return launch_stream1<KT, NT, X_PLAIN, E_SCATTER, NW, MINW>(a, stream);
   if (a.xmode == X_GATHER) return launch_stream1<KT, NT, X_GATHER, E_STATS, NW, MINW>(a, stream);
@@ -1063,7 +1102,7 @@ int launch_stream(GemmArgs &a, hipStream_t stream) {
 // scatter of the gather's backward; many rows, 64/128/256 channels on both sides, 16-byte addressable
 // operands.  EDA_GEMM_STREAM=0 switches them off, EDA_GEMM_STREAM_MINR=<rows> moves the threshold (tests).
 // Returns -1 if the launch is not theirs.
-int try_stream(GemmArgs &a, int wmode, hipStream_t stream) {
+int try_stream(GemmArgs &a, int wmode, hipStream_t stream, bool dry = false) {
   if (wmode != W_NT || a.ngroups > 1 || a.epi == E_PLAIN) return -1;
   const char *e = getenv("EDA_GEMM_STREAM");
   if (e && atoi(e) == 0) return -1;
@@ -1075,6 +1114,7 @@ int try_stream(GemmArgs &a, int wmode, hipStream_t stream) {
   if (a.epi != E_SCATTER && (a.ldy % 4 != 0 || !al16(a.y))) return -1;
   if (a.xmode == X_GATHER && a.c_feat == 3) {
     if (a.epi != E_STATS || a.N != 64) return -1;
+    if (dry) return 0;
     const long ntiles = (a.R + 15) / 16;
     const int grid = stream_grid(gemm_gather3_kernel<64>, 256, ntiles, 4);
     a.ticket_target = (unsigned)grid;
@@ -1089,7 +1129,10 @@ int try_stream(GemmArgs &a, int wmode, hipStream_t stream) {
     K = a.c_feat;
   } else {
     if (!gemm_vec_ok(a, wmode)) return -1;
-    if (a.epi == E_MASK && (a.xmode != X_PLAIN || a.ldzm % 4 != 0 || !al16(a.zm))) return -1;
+    if (a.epi == E_MASK && ((a.xmode != X_PLAIN && a.xmode != X_BNBWDPOOL) || a.ldzm % 4 != 0 || !al16(a.zm))) return -1;
+    if (a.xmode == X_BNBWDPOOL && (a.epi != E_MASK || a.ldx != a.K || a.bb_pool <= 0 || a.bb_pool % 16 != 0 || !a.bb_argmax ||
+                                   !al16(a.bb_dout) || !al16(a.bb_consts) || (reinterpret_cast<uintptr_t>(a.bb_argmax) & 3u)))
+      return -1;
     if (a.epi == E_SCATTER && (a.xmode != X_PLAIN || a.N != a.c_feat)) return -1;
   }
   const int N = a.N;
@@ -1098,12 +1141,18 @@ int try_stream(GemmArgs &a, int wmode, hipStream_t stream) {
     int sK = 0, sN = 0, sE = -1;
     if (sscanf(sk, "%d,%d,%d", &sK, &sN, &sE) >= 2 && (sK == 0 || sK == K) && (sN == 0 || sN == N) && (sE < 0 || sE == a.epi)) return -1;
   }
+  if (dry) return ((K == 64 || K == 128) && (N == 64 || N % 128 == 0)) || K == 256 ? 0 : -1;
   if (K == 64 && N == 64) return launch_stream<64, 64, 8, 4>(a, stream);
   if (K == 64 && N % 128 == 0) return launch_stream<64, 128, 8, 2>(a, stream);
   if (K == 128 && N == 64) return launch_stream<128, 64, 8, 2>(a, stream);
   if (K == 128 && N % 128 == 0) return launch_stream<128, 128, 8, 2>(a, stream);
   if (K == 256) return launch_stream<256, 64, 8, 2>(a, stream);
   return -1;
+}
+
+bool stream_takes(const GemmArgs &a, int wmode) {
+  GemmArgs t = a;
+  return try_stream(t, wmode, nullptr, true) == 0;
 }
 
 int g_force_cfg() {
@@ -1118,8 +1167,14 @@ int g_force_cfg() {
 // powers of two), 128-row blocks when that still gives >= 2 workgroups per CU, else 64-row blocks.
 // Operands that are not 16-byte addressable take the element-wise 64x64 kernel.
 // EDA_GEMM_CFG=<WR><WC> forces a tile (e.g. 26).
+bool eda_gemm_stream_takes(const GemmArgs &a, int wmode) { return stream_takes(a, wmode); }
+
 int eda_gemm_launch(GemmArgs &a, int wmode, hipStream_t stream) {
   if (a.R <= 0 || a.N <= 0) return 0;
+  if (a.xmode == X_BNBWDPOOL && !stream_takes(a, wmode)) {
+    eda_set_error("gemm: the pooled BatchNorm-backward prologue exists in the streaming kernels only");
+    return EDA_ERR_INVALID_ARG;
+  }
   if (wmode == W_NN && a.xmode != X_PLAIN) { eda_set_error("gemm: dX form takes plain rows"); return EDA_ERR_INVALID_ARG; }
   // 32-bit element offsets: per 64/128-row tile for plain rows, from the tensor base for the gather
   if ((long)(64 * 2) * a.ldx >= 0x7fffffffL || (long)(wmode == W_NT ? a.N : a.K) * a.ldw >= 0x7fffffffL ||

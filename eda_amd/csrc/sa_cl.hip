@@ -941,6 +941,30 @@ int check_mlp(int nlayers, const int *channels, long R, int pool, const MlpGeom 
 }
 }  // namespace
 
+namespace {
+// Column constants of the pooled last layer's BatchNorm+ReLU backward (the arithmetic of bn_relu_bwd_apply_kernel,
+// train mode) for the kernels that form dz while staging instead of reading it: consts = {sc, sh, ka, kb, kd} (5 x C),
+// and the layer's d(gamma), d(beta).
+__global__ void bn_bwd_consts_kernel(const float *__restrict__ mean, const float *__restrict__ rstd,
+                                     const float *__restrict__ scale, const float *__restrict__ shift,
+                                     const float *__restrict__ gamma, const double *__restrict__ s1,
+                                     const double *__restrict__ s2, long R, int C, float *__restrict__ dgamma,
+                                     float *__restrict__ dbeta, float *__restrict__ consts) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invR = 1.f / (float)R;
+  dbeta[c] = (float)s1[c];
+  dgamma[c] = (float)s2[c];
+  const float gr = gamma[c] * rstd[c];
+  const float t2 = rstd[c] * (float)s2[c] * invR;
+  consts[c] = scale[c];
+  consts[C + c] = shift[c];
+  consts[2 * C + c] = gr;
+  consts[3 * C + c] = -gr * t2;
+  consts[4 * C + c] = gr * (mean[c] * t2 - (float)s1[c] * invR);
+}
+}  // namespace
+
 extern "C" int eda_sa_fused_fwd_f32(const float *x, long ldx, const float *xyz, const float *new_xyz,
                                     const float *feats_cl, const int *idx, int b, int n, int m, int ns, int c_feat,
                                     float radius, int normalize_xyz, long R, int nlayers, const int *channels,
@@ -1011,7 +1035,8 @@ extern "C" size_t eda_sa_fused_bwd_workspace_bytes(long R, int nlayers, const in
     const size_t n = (size_t)channels[l] * channels[l + 1];
     if (n > wt) wt = n;
   }
-  return sizeof(double) * 2 * (size_t)cmax + sizeof(float) * ((wt + 3) / 4 * 4) + slabs;
+  // red (2 x cmax doubles) | transposed weight | constants of the fused pooled BatchNorm backward (5 x cmax floats) | slabs
+  return sizeof(double) * 2 * (size_t)cmax + sizeof(float) * ((wt + 3) / 4 * 4) + sizeof(float) * 5 * (size_t)((cmax + 3) / 4 * 4) + slabs;
 }
 
 extern "C" int eda_sa_fused_bwd_f32(const float *dout, const unsigned char *argmax, const float *x, long ldx,
@@ -1053,8 +1078,24 @@ extern "C" int eda_sa_fused_bwd_f32(const float *dout, const unsigned char *argm
   }
   wt_floats = (wt_floats + 3) / 4 * 4;
   float *wt = reinterpret_cast<float *>(red + 2 * cmax);
-  float *slabs = wt + wt_floats;
-  const size_t slab_bytes = ws_bytes - sizeof(double) * 2 * (size_t)cmax - sizeof(float) * wt_floats;
+  const size_t const_floats = 5 * (size_t)((cmax + 3) / 4 * 4);
+  float *pool_consts = wt + wt_floats;
+  float *slabs = pool_consts + const_floats;
+  const size_t slab_bytes = ws_bytes - sizeof(double) * 2 * (size_t)cmax - sizeof(float) * (wt_floats + const_floats);
+  // Pooled last layer in training mode: its dz = ka*d + kb*z + kd need not be written and read back -- the two kernels
+  // that consume it (weight gradient, input gradient) form it while staging z, when the input gradient is a launch
+  // of the streaming kernels (gemm.hip X_BNBWDPOOL); otherwise bn_relu_bwd_apply_kernel<true> materialises it.
+  bool fuse_pool = false;
+  if (training && pool > 1 && pool % 16 == 0 && nlayers >= 2) {
+    const char *e = getenv("EDA_SA_BNBWD_FUSE");
+    const int l = nlayers - 1, cin = channels[l], cout = channels[l + 1];
+    GemmArgs t;
+    memset(&t, 0, sizeof(t));
+    t.xmode = X_BNBWDPOOL; t.epi = E_MASK; t.x = z[l]; t.ldx = cout; t.R = R; t.K = cout;
+    t.w = wt; t.ldw = cout; t.N = cin; t.y = scratch_b; t.ldy = cin; t.zm = z[l - 1]; t.ldzm = cin;
+    t.bb_argmax = argmax; t.bb_dout = dout; t.bb_consts = pool_consts; t.bb_pool = pool;
+    fuse_pool = !(e && atoi(e) == 0) && cout % 64 == 0 && eda_gemm_stream_takes(t, W_NT);
+  }
 
   // ---- last layer: BatchNorm+ReLU(+pool) backward from d(out) -> dz in scratch_a
   {
@@ -1074,7 +1115,10 @@ extern "C" int eda_sa_fused_bwd_f32(const float *dout, const unsigned char *argm
                          st, st + C, st + 2 * C, st + 3 * C, red, red + C);
     EDA_CHECK_LAUNCH();
     const int apply_grid = grid_for(R * (C / 4));
-    if (pool > 1)
+    if (fuse_pool)
+      hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, st, st + C, st + 2 * C,
+                         st + 3 * C, gamma[l], red, red + C, R, C, dgamma[l], dbeta[l], pool_consts);
+    else if (pool > 1)
       hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<true>, dim3(apply_grid), dim3(CL_THREADS), 0, stream, dout, argmax,
                          z[l], R, C, pool, st, st + C, st + 2 * C, st + 3 * C, gamma[l], red, red + C, training,
                          dgamma[l], dbeta[l], scratch_a);
@@ -1104,6 +1148,9 @@ extern "C" int eda_sa_fused_bwd_f32(const float *dout, const unsigned char *argm
         wa.in_scale = stats[l - 1] + 2 * cin; wa.in_shift = stats[l - 1] + 3 * cin;
       }
       wa.dW = dW[l]; wa.ws = slabs; wa.ws_bytes = slab_bytes;
+      if (fuse_pool && l == nlayers - 1) {
+        wa.dy = nullptr; wa.dy_pool = pool; wa.dyz = z[l]; wa.dy_argmax = argmax; wa.dy_dout = dout; wa.dy_consts = pool_consts;
+      }
       const int rc = eda_wgrad_x_launch(wa, stream);
       if (rc) return rc;
     }
@@ -1111,6 +1158,10 @@ extern "C" int eda_sa_fused_bwd_f32(const float *dout, const unsigned char *argm
     GemmArgs a;
     memset(&a, 0, sizeof(a));
     a.xmode = X_PLAIN; a.x = cur; a.ldx = cout; a.R = R; a.K = cout;
+    if (fuse_pool && l == nlayers - 1) {
+      a.xmode = X_BNBWDPOOL; a.x = z[l];
+      a.bb_argmax = argmax; a.bb_dout = dout; a.bb_consts = pool_consts; a.bb_pool = pool;
+    }
     // dX = dz W as an NT product with W^T (output columns x cout), transposed into the workspace
     const int wcols = (l == 0 && g.gather) ? c_feat : cin, wc0 = (l == 0 && g.gather) ? 3 : 0;
     const bool need_dx = l > 0 || (g.gather ? (dfeats_cl && c_feat > 0) : dx != nullptr);

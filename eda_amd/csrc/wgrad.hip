@@ -380,7 +380,9 @@ extern "C" int eda_wgrad_f32(const float *dy, long ld_dy, const float *x, long l
 // tile of the kernels above wasted 41-56 % of the MFMAs on the 64 / 128 / 256-wide SA layers.
 // TM/16 row strips x 2 column halves of waves, a wave owns 16 x TN/2 (TN/32 accumulators fed by ONE
 // A operand read each k step).
-template <int TM, int TN, int XMODE>
+// DYP: the dY operand is not stored; it is the dz of a pooled last SharedMLP layer, formed from the layer's
+// pre-activation, the pooling arg-max and the pooled gradient while staging (gemm.h: WgradXArgs::dy_pool)
+template <int TM, int TN, int XMODE, bool DYP = false>
 __global__ __launch_bounds__(TM * 8) void wgrad_x_kernel(const WgradXArgs a, int chunks_per_split, int tiles_n,
                                                          int ntiles, int nsplits) {
   constexpr int THREADS = TM * 8;                  // (TM/16) x 2 waves
@@ -429,6 +431,22 @@ __global__ __launch_bounds__(TM * 8) void wgrad_x_kernel(const WgradXArgs a, int
       bsh[i] = *reinterpret_cast<const float4 *>(a.in_shift + c);
     }
   }
+  float4 qsc[DYP ? LDA : 1], qsh[DYP ? LDA : 1], qka[DYP ? LDA : 1], qkb[DYP ? LDA : 1], qkd[DYP ? LDA : 1];
+  unsigned ram[DYP ? LDA : 1];
+  float4 rdo[DYP ? LDA : 1];
+  int rrp[DYP ? LDA : 1];
+  if (DYP) {
+#pragma unroll
+    for (int i = 0; i < LDA; ++i) {
+      const int mc = m0 + acol[i] < M ? m0 + acol[i] : M - 4;
+      const float *c = a.dy_consts + mc;
+      qsc[i] = *reinterpret_cast<const float4 *>(c);
+      qsh[i] = *reinterpret_cast<const float4 *>(c + M);
+      qka[i] = *reinterpret_cast<const float4 *>(c + 2 * M);
+      qkb[i] = *reinterpret_cast<const float4 *>(c + 3 * M);
+      qkd[i] = *reinterpret_cast<const float4 *>(c + 4 * M);
+    }
+  }
   const bool cvec = (a.c_feat & 3) == 0;
   // plain rows that are not 16-byte addressable (odd channel counts): element loads
   const bool x_elem = XMODE == X_PLAIN && ((N & 3) != 0 || (a.ld_x & 3) != 0 || (reinterpret_cast<uintptr_t>(a.x) & 15u) != 0);
@@ -451,7 +469,15 @@ __global__ __launch_bounds__(TM * 8) void wgrad_x_kernel(const WgradXArgs a, int
       if (k >= kend) k = kend - 1;                       // clamped: zeroed when staged
       if (arow[i] >= WG_KC) k = kend - 1;
       const int mc = m0 + acol[i] < M ? m0 + acol[i] : M - 4;
-      ra[i] = *reinterpret_cast<const float4 *>(a.dy + k * a.ld_dy + mc);
+      if (DYP) {
+        ra[i] = *reinterpret_cast<const float4 *>(a.dyz + k * M + mc);
+        const long grp = k / a.dy_pool;
+        rrp[i] = (int)(k - grp * a.dy_pool);
+        ram[i] = *reinterpret_cast<const unsigned *>(a.dy_argmax + grp * M + mc);
+        rdo[i] = *reinterpret_cast<const float4 *>(a.dy_dout + grp * M + mc);
+      } else {
+        ra[i] = *reinterpret_cast<const float4 *>(a.dy + k * a.ld_dy + mc);
+      }
     }
 #pragma unroll
     for (int i = 0; i < LDB; ++i) {
@@ -494,6 +520,15 @@ __global__ __launch_bounds__(TM * 8) void wgrad_x_kernel(const WgradXArgs a, int
     for (int i = 0; i < LDA; ++i) {
       if (arow[i] < WG_KC) {
         float4 va = ra[i];
+        if (DYP) {
+          const unsigned rp = (unsigned)rrp[i], am = ram[i];
+          const float dx_ = (am & 0xffu) == rp && va.x * qsc[i].x + qsh[i].x > 0.f ? rdo[i].x : 0.f;
+          const float dy_ = ((am >> 8) & 0xffu) == rp && va.y * qsc[i].y + qsh[i].y > 0.f ? rdo[i].y : 0.f;
+          const float dz_ = ((am >> 16) & 0xffu) == rp && va.z * qsc[i].z + qsh[i].z > 0.f ? rdo[i].z : 0.f;
+          const float dw_ = (am >> 24) == rp && va.w * qsc[i].w + qsh[i].w > 0.f ? rdo[i].w : 0.f;
+          va.x = qka[i].x * dx_ + qkb[i].x * va.x + qkd[i].x; va.y = qka[i].y * dy_ + qkb[i].y * va.y + qkd[i].y;
+          va.z = qka[i].z * dz_ + qkb[i].z * va.z + qkd[i].z; va.w = qka[i].w * dw_ + qkb[i].w * va.w + qkd[i].w;
+        }
         if (k0 + arow[i] >= kend || m0 + acol[i] >= M) va = make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4 *>(&As[arow[i]][acol[i]]) = va;
       }
@@ -644,6 +679,8 @@ void wgx_launch(const WgradXArgs &a, const WgxPlan &p, hipStream_t stream) {
   const dim3 grid((unsigned)(8 * ntiles * ((p.splits + 7) / 8))), block(TM * 8);
   if (a.xmode == X_PLAIN)
     hipLaunchKernelGGL((wgrad_x_kernel<TM, TN, X_PLAIN>), grid, block, 0, stream, a, p.cps, p.tiles_n, ntiles, p.splits);
+  else if (a.xmode == X_BNRELU && a.dy_pool > 0)
+    hipLaunchKernelGGL((wgrad_x_kernel<TM, TN, X_BNRELU, true>), grid, block, 0, stream, a, p.cps, p.tiles_n, ntiles, p.splits);
   else if (a.xmode == X_BNRELU)
     hipLaunchKernelGGL((wgrad_x_kernel<TM, TN, X_BNRELU>), grid, block, 0, stream, a, p.cps, p.tiles_n, ntiles, p.splits);
   else
@@ -664,7 +701,14 @@ int eda_wgrad_x_launch(const WgradXArgs &a, hipStream_t stream) {
     const int ncols = a.xmode == X_GATHER ? a.N - 1 : a.N;
     return eda_zero_async(a.dW, sizeof(float) * (size_t)a.M * ncols, stream);
   }
-  if (a.M % 4 != 0 || a.ld_dy % 4 != 0 || (reinterpret_cast<uintptr_t>(a.dy) & 15u) != 0 || a.M < 4) {
+  if (a.dy_pool > 0) {
+    if (a.xmode != X_BNRELU || a.M % 4 != 0 || !a.dyz || !a.dy_argmax || !a.dy_dout || !a.dy_consts ||
+        ((reinterpret_cast<uintptr_t>(a.dyz) | reinterpret_cast<uintptr_t>(a.dy_dout) | reinterpret_cast<uintptr_t>(a.dy_consts)) & 15u) ||
+        (reinterpret_cast<uintptr_t>(a.dy_argmax) & 3u)) {
+      eda_set_error("wgrad_x: bad operands for the pooled BatchNorm-backward dY prologue");
+      return EDA_ERR_INVALID_ARG;
+    }
+  } else if (a.M % 4 != 0 || a.ld_dy % 4 != 0 || (reinterpret_cast<uintptr_t>(a.dy) & 15u) != 0 || a.M < 4) {
     eda_set_error("wgrad_x: dY rows must be 16-byte addressable");
     return EDA_ERR_INVALID_ARG;
   }
