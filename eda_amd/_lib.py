@@ -78,6 +78,8 @@ SIGNATURES = {
     "eda_sa_fused_bwd_workspace_bytes": (_sz, [_l, _i, _p, _i]),
     "eda_sa_fused_bwd_f32": (_i, [_p, _p, _p, _l, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _l, _i, _p, _p, _p,
                                  _p, _p, _i, _i, _p, _p, _p, _sz, _p, _p, _p, _p, _l, _p, _p]),
+    "eda_sa_fused_bwd_wt_f32": (_i, [_p, _p, _p, _l, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _l, _i, _p, _p, _p,
+                                    _p, _p, _p, _i, _i, _p, _p, _p, _sz, _p, _p, _p, _p, _l, _p, _p]),
 }
 
 _lib = None

@@ -1039,14 +1039,17 @@ extern "C" size_t eda_sa_fused_bwd_workspace_bytes(long R, int nlayers, const in
   return sizeof(double) * 2 * (size_t)cmax + sizeof(float) * ((wt + 3) / 4 * 4) + sizeof(float) * 5 * (size_t)((cmax + 3) / 4 * 4) + slabs;
 }
 
-extern "C" int eda_sa_fused_bwd_f32(const float *dout, const unsigned char *argmax, const float *x, long ldx,
-                                    const float *xyz, const float *new_xyz, const float *feats_cl, const int *idx,
-                                    int b, int n, int m, int ns, int c_feat, float radius, int normalize_xyz, long R,
-                                    int nlayers, const int *channels, const float *const *weight,
-                                    const float *const *gamma, const float *const *z, const float *const *stats,
-                                    int training, int pool, float *scratch_a, float *scratch_b, void *ws_,
-                                    size_t ws_bytes, float *const *dW, float *const *dgamma, float *const *dbeta,
-                                    float *dx, long lddx, float *dfeats_cl, void *stream_) {
+// weight_t: optional per-layer pointers to W^T ((cin, cout) row-major, contiguous), e.g. from the caller's W^T shadow
+// (eda_amd/wt_shadow.py); a NULL array or entry makes the call transpose that layer's weight itself.
+static int sa_fused_bwd_impl(const float *dout, const unsigned char *argmax, const float *x, long ldx,
+                             const float *xyz, const float *new_xyz, const float *feats_cl, const int *idx,
+                             int b, int n, int m, int ns, int c_feat, float radius, int normalize_xyz, long R,
+                             int nlayers, const int *channels, const float *const *weight,
+                             const float *const *weight_t,
+                             const float *const *gamma, const float *const *z, const float *const *stats,
+                             int training, int pool, float *scratch_a, float *scratch_b, void *ws_,
+                             size_t ws_bytes, float *const *dW, float *const *dgamma, float *const *dbeta,
+                             float *dx, long lddx, float *dfeats_cl, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   MlpGeom g = {x, ldx, xyz, new_xyz, feats_cl, idx, b, n, m, ns, c_feat, normalize_xyz ? 1.0f / radius : 1.0f, idx != nullptr};
   { const int rc = check_mlp(nlayers, channels, R, pool, g); if (rc) return rc; }
@@ -1165,12 +1168,15 @@ extern "C" int eda_sa_fused_bwd_f32(const float *dout, const unsigned char *argm
     // dX = dz W as an NT product with W^T (output columns x cout), transposed into the workspace
     const int wcols = (l == 0 && g.gather) ? c_feat : cin, wc0 = (l == 0 && g.gather) ? 3 : 0;
     const bool need_dx = l > 0 || (g.gather ? (dfeats_cl && c_feat > 0) : dx != nullptr);
-    if (need_dx) {
+    const float *wt_l = wt;
+    if (need_dx && weight_t && weight_t[l] && (reinterpret_cast<uintptr_t>(weight_t[l]) & 15u) == 0 && cout % 4 == 0) {
+      wt_l = weight_t[l] + (size_t)wc0 * cout;              // rows wc0.. of W^T: the feature columns of a gather layer
+    } else if (need_dx) {
       hipLaunchKernelGGL(weight_transpose_kernel, dim3((wcols + 31) / 32, (cout + 31) / 32), dim3(32, 8), 0, stream,
                          weight[l], cout, cin, wc0, wcols, wt);
       EDA_CHECK_LAUNCH();
     }
-    a.w = wt; a.ldw = cout;
+    a.w = wt_l; a.ldw = cout;
     if (l > 0) {
       const float *st = stats[l - 1];
       { const int zrc = eda_zero_async(red, sizeof(double) * 2 * cin, stream); if (zrc) return zrc; }
@@ -1203,6 +1209,33 @@ extern "C" int eda_sa_fused_bwd_f32(const float *dout, const unsigned char *argm
   return 0;
 }
 
+
+extern "C" int eda_sa_fused_bwd_f32(const float *dout, const unsigned char *argmax, const float *x, long ldx,
+                                    const float *xyz, const float *new_xyz, const float *feats_cl, const int *idx,
+                                    int b, int n, int m, int ns, int c_feat, float radius, int normalize_xyz, long R,
+                                    int nlayers, const int *channels, const float *const *weight,
+                                    const float *const *gamma, const float *const *z, const float *const *stats,
+                                    int training, int pool, float *scratch_a, float *scratch_b, void *ws_,
+                                    size_t ws_bytes, float *const *dW, float *const *dgamma, float *const *dbeta,
+                                    float *dx, long lddx, float *dfeats_cl, void *stream_) {
+  return sa_fused_bwd_impl(dout, argmax, x, ldx, xyz, new_xyz, feats_cl, idx, b, n, m, ns, c_feat, radius, normalize_xyz, R,
+                           nlayers, channels, weight, nullptr, gamma, z, stats, training, pool, scratch_a, scratch_b, ws_,
+                           ws_bytes, dW, dgamma, dbeta, dx, lddx, dfeats_cl, stream_);
+}
+
+extern "C" int eda_sa_fused_bwd_wt_f32(const float *dout, const unsigned char *argmax, const float *x, long ldx,
+                                       const float *xyz, const float *new_xyz, const float *feats_cl, const int *idx,
+                                       int b, int n, int m, int ns, int c_feat, float radius, int normalize_xyz, long R,
+                                       int nlayers, const int *channels, const float *const *weight,
+                                       const float *const *weight_t,
+                                       const float *const *gamma, const float *const *z, const float *const *stats,
+                                       int training, int pool, float *scratch_a, float *scratch_b, void *ws_,
+                                       size_t ws_bytes, float *const *dW, float *const *dgamma, float *const *dbeta,
+                                       float *dx, long lddx, float *dfeats_cl, void *stream_) {
+  return sa_fused_bwd_impl(dout, argmax, x, ldx, xyz, new_xyz, feats_cl, idx, b, n, m, ns, c_feat, radius, normalize_xyz, R,
+                           nlayers, channels, weight, weight_t, gamma, z, stats, training, pool, scratch_a, scratch_b, ws_,
+                           ws_bytes, dW, dgamma, dbeta, dx, lddx, dfeats_cl, stream_);
+}
 
 // ---- sibling BatchNorm+ReLU(+Dropout) modules on column blocks of one (R, ngroups*cpg) matrix ------
 // (the three ThreeLayerMLPs of a ClsAgnosticPredictHead, models/modules.py:111-178, run side by

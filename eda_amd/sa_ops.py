@@ -270,18 +270,26 @@ class FusedMLP(Function):
         lib = _lib.lib()
         ws_bytes = lib.eda_sa_fused_bwd_workspace_bytes(R, L, chan_arr, int(gather))
         ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
+        # W^T of the layers' weights, where the caller's shadow has them (eda_amd/wt_shadow.py): the call then skips
+        # its per-layer transpose launches
+        from . import wt_shadow
+        wts = [None] * L
+        if wt_shadow.active is not None:
+            for l in range(L):
+                v = wt_shadow.active.lookup(Ws[l])
+                wts[l] = v if (v is not None and v.is_contiguous()) else None
         with torch.cuda.device(dev), _timed('sa_fused_bwd', (R, pool, int(training)) + tuple(chans)):
-            rc = lib.eda_sa_fused_bwd_f32(
+            rc = lib.eda_sa_fused_bwd_wt_f32(
                 dout.data_ptr(), argmax.data_ptr() if argmax is not None else None,
                 x_rows.data_ptr() if not gather else None, x_rows.stride(0) if not gather else 0,
                 xyz.data_ptr() if gather else None, new_xyz.data_ptr() if gather else None,
                 feats_cl.data_ptr() if gather and C else None, idx.data_ptr() if gather else None,
-                B, N, m, ns, C, radius, int(normalize), R, L, chan_arr, _ptr_array(Ws), _ptr_array(gammas),
+                B, N, m, ns, C, radius, int(normalize), R, L, chan_arr, _ptr_array(Ws), _ptr_array(wts), _ptr_array(gammas),
                 _ptr_array(z), _ptr_array(stats), int(training), pool, sa.data_ptr(), sb.data_ptr(),
                 ws.data_ptr(), ws_bytes, _ptr_array(dW), _ptr_array([g[0] for g in dgb]),
                 _ptr_array([g[1] for g in dgb]), dx.data_ptr() if dx is not None else None,
                 dx.stride(0) if dx is not None else 0, dfeats.data_ptr() if dfeats is not None else None, _stream())
-        _lib.check(rc, "eda_sa_fused_bwd_f32")
+        _lib.check(rc, "eda_sa_fused_bwd_wt_f32")
         grads = []
         for l in range(L):
             grads += [dW[l].view(wshapes[l]), dgb[l][0], dgb[l][1]]

@@ -375,6 +375,19 @@ int eda_sa_fused_bwd_f32(const float *dout, const unsigned char *argmax, const f
                          size_t ws_bytes, float *const *dW, float *const *dgamma, float *const *dbeta,
                          float *dx, long lddx, float *dfeats_cl, void *stream);
 
+/* eda_sa_fused_bwd_f32 with one more argument: weight_t[l] = W_l^T ((channels[l], channels[l+1]) row-major, 16-byte
+ * aligned) where the caller keeps the transposes at hand (eda_transpose_batch_f32), NULL entries where not: the call then
+ * skips its own per-layer transpose launch. */
+int eda_sa_fused_bwd_wt_f32(const float *dout, const unsigned char *argmax, const float *x, long ldx,
+                            const float *xyz, const float *new_xyz, const float *feats_cl, const int *idx,
+                            int b, int n, int m, int ns, int c_feat, float radius, int normalize_xyz, long R,
+                            int nlayers, const int *channels, const float *const *weight,
+                            const float *const *weight_t,
+                            const float *const *gamma, const float *const *z, const float *const *stats,
+                            int training, int pool, float *scratch_a, float *scratch_b, void *ws,
+                            size_t ws_bytes, float *const *dW, float *const *dgamma, float *const *dbeta,
+                            float *dx, long lddx, float *dfeats_cl, void *stream);
+
 /* ---- sibling layers in one launch ---------------------------------------------------------------
  * The three ThreeLayerMLPs of a ClsAgnosticPredictHead (models/modules.py:111-178: centre, size,
  * semantic scores) are independent stacks of the same shape; the reference runs them one layer at
