@@ -1035,8 +1035,8 @@ extern "C" size_t eda_sa_fused_bwd_workspace_bytes(long R, int nlayers, const in
     const size_t n = (size_t)channels[l] * channels[l + 1];
     if (n > wt) wt = n;
   }
-  // red (2 x cmax doubles) | transposed weight | constants of the fused pooled BatchNorm backward (5 x cmax floats) | slabs
-  return sizeof(double) * 2 * (size_t)cmax + sizeof(float) * ((wt + 3) / 4 * 4) + sizeof(float) * 5 * (size_t)((cmax + 3) / 4 * 4) + slabs;
+  // red (one region of 2 x cmax doubles per layer, all zeroed by ONE launch) | transposed weight | constants of the fused pooled BatchNorm backward (5 x cmax floats) | slabs
+  return sizeof(double) * 2 * (size_t)cmax * nlayers + sizeof(float) * ((wt + 3) / 4 * 4) + sizeof(float) * 5 * (size_t)((cmax + 3) / 4 * 4) + slabs;
 }
 
 // weight_t: optional per-layer pointers to W^T ((cin, cout) row-major, contiguous), e.g. from the caller's W^T shadow
@@ -1073,18 +1073,19 @@ static int sa_fused_bwd_impl(const float *dout, const unsigned char *argmax, con
   EDA_CHECK_ARG(pool == 1 || argmax, "argmax required when pooling");
   int cmax = 0;
   for (int l = 1; l <= nlayers; ++l) if (channels[l] > cmax) cmax = channels[l];
-  double *red = reinterpret_cast<double *>(ws_);
+  double *red_all = reinterpret_cast<double *>(ws_);      // region l: the two BatchNorm-backward reductions of layer l
   size_t wt_floats = 0;
   for (int l = 0; l < nlayers; ++l) {
     const size_t nn = (size_t)channels[l] * channels[l + 1];
     if (nn > wt_floats) wt_floats = nn;
   }
   wt_floats = (wt_floats + 3) / 4 * 4;
-  float *wt = reinterpret_cast<float *>(red + 2 * cmax);
+  { const int zrc = eda_zero_async(red_all, sizeof(double) * 2 * (size_t)cmax * nlayers, stream); if (zrc) return zrc; }
+  float *wt = reinterpret_cast<float *>(red_all + 2 * (size_t)cmax * nlayers);
   const size_t const_floats = 5 * (size_t)((cmax + 3) / 4 * 4);
   float *pool_consts = wt + wt_floats;
   float *slabs = pool_consts + const_floats;
-  const size_t slab_bytes = ws_bytes - sizeof(double) * 2 * (size_t)cmax - sizeof(float) * (wt_floats + const_floats);
+  const size_t slab_bytes = ws_bytes - sizeof(double) * 2 * (size_t)cmax * nlayers - sizeof(float) * (wt_floats + const_floats);
   // Pooled last layer in training mode: its dz = ka*d + kb*z + kd need not be written and read back -- the two kernels
   // that consume it (weight gradient, input gradient) form it while staging z, when the input gradient is a launch
   // of the streaming kernels (gemm.hip X_BNBWDPOOL); otherwise bn_relu_bwd_apply_kernel<true> materialises it.
@@ -1104,7 +1105,7 @@ static int sa_fused_bwd_impl(const float *dout, const unsigned char *argmax, con
   {
     const int l = nlayers - 1, C = channels[nlayers];
     const float *st = stats[l];
-    { const int zrc = eda_zero_async(red, sizeof(double) * 2 * C, stream); if (zrc) return zrc; }
+    double *red = red_all + 2 * (size_t)cmax * l;
     int nblocks = 1024;
     long rpb = (R + nblocks - 1) / nblocks;
     if (rpb < 64) rpb = 64;
@@ -1179,7 +1180,7 @@ static int sa_fused_bwd_impl(const float *dout, const unsigned char *argmax, con
     a.w = wt_l; a.ldw = cout;
     if (l > 0) {
       const float *st = stats[l - 1];
-      { const int zrc = eda_zero_async(red, sizeof(double) * 2 * cin, stream); if (zrc) return zrc; }
+      double *red = red_all + 2 * (size_t)cmax * (l - 1);
       a.N = cin; a.y = other; a.ldy = cin;
       a.epi = E_MASK;
       a.zm = z[l - 1]; a.ldzm = cin;
