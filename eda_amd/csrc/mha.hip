@@ -29,6 +29,9 @@
 // p is quantised to 1/65536).  seed = *seed_ptr (device counter, so a replayed HIP graph sees a new
 // mask every step) mixed with a per-call-site salt.
 #include "eda_common.h"
+#include "mha2.h"
+
+#include <stdlib.h>
 
 namespace {
 
@@ -848,6 +851,12 @@ __global__ __launch_bounds__(256) void mha_part_reduce_kernel(const float *__res
 // durations, e.g. 256x1024 dK/dV 90 -> 152 us, 256x80 fwd 13.0 -> 16.9 us: each workgroup then
 // stages all of K/V alone) and is no longer instantiated.
 bool mult4(long v) { return (v & 3) == 0; }
+// EDA_MHA_IMPL=1 selects the round-1/2 kernels of this file (64-row tiles, two-kernel backward) instead of
+// csrc/mha2.hip (read once; for A/B measurements and as a cross-check in the tests)
+int mha_impl() {
+  static const int impl = [] { const char *e = getenv("EDA_MHA_IMPL"); return e ? atoi(e) : 2; }();
+  return impl;
+}
 bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
@@ -876,6 +885,14 @@ extern "C" int eda_mha_fwd_f32(const float *q, const float *k, const float *v, l
                     al16(q) && al16(k) && al16(v) && al16(out),
                 "rows must be 16-byte aligned");
   EDA_CHECK_ARG((long)B * H <= 65535, "B*H too large");
+  if (mha_impl() != 1 && Lk > 0) {
+    Mha2Args m = {};
+    m.q = q; m.k = k; m.v = v; m.q_sb = q_sb; m.q_sl = q_sl; m.k_sb = k_sb; m.k_sl = k_sl;
+    m.v_sb = v_sb; m.v_sl = v_sl; m.o = out; m.o_sb = (long)Lq * H * HD; m.o_sl = (long)H * HD;
+    m.lse = lse; m.mask = key_padding_mask; m.B = B; m.H = H; m.Lq = Lq; m.Lk = Lk; m.scale = scale;
+    m.p_drop = p_drop; m.seed_ptr = seed_ptr; m.salt = salt;
+    return eda_mha2_fwd_launch(m, stream);
+  }
   MhaArgs a = {};
   a.q = q; a.k = k; a.v = v; a.q_sb = q_sb; a.q_sl = q_sl; a.k_sb = k_sb; a.k_sl = k_sl;
   a.v_sb = v_sb; a.v_sl = v_sl; a.o = out; a.o_sb = (long)Lq * H * HD; a.o_sl = (long)H * HD;
@@ -902,6 +919,7 @@ static int dkv_splits(int B, int H, int Lq, int Lk) {
 }
 
 extern "C" size_t eda_mha_bwd_workspace_bytes(int B, int H, int Lq, int Lk) {
+  if (mha_impl() != 1) return eda_mha2_bwd_workspace_bytes(B, H, Lq, Lk);
   // one scratch area, used first by the dQ key split, then by the dK/dV query split
   const int s = dkv_splits(B, H, Lq, Lk), sq = dkv_splits(B, H, Lk, Lq);
   size_t need = 0;
@@ -933,6 +951,16 @@ extern "C" int eda_mha_bwd_f32(const float *q, const float *k, const float *v, l
                     al16(dout) && al16(dq) && al16(dk) && al16(dv),
                 "rows must be 16-byte aligned");
   EDA_CHECK_ARG((long)B * H <= 65535, "B*H too large");
+  if (mha_impl() != 1 && Lq > 0 && Lk > 0) {
+    Mha2Args m = {};
+    m.q = q; m.k = k; m.v = v; m.q_sb = q_sb; m.q_sl = q_sl; m.k_sb = k_sb; m.k_sl = k_sl;
+    m.v_sb = v_sb; m.v_sl = v_sl; m.o = const_cast<float *>(out); m.o_sb = (long)Lq * H * HD; m.o_sl = (long)H * HD;
+    m.lse = const_cast<float *>(lse); m.mask = key_padding_mask; m.B = B; m.H = H; m.Lq = Lq; m.Lk = Lk;
+    m.scale = scale; m.p_drop = p_drop; m.seed_ptr = seed_ptr; m.salt = salt;
+    m.dout = dout; m.do_sb = do_sb; m.do_sl = do_sl; m.dq = dq; m.dk = dk; m.dv = dv;
+    m.dq_sb = dq_sb; m.dq_sl = dq_sl; m.dk_sb = dk_sb; m.dk_sl = dk_sl; m.dv_sb = dv_sb; m.dv_sl = dv_sl;
+    return eda_mha2_bwd_launch(m, ws, ws_bytes, stream);
+  }
   MhaArgs a = {};
   a.q = q; a.k = k; a.v = v; a.q_sb = q_sb; a.q_sl = q_sl; a.k_sb = k_sb; a.k_sl = k_sl;
   a.v_sb = v_sb; a.v_sl = v_sl; a.lse = const_cast<float *>(lse); a.mask = key_padding_mask;

@@ -1,0 +1,30 @@
+// mha2.h -- launch interface of the round-3 attention kernels (csrc/mha2.hip); the C ABI stays
+// eda_mha_fwd_f32 / eda_mha_bwd_f32 (csrc/mha.hip), which dispatch here.
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct Mha2Args {
+  const float *q, *k, *v;                     // head h at column h*36 of a row; rows strided
+  long q_sb, q_sl, k_sb, k_sl, v_sb, v_sl;    // element strides (batch, row)
+  float *o; long o_sb, o_sl;                  // forward output / saved output (B,Lq,288)
+  float *lse;                                 // (B,H,Lq) natural-log log-sum-exp of the scaled masked scores
+  const unsigned char *mask;                  // (B,Lk) 1 = ignore, or null
+  int B, H, Lq, Lk;
+  float scale, p_drop;
+  const unsigned long long *seed_ptr; unsigned salt;
+  // backward
+  const float *dout; long do_sb, do_sl;
+  float *dq, *dk, *dv;
+  long dq_sb, dq_sl, dk_sb, dk_sl, dv_sb, dv_sl;
+  // decomposition (filled by the launchers)
+  int n_kb;          // bwd: key blocks of 16*NW keys        fwd: unused
+  int n_qs;          // bwd: query splits                    fwd: query blocks of 16*NQ queries
+  int q_per_wg;      // bwd: queries per query split (multiple of the chunk)
+  float *dq_part;    // bwd: [key block][B][Lq][H*36] dense partials of dQ (n_kb > 1)
+  float *dkv_part;   // bwd: [query split][dk | dv][B][Lk][H*36] dense partials (n_qs > 1)
+};
+
+// 0 = launched, EDA_ERR_* otherwise.  Both enqueue on `stream` only, allocate nothing, never synchronise.
+int eda_mha2_fwd_launch(Mha2Args &a, hipStream_t stream);
+int eda_mha2_bwd_launch(Mha2Args &a, void *ws, size_t ws_bytes, hipStream_t stream);
+size_t eda_mha2_bwd_workspace_bytes(int B, int H, int Lq, int Lk);

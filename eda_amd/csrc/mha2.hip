@@ -1,0 +1,788 @@
+// mha2.hip -- round-3 fused multi-head attention for gfx950 (fp32 MFMA), forward and ONE-PASS backward.
+//
+// Replaces the 64-row-tile kernels of mha.hip (kept behind EDA_MHA_IMPL=1) for the attention the reference runs
+// through torch.nn.MultiheadAttention (models/encoder_decoder_layers.py:87-117, 149-153, 179-183, 366-401 ->
+// F.multi_head_attention_forward: q*scale, bmm QK^T, -inf key-padding fill, softmax, dropout(0.1), bmm PV).
+//
+// What was wrong with the old structure (profiles/r01k_mha_pmc.md): 4-wave workgroups that stage a 64-row tile,
+// meet at a barrier and do ~2700 cycles of MFMA per 7700-cycle tile; 168 registers -> 3 waves per SIMD, so the
+// 1024 workgroups of a 1024 x 1024 launch run as 768 + 256; and the backward computed S and dP twice (dQ kernel
+// and dK/dV kernel: 72 MFMAs per 16 x 16 pair for 45 useful).
+//
+// Structure here (both kernels): ONE big workgroup per CU (up to 16 waves = 4 per SIMD, <= 128 registers), the
+// streamed operand arrives in LARGE chunks (128 query rows / 256 key rows) by LDS-DMA (global_load_lds_dwordx4:
+// no staging registers, no LDS store pass) into a double buffer, and between two chunk barriers every wave works
+// through its 4-16 sixteen-row sub-tiles on its own -- the waves of a SIMD drift apart and one wave's
+// softmax / exp / dropout VALU runs under another's MFMAs.
+//
+//   forward   wave = 16 queries (x a share of the key tiles when Lq is short: the partial (m, l, O) of the KS
+//             key shares are merged through LDS at the end); S^T = K Q^T so that a query's softmax statistics
+//             are lane-local (as in mha.hip), exp2 with log2(e) folded into the query scale, 1/(1-p) folded
+//             into the final 1/l.
+//   backward  wave = 16 keys: K, V rows in registers for the lifetime of the workgroup, dK^T / dV^T
+//             accumulators in registers.  Per 16-query sub-tile: S = Q K^T and dP = dO V^T (9 + 9 MFMA),
+//             P = exp2(S - lse), dS = P o (dP - delta); dV^T += dO^T P, dK^T += Q^T dS (12 + 12); dS is
+//             TRANSPOSED through a wave-private LDS scratch (4 ds_write_b32 + 1 ds_read_b128; an in-wave LDS
+//             write -> read needs no barrier) and dQ^T = K^T dS^T (12) is added into a per-chunk LDS
+//             accumulator with ds_add_f32 (the 16 waves own different keys of the same queries); the chunk's
+//             dQ is flushed one chunk later -- a plain store when the workgroup owns all keys of its (scene,
+//             head), fp32 atomics when the key range is split over workgroups (then an up-front zero launch).
+//             54 MFMAs per pair, 45 useful (head_dim 36 = 9 k-steps in the contraction, 3 x 16 rows as output).
+//             delta = rowsum(dO o O) is computed while a chunk is staged.
+//
+// Dropout: the counter hash of mha.hip (one 32-bit hash per two keys, 16 bits each) -- the masks of the two
+// implementations are identical, so either forward pairs with either backward.
+#include "eda_common.h"
+#include "mha2.h"
+
+#include <stdlib.h>
+
+namespace {
+
+constexpr int HD = 36;
+constexpr int KSTEPS = 9;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ unsigned hash32(unsigned x) {     // = mha.hip
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+
+// reductions over the 4 lane groups (lanes l, l^16, l^32, l^48) with the gfx950 row / half swaps
+__device__ __forceinline__ float grp_max(float v) {
+  u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+  r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+}
+__device__ __forceinline__ float grp_sum(float v) {
+  u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r.x) + __uint_as_float(r.y);
+  r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+
+// A lane's 9 contraction values of one 36-float row: MFMA k-step s of lane group g contracts head dim 8g+s
+// (s < 8) and 32+g (s = 8) -- any permutation is fine as long as both operands use it -- so the first eight are
+// two 16-byte reads (mha.hip "LDS operand layouts"; row stride 36 is conflict-free for them).
+__device__ __forceinline__ void load_row_operand(float (&r)[KSTEPS], const float *row, int g) {
+  const float4 x = *reinterpret_cast<const float4 *>(row + 8 * g);
+  const float4 y = *reinterpret_cast<const float4 *>(row + 8 * g + 4);
+  r[0] = x.x; r[1] = x.y; r[2] = x.z; r[3] = x.w;
+  r[4] = y.x; r[5] = y.y; r[6] = y.z; r[7] = y.w;
+  r[8] = row[32 + g];
+}
+
+// The lane's transposed-operand values of one 16-row sub-tile of a ROW-major tile (contracted over the rows):
+// v[t][n] = X[row 4g + t][dim c + 16n]; third column tile: dim 32 + (c & 3), its output rows >= 36 are never used.
+struct ColOperand { float v[4][3]; };
+__device__ __forceinline__ void load_col_operand(ColOperand &o, const float *rows, int c, int g) {
+  const float *p = rows + 4 * g * HD;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    o.v[t][0] = p[t * HD + c];
+    o.v[t][1] = p[t * HD + 16 + c];
+    o.v[t][2] = p[t * HD + 32 + (c & 3)];
+  }
+}
+
+struct DropCfg { unsigned seed, thresh; float inv_keep; };
+__device__ __forceinline__ DropCfg drop_cfg(const Mha2Args &a) {
+  DropCfg dc = {0u, 0u, 1.f};
+  if (a.p_drop > 0.f) {
+    dc.seed = hash32((unsigned)(*a.seed_ptr) * 0x9E3779B1u + a.salt);
+    dc.thresh = (unsigned)((double)a.p_drop * 65536.0 + 0.5);
+    dc.inv_keep = 1.f / (1.f - a.p_drop);
+  }
+  return dc;
+}
+
+// LDS-DMA of `rows` x 36 floats (row r of the tile = global row min(row0 + r, nrows - 1) of one head) into a
+// LINEAR [rows][36] LDS tile: piece p = 64 consecutive 16-byte granules, one wave-instruction each
+// (the destination of lane l is base + 1 KiB * p + 16 l; the source address is per lane).
+template <int ROWS, int NW>
+__device__ __forceinline__ void dma_rows(float *lds, const float *base, long row_stride, int row0, int nrows,
+                                         int wave, int lane, int first_piece) {
+  constexpr int G = ROWS * 9;                  // 16-byte granules of the tile
+  constexpr int P = (G + 63) / 64;             // pieces (the last one may be partial: its surplus lanes are masked off)
+  for (int p = first_piece + wave; p < first_piece + P; p += NW) {
+    const int pp = p - first_piece;
+    const int i = 64 * pp + lane;
+    if (G % 64 == 0 || i < G) {
+      const int row = i / 9, c4 = i - row * 9;
+      const int grow = min(row0 + row, nrows - 1);
+      const float *src = base + (long)grow * row_stride + 4 * c4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)(lds + 256 * pp), 16, 0, 0);
+    }
+  }
+}
+
+// ======================================================================================== forward ==========
+// One 64-key tile for one wave (16 queries): NSUB live 16-key sub-tiles (compile time).  Scores arrive in the
+// log2 domain (the query operand carries scale * log2 e).
+template <int NSUB, bool DROP>
+__device__ __forceinline__ void fwd_tile(const float *__restrict__ Kt, const float *__restrict__ Vt,
+                                         const unsigned *__restrict__ deadw, bool need_mask,
+                                         const float (&qreg)[KSTEPS], int c, int g, int key0, unsigned rowbase,
+                                         const DropCfg &dc, float &m, float &lsum, f32x4 (&o)[3]) {
+  f32x4 st[NSUB];
+#pragma unroll
+  for (int j = 0; j < NSUB; ++j) st[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    float kreg[NSUB][KSTEPS];
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j) load_row_operand(kreg[j], Kt + (16 * j + c) * HD, g);
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+      for (int j = 0; j < NSUB; ++j) st[j] = mfma4(kreg[j][s], qreg[s], st[j]);
+  }
+  ColOperand va;
+  load_col_operand(va, Vt, c, g);
+  float tmax = -INFINITY;
+  if (need_mask) {
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j) {
+      const unsigned dw = deadw[4 * j + g];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool dead = ((dw >> (8 * r)) & 0xffu) != 0u;
+        st[j][r] = dead ? -INFINITY : st[j][r];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, st[j][r]);
+  tmax = grp_max(tmax);
+  const float m_new = fmaxf(m, tmax);
+  const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+  const float alpha = __builtin_amdgcn_exp2f(m - m_safe);       // m = -inf -> 0
+  float psum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float p = __builtin_amdgcn_exp2f(st[j][r] - m_safe);
+      st[j][r] = p;
+      psum += p;
+    }
+  lsum = lsum * alpha + psum;          // per lane group; the 4 groups are summed once at the end
+  m = m_new;
+#pragma unroll
+  for (int nt = 0; nt < 3; ++nt) o[nt] *= alpha;
+  if (DROP) {
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+      for (int r2 = 0; r2 < 4; r2 += 2) {
+        const unsigned h = hash32(dc.seed ^ (rowbase + (unsigned)(key0 + 16 * j + 4 * g + r2)));
+        st[j][r2] = (h & 0xffffu) >= dc.thresh ? st[j][r2] : 0.f;
+        st[j][r2 + 1] = (h >> 16) >= dc.thresh ? st[j][r2 + 1] : 0.f;
+      }
+  }
+  // O^T[dim][query] += V^T P^T
+#pragma unroll
+  for (int j = 0; j < NSUB; ++j) {
+    ColOperand vb;
+    if (j + 1 < NSUB) load_col_operand(vb, Vt + 16 * (j + 1) * HD, c, g);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float pb = st[j][t];
+      o[0] = mfma4(va.v[t][0], pb, o[0]);
+      o[1] = mfma4(va.v[t][1], pb, o[1]);
+      o[2] = mfma4(va.v[t][2], pb, o[2]);
+    }
+    if (j + 1 < NSUB) va = vb;
+  }
+}
+
+// NQ query sub-tiles x KS key shares = NW waves; CHK keys per LDS chunk, NBUF chunk buffers.
+template <int NQ, int KS, int CHK, int NBUF, bool DROP>
+__global__ __launch_bounds__(NQ * KS * 64) void mha2_fwd_kernel(const Mha2Args a) {
+  constexpr int NW = NQ * KS, NT = NW * 64;
+  constexpr int TILES = CHK / 64;
+  static_assert(CHK % 64 == 0 && (NBUF == 1 || NBUF == 2), "config");
+  __shared__ __attribute__((aligned(16))) float Ks0[CHK * HD];
+  __shared__ __attribute__((aligned(16))) float Vs0[CHK * HD];
+  __shared__ __attribute__((aligned(16))) float Ks1[NBUF == 2 ? CHK * HD : 4];
+  __shared__ __attribute__((aligned(16))) float Vs1[NBUF == 2 ? CHK * HD : 4];
+  __shared__ unsigned dead_s[NBUF][CHK / 4];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int BH = a.B * a.H;
+  const int bh = (int)(blockIdx.x % (unsigned)BH), qb = (int)(blockIdx.x / (unsigned)BH);
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int qs = wave / KS, ks = wave - qs * KS;
+  const int qi = qb * (16 * NQ) + 16 * qs + c;
+  const bool qvalid = qi < a.Lq;
+  const bool wave_live = qb * (16 * NQ) + 16 * qs < a.Lq;       // uniform: any valid query in this wave
+
+  const float *kbase = a.k + (long)b * a.k_sb + h * HD;
+  const float *vbase = a.v + (long)b * a.v_sb + h * HD;
+  const unsigned char *mrow = a.mask ? a.mask + (long)b * a.Lk : nullptr;
+
+  float qreg[KSTEPS];
+  {
+    const float *qrow = a.q + (long)b * a.q_sb + (long)(qvalid ? qi : 0) * a.q_sl + h * HD;
+    load_row_operand(qreg, qrow, g);
+    const float sc = a.scale * LOG2E;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) qreg[s] = qvalid ? qreg[s] * sc : 0.f;
+  }
+  DropCfg dc = {0u, 0u, 1.f};
+  if (DROP) dc = drop_cfg(a);
+  const unsigned rowbase = ((unsigned)bh * (unsigned)a.Lq + (unsigned)qi) * (unsigned)a.Lk;
+
+  auto stage = [&](float *Kd, float *Vd, unsigned *dd, int k0) {
+    // dead-key flags first (ordinary loads: keep them out of the span in which the DMA is in flight)
+    for (int w = tid; w < CHK / 4; w += NT) {
+      unsigned word = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = k0 + 4 * w + r;
+        unsigned dead = key >= a.Lk ? 1u : 0u;
+        if (key < a.Lk && mrow) dead = mrow[key] ? 1u : 0u;
+        word |= dead << (8 * r);
+      }
+      dd[w] = word;
+    }
+    dma_rows<CHK, NW>(Kd, kbase, a.k_sl, k0, a.Lk, wave, lane, 0);
+    dma_rows<CHK, NW>(Vd, vbase, a.v_sl, k0, a.Lk, wave, lane, CHK * 9 / 64);
+  };
+
+  float m = -INFINITY, lsum = 0.f;
+  f32x4 o[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+
+  auto compute = [&](const float *Kc, const float *Vc, const unsigned *dd, int k0) {
+    if (!wave_live) return;
+#pragma unroll 1
+    for (int t = ks; t < TILES; t += KS) {
+      const int key0 = k0 + 64 * t;
+      if (key0 >= a.Lk) break;
+      const int nsub = min(4, (a.Lk - key0 + 15) >> 4);
+      const bool need_mask = (mrow != nullptr) || (key0 + 64 > a.Lk);
+      const float *Kt = Kc + 64 * t * HD, *Vt = Vc + 64 * t * HD;
+      const unsigned *dw = dd + 16 * t;
+      if (nsub == 4) fwd_tile<4, DROP>(Kt, Vt, dw, need_mask, qreg, c, g, key0, rowbase, dc, m, lsum, o);
+      else if (nsub == 3) fwd_tile<3, DROP>(Kt, Vt, dw, need_mask, qreg, c, g, key0, rowbase, dc, m, lsum, o);
+      else if (nsub == 2) fwd_tile<2, DROP>(Kt, Vt, dw, need_mask, qreg, c, g, key0, rowbase, dc, m, lsum, o);
+      else fwd_tile<1, DROP>(Kt, Vt, dw, need_mask, qreg, c, g, key0, rowbase, dc, m, lsum, o);
+    }
+  };
+
+  const int nchunks = (a.Lk + CHK - 1) / CHK;
+  if (nchunks > 0) stage(Ks0, Vs0, dead_s[0], 0);
+  __syncthreads();
+  for (int ci = 0; ci < nchunks; ci += NBUF) {
+    // even chunk in buffer 0 (the next one is fetched into buffer 1 meanwhile), odd chunk in buffer 1
+    if (NBUF == 2 && ci + 1 < nchunks) stage(Ks1, Vs1, dead_s[1], (ci + 1) * CHK);
+    compute(Ks0, Vs0, dead_s[0], ci * CHK);
+    __syncthreads();
+    if (NBUF == 2) {
+      if (ci + 1 >= nchunks) break;
+      if (ci + 2 < nchunks) stage(Ks0, Vs0, dead_s[0], (ci + 2) * CHK);
+      compute(Ks1, Vs1, dead_s[1], (ci + 1) * CHK);
+      __syncthreads();
+    } else if (ci + 1 < nchunks) {
+      stage(Ks0, Vs0, dead_s[0], (ci + 1) * CHK);
+      __syncthreads();
+    }
+  }
+
+  // merge the KS key shares of a query sub-tile (K/V are dead now: their LDS is the scratch; one slot = 64
+  // lanes x 16 floats: O (12), m, l)
+  lsum = grp_sum(lsum);
+  if (KS > 1) {
+    constexpr int PER = 64 * 16, NPER = CHK * HD / PER;
+    static_assert((KS - 1) * NQ <= 2 * NPER, "merge scratch must fit the K/V buffers");
+    auto slot = [&](int q_, int k_) -> float * {
+      const int idx = q_ * (KS - 1) + (k_ - 1);
+      return idx < NPER ? Ks0 + idx * PER : Vs0 + (idx - NPER) * PER;
+    };
+    if (ks > 0 && wave_live) {
+      float *s_ = slot(qs, ks) + lane * 16;
+      *reinterpret_cast<f32x4 *>(s_) = o[0];
+      *reinterpret_cast<f32x4 *>(s_ + 4) = o[1];
+      *reinterpret_cast<f32x4 *>(s_ + 8) = o[2];
+      s_[12] = m; s_[13] = lsum;
+    }
+    __syncthreads();
+    if (ks == 0 && wave_live) {
+#pragma unroll 1
+      for (int k_ = 1; k_ < KS; ++k_) {
+        const float *s_ = slot(qs, k_) + lane * 16;
+        const f32x4 p0 = *reinterpret_cast<const f32x4 *>(s_);
+        const f32x4 p1 = *reinterpret_cast<const f32x4 *>(s_ + 4);
+        const f32x4 p2 = *reinterpret_cast<const f32x4 *>(s_ + 8);
+        const float mo = s_[12], lo = s_[13];
+        const float mn = fmaxf(m, mo);
+        const float ms = (mn == -INFINITY) ? 0.f : mn;
+        const float fa = __builtin_amdgcn_exp2f(m - ms), fb = __builtin_amdgcn_exp2f(mo - ms);
+        o[0] = o[0] * fa + p0 * fb; o[1] = o[1] * fa + p1 * fb; o[2] = o[2] * fa + p2 * fb;
+        lsum = lsum * fa + lo * fb;
+        m = mn;
+      }
+    }
+  }
+  if (qvalid && (KS == 1 || ks == 0)) {
+    const float inv = dc.inv_keep / lsum;          // all keys masked -> NaN, like the reference
+    float *orow = a.o + (long)b * a.o_sb + (long)qi * a.o_sl + h * HD;
+    *reinterpret_cast<float4 *>(orow + 4 * g) = make_float4(o[0][0] * inv, o[0][1] * inv, o[0][2] * inv, o[0][3] * inv);
+    *reinterpret_cast<float4 *>(orow + 16 + 4 * g) = make_float4(o[1][0] * inv, o[1][1] * inv, o[1][2] * inv, o[1][3] * inv);
+    if (g == 0) {
+      *reinterpret_cast<float4 *>(orow + 32) = make_float4(o[2][0] * inv, o[2][1] * inv, o[2][2] * inv, o[2][3] * inv);
+      a.lse[(long)bh * a.Lq + qi] = (m + __builtin_amdgcn_logf(lsum)) * LN2;     // v_log_f32 = log2
+    }
+  }
+}
+
+// ======================================================================================= backward ==========
+// KSUB key sub-tiles (16 keys each) x QG query groups = NW waves; QC queries per chunk, NBUF chunk buffers.
+//   phase A  wave (ks, qg): for the chunk's 16-query sub-tiles j = qg, qg + QG, ...: S = Q K^T, dP = dO V^T (18 MFMA),
+//            P, dS; dV^T += dO^T P, dK^T += Q^T dS (24 MFMA); dS goes to the LDS tile DS[query][key of the block]
+//   barrier
+//   phase B  work item (j, n) = one 16-dim x 16-query tile of dQ^T = K^T dS^T, contracted over ALL keys of the block
+//            (K^T from the block's K rows in LDS, dS^T as 16-byte reads of DS): 4 x live sub-tiles MFMAs per item, two
+//            interleaved accumulators; no partial sums, no atomics (ds_add_f32 from 16 waves measured 3x the whole
+//            kernel, scattered global fp32 atomics worse) -- written straight to dQ, or to this key block's partial
+//   barrier
+template <int KSUB, int QG, int QC, int NBUF, bool DROP>
+__global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args a) {
+  constexpr int NW = KSUB * QG, NT = NW * 64;
+  constexpr int KB = 16 * KSUB;        // keys per block
+  constexpr int DSS = KB + 4;          // dS tile row stride ([query][key])
+  constexpr int NSUBQ = QC / 16;
+  static_assert(QC % 16 == 0 && NSUBQ % QG == 0 && (NBUF == 1 || NBUF == 2) && NW <= 16, "config");
+  static_assert(QG == 1 || KSUB * 64 * 24 <= NSUBQ * 16 * DSS, "dK/dV merge scratch must fit the dS tile");
+  __shared__ __attribute__((aligned(16))) float Qs0[QC * HD];
+  __shared__ __attribute__((aligned(16))) float Ds0[QC * HD];
+  __shared__ __attribute__((aligned(16))) float Qs1[NBUF == 2 ? QC * HD : 4];
+  __shared__ __attribute__((aligned(16))) float Ds1[NBUF == 2 ? QC * HD : 4];
+  __shared__ __attribute__((aligned(16))) float lse_s[2][QC];
+  __shared__ __attribute__((aligned(16))) float del_s[2][QC];
+  __shared__ __attribute__((aligned(16))) float Kb[KB * HD];
+  __shared__ __attribute__((aligned(16))) float DS[NSUBQ * 16 * DSS];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int BH = a.B * a.H;
+  const int bh = (int)(blockIdx.x % (unsigned)BH);
+  const int rest = (int)(blockIdx.x / (unsigned)BH);
+  const int kb = rest % a.n_kb, qsp = rest / a.n_kb;
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int qg = wave / KSUB, ks = wave - qg * KSUB;
+
+  const int kblock0 = kb * KB;
+  const int key0 = kblock0 + 16 * ks;
+  const bool wave_live = key0 < a.Lk;                                   // uniform
+  const int nks_live = min(KSUB, (a.Lk - kblock0 + 15) >> 4);           // live key sub-tiles of this block
+  const int ki = key0 + c;
+  const bool kvalid = ki < a.Lk;
+  const bool kdead = !kvalid || (a.mask && a.mask[(long)b * a.Lk + (kvalid ? ki : 0)]);
+
+  DropCfg dc = {0u, 0u, 1.f};
+  if (DROP) dc = drop_cfg(a);
+
+  // the block's K rows -> LDS (operand of phase B), this wave's K / V rows -> registers (lane = key)
+  const float *kbase = a.k + (long)b * a.k_sb + h * HD;
+  for (int i = tid; i < KB * 9; i += NT) {
+    const int row = i / 9, c4 = i - row * 9;
+    const int kr = min(kblock0 + row, a.Lk - 1);
+    *reinterpret_cast<float4 *>(Kb + row * HD + 4 * c4) =
+        *reinterpret_cast<const float4 *>(kbase + (long)kr * a.k_sl + 4 * c4);
+  }
+  float kreg[KSTEPS], vreg[KSTEPS];
+  if (wave_live) {
+    const int kr = min(ki, a.Lk - 1);
+    load_row_operand(kreg, kbase + (long)kr * a.k_sl, g);
+    load_row_operand(vreg, a.v + (long)b * a.v_sb + (long)kr * a.v_sl + h * HD, g);
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      kreg[s] = kvalid ? kreg[s] : 0.f;
+      vreg[s] = kvalid ? vreg[s] * dc.inv_keep : 0.f;       // dP arrives already divided by the keep rate
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) { kreg[s] = 0.f; vreg[s] = 0.f; }
+  }
+
+  const int qbeg = qsp * a.q_per_wg;
+  const int qend = min(a.Lq, qbeg + a.q_per_wg);
+  const float *qbase = a.q + (long)b * a.q_sb + h * HD;
+  const float *dbase = a.dout + (long)b * a.do_sb + h * HD;
+  const float *obase = a.o + (long)b * a.o_sb + h * HD;
+  const float sl2 = a.scale * LOG2E;
+  // outputs: the tensors themselves, or this workgroup's dense partial (B, L, H*36) when the range is split
+  const int D = a.H * HD;
+  float *dq_out = a.dq + (long)b * a.dq_sb + h * HD;
+  long dq_sl = a.dq_sl;
+  if (a.n_kb > 1) { dq_out = a.dq_part + ((long)kb * a.B + b) * a.Lq * D + h * HD; dq_sl = D; }
+
+  // stage one chunk: lse (log2 domain, +inf for rows outside the range: their P is exactly 0) and
+  // delta = rowsum(dO o O) with ordinary loads, then Q and dO by LDS-DMA
+  auto stage = [&](float *Qd, float *Dd, float *lse_d, float *del_d, int q0) {
+    for (int item = tid; item < QC * 8; item += NT) {
+      const int row = item >> 3, sub = item & 7;
+      const int gq = q0 + row;
+      const bool valid = gq < qend;
+      const int gr = min(gq, a.Lq - 1);
+      const float *dr = dbase + (long)gr * a.do_sl, *orow = obase + (long)gr * a.o_sl;
+      const float4 d4 = *reinterpret_cast<const float4 *>(dr + 4 * sub);
+      const float4 o4 = *reinterpret_cast<const float4 *>(orow + 4 * sub);
+      float part = d4.x * o4.x + d4.y * o4.y + d4.z * o4.z + d4.w * o4.w;
+      if (sub == 0) {
+        const float4 d8 = *reinterpret_cast<const float4 *>(dr + 32);
+        const float4 o8 = *reinterpret_cast<const float4 *>(orow + 32);
+        part += d8.x * o8.x + d8.y * o8.y + d8.z * o8.z + d8.w * o8.w;
+      }
+      part += __shfl_xor(part, 1);
+      part += __shfl_xor(part, 2);
+      part += __shfl_xor(part, 4);
+      if (sub == 0) {
+        lse_d[row] = valid ? a.lse[(long)bh * a.Lq + gr] * LOG2E : INFINITY;
+        del_d[row] = valid ? part : 0.f;
+      }
+    }
+    constexpr int P = (QC * 9 + 63) / 64;
+    dma_rows<QC, NW>(Qd, qbase, a.q_sl, q0, a.Lq, wave, lane, 0);
+    dma_rows<QC, NW>(Dd, dbase, a.do_sl, q0, a.Lq, wave, lane, P);
+  };
+
+  f32x4 dk[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  f32x4 dv[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+
+  auto phase_a = [&](const float *Ql, const float *Dl, const float *lse_l, const float *del_l, int q0) {
+    if (!wave_live) return;
+    const int nsub = min(NSUBQ, (qend - q0 + 15) >> 4);
+#pragma unroll 1
+    for (int j = qg; j < nsub; j += QG) {
+      f32x4 sacc = {0, 0, 0, 0}, pacc = {0, 0, 0, 0};
+      {
+        float qa[KSTEPS], da[KSTEPS];
+        load_row_operand(qa, Ql + (16 * j + c) * HD, g);
+        load_row_operand(da, Dl + (16 * j + c) * HD, g);
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+          sacc = mfma4(qa[s], kreg[s], sacc);          // S[query 4g+r][key c]
+          pacc = mfma4(da[s], vreg[s], pacc);          // dP / keep
+        }
+      }
+      const float4 lse4 = *reinterpret_cast<const float4 *>(lse_l + 16 * j + 4 * g);
+      const float4 del4 = *reinterpret_cast<const float4 *>(del_l + 16 * j + 4 * g);
+      const float lse_r[4] = {lse4.x, lse4.y, lse4.z, lse4.w};
+      const float del_r[4] = {del4.x, del4.y, del4.z, del4.w};
+      // dropout bits: lanes c and c^1 (keys 2m, 2m+1) need the same four pair hashes (one per query r);
+      // each computes two of them and they swap through a quad-permute DPP move (= mha.hip)
+      unsigned h16[4] = {0xffffu, 0xffffu, 0xffffu, 0xffffu};
+      if (DROP) {
+        const int odd = c & 1;
+        const unsigned qa0 = (unsigned)(q0 + 16 * j + 4 * g + 2 * odd);
+        const unsigned kev = (unsigned)(ki & ~1);
+        const unsigned hx = hash32(dc.seed ^ (((unsigned)bh * (unsigned)a.Lq + qa0) * (unsigned)a.Lk + kev));
+        const unsigned hy = hash32(dc.seed ^ (((unsigned)bh * (unsigned)a.Lq + qa0 + 1u) * (unsigned)a.Lk + kev));
+        const unsigned nx = (unsigned)__builtin_amdgcn_mov_dpp((int)hx, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+        const unsigned ny = (unsigned)__builtin_amdgcn_mov_dpp((int)hy, 0xB1, 0xf, 0xf, true);
+        const unsigned h0 = odd ? nx : hx, h1 = odd ? ny : hy, h2 = odd ? hx : nx, h3 = odd ? hy : ny;
+        const int sh = 16 * odd;
+        h16[0] = (h0 >> sh) & 0xffffu; h16[1] = (h1 >> sh) & 0xffffu;
+        h16[2] = (h2 >> sh) & 0xffffu; h16[3] = (h3 >> sh) & 0xffffu;
+      }
+      f32x4 pd, ds;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], sl2, -lse_r[r]));     // rows outside the range: exp2(-inf) = 0
+        p = kdead ? 0.f : p;
+        float dp = pacc[r], pk = p;
+        if (DROP) {
+          const bool keep = h16[r] >= dc.thresh;
+          dp = keep ? dp : 0.f;
+          pk = keep ? p : 0.f;
+        }
+        pd[r] = pk;
+        ds[r] = p * (dp - del_r[r]);
+      }
+      // dS[query 4g+r][key c] -> the block's dS tile
+      float *dsw = DS + (16 * j + 4 * g) * DSS + 16 * ks + c;
+      dsw[0] = ds[0]; dsw[DSS] = ds[1]; dsw[2 * DSS] = ds[2]; dsw[3 * DSS] = ds[3];
+      // dV^T[dim][key] += dO^T pd ; dK^T[dim][key] += Q^T dS
+      {
+        ColOperand cd;
+        load_col_operand(cd, Dl + 16 * j * HD, c, g);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float pb = pd[t];
+          dv[0] = mfma4(cd.v[t][0], pb, dv[0]);
+          dv[1] = mfma4(cd.v[t][1], pb, dv[1]);
+          dv[2] = mfma4(cd.v[t][2], pb, dv[2]);
+        }
+      }
+      {
+        ColOperand cq;
+        load_col_operand(cq, Ql + 16 * j * HD, c, g);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float sb = ds[t];
+          dk[0] = mfma4(cq.v[t][0], sb, dk[0]);
+          dk[1] = mfma4(cq.v[t][1], sb, dk[1]);
+          dk[2] = mfma4(cq.v[t][2], sb, dk[2]);
+        }
+      }
+    }
+  };
+
+  // dQ^T tile (dims of column tile n) x (queries of sub-tile j), contracted over the block's live keys
+  auto phase_b = [&](int q0) {
+    const int nsub = min(NSUBQ, (qend - q0 + 15) >> 4);
+    const int nitems = 3 * nsub;
+#pragma unroll 1
+    for (int it = wave; it < nitems; it += NW) {
+      const int j = it / 3, n = it - 3 * j;
+      const int col = n < 2 ? 16 * n + c : 32 + (c & 3);
+      const float *kp = Kb + 4 * g * HD + col;                 // K[key 16s + 4g + t][col]
+      const float *dp_ = DS + (16 * j + c) * DSS + 4 * g;      // dS[query c][key 16s + 4g + t]
+      f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+      int s = 0;
+      for (; s + 1 < nks_live; s += 2) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(dp_ + 16 * s);
+        const f32x4 b1 = *reinterpret_cast<const f32x4 *>(dp_ + 16 * s + 16);
+        const float *k0 = kp + 16 * s * HD, *k1 = k0 + 16 * HD;
+        const float a00 = k0[0], a01 = k0[HD], a02 = k0[2 * HD], a03 = k0[3 * HD];
+        const float a10 = k1[0], a11 = k1[HD], a12 = k1[2 * HD], a13 = k1[3 * HD];
+        acc0 = mfma4(a00, b0[0], acc0); acc1 = mfma4(a10, b1[0], acc1);
+        acc0 = mfma4(a01, b0[1], acc0); acc1 = mfma4(a11, b1[1], acc1);
+        acc0 = mfma4(a02, b0[2], acc0); acc1 = mfma4(a12, b1[2], acc1);
+        acc0 = mfma4(a03, b0[3], acc0); acc1 = mfma4(a13, b1[3], acc1);
+      }
+      if (s < nks_live) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(dp_ + 16 * s);
+        const float *k0 = kp + 16 * s * HD;
+        acc0 = mfma4(k0[0], b0[0], acc0);
+        acc0 = mfma4(k0[HD], b0[1], acc0);
+        acc0 = mfma4(k0[2 * HD], b0[2], acc0);
+        acc0 = mfma4(k0[3 * HD], b0[3], acc0);
+      }
+      const int gq = q0 + 16 * j + c;
+      if (gq < qend && (n < 2 || g == 0)) {
+        const float sc = a.scale;
+        *reinterpret_cast<float4 *>(dq_out + (long)gq * dq_sl + 16 * n + 4 * g) =
+            make_float4((acc0[0] + acc1[0]) * sc, (acc0[1] + acc1[1]) * sc, (acc0[2] + acc1[2]) * sc,
+                        (acc0[3] + acc1[3]) * sc);
+      }
+    }
+  };
+
+  const int nchunks = qend > qbeg ? (qend - qbeg + QC - 1) / QC : 0;
+  if (nchunks > 0) stage(Qs0, Ds0, lse_s[0], del_s[0], qbeg);
+  __syncthreads();
+  for (int ci = 0; ci < nchunks; ci += NBUF) {
+    const int q0 = qbeg + ci * QC;
+    if (NBUF == 2) {
+      if (ci + 1 < nchunks) stage(Qs1, Ds1, lse_s[1], del_s[1], q0 + QC);
+      phase_a(Qs0, Ds0, lse_s[0], del_s[0], q0);
+      __syncthreads();
+      phase_b(q0);
+      __syncthreads();
+      if (ci + 1 >= nchunks) break;
+      if (ci + 2 < nchunks) stage(Qs0, Ds0, lse_s[0], del_s[0], q0 + 2 * QC);
+      phase_a(Qs1, Ds1, lse_s[1], del_s[1], q0 + QC);
+      __syncthreads();
+      phase_b(q0 + QC);
+      __syncthreads();
+    } else {
+      phase_a(Qs0, Ds0, lse_s[0], del_s[0], q0);
+      __syncthreads();
+      phase_b(q0);
+      if (ci + 1 < nchunks) stage(Qs0, Ds0, lse_s[0], del_s[0], q0 + QC);      // (Q / dO of this chunk are dead)
+      __syncthreads();
+    }
+  }
+
+  // dK / dV: merge the QG query groups of a key sub-tile through LDS (the dS tile is dead), then store
+  if (QG > 1) {
+    for (int r_ = 1; r_ < QG; ++r_) {
+      float *slot = DS + (ks * 64 + lane) * 24;
+      if (qg == r_ && wave_live) {
+        *reinterpret_cast<f32x4 *>(slot) = dk[0]; *reinterpret_cast<f32x4 *>(slot + 4) = dk[1];
+        *reinterpret_cast<f32x4 *>(slot + 8) = dk[2]; *reinterpret_cast<f32x4 *>(slot + 12) = dv[0];
+        *reinterpret_cast<f32x4 *>(slot + 16) = dv[1]; *reinterpret_cast<f32x4 *>(slot + 20) = dv[2];
+      }
+      __syncthreads();
+      if (qg == 0 && wave_live) {
+        dk[0] += *reinterpret_cast<const f32x4 *>(slot); dk[1] += *reinterpret_cast<const f32x4 *>(slot + 4);
+        dk[2] += *reinterpret_cast<const f32x4 *>(slot + 8); dv[0] += *reinterpret_cast<const f32x4 *>(slot + 12);
+        dv[1] += *reinterpret_cast<const f32x4 *>(slot + 16); dv[2] += *reinterpret_cast<const f32x4 *>(slot + 20);
+      }
+      __syncthreads();
+    }
+  }
+  if (kvalid && wave_live && qg == 0) {
+    const float sc = a.scale, ik = dc.inv_keep;
+    float *ok = a.dk + (long)b * a.dk_sb + (long)ki * a.dk_sl + h * HD;
+    float *ov = a.dv + (long)b * a.dv_sb + (long)ki * a.dv_sl + h * HD;
+    if (a.n_qs > 1) {          // dense partial of this query split: [split][dk | dv][B][Lk][D]
+      const long per = (long)a.B * a.Lk * D;
+      ok = a.dkv_part + (long)qsp * 2 * per + ((long)b * a.Lk + ki) * D + h * HD;
+      ov = ok + per;
+    }
+    *reinterpret_cast<float4 *>(ok + 4 * g) = make_float4(dk[0][0] * sc, dk[0][1] * sc, dk[0][2] * sc, dk[0][3] * sc);
+    *reinterpret_cast<float4 *>(ok + 16 + 4 * g) = make_float4(dk[1][0] * sc, dk[1][1] * sc, dk[1][2] * sc, dk[1][3] * sc);
+    *reinterpret_cast<float4 *>(ov + 4 * g) = make_float4(dv[0][0] * ik, dv[0][1] * ik, dv[0][2] * ik, dv[0][3] * ik);
+    *reinterpret_cast<float4 *>(ov + 16 + 4 * g) = make_float4(dv[1][0] * ik, dv[1][1] * ik, dv[1][2] * ik, dv[1][3] * ik);
+    if (g == 0) {
+      *reinterpret_cast<float4 *>(ok + 32) = make_float4(dk[2][0] * sc, dk[2][1] * sc, dk[2][2] * sc, dk[2][3] * sc);
+      *reinterpret_cast<float4 *>(ov + 32) = make_float4(dv[2][0] * ik, dv[2][1] * ik, dv[2][2] * ik, dv[2][3] * ik);
+    }
+  }
+}
+
+// out tensors (1: dq; 2: dk, dv) = sum over the splits of the dense partials [split][tensor][B][L][D], written
+// with the outputs' strides, in split order (deterministic)
+__global__ __launch_bounds__(256) void mha2_part_reduce_kernel(const float *__restrict__ part, int nsplit, int ntens,
+                                                               int B, int L, int D, float *__restrict__ o0, long o0_sb,
+                                                               long o0_sl, float *__restrict__ o1, long o1_sb,
+                                                               long o1_sl) {
+  const long per = (long)B * L * D, n4 = per / 4;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ntens * n4) return;
+  const int which = i >= n4;
+  const long e = (i - which * n4) * 4;
+  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z = 0; z < nsplit; ++z) {
+    const float4 v = *reinterpret_cast<const float4 *>(part + ((long)z * ntens + which) * per + e);
+    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+  }
+  const long row = e / D;
+  const int col = (int)(e - row * D);
+  const long bb = row / L, l = row - bb * L;
+  float *o = which ? o1 + bb * o1_sb + l * o1_sl + col : o0 + bb * o0_sb + l * o0_sl + col;
+  *reinterpret_cast<float4 *>(o) = t;
+}
+
+template <int NQ, int KS, int CHK, int NBUF>
+int launch_fwd(Mha2Args &a, hipStream_t stream) {
+  a.n_qs = (a.Lq + 16 * NQ - 1) / (16 * NQ);
+  const unsigned grid = (unsigned)(a.B * a.H * a.n_qs);
+  if (a.p_drop > 0.f)
+    hipLaunchKernelGGL((mha2_fwd_kernel<NQ, KS, CHK, NBUF, true>), dim3(grid), dim3(NQ * KS * 64), 0, stream, a);
+  else
+    hipLaunchKernelGGL((mha2_fwd_kernel<NQ, KS, CHK, NBUF, false>), dim3(grid), dim3(NQ * KS * 64), 0, stream, a);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}
+
+// Backward decomposition of a shape: which kernel variant, how many key blocks / query splits.
+struct BwdPlan { int variant, n_kb, n_qs, q_per_wg; };
+BwdPlan bwd_plan(int B, int H, int Lq, int Lk) {
+  const long BH = (long)B * H;
+  BwdPlan p = {0, 1, 1, 0};
+  int ksub, qc;
+  if (Lk <= 80) { p.variant = 2; ksub = 5; qc = 96; }          // text tokens: 5 key waves x 3 query groups
+  else if (Lk <= 144) { p.variant = 1; ksub = 9; qc = 64; }    // detected boxes / long utterances: 9 key waves
+  else { p.variant = 0; ksub = 16; qc = 64; }
+  p.n_kb = (Lk + 16 * ksub - 1) / (16 * ksub);
+  if (p.n_kb < 1) p.n_kb = 1;
+  const int chunks = Lq > 0 ? (Lq + qc - 1) / qc : 1;
+  // enough workgroups to fill 256 CUs (x 2 where two fit a CU), but no more query splits than chunks
+  const long want_wgs = p.variant == 0 ? 256 : 512;
+  long n_qs = (want_wgs + BH * p.n_kb - 1) / (BH * p.n_kb);
+  if (n_qs < 1) n_qs = 1;
+  if (n_qs > chunks) n_qs = chunks;
+  const int cpw = (int)((chunks + n_qs - 1) / n_qs);            // chunks per workgroup
+  p.q_per_wg = cpw * qc;
+  p.n_qs = (Lq + p.q_per_wg - 1) / p.q_per_wg;
+  if (p.n_qs < 1) p.n_qs = 1;
+  return p;
+}
+
+size_t bwd_workspace_floats(const BwdPlan &p, int B, int H, int Lq, int Lk) {
+  size_t n = 0;
+  if (p.n_kb > 1) n += (size_t)p.n_kb * B * Lq * H * HD;
+  if (p.n_qs > 1) n += (size_t)p.n_qs * 2 * B * Lk * H * HD;
+  return n;
+}
+
+template <int KSUB, int QG, int QC, int NBUF>
+int launch_bwd(Mha2Args &a, hipStream_t stream) {
+  const unsigned grid = (unsigned)(a.B * a.H * a.n_kb * a.n_qs);
+  if (a.p_drop > 0.f)
+    hipLaunchKernelGGL((mha2_bwd_kernel<KSUB, QG, QC, NBUF, true>), dim3(grid), dim3(KSUB * QG * 64), 0, stream, a);
+  else
+    hipLaunchKernelGGL((mha2_bwd_kernel<KSUB, QG, QC, NBUF, false>), dim3(grid), dim3(KSUB * QG * 64), 0, stream, a);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}
+
+int env_int(const char *name, int dflt) {
+  const char *s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+
+}  // namespace
+
+// Shape -> configuration.  B*H = 64 in EDA; the chip has 256 CUs.
+int eda_mha2_fwd_launch(Mha2Args &a, hipStream_t stream) {
+  if (a.B == 0 || a.Lq == 0) return 0;
+  const int BH = a.B * a.H;
+  const bool short_q = (long)BH * ((a.Lq + 255) / 256) < 192;        // 16-query waves alone would leave CUs idle
+  if (a.Lk <= 144) {
+    if (short_q) return launch_fwd<4, 2, 192, 1>(a, stream);
+    return launch_fwd<16, 1, 192, 1>(a, stream);
+  }
+  if (a.Lk <= 256) {
+    if (short_q) return launch_fwd<4, 4, 256, 1>(a, stream);
+    return launch_fwd<16, 1, 256, 1>(a, stream);
+  }
+  if (short_q) return launch_fwd<4, 4, 256, 2>(a, stream);
+  return launch_fwd<16, 1, 256, 2>(a, stream);
+}
+
+size_t eda_mha2_bwd_workspace_bytes(int B, int H, int Lq, int Lk) {
+  if (B <= 0 || Lq <= 0 || Lk <= 0) return 0;
+  return sizeof(float) * bwd_workspace_floats(bwd_plan(B, H, Lq, Lk), B, H, Lq, Lk);
+}
+
+int eda_mha2_bwd_launch(Mha2Args &a, void *ws, size_t ws_bytes, hipStream_t stream) {
+  if (a.B == 0) return 0;
+  const BwdPlan p = bwd_plan(a.B, a.H, a.Lq, a.Lk);
+  a.n_kb = p.n_kb; a.n_qs = p.n_qs; a.q_per_wg = p.q_per_wg;
+  const size_t need = sizeof(float) * bwd_workspace_floats(p, a.B, a.H, a.Lq, a.Lk);
+  EDA_CHECK_ARG(need == 0 || (ws && ws_bytes >= need && (reinterpret_cast<uintptr_t>(ws) & 15u) == 0),
+                "workspace of eda_mha_bwd_workspace_bytes() required (16-byte aligned)");
+  float *w = reinterpret_cast<float *>(ws);
+  a.dq_part = nullptr; a.dkv_part = nullptr;
+  if (p.n_kb > 1) { a.dq_part = w; w += (size_t)p.n_kb * a.B * a.Lq * a.H * HD; }
+  if (p.n_qs > 1) a.dkv_part = w;
+  int rc;
+  if (p.variant == 0) rc = launch_bwd<16, 1, 64, 2>(a, stream);
+  else if (p.variant == 1) rc = launch_bwd<9, 1, 64, 1>(a, stream);
+  else rc = launch_bwd<5, 3, 96, 1>(a, stream);
+  if (rc) return rc;
+  const int D = a.H * HD;
+  if (p.n_kb > 1) {
+    const long items = (long)a.B * a.Lq * D / 4;
+    hipLaunchKernelGGL(mha2_part_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream,
+                       a.dq_part, p.n_kb, 1, a.B, a.Lq, D, a.dq, a.dq_sb, a.dq_sl, a.dq, a.dq_sb, a.dq_sl);
+    EDA_CHECK_LAUNCH();
+  }
+  if (p.n_qs > 1) {
+    const long items = 2L * a.B * a.Lk * D / 4;
+    hipLaunchKernelGGL(mha2_part_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream,
+                       a.dkv_part, p.n_qs, 2, a.B, a.Lk, D, a.dk, a.dk_sb, a.dk_sl, a.dv, a.dv_sb, a.dv_sl);
+    EDA_CHECK_LAUNCH();
+  }
+  return 0;
+}
