@@ -8,7 +8,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libeda_hip.so")
+# EDA_HIP_LIB selects an experiment build of the same sources (eda_amd.build.build_variant: instrumented or
+# differently tuned kernels); the product path is the default
+LIB_PATH = os.environ.get("EDA_HIP_LIB") or os.path.join(_HERE, "csrc", "libeda_hip.so")
 
 _i, _f, _p, _sz = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 _l, _u = ctypes.c_long, ctypes.c_uint

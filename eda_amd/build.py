@@ -45,5 +45,17 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, extra_flags, verbose=False):
+    """An experiment build of the same sources with extra -D flags -> csrc/libeda_hip_<name>.so (select it with
+    EDA_HIP_LIB=<path>; tools/mha2_phase_profile.py uses -DEDA_MHA2_PROFILE)."""
+    out = os.path.join(CSRC, f"libeda_hip_{name}.so")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + sources() + ["-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

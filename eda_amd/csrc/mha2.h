@@ -20,6 +20,7 @@ struct Mha2Args {
   int n_kb;          // bwd: key blocks of 16*NW keys        fwd: unused
   int n_qs;          // bwd: query splits                    fwd: query blocks of 16*NQ queries
   int q_per_wg;      // bwd: queries per query split (multiple of the chunk)
+  int prio_mode;     // experiment: 1 = s_setprio by remaining work in phase A
   float *dq_part;    // bwd: [key block][B][Lq][H*36] dense partials of dQ (n_kb > 1)
   float *dkv_part;   // bwd: [query split][dk | dv][B][Lk][H*36] dense partials (n_qs > 1)
 };

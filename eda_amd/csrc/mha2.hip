@@ -47,8 +47,35 @@ constexpr float LN2 = 0.6931471805599453f;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+#ifdef EDA_MHA2_PROFILE
+// Phase timing of the backward kernel (experiments only; tools/mha2_phase_profile.py): per-wave s_memtime deltas,
+// summed over all waves of all launches since the last read.
+__device__ unsigned long long mha2_prof[64 * 8];
+#define PSTAMP(slot)                                                   \
+  do {                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+    const unsigned long long now__ = __builtin_amdgcn_s_memtime();     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(now__));                 \
+    prof_acc[slot] += now__ - prof_t;                                  \
+    prof_t = now__;                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+  } while (0)
+#else
+#define PSTAMP(slot) do { } while (0)
+#endif
+
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// 16 blocks of 4x4x1 (probed on gfx950, tools/probe/mfma44_layout.hip): D[reg i][lane 4b+j] += A[lane 4b+i] * B[lane 4b+j].
+// Used for the LAST FOUR of the 36 head dims of every "output = head dim" product (P V, dO^T P, Q^T dS, K^T dS^T):
+// with the 16x16x4 form they cost a whole 16-row tile (12 of 16 rows wasted: 54 MFMA-equivalents per backward pair
+// for 45 useful); here block b = (lane group g, quad of the lane-local index), the four k-steps t of a sub-tile are
+// four 8-cycle instructions, and every lane group accumulates the partial sum over ITS quarter of the contraction
+// index -- the four partials are added once, at the very end (grp_sum4).  45 issued for 45 useful.
+__device__ __forceinline__ f32x4 mfma44(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
 
 __device__ __forceinline__ unsigned hash32(unsigned x) {     // = mha.hip
@@ -68,6 +95,12 @@ __device__ __forceinline__ float grp_sum(float v) {
   v = __uint_as_float(r.x) + __uint_as_float(r.y);
   r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+
+__device__ __forceinline__ f32x4 grp_sum4(f32x4 v) {
+  f32x4 r;
+  r[0] = grp_sum(v[0]); r[1] = grp_sum(v[1]); r[2] = grp_sum(v[2]); r[3] = grp_sum(v[3]);
+  return r;
 }
 
 // A lane's 9 contraction values of one 36-float row: MFMA k-step s of lane group g contracts head dim 8g+s
@@ -108,12 +141,12 @@ __device__ __forceinline__ DropCfg drop_cfg(const Mha2Args &a) {
 // LDS-DMA of `rows` x 36 floats (row r of the tile = global row min(row0 + r, nrows - 1) of one head) into a
 // LINEAR [rows][36] LDS tile: piece p = 64 consecutive 16-byte granules, one wave-instruction each
 // (the destination of lane l is base + 1 KiB * p + 16 l; the source address is per lane).
-template <int ROWS, int NW>
+template <int ROWS>
 __device__ __forceinline__ void dma_rows(float *lds, const float *base, long row_stride, int row0, int nrows,
-                                         int wave, int lane, int first_piece) {
+                                         int wave, int nwaves, int lane, int first_piece) {
   constexpr int G = ROWS * 9;                  // 16-byte granules of the tile
   constexpr int P = (G + 63) / 64;             // pieces (the last one may be partial: its surplus lanes are masked off)
-  for (int p = first_piece + wave; p < first_piece + P; p += NW) {
+  for (int p = first_piece + wave; p < first_piece + P; p += nwaves) {
     const int pp = p - first_piece;
     const int i = 64 * pp + lane;
     if (G % 64 == 0 || i < G) {
@@ -201,7 +234,7 @@ __device__ __forceinline__ void fwd_tile(const float *__restrict__ Kt, const flo
       const float pb = st[j][t];
       o[0] = mfma4(va.v[t][0], pb, o[0]);
       o[1] = mfma4(va.v[t][1], pb, o[1]);
-      o[2] = mfma4(va.v[t][2], pb, o[2]);
+      o[2] = mfma44(va.v[t][2], pb, o[2]);       // dims 32..35: per-lane-group partials
     }
     if (j + 1 < NSUB) va = vb;
   }
@@ -259,8 +292,8 @@ __global__ __launch_bounds__(NQ * KS * 64) void mha2_fwd_kernel(const Mha2Args a
       }
       dd[w] = word;
     }
-    dma_rows<CHK, NW>(Kd, kbase, a.k_sl, k0, a.Lk, wave, lane, 0);
-    dma_rows<CHK, NW>(Vd, vbase, a.v_sl, k0, a.Lk, wave, lane, CHK * 9 / 64);
+    dma_rows<CHK>(Kd, kbase, a.k_sl, k0, a.Lk, wave, NW, lane, 0);
+    dma_rows<CHK>(Vd, vbase, a.v_sl, k0, a.Lk, wave, NW, lane, CHK * 9 / 64);
   };
 
   float m = -INFINITY, lsum = 0.f;
@@ -337,6 +370,7 @@ __global__ __launch_bounds__(NQ * KS * 64) void mha2_fwd_kernel(const Mha2Args a
       }
     }
   }
+  if (KS == 1 || ks == 0) o[2] = grp_sum4(o[2]);
   if (qvalid && (KS == 1 || ks == 0)) {
     const float inv = dc.inv_keep / lsum;          // all keys masked -> NaN, like the reference
     float *orow = a.o + (long)b * a.o_sb + (long)qi * a.o_sl + h * HD;
@@ -396,6 +430,11 @@ __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args
 
   DropCfg dc = {0u, 0u, 1.f};
   if (DROP) dc = drop_cfg(a);
+#ifdef EDA_MHA2_PROFILE
+  unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long prof_t = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(prof_t));
+#endif
 
   // the block's K rows -> LDS (operand of phase B), this wave's K / V rows -> registers (lane = key)
   const float *kbase = a.k + (long)b * a.k_sb + h * HD;
@@ -434,32 +473,73 @@ __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args
 
   // stage one chunk: lse (log2 domain, +inf for rows outside the range: their P is exactly 0) and
   // delta = rowsum(dO o O) with ordinary loads, then Q and dO by LDS-DMA
-  auto stage = [&](float *Qd, float *Dd, float *lse_d, float *del_d, int q0) {
-    for (int item = tid; item < QC * 8; item += NT) {
+  auto stage = [&](float *Qd, float *Dd, float *lse_d, float *del_d, int q0, int w0, int nw) {
+    // executed by waves [w0, w0 + nw).  The DMA goes first and ALL ordinary loads of the wave are issued before
+    // the first one is consumed: one memory round trip for the whole stage instead of four in a row.
+    constexpr int P = (QC * 9 + 63) / 64;
+    dma_rows<QC>(Qd, qbase, a.q_sl, q0, a.Lq, wave - w0, nw, lane, 0);
+    dma_rows<QC>(Dd, dbase, a.do_sl, q0, a.Lq, wave - w0, nw, lane, P);
+    constexpr int MAXIT = (QC * 8 + 63) / 64;            // items per thread if a single wave stages (upper bound)
+    const int nthr = 64 * nw, t0 = tid - 64 * w0;
+    const int nit = (QC * 8 + nthr - 1) / nthr;
+    float4 d4[4], o4[4], d8[4], o8[4];
+    float ls[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      d4[it] = o4[it] = d8[it] = o8[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      ls[it] = 0.f;
+      const int item = t0 + it * nthr;
+      if (it < nit && item < QC * 8) {
+        const int row = item >> 3, sub = item & 7;
+        const int gr = min(q0 + row, a.Lq - 1);
+        const float *dr = dbase + (long)gr * a.do_sl, *orow = obase + (long)gr * a.o_sl;
+        d4[it] = *reinterpret_cast<const float4 *>(dr + 4 * sub);
+        o4[it] = *reinterpret_cast<const float4 *>(orow + 4 * sub);
+        if (sub == 0) {
+          d8[it] = *reinterpret_cast<const float4 *>(dr + 32);
+          o8[it] = *reinterpret_cast<const float4 *>(orow + 32);
+          ls[it] = a.lse[(long)bh * a.Lq + gr];
+        }
+      }
+    }
+    static_assert(MAXIT <= 4 * 16, "stage: chunk too large");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int item = t0 + it * nthr;
+      if (it < nit && item < QC * 8) {         // (whole 8-lane groups take this branch together)
+        const int row = item >> 3, sub = item & 7;
+        float part = d4[it].x * o4[it].x + d4[it].y * o4[it].y + d4[it].z * o4[it].z + d4[it].w * o4[it].w;
+        part += d8[it].x * o8[it].x + d8[it].y * o8[it].y + d8[it].z * o8[it].z + d8[it].w * o8[it].w;
+        part += __shfl_xor(part, 1);
+        part += __shfl_xor(part, 2);
+        part += __shfl_xor(part, 4);
+        if (sub == 0) {
+          const bool valid = q0 + row < qend;
+          lse_d[row] = valid ? ls[it] * LOG2E : INFINITY;
+          del_d[row] = valid ? part : 0.f;
+        }
+      }
+    }
+    // more than 4 items per thread (few staging waves, large chunk): the remainder, one at a time
+    for (int item = t0 + 4 * nthr; item < QC * 8; item += nthr) {
       const int row = item >> 3, sub = item & 7;
-      const int gq = q0 + row;
-      const bool valid = gq < qend;
-      const int gr = min(gq, a.Lq - 1);
+      const int gr = min(q0 + row, a.Lq - 1);
       const float *dr = dbase + (long)gr * a.do_sl, *orow = obase + (long)gr * a.o_sl;
-      const float4 d4 = *reinterpret_cast<const float4 *>(dr + 4 * sub);
-      const float4 o4 = *reinterpret_cast<const float4 *>(orow + 4 * sub);
-      float part = d4.x * o4.x + d4.y * o4.y + d4.z * o4.z + d4.w * o4.w;
+      const float4 x = *reinterpret_cast<const float4 *>(dr + 4 * sub), y = *reinterpret_cast<const float4 *>(orow + 4 * sub);
+      float part = x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
       if (sub == 0) {
-        const float4 d8 = *reinterpret_cast<const float4 *>(dr + 32);
-        const float4 o8 = *reinterpret_cast<const float4 *>(orow + 32);
-        part += d8.x * o8.x + d8.y * o8.y + d8.z * o8.z + d8.w * o8.w;
+        const float4 x8 = *reinterpret_cast<const float4 *>(dr + 32), y8 = *reinterpret_cast<const float4 *>(orow + 32);
+        part += x8.x * y8.x + x8.y * y8.y + x8.z * y8.z + x8.w * y8.w;
       }
       part += __shfl_xor(part, 1);
       part += __shfl_xor(part, 2);
       part += __shfl_xor(part, 4);
       if (sub == 0) {
+        const bool valid = q0 + row < qend;
         lse_d[row] = valid ? a.lse[(long)bh * a.Lq + gr] * LOG2E : INFINITY;
         del_d[row] = valid ? part : 0.f;
       }
     }
-    constexpr int P = (QC * 9 + 63) / 64;
-    dma_rows<QC, NW>(Qd, qbase, a.q_sl, q0, a.Lq, wave, lane, 0);
-    dma_rows<QC, NW>(Dd, dbase, a.do_sl, q0, a.Lq, wave, lane, P);
   };
 
   f32x4 dk[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -470,6 +550,16 @@ __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args
     const int nsub = min(NSUBQ, (qend - q0 + 15) >> 4);
 #pragma unroll 1
     for (int j = qg; j < nsub; j += QG) {
+      // the waves of a SIMD share its matrix pipe; arbitration is priority, then age: a wave that is BEHIND
+      // (fewer sub-tiles done) gets the higher priority, so the four finish a phase together instead of one after
+      // the other (the last one alone on the pipe runs at half the rate)
+      if (a.prio_mode == 1) {
+        const int left = (nsub - 1 - j) / QG;          // sub-tiles after this one
+        if (left >= 3) __builtin_amdgcn_s_setprio(3);
+        else if (left == 2) __builtin_amdgcn_s_setprio(2);
+        else if (left == 1) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+      }
       f32x4 sacc = {0, 0, 0, 0}, pacc = {0, 0, 0, 0};
       {
         float qa[KSTEPS], da[KSTEPS];
@@ -527,7 +617,7 @@ __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args
           const float pb = pd[t];
           dv[0] = mfma4(cd.v[t][0], pb, dv[0]);
           dv[1] = mfma4(cd.v[t][1], pb, dv[1]);
-          dv[2] = mfma4(cd.v[t][2], pb, dv[2]);
+          dv[2] = mfma44(cd.v[t][2], pb, dv[2]);
         }
       }
       {
@@ -538,76 +628,123 @@ __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args
           const float sb = ds[t];
           dk[0] = mfma4(cq.v[t][0], sb, dk[0]);
           dk[1] = mfma4(cq.v[t][1], sb, dk[1]);
-          dk[2] = mfma4(cq.v[t][2], sb, dk[2]);
+          dk[2] = mfma44(cq.v[t][2], sb, dk[2]);
         }
       }
     }
   };
 
-  // dQ^T tile (dims of column tile n) x (queries of sub-tile j), contracted over the block's live keys
+  // dQ^T tile (dims of column tile n) x (queries of sub-tile j), contracted over the block's live keys.  Items are
+  // ordered full tiles first (n = 0, 1: 4 MFMAs per key sub-tile), then the 4-dim tiles (n = 2: four 4x4x1 steps,
+  // a quarter of the time), so that with 16 waves every SIMD gets two full items and one short one.
   auto phase_b = [&](int q0) {
     const int nsub = min(NSUBQ, (qend - q0 + 15) >> 4);
     const int nitems = 3 * nsub;
 #pragma unroll 1
     for (int it = wave; it < nitems; it += NW) {
-      const int j = it / 3, n = it - 3 * j;
-      const int col = n < 2 ? 16 * n + c : 32 + (c & 3);
+      const bool full = it < 2 * nsub;
+      const int j = full ? it >> 1 : it - 2 * nsub, n = full ? it & 1 : 2;
+      const int col = full ? 16 * n + c : 32 + (c & 3);
       const float *kp = Kb + 4 * g * HD + col;                 // K[key 16s + 4g + t][col]
       const float *dp_ = DS + (16 * j + c) * DSS + 4 * g;      // dS[query c][key 16s + 4g + t]
       f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
       int s = 0;
-      for (; s + 1 < nks_live; s += 2) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(dp_ + 16 * s);
-        const f32x4 b1 = *reinterpret_cast<const f32x4 *>(dp_ + 16 * s + 16);
-        const float *k0 = kp + 16 * s * HD, *k1 = k0 + 16 * HD;
-        const float a00 = k0[0], a01 = k0[HD], a02 = k0[2 * HD], a03 = k0[3 * HD];
-        const float a10 = k1[0], a11 = k1[HD], a12 = k1[2 * HD], a13 = k1[3 * HD];
-        acc0 = mfma4(a00, b0[0], acc0); acc1 = mfma4(a10, b1[0], acc1);
-        acc0 = mfma4(a01, b0[1], acc0); acc1 = mfma4(a11, b1[1], acc1);
-        acc0 = mfma4(a02, b0[2], acc0); acc1 = mfma4(a12, b1[2], acc1);
-        acc0 = mfma4(a03, b0[3], acc0); acc1 = mfma4(a13, b1[3], acc1);
+      if (full) {
+        for (; s + 1 < nks_live; s += 2) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4 *>(dp_ + 16 * s);
+          const f32x4 b1 = *reinterpret_cast<const f32x4 *>(dp_ + 16 * s + 16);
+          const float *k0 = kp + 16 * s * HD, *k1 = k0 + 16 * HD;
+          const float a00 = k0[0], a01 = k0[HD], a02 = k0[2 * HD], a03 = k0[3 * HD];
+          const float a10 = k1[0], a11 = k1[HD], a12 = k1[2 * HD], a13 = k1[3 * HD];
+          acc0 = mfma4(a00, b0[0], acc0); acc1 = mfma4(a10, b1[0], acc1);
+          acc0 = mfma4(a01, b0[1], acc0); acc1 = mfma4(a11, b1[1], acc1);
+          acc0 = mfma4(a02, b0[2], acc0); acc1 = mfma4(a12, b1[2], acc1);
+          acc0 = mfma4(a03, b0[3], acc0); acc1 = mfma4(a13, b1[3], acc1);
+        }
+        if (s < nks_live) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4 *>(dp_ + 16 * s);
+          const float *k0 = kp + 16 * s * HD;
+          acc0 = mfma4(k0[0], b0[0], acc0);
+          acc0 = mfma4(k0[HD], b0[1], acc0);
+          acc0 = mfma4(k0[2 * HD], b0[2], acc0);
+          acc0 = mfma4(k0[3 * HD], b0[3], acc0);
+        }
+      } else {
+        for (; s + 1 < nks_live; s += 2) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4 *>(dp_ + 16 * s);
+          const f32x4 b1 = *reinterpret_cast<const f32x4 *>(dp_ + 16 * s + 16);
+          const float *k0 = kp + 16 * s * HD, *k1 = k0 + 16 * HD;
+          const float a00 = k0[0], a01 = k0[HD], a02 = k0[2 * HD], a03 = k0[3 * HD];
+          const float a10 = k1[0], a11 = k1[HD], a12 = k1[2 * HD], a13 = k1[3 * HD];
+          acc0 = mfma44(a00, b0[0], acc0); acc1 = mfma44(a10, b1[0], acc1);
+          acc0 = mfma44(a01, b0[1], acc0); acc1 = mfma44(a11, b1[1], acc1);
+          acc0 = mfma44(a02, b0[2], acc0); acc1 = mfma44(a12, b1[2], acc1);
+          acc0 = mfma44(a03, b0[3], acc0); acc1 = mfma44(a13, b1[3], acc1);
+        }
+        if (s < nks_live) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4 *>(dp_ + 16 * s);
+          const float *k0 = kp + 16 * s * HD;
+          acc0 = mfma44(k0[0], b0[0], acc0);
+          acc0 = mfma44(k0[HD], b0[1], acc0);
+          acc0 = mfma44(k0[2 * HD], b0[2], acc0);
+          acc0 = mfma44(k0[3 * HD], b0[3], acc0);
+        }
       }
-      if (s < nks_live) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(dp_ + 16 * s);
-        const float *k0 = kp + 16 * s * HD;
-        acc0 = mfma4(k0[0], b0[0], acc0);
-        acc0 = mfma4(k0[HD], b0[1], acc0);
-        acc0 = mfma4(k0[2 * HD], b0[2], acc0);
-        acc0 = mfma4(k0[3 * HD], b0[3], acc0);
-      }
+      f32x4 r = acc0 + acc1;
+      if (!full) r = grp_sum4(r);                              // the four lane groups hold partial sums over their key quarters
       const int gq = q0 + 16 * j + c;
-      if (gq < qend && (n < 2 || g == 0)) {
+      if (gq < qend && (full || g == 0)) {
         const float sc = a.scale;
         *reinterpret_cast<float4 *>(dq_out + (long)gq * dq_sl + 16 * n + 4 * g) =
-            make_float4((acc0[0] + acc1[0]) * sc, (acc0[1] + acc1[1]) * sc, (acc0[2] + acc1[2]) * sc,
-                        (acc0[3] + acc1[3]) * sc);
+            make_float4(r[0] * sc, r[1] * sc, r[2] * sc, r[3] * sc);
       }
     }
   };
 
   const int nchunks = qend > qbeg ? (qend - qbeg + QC - 1) / QC : 0;
-  if (nchunks > 0) stage(Qs0, Ds0, lse_s[0], del_s[0], qbeg);
+  // With 16 waves and <= 12 phase-B items the last four waves have no dQ tile: they stage the NEXT chunk (lse, delta,
+  // DMA) during phase B instead of everybody doing it in front of phase A.
+  constexpr bool STAGE_IN_B = NBUF == 2 && NW == 16 && 3 * NSUBQ <= 12;
+  if (nchunks > 0) stage(Qs0, Ds0, lse_s[0], del_s[0], qbeg, 0, NW);
   __syncthreads();
+  PSTAMP(0);
   for (int ci = 0; ci < nchunks; ci += NBUF) {
     const int q0 = qbeg + ci * QC;
     if (NBUF == 2) {
-      if (ci + 1 < nchunks) stage(Qs1, Ds1, lse_s[1], del_s[1], q0 + QC);
+      if (!STAGE_IN_B && ci + 1 < nchunks) stage(Qs1, Ds1, lse_s[1], del_s[1], q0 + QC, 0, NW);
+      PSTAMP(1);
       phase_a(Qs0, Ds0, lse_s[0], del_s[0], q0);
+      PSTAMP(2);
       __syncthreads();
+      PSTAMP(3);
+      if (STAGE_IN_B && ci + 1 < nchunks && wave >= 12) stage(Qs1, Ds1, lse_s[1], del_s[1], q0 + QC, 12, 4);
       phase_b(q0);
+      PSTAMP(4);
       __syncthreads();
+      PSTAMP(5);
       if (ci + 1 >= nchunks) break;
-      if (ci + 2 < nchunks) stage(Qs0, Ds0, lse_s[0], del_s[0], q0 + 2 * QC);
+      if (!STAGE_IN_B && ci + 2 < nchunks) stage(Qs0, Ds0, lse_s[0], del_s[0], q0 + 2 * QC, 0, NW);
+      PSTAMP(1);
       phase_a(Qs1, Ds1, lse_s[1], del_s[1], q0 + QC);
+      PSTAMP(2);
       __syncthreads();
+      PSTAMP(3);
+      if (STAGE_IN_B && ci + 2 < nchunks && wave >= 12) stage(Qs0, Ds0, lse_s[0], del_s[0], q0 + 2 * QC, 12, 4);
       phase_b(q0 + QC);
+      PSTAMP(4);
       __syncthreads();
+      PSTAMP(5);
     } else {
       phase_a(Qs0, Ds0, lse_s[0], del_s[0], q0);
+      PSTAMP(2);
       __syncthreads();
+      PSTAMP(3);
       phase_b(q0);
-      if (ci + 1 < nchunks) stage(Qs0, Ds0, lse_s[0], del_s[0], q0 + QC);      // (Q / dO of this chunk are dead)
+      PSTAMP(4);
+      if (ci + 1 < nchunks) stage(Qs0, Ds0, lse_s[0], del_s[0], q0 + QC, 0, NW);      // (Q / dO of this chunk are dead)
+      PSTAMP(1);
       __syncthreads();
+      PSTAMP(5);
     }
   }
 
@@ -629,6 +766,7 @@ __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args
       __syncthreads();
     }
   }
+  if (wave_live && qg == 0) { dk[2] = grp_sum4(dk[2]); dv[2] = grp_sum4(dv[2]); }
   if (kvalid && wave_live && qg == 0) {
     const float sc = a.scale, ik = dc.inv_keep;
     float *ok = a.dk + (long)b * a.dk_sb + (long)ki * a.dk_sl + h * HD;
@@ -647,6 +785,12 @@ __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args
       *reinterpret_cast<float4 *>(ov + 32) = make_float4(dv[2][0] * ik, dv[2][1] * ik, dv[2][2] * ik, dv[2][3] * ik);
     }
   }
+#ifdef EDA_MHA2_PROFILE
+  PSTAMP(6);
+  prof_acc[7] = 1;
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&mha2_prof[((blockIdx.x * 16 + wave) & 63) * 8 + i], prof_acc[i]);
+#endif
 }
 
 // out tensors (1: dq; 2: dk, dv) = sum over the splits of the dense partials [split][tensor][B][L][D], written
@@ -750,6 +894,17 @@ int eda_mha2_fwd_launch(Mha2Args &a, hipStream_t stream) {
   return launch_fwd<16, 1, 256, 2>(a, stream);
 }
 
+#ifdef EDA_MHA2_PROFILE
+extern "C" int eda_mha2_profile_read(unsigned long long *out16) {
+  static unsigned long long all[64 * 8], zero[64 * 8];
+  if (hipMemcpyFromSymbol(all, HIP_SYMBOL(mha2_prof), sizeof(all)) != hipSuccess) return 1;
+  for (int i = 0; i < 16; ++i) out16[i] = 0;
+  for (int s = 0; s < 64; ++s)
+    for (int i = 0; i < 8; ++i) out16[i] += all[s * 8 + i];
+  return hipMemcpyToSymbol(HIP_SYMBOL(mha2_prof), zero, sizeof(zero)) != hipSuccess;
+}
+#endif
+
 size_t eda_mha2_bwd_workspace_bytes(int B, int H, int Lq, int Lk) {
   if (B <= 0 || Lq <= 0 || Lk <= 0) return 0;
   return sizeof(float) * bwd_workspace_floats(bwd_plan(B, H, Lq, Lk), B, H, Lq, Lk);
@@ -757,6 +912,8 @@ size_t eda_mha2_bwd_workspace_bytes(int B, int H, int Lq, int Lk) {
 
 int eda_mha2_bwd_launch(Mha2Args &a, void *ws, size_t ws_bytes, hipStream_t stream) {
   if (a.B == 0) return 0;
+  static const int prio = env_int("EDA_MHA2_PRIO", 1);
+  a.prio_mode = prio;
   const BwdPlan p = bwd_plan(a.B, a.H, a.Lq, a.Lk);
   a.n_kb = p.n_kb; a.n_qs = p.n_qs; a.q_per_wg = p.q_per_wg;
   const size_t need = sizeof(float) * bwd_workspace_floats(p, a.B, a.H, a.Lq, a.Lk);
