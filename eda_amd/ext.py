@@ -99,11 +99,23 @@ def _fps_workspace(device, nbytes):
     key = (device, _stream())
     ws = _fps_ws.get(key)
     if ws is None or ws.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            # a fill kernel captured here would re-zero the sticky flag on every replay (a give-up of an earlier
+            # replay would vanish): the workspace must exist before the capture starts
+            raise RuntimeError("furthest_point_sampling: no workspace for this (device, stream) yet -- run one eager "
+                               "sampling of this size on the stream before capturing it in a HIP graph "
+                               "(eda_amd.ext.fps_prepare)")
         new = torch.full((max(nbytes, 4096),), 0, dtype=torch.uint8, device=device)
         if ws is not None:
             new[:16].copy_(ws[:16])
         _fps_ws[key] = ws = new
     return ws
+
+
+def fps_prepare(device, batch, n_points, n_samples):
+    """Create (outside any capture) the current stream's FPS workspace for samplings of up to this size."""
+    nbytes = int(_lib.lib().eda_fps_workspace_bytes(int(batch), int(n_points), int(n_samples)))
+    _fps_workspace(torch.device(device), nbytes)
 
 
 def fps_status(device=None, reset=False):

@@ -100,9 +100,14 @@ class FlatParams:
             off += p.numel()
         from .wgrad_queue import WgradQueue
         self.queue = WgradQueue(self._locate_grad)
-        self.shadow = None                 # W^T of the linear weights (eda_amd/wt_shadow.py), built at the first deferred backward
+        self.shadow = None                 # W^T of the linear weights (eda_amd/wt_shadow.py)
         if dev.type == "cuda":
             self.queue.reserve(dev)              # pinned staging must exist before any stream capture
+            if os.environ.get("EDA_WT_SHADOW", "1") != "0":
+                # ... and so must the shadow (its descriptor table is a host -> device copy): built here, not at the
+                # first deferred backward, which may already run under capture (eda_amd/pipeline.py)
+                from . import wt_shadow
+                self.shadow = wt_shadow.TransposedShadow([p for p in self.params if p.requires_grad])
         self._prefilled = False
         self._deferred_ptrs = set()
         self.groups = {}

@@ -1,0 +1,178 @@
+"""The software-pipelined training step: three HIP graphs on two streams, with the double buffers a data loader
+feeds.
+
+The reference's loop (`main_utils.py:463-470`: `for batch in loader: loss = model(batch); backward; step`) runs
+everything of a batch inside its step.  Two pieces of a BeaUTyDETR step depend on the INPUT alone -- the furthest
+point sampling of SA1 (3 ms of dependent rounds on ~100 of the 256 CUs) and the frozen RoBERTa text encoder -- so they
+can be computed for batch i+1 on a second stream while step i trains, and handed to the model through the reference's
+own hooks (`PointnetSAModuleVotes.forward(xyz, features, inds)`, pointnet2_modules.py:217-235; the hidden states the
+frozen encoder would produce).  This class owns what that needs:
+
+    nxt   static buffers of the batch that will be trained NEXT (the loader writes them: `step(next_batch=...)`)
+    cur   static buffers of the batch being trained (rotated from nxt by the first nodes of the point graph)
+    inds_next / inds_cur, text_next / text_cur   the prefetched sampling indices and hidden states, same rotation
+
+    main stream   [wait prefetch(i)] point graph(i): rotate nxt -> cur, SA stack     | rest graph(i): encoder/decoder,
+                                                                                        loss, backward, (clip + AdamW)
+    side stream                      [wait rotation(i)] copy batch i+1 -> nxt, FPS(i+1), text encoder(i+1)
+
+Every step executes exactly one sampling and one text-encoder pass (nothing is cached or skipped); with
+`next_batch=None` the nxt buffers are left as they are (the same batch again).  tests/test_pipeline_gpu.py drives it
+with alternating batches and checks, per step, that the indices used are the FPS of the batch being trained and that
+the loss history equals eager training on the same sequence.
+"""
+import torch
+
+from . import attention, ext, pointnet2_utils
+
+
+def _flat(batch):
+    """The tensors of a batch dict in a fixed order (nested dict `tokenized` included)."""
+    out = []
+    for k in sorted(batch):
+        v = batch[k]
+        if isinstance(v, dict):
+            out.extend(v[kk] for kk in sorted(v))
+        elif torch.is_tensor(v):
+            out.append(v)
+    return out
+
+
+def _clone(batch):
+    return {k: ({kk: vv.clone() for kk, vv in v.items()} if isinstance(v, dict) else (v.clone() if torch.is_tensor(v) else v))
+            for k, v in batch.items()}
+
+
+class PipelinedTrainStep:
+    def __init__(self, model, first_batch, loss_fn, backward_fn, update_fn, *, stream=None, all_reduce=None,
+                 split_update=False, prefetch="sa1", text_prefetch=True, after_loss=None, sa1_samples=2048):
+        """model: BeaUTyDETR (train mode, text encoder frozen).  first_batch: dict of DEVICE tensors (the layout of
+        every later batch; extra tensors, e.g. loss targets, ride along).  loss_fn(end_points, batch) -> scalar.  backward_fn(loss): backward + gradient gather (e.g. under
+        FlatParams.deferred_wgrad()).  update_fn(): clip + optimizer step (capturable).  all_reduce(): eager
+        collective between the backward graph and the update graph (N > 1; implies split_update).
+        prefetch: "sa1" (SA1's sampling for the next batch), "geometry" (everything the backbone derives from the
+        coordinates alone: Pointnet2Backbone.geometry) or None (sampling inside the step; then the text encoder runs for
+        the CURRENT batch underneath the point backbone).  text_prefetch: the text encoder, too, works for the next batch.
+        stream: the stream the graphs are captured / replayed on (warm-up eager steps must have run on it)."""
+        prefetch_geometry = prefetch == "geometry"
+        text_prefetch = bool(text_prefetch) and prefetch is not None
+        self.model, self.loss_fn = model, loss_fn
+        self.all_reduce = all_reduce
+        split_update = split_update or all_reduce is not None
+        dev = first_batch["point_clouds"].device
+        self.main = stream or torch.cuda.current_stream()
+        self.side = torch.cuda.Stream()
+        self.cur, self.nxt = _clone(first_batch), _clone(first_batch)
+        self._cur_flat, self._nxt_flat = _flat(self.cur), _flat(self.nxt)
+        mode = dict(capture_error_mode="thread_local")
+        # the text encoder reads the NEXT batch's tokens when it is prefetched, else the current batch's
+        tok = (self.nxt if text_prefetch else self.cur)["tokenized"]
+
+        # ---- side stream: sampling (+ optionally all coordinate-only geometry) and text encoder of the NEXT batch ----
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side):
+            # eager once: creates this stream's FPS workspace outside the capture (its sticky give-up flag must not be
+            # re-zeroed by a captured fill) and warms the text encoder's library kernels
+            xyz = self.nxt["point_clouds"][..., 0:3].contiguous()
+            if prefetch_geometry:
+                model.backbone_net.geometry(xyz)
+            elif prefetch is not None:
+                pointnet2_utils.furthest_point_sample(xyz, sa1_samples)
+            model.encode_text_frozen(tok["input_ids"], tok["attention_mask"])
+        self.side.synchronize()
+        self.g_fps, self.g_text = None, torch.cuda.CUDAGraph()
+        self.inds_next, self.inds_cur = [], []
+        if prefetch is not None:
+            self.g_fps = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_fps, stream=self.side, **mode):
+                xyz_next = self.nxt["point_clouds"][..., 0:3].contiguous()
+                if prefetch_geometry:
+                    geo_next = model.backbone_net.geometry(xyz_next)
+                    self.inds_next = list(geo_next.values())
+                else:
+                    self.inds_next = [pointnet2_utils.furthest_point_sample(xyz_next, sa1_samples)]
+        with torch.cuda.graph(self.g_text, stream=self.side, **mode):
+            self.text_next = model.encode_text_frozen(tok["input_ids"], tok["attention_mask"])
+        self.side.synchronize()
+        if self.g_fps is not None:
+            self.g_fps.replay()
+        self.g_text.replay()
+        torch.cuda.synchronize()
+        self.inds_cur = [t.clone() for t in self.inds_next]
+        self.text_prefetch = text_prefetch
+        self.text_cur = self.text_next.clone() if self.text_prefetch else self.text_next
+        inputs_h = dict(self.cur)
+        inputs_h["text_hidden"] = self.text_cur
+        if prefetch_geometry:
+            inputs_h["backbone_geometry"] = dict(zip(geo_next.keys(), self.inds_cur))
+        elif prefetch is not None:
+            inputs_h["sa1_inds"] = self.inds_cur[0]
+        self.inputs = inputs_h
+
+        # ---- main stream: point graph | rest graph (| update graph) -----------------------------------------------------
+        self.g_pts, self.g_rest = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self.g_up = torch.cuda.CUDAGraph() if split_update else None
+        pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(self.g_pts, pool=pool, stream=self.main, **mode):
+            # rotate: the batch prefetched during the previous step becomes the batch of this step
+            torch._foreach_copy_(self._cur_flat, self._nxt_flat)
+            if self.inds_cur:
+                torch._foreach_copy_(self.inds_cur, self.inds_next)
+            if self.text_prefetch:
+                self.text_cur.copy_(self.text_next)
+            attention.advance_dropout_state(dev)
+            ep_static = model.forward_point_backbone(inputs_h)
+        with torch.cuda.graph(self.g_rest, pool=pool, stream=self.main, **mode):
+            self.loss = loss_fn(model.forward_rest(inputs_h, ep_static), self.cur)
+            backward_fn(self.loss)
+            if after_loss is not None:
+                after_loss(self.loss)
+            if self.g_up is None:
+                update_fn()
+        if self.g_up is not None:
+            with torch.cuda.graph(self.g_up, pool=pool, stream=self.main, **mode):
+                update_fn()
+        self.ev_pts, self.ev_fps, self.ev_done, self.ev_text = (torch.cuda.Event() for _ in range(4))
+        self.ev_fps.record(self.side)
+        self.ev_done.record(self.main)
+
+    def _feed(self, batch):
+        """Copy `batch` (same layout as the first one) into the nxt buffers, on the side stream."""
+        torch._foreach_copy_(self._nxt_flat, _flat(batch))
+
+    def step(self, next_batch=None):
+        """Train on the batch fed by the previous call (the first batch initially); start the sampling / text encoding
+        of `next_batch` underneath.  Returns the (static) loss tensor of this step."""
+        cur = torch.cuda.current_stream()
+        # the point graph first: a replay call returns when its last node has been queued, which for the long graph is
+        # close to its end on the GPU -- whatever the host issues before the point graph is time the main queue idles
+        cur.wait_event(self.ev_fps)                # this batch's sampling / hidden states / data are in the nxt buffers
+        self.g_pts.replay()
+        self.ev_pts.record(cur)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ev_pts)      # the rotation has taken its copies: nxt may be overwritten
+            if not self.text_prefetch:
+                # the encoder works for THIS step (tokens of cur, rotated by the point graph), underneath the SA stack
+                self.side.wait_event(self.ev_done)     # the previous step has consumed the hidden states
+                self.g_text.replay()
+                self.ev_text.record(self.side)
+            if next_batch is not None:
+                self._feed(next_batch)
+            if self.g_fps is not None:
+                self.g_fps.replay()
+            if self.text_prefetch:
+                self.g_text.replay()
+            self.ev_fps.record(self.side)          # (one event: the next point graph waits for all of it)
+        if not self.text_prefetch:
+            cur.wait_event(self.ev_text)
+        self.g_rest.replay()
+        self.ev_done.record(cur)
+        if self.g_up is not None:
+            if self.all_reduce is not None:
+                self.all_reduce()
+            self.g_up.replay()
+        return self.loss
+
+    def fps_status(self):
+        """Sticky give-up flag of the multi-workgroup sampler over all steps so far (0 = every sampling completed)."""
+        return ext.fps_status(self.nxt["point_clouds"].device)

@@ -156,21 +156,38 @@ def run_encoder_decoder(dev, butd):
     MF.assert_matches(g, "grad_w", dec.cross_v.in_proj_weight.grad)
 
 
-def run_full_model(dev, butd):
+def run_full_model(dev, butd, tag=None, attn_dtype="f32"):
+    """Full BeaUTyDETR forward against the reference's golden `model_full_<tag>.npz`.
+
+    attn_dtype "bf16" / "f16" (GPU only): BASELINE.json configs[2] / configs[4] -- the QK^T / PV contractions of every
+    attention run on the 16-bit MFMA path (csrc/mha16.hip), everything else stays fp32.  Decision recorded here: the
+    seed objectness / query top-k is NOT special-cased -- it reads encoder features that went through the 16-bit
+    attention, exactly as a mixed-precision run of the reference would.  The test therefore (1) counts how many of
+    the selected queries differ from the golden's (the fixtures have a gap of >= 2e-4 in sigmoid space at the k / k+1
+    boundary; bound below) and (2) compares every tensor with a tolerance derived from the contraction error of the
+    16-bit products: u = 2^-8 (bf16) / 2^-11 (f16) per operand, <= 6u of the attention output's scale per site
+    (tests/test_attention.py), 15 encoder + 24 decoder sites behind residual LayerNorms that renormalise the scale
+    each time -> the errors add like a random walk over the ~6-13 sites on any path: K_DTYPE * u * max|golden|."""
+    from eda_amd import attention
     from eda_amd.bdetr import BeaUTyDETR
-    tag = "butd" if butd else "nobutd"
+    tag = tag or ("butd" if butd else "nobutd")
     g = gold(f"full_{tag}")
+    max_len = int(g["fixture_max_len"]) if "fixture_max_len" in g.files else 16
     model = BeaUTyDETR(num_queries=64, butd=butd)
     model.text_encoder = MF.small_roberta(1)
     MF.fill_det_state(model, seed=30)
     with torch.no_grad():
         model.points_obj_cls.conv3.bias.fill_(float(g["fixture_obj_cls_bias"]))
     model.eval().to(dev)
-    inputs = MF.full_model_inputs(int(g["fixture_input_seed"]))
+    inputs = MF.full_model_inputs(int(g["fixture_input_seed"]), max_len=max_len)
     inputs = {k: ({kk: vv.to(dev) for kk, vv in v.items()} if isinstance(v, dict) else v.to(dev))
               for k, v in inputs.items()}
-    with torch.no_grad():
-        ep = model(inputs)
+    attention.set_compute_dtype(attn_dtype)
+    try:
+        with torch.no_grad():
+            ep = model(inputs)
+    finally:
+        attention.set_compute_dtype("f32")
     out = {k: v for k, v in ep.items() if torch.is_tensor(v)}
     gnames = [k for k in MF.names(g) if not k.startswith("fixture_")]
     assert sorted(out) == gnames, (sorted(set(out) ^ set(gnames)))
@@ -180,20 +197,54 @@ def run_full_model(dev, butd):
     # run's query order with the golden's before comparing per-query tensors.
     mine = out["query_points_sample_inds"].cpu().long()
     ref = torch.from_numpy(g["query_points_sample_inds"]).long()
-    assert (mine.sort(1)[0] == ref.sort(1)[0]).all(), "different query SET selected"
-    perm = torch.stack([torch.tensor([(mine[b] == r).nonzero()[0, 0] for r in ref[b]]) for b in range(len(ref))])
     prefixes = ("proposal_", "0head_", "1head_", "2head_", "3head_", "4head_", "last_")
+    per_query = lambda k: k.startswith(prefixes) or k in ("query_points_xyz", "query_points_sample_inds")  # noqa: E731
+    if attn_dtype == "f32":
+        assert (mine.sort(1)[0] == ref.sort(1)[0]).all(), "different query SET selected"
+        perm = torch.stack([torch.tensor([(mine[b] == r).nonzero()[0, 0] for r in ref[b]]) for b in range(len(ref))])
 
-    def aligned(k, v):
-        v = v.cpu()
-        if k.startswith(prefixes) or k in ("query_points_xyz", "query_points_sample_inds"):
-            return torch.stack([v[b][perm[b]] for b in range(len(v))])
-        if k == "query_points_feature":
-            return torch.stack([v[b][:, perm[b]] for b in range(len(v))])
-        return v
+        def aligned(k, v):
+            v = v.cpu()
+            if per_query(k):
+                return torch.stack([v[b][perm[b]] for b in range(len(v))])
+            if k == "query_points_feature":
+                return torch.stack([v[b][:, perm[b]] for b in range(len(v))])
+            return v
+        for k in gnames:
+            # the fixture scales the objectness head's last layer x40 (clear top-k gaps), which
+            # scales its rounding noise too: logits of O(1) with ~5e-5 absolute noise
+            # the seed objectness logits sit behind the whole encoder + two BatchNorm layers in eval mode
+            # (division by sqrt(running_var)): 1e-4 of the tensor's scale instead of 1e-5
+            MF.assert_matches(g, k, aligned(k, out[k]), atol_rel=1e-4 if k == "seeds_obj_cls_logits" else 1e-5)
+        return None
+
+    # ---- 16-bit attention: query-set stability + derived tolerances -------------------------------------------------
+    u = 2.0 ** -8 if attn_dtype == "bf16" else 2.0 ** -11
+    n_diff = sum(len(set(mine[b].tolist()) ^ set(ref[b].tolist())) // 2 for b in range(len(ref)))
+    report = {"queries_changed": n_diff, "queries_total": int(ref.numel()), "worst": {}}
+    # queries present in both runs, in the golden's order
+    common = [[(int((mine[b] == r).nonzero()[0, 0]), i) for i, r in enumerate(ref[b]) if (mine[b] == r).any()]
+              for b in range(len(ref))]
+    worst_use = 0.0
     for k in gnames:
-        # the fixture scales the objectness head's last layer x40 (clear top-k gaps), which
-        # scales its rounding noise too: logits of O(1) with ~5e-5 absolute noise
-        # the seed objectness logits sit behind the whole encoder + two BatchNorm layers in eval mode
-        # (division by sqrt(running_var)): 1e-4 of the tensor's scale instead of 1e-5
-        MF.assert_matches(g, k, aligned(k, out[k]), atol_rel=1e-4 if k == "seeds_obj_cls_logits" else 1e-5)
+        gk = k if k in g.files else None
+        if gk is None:
+            continue                      # big tensors are stored sub-sampled; the small per-query / per-token ones suffice here
+        gv = g[k]
+        if gv.dtype.kind != "f" or gv.size == 0:
+            continue
+        v = out[k].cpu().numpy()
+        if per_query(k):
+            a = np.concatenate([v[b][[m for m, _ in common[b]]] for b in range(len(ref))])
+            e = np.concatenate([gv[b][[i for _, i in common[b]]] for b in range(len(ref))])
+        elif k == "query_points_feature":
+            a = np.concatenate([v[b][:, [m for m, _ in common[b]]].T for b in range(len(ref))])
+            e = np.concatenate([gv[b][:, [i for _, i in common[b]]].T for b in range(len(ref))])
+        else:
+            a, e = v, gv
+        scale = float(np.abs(e).max()) + 1e-30
+        use = float(np.abs(a.astype(np.float64) - e.astype(np.float64)).max()) / (u * scale)
+        report["worst"][k] = use
+        worst_use = max(worst_use, use)
+    report["worst_use_in_u"] = worst_use
+    return report

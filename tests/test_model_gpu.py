@@ -31,3 +31,32 @@ def test_encoder_decoder(butd):
 @pytest.mark.parametrize("butd", [True, False])
 def test_full_model(butd):
     MC.run_full_model("cuda", butd)
+
+
+def test_full_model_130_tokens():
+    """SR3D-shaped long utterances (BASELINE.json configs[4]): padded length 130, fp32 attention."""
+    MC.run_full_model("cuda", True, tag="butd_l130")
+
+
+# max |error| / (u * max|golden|) allowed with 16-bit attention (u = 2^-8 bf16, 2^-11 f16; derivation in
+# model_cases.run_full_model).  Measured on MI355X (round 3): bf16 -- seed objectness logits 7.9 u (butd) / 9.6 u
+# (no butd), every other tensor <= 1.7 u, 2 of the 128 selected queries differ from the fp32 golden's; f16 at 130
+# tokens -- logits 3.1 u, the rest <= 0.8 u, identical query set.  The objectness logits sit behind the fixture's x40
+# scaling of the last objectness layer (it widens the top-k gaps for the fp32 tests), hence their own bound.
+K_16BIT = {"seeds_obj_cls_logits": 20.0, "default": 4.0}
+MAX_QUERIES_CHANGED = 4          # of 128; decided and documented: the top-k is NOT kept in fp32 (model_cases.run_full_model)
+
+
+@pytest.mark.parametrize("dtype,tag", [("bf16", "butd"), ("bf16", "nobutd"), ("f16", "butd_l130")])
+def test_full_model_16bit_attention(dtype, tag):
+    """BASELINE.json configs[2] (bf16) and configs[4] (fp16, 130 tokens) at MODEL level: the whole forward with 16-bit
+    MFMA attention against the reference's fp32 golden, incl. the stability of the selected query set under the
+    16-bit noise (per-query tensors are compared on the queries both runs selected)."""
+    rep = MC.run_full_model("cuda", tag != "nobutd", tag=tag, attn_dtype=dtype)
+    top = sorted(rep["worst"].items(), key=lambda kv: -kv[1])[:5]
+    print("16-bit attention report", dtype, tag, {k: (round(v, 2) if isinstance(v, float) else v)
+                                                    for k, v in rep.items() if k != "worst"})
+    print("  largest errors in units of u * max|golden|:", [(k, round(v, 2)) for k, v in top])
+    assert rep["queries_changed"] <= MAX_QUERIES_CHANGED, rep["queries_changed"]
+    for k, use in rep["worst"].items():
+        assert use <= K_16BIT.get(k, K_16BIT["default"]), (k, use, top)

@@ -1,0 +1,104 @@
+"""The software-pipelined training step (eda_amd/pipeline.py: three HIP graphs on two streams, next batch's SA1
+sampling and text encoding underneath the current step) driven the way a loader drives it: a DIFFERENT batch every
+step.  With a constant batch an off-by-one in the hand-over (indices of batch i used with points of batch i+1) could
+not fail any test; here it does, twice over:
+  * per step, the indices / hidden states / points the graphs used are those of the batch being trained;
+  * the loss history equals eager training of an identical model on the same batch sequence.
+Reference loop: main_utils.py:463-470 (a new batch every iteration)."""
+import copy
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.mark.parametrize("prefetch,text_prefetch", [("sa1", True), ("geometry", True), ("sa1", False), (None, False)])
+def test_pipelined_step_with_alternating_batches(prefetch, text_prefetch):
+    import bench
+    import check_graph_vs_eager as C
+    from eda_amd import pipeline, pointnet2_utils
+    from eda_amd.parallel import FlatParams
+    dev = torch.device("cuda", 0)
+    scenes, points, tokens, steps = 2, 20000, 24, 6
+    a = C.make(0, dev, num_queries=64, num_decoder_layers=2)          # dropout off: both runs deterministic up to atomics
+    b = copy.deepcopy(a)
+    batches = [bench.make_inputs(s, scenes, dev, points, tokens) for s in (0, 5, 9)]
+    assert not torch.equal(batches[0]["point_clouds"], batches[1]["point_clouds"])
+    seq = [batches[i % 3] for i in range(steps + 1)]
+
+    def trainer(model):
+        flat = FlatParams(model)
+
+        def backward(loss):
+            with flat.deferred_wgrad():
+                loss.backward()
+            flat.collect_grads()
+
+        def update():
+            # clipped SGD, not AdamW: Adam's first steps move EVERY parameter by +-lr whatever its gradient, so the
+            # atomics-level noise of near-zero gradients decides signs and two correct runs drift apart by percents
+            # within five steps (tests/test_graph_gpu.py allows 15 % for that reason); a proportional update keeps
+            # two correct runs within 1e-3 and lets the loss history discriminate
+            flat.clip_grad_norm_(0.1)
+            with torch.no_grad():
+                for gp in flat.groups.values():
+                    gp.add_(gp.grad, alpha=-0.05)
+        return backward, update
+
+    loss_fn = lambda ep, batch: bench.synthetic_loss(ep)          # noqa: E731
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        # eager reference on the same sequence
+        backward, update = trainer(a)
+        eager = []
+        for i in range(steps):
+            loss = loss_fn(a(seq[i]), seq[i])
+            backward(loss)
+            update()
+            eager.append(float(loss.detach()))
+        torch.cuda.synchronize()
+
+        backward, update = trainer(b)
+        # (the graphs are captured on the stream the eager steps above ran on: every lazily created workspace exists)
+        pipe = pipeline.PipelinedTrainStep(b, seq[0], loss_fn, backward, update, stream=side, prefetch=prefetch,
+                                           text_prefetch=text_prefetch)
+        got = []
+        for i in range(steps):
+            loss = pipe.step(next_batch=seq[i + 1])
+            torch.cuda.synchronize()
+            got.append(float(loss.detach()))
+            # what the graphs of step i read: the batch being trained, and ITS sampling / hidden states
+            assert torch.equal(pipe.cur["point_clouds"], seq[i]["point_clouds"]), f"step {i}: wrong points"
+            assert torch.equal(pipe.cur["tokenized"]["input_ids"], seq[i]["tokenized"]["input_ids"]), f"step {i}: wrong tokens"
+            xyz = seq[i]["point_clouds"][..., 0:3].contiguous()
+            if prefetch is not None:
+                want = pointnet2_utils.furthest_point_sample(xyz, 2048)
+                assert torch.equal(pipe.inds_cur[0], want), f"step {i}: the indices used are not the FPS of the batch trained"
+            tok = seq[i]["tokenized"]
+            hidden = b.encode_text_frozen(tok["input_ids"], tok["attention_mask"])
+            torch.testing.assert_close(pipe.text_cur, hidden, rtol=1e-5, atol=1e-5)
+            # ... and the prefetch for step i+1 is in flight / done for the batch fed
+            torch.cuda.synchronize()
+            if prefetch is not None:
+                nxt = pointnet2_utils.furthest_point_sample(seq[i + 1]["point_clouds"][..., 0:3].contiguous(), 2048)
+                assert torch.equal(pipe.inds_next[0], nxt), f"step {i}: prefetch of the wrong batch"
+        assert pipe.fps_status() == 0
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert abs(eager[0] - got[0]) <= 1e-5 * abs(eager[0]), (eager, got)
+    bad = max(abs(x - y) / max(abs(x), 1e-9) for x, y in zip(eager, got))
+    assert bad < 2e-3, (eager, got)
+    # three different batches: the losses of consecutive steps differ by far more than that tolerance, so an
+    # off-by-one batch would be seen
+    assert abs(eager[0] - eager[1]) > 20 * 2e-3 * abs(eager[0]) or abs(eager[1] - eager[2]) > 20 * 2e-3 * abs(eager[1]), eager
+    pa = torch.cat([p.detach().reshape(-1) for p in a.parameters() if p.requires_grad])
+    pb = torch.cat([p.detach().reshape(-1) for p in b.parameters() if p.requires_grad])
+    assert ((pa - pb).abs().max() / pa.abs().max()).item() < 2e-3

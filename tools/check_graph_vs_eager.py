@@ -91,7 +91,7 @@ def compare(steps=4, scenes=8, points=50000, tokens=80, verbose=True, defer_in_g
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                 static_loss = step()                          # capture = step 2's kernels (not executed)
             if pipelined:
                 hist = torch.full((steps,), 0.0, device=dev)

@@ -120,16 +120,23 @@ def main():
         save(f"bidecoder_{tag}", out=qo, grad_query=query.grad, grad_vis=vis2.grad, grad_lang=lang.grad,
              grad_w=dec.cross_v.in_proj_weight.grad)
 
+    full_model(mods)
+
+
+def full_model(mods, only=None):
     # ---- (4) full model --------------------------------------------------------
-    for butd in (True, False):
-        tag = "butd" if butd else "nobutd"
-        ref_import.FakeTokenizer.max_len = 16
+    # (tag, butd, padded utterance length): the 130-token case is the SR3D-shaped long utterance of BASELINE.json
+    # configs[4] (python tools/gen_golden_model.py --only full_butd_l130 regenerates just that file)
+    for tag, butd, max_len in (("butd", True, 16), ("nobutd", False, 16), ("butd_l130", True, 130)):
+        if only and only != f"full_{tag}":
+            continue
+        ref_import.FakeTokenizer.max_len = max_len
         model = ref_import.build_reference_model(mods, seed=0, num_queries=64, butd=butd)
         model.text_encoder = MF.small_roberta(1)
         MF.fill_det_state(model, seed=30)
         model.eval()
         for input_seed in range(3, 20):
-            inputs = MF.full_model_inputs(input_seed)
+            inputs = MF.full_model_inputs(input_seed, max_len=max_len)
             tok = ref_import.FakeTokenized(inputs["tokenized"]["input_ids"],
                                            inputs["tokenized"]["attention_mask"])
 
@@ -157,9 +164,13 @@ def main():
             raise SystemExit("no stable fixture seed found")
         out["fixture_obj_cls_bias"] = torch.tensor(bias)
         out["fixture_input_seed"] = torch.tensor(input_seed)
+        out["fixture_max_len"] = torch.tensor(max_len)
         save(f"full_{tag}", **out)
         print(len(out), "tensors")
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) == 3 and sys.argv[1] == "--only" and sys.argv[2].startswith("full_"):
+        full_model(ref_import.load(), only=sys.argv[2])
+    else:
+        main()
