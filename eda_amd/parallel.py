@@ -85,12 +85,14 @@ class FlatParams:
         self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self._grad_views = []
+        self.layout = []                   # (parameter name, group key, offset in the flat buffers, numel)
         off = 0
         bounds = {}
         for n, p in ordered:
             k = group_of(n)
             off = (off + 3) // 4 * 4
             sl = slice(off, off + p.numel())
+            self.layout.append((n, k, off, p.numel()))
             self.flat_param[sl].copy_(p.data.reshape(-1))
             p.data = self.flat_param[sl].view_as(p)          # the parameter now lives in the flat buffer
             p.grad = None
@@ -110,6 +112,7 @@ class FlatParams:
                 self.shadow = wt_shadow.TransposedShadow([p for p in self.params if p.requires_grad])
         self._prefilled = False
         self._deferred_ptrs = set()
+        self.group_bounds = dict(bounds)   # group key -> [lo, hi) in the flat buffers
         self.groups = {}
         for k, (lo, hi) in bounds.items():
             gp = torch.nn.Parameter(self.flat_param[lo:hi], requires_grad=True)

@@ -9,7 +9,7 @@ NATIVE = [
     ("native: own row GEMMs fwd / dX, tiled (gemm_rows: linear layers, small SA/FP layers)", r"^gemm_rows_kernel"),
     ("native: own row GEMMs fwd / dX, streaming (gemm_stream / gemm_gather3: many-row SA layers)", r"^gemm_stream_kernel|^gemm_gather3"),
     ("native: furthest point sampling", r"^fps_"),
-    ("native: fused attention (fwd, dQ, dK/dV)", r"^mha_"),
+    ("native: fused attention (fwd, dQ, dK/dV)", r"^mha2?_"),
     ("native: BN+ReLU(+pool) fwd/bwd", r"^bn_"),
     ("native: residual+dropout+LayerNorm", r"^add_dropout_ln|^ln_reduce"),
     ("native: weight/bias gradients (grouped wgrad, wgrad_x, colsum)", r"^wgrad_|^colsum_|^wcolsum_|^weight_transpose"),
