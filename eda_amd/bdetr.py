@@ -138,8 +138,13 @@ class BeaUTyDETR(nn.Module):
         return hidden, am.ne(1).bool(), {"input_ids": ids, "attention_mask": am}
 
     def encode_text_frozen(self, input_ids, attention_mask):
-        """last_hidden_state of the frozen RoBERTa (bdetr.py:78-80, 210-216 of the reference): no gradient."""
+        """last_hidden_state of the frozen RoBERTa (bdetr.py:78-80, 210-216 of the reference): no gradient.  On the GPU
+        the forward runs on the repo's own kernels (eda_amd/roberta_fast.py: packed q|k|v GEMM, head_dim-64 attention,
+        fused residual LayerNorm, GELU epilogue); EDA_FAST_ROBERTA=0 keeps the stock Hugging Face forward."""
+        from . import roberta_fast
         with torch.no_grad():
+            if os.environ.get("EDA_FAST_ROBERTA", "1") != "0" and roberta_fast.supported(self.text_encoder, input_ids):
+                return roberta_fast.encode(self.text_encoder, input_ids, attention_mask)
             return self.text_encoder(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state
 
     def _text_branch(self, inputs, device):

@@ -480,7 +480,8 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a_i
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           o[u] = acc[j][i][u] + bb[u];
-          if (a.relu) o[u] = fmaxf(o[u], 0.f);
+          if (a.relu == 1) o[u] = fmaxf(o[u], 0.f);
+          else if (a.relu == 2) o[u] = 0.5f * o[u] * (1.f + erff(o[u] * 0.70710678118654752f));   // GELU (erf form)
         }
         if (row < R && col < N) {
           if (drop) {

@@ -1,0 +1,147 @@
+"""The frozen RoBERTa text encoder on this repo's own kernels.
+
+The reference builds `RobertaModel.from_pretrained(...)`, freezes it (`requires_grad = False`, models/bdetr.py:77-80)
+and reads `last_hidden_state` once per step (:170-175).  The module and its state_dict stay Hugging Face's (checkpoints
+carry its parameter names); what changes on the GPU is how the forward is computed -- inference only, no autograd:
+
+    embeddings   word[ids] + position[cumsum(ids != pad)] + token_type[0]  -> fused residual LayerNorm (csrc/ln.hip)
+    per layer    ONE packed q|k|v projection (own fp32-MFMA row GEMM, csrc/gemm.hip; the three weights are concatenated
+                 once, the encoder is frozen), head_dim-64 attention (csrc/mha_hd64.hip), output projection without its bias
+                 -> LayerNorm(x + y + bias); intermediate projection with GELU in the GEMM epilogue; output projection
+                 -> LayerNorm(x + y + bias)
+
+i.e. 7 launches per layer, none of them a library GEMM, an AOTriton attention or a TunableOp-selected kernel (what the
+stock module ran: 85 hipBLASLt + 12 Triton `attn_fwd` launches per step).  Numerics: fp32 throughout (exact-f32 MFMA);
+tests/test_roberta_fast_gpu.py compares with the Hugging Face forward of the same weights.
+"""
+import torch
+
+from . import _lib, gemm
+from .ext import _timed
+
+
+def _ln_residual(x2, y2, y_bias, gamma, beta, eps, out=None):
+    """LayerNorm(x2 + y2 + y_bias) over the last dim of (R, C) fp32 matrices (csrc/ln.hip, dropout off)."""
+    R, C = x2.shape
+    if out is None:
+        out = torch.empty_like(x2)
+    stats = torch.empty((2, R), dtype=torch.float32, device=x2.device)
+    with torch.cuda.device(x2.device), _timed("add_dropout_ln_fwd", (R, C)):
+        rc = _lib.lib().eda_add_dropout_ln_fwd_f32(
+            x2.data_ptr(), y2.data_ptr(), y_bias.data_ptr() if y_bias is not None else None, gamma.data_ptr(),
+            beta.data_ptr(), R, C, float(eps), 0.0, None, 0, out.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+            None, None, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "eda_add_dropout_ln_fwd_f32")
+    return out
+
+
+def attention_hd64(q, k, v, key_padding_mask, num_heads, scale):
+    """softmax(q k^T * scale + mask) v for head_dim 64, q (B,Lq,D), k / v (B,Lk,D) column views with unit last stride;
+    key_padding_mask (B,Lk) bool, True = ignore.  Forward only."""
+    B, Lq, D = q.shape
+    Lk = k.shape[1]
+    assert D == 64 * num_heads
+    out = torch.empty((B, Lq, D), dtype=torch.float32, device=q.device)
+    m8 = key_padding_mask.contiguous().view(torch.uint8) if key_padding_mask is not None else None
+    with torch.cuda.device(q.device), _timed("mha_fwd_hd64", (B, num_heads, Lq, Lk)):
+        rc = _lib.lib().eda_mha_fwd_hd64_f32(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0),
+            v.stride(1), m8.data_ptr() if m8 is not None else None, B, num_heads, Lq, Lk, float(scale), out.data_ptr(),
+            torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "eda_mha_fwd_hd64_f32")
+    return out
+
+
+class FrozenRobertaFast:
+    """Forward of a frozen `transformers.RobertaModel` (absolute position embeddings, GELU, no cross-attention) on the
+    repo's kernels.  Holds packed copies of the attention projection weights; `stale()` tells when the module's
+    parameters were modified in place (load_state_dict) since packing."""
+
+    def __init__(self, hf_model):
+        cfg = hf_model.config
+        if cfg.hidden_act != "gelu" or cfg.hidden_size % cfg.num_attention_heads or \
+                cfg.hidden_size // cfg.num_attention_heads != 64 or getattr(cfg, "is_decoder", False):
+            raise NotImplementedError("FrozenRobertaFast: RoBERTa-base-shaped encoders only (GELU, head_dim 64)")
+        if getattr(cfg, "position_embedding_type", "absolute") not in (None, "absolute"):
+            raise NotImplementedError("FrozenRobertaFast: absolute position embeddings only")
+        self.m = hf_model
+        self.cfg = cfg
+        self.heads = cfg.num_attention_heads
+        self.eps = float(cfg.layer_norm_eps)
+        self.pad = int(hf_model.embeddings.padding_idx)
+        self._versions = self._param_versions()
+        self.layers = []
+        with torch.no_grad():
+            for lyr in hf_model.encoder.layer:
+                sa = lyr.attention.self
+                self.layers.append({
+                    "wqkv": torch.cat([sa.query.weight, sa.key.weight, sa.value.weight], 0).contiguous(),
+                    "bqkv": torch.cat([sa.query.bias, sa.key.bias, sa.value.bias], 0).contiguous(),
+                    "lyr": lyr})
+
+    def _param_versions(self):
+        return tuple(p._version for p in self.m.parameters()) + (next(self.m.parameters()).data_ptr(),)
+
+    def stale(self):
+        return self._param_versions() != self._versions
+
+    @torch.no_grad()
+    def __call__(self, input_ids, attention_mask):
+        """last_hidden_state (B, L, hidden) for token ids / attention mask (1 = token) on the GPU."""
+        m, d = self.m, self.cfg.hidden_size
+        B, L = input_ids.shape
+        if L > 256:
+            raise NotImplementedError("FrozenRobertaFast: utterances of up to 256 tokens (csrc/mha_hd64.hip keeps K/V in LDS)")
+        emb = m.embeddings
+        nonpad = input_ids.ne(self.pad)
+        position_ids = torch.cumsum(nonpad.long(), dim=1) * nonpad.long() + self.pad    # create_position_ids_from_input_ids
+        x = emb.word_embeddings.weight[input_ids].view(B * L, d)
+        y = (emb.position_embeddings.weight[position_ids] + emb.token_type_embeddings.weight[0]).view(B * L, d)
+        h = _ln_residual(x, y, None, emb.LayerNorm.weight, emb.LayerNorm.bias, self.eps)
+        kpm = attention_mask.eq(0)                                              # True = padding key
+        scale = 64 ** -0.5
+        for ent in self.layers:
+            lyr = ent["lyr"]
+            qkv = gemm.linear_fwd(h, ent["wqkv"], ent["bqkv"]).view(B, L, 3 * d)
+            ctx = attention_hd64(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], kpm, self.heads, scale)
+            ao = lyr.attention.output
+            y = gemm.linear_fwd(ctx.view(B * L, d), ao.dense.weight)            # (bias added by the LayerNorm kernel)
+            h = _ln_residual(h, y, ao.dense.bias, ao.LayerNorm.weight, ao.LayerNorm.bias, self.eps)
+            t = _gelu_linear(h, lyr.intermediate.dense.weight, lyr.intermediate.dense.bias)
+            y = gemm.linear_fwd(t, lyr.output.dense.weight)
+            h = _ln_residual(h, y, lyr.output.dense.bias, lyr.output.LayerNorm.weight, lyr.output.LayerNorm.bias, self.eps)
+        return h.view(B, L, d)
+
+
+def _gelu_linear(x2, w, bias):
+    """gelu(x2 @ w.T + bias), erf form, in the GEMM's epilogue (eda_linear_fwd_f32 with activation code 2)."""
+    x2, w = gemm._rows2d(x2), gemm._rows2d(w)
+    R, K = x2.shape
+    N = w.shape[0]
+    out = torch.empty((R, N), dtype=torch.float32, device=x2.device)
+    with torch.cuda.device(x2.device), _timed("gemm_fwd", (R, K, N)):
+        rc = _lib.lib().eda_linear_fwd_f32(x2.data_ptr(), gemm._ld(x2), R, K, w.data_ptr(), gemm._ld(w), N, bias.data_ptr(), 2,
+                                           out.data_ptr(), gemm._ld(out), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "eda_linear_fwd_f32")
+    return out
+
+
+_cache = {}
+
+
+def encode(hf_model, input_ids, attention_mask):
+    """last_hidden_state of `hf_model` through the fast path (built and cached per module; rebuilt when its parameters
+    were written in place since)."""
+    key = id(hf_model)
+    fast = _cache.get(key)
+    if fast is None or fast.m is not hf_model or fast.stale():
+        fast = _cache[key] = FrozenRobertaFast(hf_model)
+    return fast(input_ids, attention_mask)
+
+
+def supported(hf_model, input_ids):
+    cfg = getattr(hf_model, "config", None)
+    return (input_ids.is_cuda and cfg is not None and getattr(cfg, "hidden_act", None) == "gelu"
+            and hasattr(hf_model, "encoder") and hasattr(hf_model, "embeddings")
+            and cfg.hidden_size == 64 * cfg.num_attention_heads and input_ids.shape[1] <= 256
+            and not hf_model.training)

@@ -159,6 +159,15 @@ int eda_mha_bwd_f32(const float *q, const float *k, const float *v, long q_sb, l
                     float *delta_ws, float *dq, float *dk, float *dv, long dq_sb, long dq_sl,
                     long dk_sb, long dk_sl, long dv_sb, long dv_sl, void *ws, size_t ws_bytes,
                     void *stream);
+/* Forward-only attention for head_dim 64 (csrc/mha_hd64.hip): the self-attention of the frozen RoBERTa-base text
+ * encoder (models/bdetr.py:77-80, 170-175 -> transformers RobertaSelfAttention: softmax(q k^T * scale + padding mask) v).
+ * q (B,Lq,.), k/v (B,Lk,.) with head h at columns [64h, 64h+64), element strides as in eda_mha_fwd_f32;
+ * key_padding_mask (B,Lk) bytes, 1 = ignore, or NULL; out (B,Lq,H*64) dense.  1 <= Lk <= 256.  No dropout, no
+ * backward: the encoder is frozen (requires_grad = False, bdetr.py:78-80). */
+int eda_mha_fwd_hd64_f32(const float *q, const float *k, const float *v, long q_sb, long q_sl, long k_sb, long k_sl,
+                         long v_sb, long v_sl, const unsigned char *key_padding_mask, int B, int H, int Lq, int Lk,
+                         float scale, float *out, void *stream);
+
 /* ws: optional scratch of eda_mha_bwd_workspace_bytes() (0 = none needed): with it, short key
  * dimensions split the query range of the dK/dV kernel over more workgroups (partials summed in
  * split order); without it (NULL) the unsplit kernel runs.                                   */
@@ -331,7 +340,9 @@ int eda_device_copy_f32(const float *src, float *dst, size_t n, void *stream);
 /* ---- row GEMMs of the pointwise layers (csrc/gemm.hip, fp32 MFMA) ---------------------------
  * eda_linear_fwd_f32 replaces the cuBLAS/cuDNN call behind every nn.Linear / Conv1d(k=1) /
  * Conv2d(1x1) of the path (pointnet2/pytorch_utils.py:88-120; models/encoder_decoder_layers.py:
- * 47-75,324-330; models/modules.py:19-178): y (R,N) = x (R,K) w(N,K)^T + bias, optional ReLU.
+ * 47-75,324-330; models/modules.py:19-178): y (R,N) = x (R,K) w(N,K)^T + bias, optional activation
+ * (relu = 1: ReLU; relu = 2: GELU in its erf form, the `intermediate` activation of the frozen RoBERTa encoder,
+ * models/bdetr.py:77-80).
  * Row strides ldx/ldw/ldy in floats; 16-byte loads/stores are used when K, N, the strides and
  * the pointers allow, element accesses otherwise (any K, N >= 1).                             */
 int eda_linear_fwd_f32(const float *x, long ldx, long R, int K, const float *w, long ldw, int N,
