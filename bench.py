@@ -337,8 +337,9 @@ def main():
                          "a SEPARATE bench line, never the headline")
     ap.add_argument("--sync-bn", action="store_true",
                     help="N > 1: global-batch BatchNorm statistics like the reference's SyncBatchNorm "
-                         "(eda_amd/sync_bn.py: one fused statistics all-reduce per BN layer and direction; the fused "
-                         "single-launch BN paths are bypassed).  Default: per-GPU statistics (DESIGN.md §5)")
+                         "(eda_amd/sync_bn.py: one packed statistics all-reduce per BN layer and direction; the fused SA / FP "
+                         "calls stay fused and exchange their sums through eda_set_bn_sync, the single-launch small-row BN "
+                         "kernels are replaced by torch ops).  Default: per-GPU statistics (DESIGN.md §5)")
     ap.add_argument("--split-graphs", action="store_true",
                     help="use the N>1 graph structure (two graphs, eager all-reduce slot) even at N=1")
     ap.add_argument("--kernel-steps", type=int, default=3,
@@ -369,8 +370,8 @@ def main():
     from eda_amd import ext
     if args.sync_bn and world > 1:
         from eda_amd import sync_bn
-        sync_bn.enable()
-        args.graph = 0          # the statistics collectives run between kernels: eager launches
+        sync_bn.enable()        # fused SA / FP calls keep their fusion (library hook); no host synchronisation anywhere, so the
+        # step is captured like the default one (a capture failure falls back to eager launches below)
     from eda_amd.bdetr import BeaUTyDETR
     from eda_amd.parallel import FlatParams, reference_lr_groups
     if args.blas != "default":

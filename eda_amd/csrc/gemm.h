@@ -47,6 +47,8 @@ struct GemmArgs {
   // whose activated output `gate` is, applied to the input gradient that flows into it
   float drop_p; const unsigned long long *drop_seed; unsigned drop_salt;
   const float *gate; long ldgate; float gate_scale;
+  int defer_finalize;   // E_STATS: the last workgroup only re-arms the ticket; the column sums stay in `sum` / `sumsq`
+                        // for a cross-rank all-reduce, a separate kernel finalises (sa_cl.hip, eda_set_bn_sync)
   int dbg;   // EDA_GEMM_DBG timing experiments (results are then wrong): 1 skip park, 2 no grid cap, 4 skip atomics, 8 skip z loads
 };
 

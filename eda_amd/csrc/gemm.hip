@@ -68,6 +68,10 @@ __device__ __forceinline__ float row_sum16(float v) {
 // E_STATS, last workgroup: column sums -> mean / rstd / scale / shift and the running statistics
 // (train-mode BatchNorm, pointnet2/pytorch_utils.py:67-120); re-arms the accumulators and the ticket.
 __device__ __forceinline__ void bn_finalize(const GemmArgs &a, int tid, int nthreads) {
+  if (a.defer_finalize) {          // global-batch statistics: the sums are all-reduced over the ranks first
+    if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   const long R = a.R;
   for (int c = tid; c < a.N; c += nthreads) {
     const double su = __hip_atomic_load(a.sum + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -359,18 +359,19 @@ __global__ __launch_bounds__(CL_THREADS) void bn_relu_bwd_apply_kernel(
     const float *__restrict__ rstd, const float *__restrict__ scale,
     const float *__restrict__ shift, const float *__restrict__ gamma,
     const double *__restrict__ s1, const double *__restrict__ s2, int train,
-    float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dz) {
+    float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dz, float invR, float gscale) {
+  // invR = 1 / (rows the statistics were taken over): 1/R, or 1/(R * ranks) with global-batch statistics, where s1 / s2
+  // are the all-reduced sums and gscale = 1/ranks turns them into what the gradient all-reduce's mean expects
   const int cgroups = C / 4;
   const int rpp = CL_THREADS / cgroups;
   const int tcol = threadIdx.x % cgroups, trow = threadIdx.x / cgroups;
   if (trow >= rpp) return;
   const int c0 = tcol * 4;
-  const float invR = 1.f / (float)R;
   float sc[4], sh[4], ka[4], kb[4], kd[4];
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     const int c = c0 + v;
-    if (blockIdx.x == 0 && trow == 0) { dbeta[c] = (float)s1[c]; dgamma[c] = (float)s2[c]; }
+    if (blockIdx.x == 0 && trow == 0) { dbeta[c] = (float)s1[c] * gscale; dgamma[c] = (float)s2[c] * gscale; }
     sc[v] = scale[c]; sh[v] = shift[c];
     const float gr = gamma[c] * rstd[c];
     ka[v] = gr;
@@ -856,11 +857,11 @@ extern "C" int eda_bn_relu_bwd_f32(const float *dout, const unsigned char *argma
   if (pool > 1)
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<true>, dim3(apply_grid), dim3(CL_THREADS), 0, stream,
                        dout, argmax, z, R, C, pool, mean, rstd, scale, shift, gamma, ws, ws + C, training,
-                       dgamma, dbeta, dz);
+                       dgamma, dbeta, dz, 1.f / (float)R, 1.f);
   else
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<false>, dim3(apply_grid), dim3(CL_THREADS), 0, stream,
                        dout, argmax, z, R, C, pool, mean, rstd, scale, shift, gamma, ws, ws + C, training,
-                       dgamma, dbeta, dz);
+                       dgamma, dbeta, dz, 1.f / (float)R, 1.f);
   EDA_CHECK_LAUNCH();
   return 0;
 }
@@ -948,13 +949,12 @@ namespace {
 __global__ void bn_bwd_consts_kernel(const float *__restrict__ mean, const float *__restrict__ rstd,
                                      const float *__restrict__ scale, const float *__restrict__ shift,
                                      const float *__restrict__ gamma, const double *__restrict__ s1,
-                                     const double *__restrict__ s2, long R, int C, float *__restrict__ dgamma,
-                                     float *__restrict__ dbeta, float *__restrict__ consts) {
+                                     const double *__restrict__ s2, float invR, float gscale, int C,
+                                     float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ consts) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const float invR = 1.f / (float)R;
-  dbeta[c] = (float)s1[c];
-  dgamma[c] = (float)s2[c];
+  dbeta[c] = (float)s1[c] * gscale;
+  dgamma[c] = (float)s2[c] * gscale;
   const float gr = gamma[c] * rstd[c];
   const float t2 = rstd[c] * (float)s2[c] * invR;
   consts[c] = scale[c];
@@ -964,6 +964,52 @@ __global__ void bn_bwd_consts_kernel(const float *__restrict__ mean, const float
   consts[4 * C + c] = gr * (mean[c] * t2 - (float)s1[c] * invR);
 }
 }  // namespace
+
+// ---- global-batch BatchNorm statistics (the reference's SyncBatchNorm, main_utils.py:336-338) inside the fused calls ----
+// A fused SA / FP call produces a layer's column sums in a kernel epilogue and consumes them in the next kernel's
+// prologue; with more than one rank the sums have to be added over the ranks in between.  The host registers a hook
+// (eda_set_bn_sync): the fused calls then leave the sums un-finalised, call the hook on the packed fp64 vector
+// [sum | sum of squares] (forward) / [sum gy | sum gy (z - mean)] (backward) -- ONE collective per layer and direction,
+// enqueued on the same stream, no host synchronisation -- and finalise with the GLOBAL row count R * world (every rank
+// holds the same number of rows: scenes x positions are fixed per GPU).  d(gamma), d(beta) are the global sums / world,
+// i.e. what the gradient all-reduce's mean makes of the ranks' local sums.
+namespace {
+eda_bn_sync_fn g_sync_fn = nullptr;
+void *g_sync_user = nullptr;
+int g_sync_world = 1;
+bool bn_sync_on() { return g_sync_fn != nullptr; }   // (world == 1 with a hook: the split kernels alone -- tests)
+
+__global__ void bn_sync_finalize_kernel(double *__restrict__ sum, double *__restrict__ sumsq, double count, int C,
+                                        const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                        float momentum, float *__restrict__ running_mean, float *__restrict__ running_var,
+                                        float *__restrict__ mean_out, float *__restrict__ rstd_out,
+                                        float *__restrict__ scale, float *__restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = sum[c] / count;
+  double var = sumsq[c] / count - mean * mean;
+  sum[c] = 0.0; sumsq[c] = 0.0;                      // re-armed for the next statistics launch
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float meanf = (float)mean;
+  mean_out[c] = meanf;
+  rstd_out[c] = rstd;
+  const float sc = gamma[c] * rstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - meanf * sc;
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+}  // namespace
+
+extern "C" int eda_set_bn_sync(eda_bn_sync_fn fn, void *user, int world) {
+  EDA_CHECK_ARG(world >= 1, "world size must be >= 1");
+  g_sync_fn = fn; g_sync_user = user; g_sync_world = fn ? world : 1;
+  return 0;
+}
 
 extern "C" int eda_sa_fused_fwd_f32(const float *x, long ldx, const float *xyz, const float *new_xyz,
                                     const float *feats_cl, const int *idx, int b, int n, int m, int ns, int c_feat,
@@ -1002,11 +1048,21 @@ extern "C" int eda_sa_fused_fwd_f32(const float *x, long ldx, const float *xyz, 
       a.running_mean = running_mean ? running_mean[l] : nullptr;
       a.running_var = running_var ? running_var[l] : nullptr;
       a.mean_out = st; a.rstd_out = st + cout; a.scale_out = st + 2 * cout; a.shift_out = st + 3 * cout;
+      a.defer_finalize = bn_sync_on() ? 1 : 0;
     } else {
       a.epi = E_PLAIN;
     }
     const int rc = eda_gemm_launch(a, W_NT, stream);
     if (rc) return rc;
+    if (training && bn_sync_on()) {
+      const int src = g_sync_fn(g_sync_user, ws, 2L * cout, stream_);
+      if (src) { eda_set_error("eda_sa_fused_fwd_f32: the BatchNorm statistics hook failed (%d)", src); return EDA_ERR_UNSUPPORTED; }
+      hipLaunchKernelGGL(bn_sync_finalize_kernel, dim3((cout + 255) / 256), dim3(256), 0, stream, ws, ws + cout,
+                         (double)R * g_sync_world, cout, gamma[l], beta[l], eps, momentum,
+                         running_mean ? running_mean[l] : nullptr, running_var ? running_var[l] : nullptr, st, st + cout,
+                         st + 2 * cout, st + 3 * cout);
+      EDA_CHECK_LAUNCH();
+    }
   }
   const int C = channels[nlayers];
   const float *st = stats[nlayers - 1];
@@ -1071,6 +1127,10 @@ static int sa_fused_bwd_impl(const float *dout, const unsigned char *argmax, con
   EDA_CHECK_ARG(ws_bytes >= eda_sa_fused_bwd_workspace_bytes(R, nlayers, channels, g.gather) &&
                     (reinterpret_cast<uintptr_t>(ws_) & 15u) == 0, "workspace too small or misaligned");
   EDA_CHECK_ARG(pool == 1 || argmax, "argmax required when pooling");
+  // global-batch statistics (eda_set_bn_sync): the reductions are all-reduced before they are used
+  const bool sync = training && bn_sync_on();
+  const float inv_n = 1.f / ((float)R * (sync ? g_sync_world : 1));
+  const float gscale = sync ? 1.f / g_sync_world : 1.f;
   int cmax = 0;
   for (int l = 1; l <= nlayers; ++l) if (channels[l] > cmax) cmax = channels[l];
   double *red_all = reinterpret_cast<double *>(ws_);      // region l: the two BatchNorm-backward reductions of layer l
@@ -1118,18 +1178,22 @@ static int sa_fused_bwd_impl(const float *dout, const unsigned char *argmax, con
       hipLaunchKernelGGL(bn_relu_bwd_stats_vec_kernel, dim3(nblocks), dim3(CL_THREADS), 0, stream, dout, z[l], R, C, rpb,
                          st, st + C, st + 2 * C, st + 3 * C, red, red + C);
     EDA_CHECK_LAUNCH();
+    if (sync) {
+      const int src = g_sync_fn(g_sync_user, red, 2L * C, stream_);
+      if (src) { eda_set_error("eda_sa_fused_bwd_f32: the BatchNorm statistics hook failed (%d)", src); return EDA_ERR_UNSUPPORTED; }
+    }
     const int apply_grid = grid_for(R * (C / 4));
     if (fuse_pool)
       hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, st, st + C, st + 2 * C,
-                         st + 3 * C, gamma[l], red, red + C, R, C, dgamma[l], dbeta[l], pool_consts);
+                         st + 3 * C, gamma[l], red, red + C, inv_n, gscale, C, dgamma[l], dbeta[l], pool_consts);
     else if (pool > 1)
       hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<true>, dim3(apply_grid), dim3(CL_THREADS), 0, stream, dout, argmax,
                          z[l], R, C, pool, st, st + C, st + 2 * C, st + 3 * C, gamma[l], red, red + C, training,
-                         dgamma[l], dbeta[l], scratch_a);
+                         dgamma[l], dbeta[l], scratch_a, inv_n, gscale);
     else
       hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<false>, dim3(apply_grid), dim3(CL_THREADS), 0, stream, dout, argmax,
                          z[l], R, C, pool, st, st + C, st + 2 * C, st + 3 * C, gamma[l], red, red + C, training,
-                         dgamma[l], dbeta[l], scratch_a);
+                         dgamma[l], dbeta[l], scratch_a, inv_n, gscale);
     EDA_CHECK_LAUNCH();
   }
   float *cur = scratch_a, *other = scratch_b;
@@ -1188,10 +1252,14 @@ static int sa_fused_bwd_impl(const float *dout, const unsigned char *argmax, con
       a.s1 = red; a.s2 = red + cin;
       const int rc = eda_gemm_launch(a, W_NT, stream);
       if (rc) return rc;
+      if (sync) {
+        const int src = g_sync_fn(g_sync_user, red, 2L * cin, stream_);
+        if (src) { eda_set_error("eda_sa_fused_bwd_f32: the BatchNorm statistics hook failed (%d)", src); return EDA_ERR_UNSUPPORTED; }
+      }
       // dz_{l-1} = A*gy + B*z + D, in place (gy is already masked: the kernel's mask is idempotent)
       hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<false>, dim3(grid_for(R * (cin / 4))), dim3(CL_THREADS), 0, stream,
                          other, nullptr, z[l - 1], R, cin, 1, st, st + cin, st + 2 * cin, st + 3 * cin, gamma[l - 1],
-                         red, red + cin, training, dgamma[l - 1], dbeta[l - 1], other);
+                         red, red + cin, training, dgamma[l - 1], dbeta[l - 1], other, inv_n, gscale);
       EDA_CHECK_LAUNCH();
       float *t = cur; cur = other; other = t;
     } else if (g.gather) {

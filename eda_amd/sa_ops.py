@@ -228,6 +228,9 @@ class FusedMLP(Function):
         argmax = torch.empty((R // pool, chans[L]), dtype=torch.uint8, device=dev) if pool > 1 else None
         running = cfg["running"]
         ws = _bn_workspace(dev)
+        from . import sync_bn
+        if sync_bn.fused_hook_installed():
+            sync_bn.note_buffer(ws)              # (its column sums are all-reduced between the layers' kernels)
         chan_arr = (ctypes.c_int * (L + 1))(*chans)
         with torch.cuda.device(dev), _timed('sa_fused_fwd', (R, pool, int(training)) + tuple(chans)):
             rc = _lib.lib().eda_sa_fused_fwd_f32(
@@ -270,6 +273,10 @@ class FusedMLP(Function):
         lib = _lib.lib()
         ws_bytes = lib.eda_sa_fused_bwd_workspace_bytes(R, L, chan_arr, int(gather))
         ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
+        from . import sync_bn
+        hooked = sync_bn.fused_hook_installed()
+        if hooked:
+            sync_bn.note_buffer(ws)
         # W^T of the layers' weights, where the caller's shadow has them (eda_amd/wt_shadow.py): the call then skips
         # its per-layer transpose launches
         from . import wt_shadow
@@ -289,6 +296,8 @@ class FusedMLP(Function):
                 ws.data_ptr(), ws_bytes, _ptr_array(dW), _ptr_array([g[0] for g in dgb]),
                 _ptr_array([g[1] for g in dgb]), dx.data_ptr() if dx is not None else None,
                 dx.stride(0) if dx is not None else 0, dfeats.data_ptr() if dfeats is not None else None, _stream())
+        if hooked:
+            sync_bn.forget_buffer(ws)
         _lib.check(rc, "eda_sa_fused_bwd_wt_f32")
         grads = []
         for l in range(L):
@@ -298,8 +307,8 @@ class FusedMLP(Function):
 
 def _fusable(layers):
     from . import sync_bn
-    if sync_bn.enabled():          # global-batch statistics: a collective between GEMM and BN (eda_amd/sync_bn.py)
-        return False
+    if sync_bn.enabled() and not sync_bn.fused_hook_installed():
+        return False               # global-batch statistics without the library hook: layer by layer (eda_amd/sync_bn.py)
     return _FUSED and all(l.bn is not None and l.conv.bias is None and l.conv.out_channels % 4 == 0 for l in layers)
 
 

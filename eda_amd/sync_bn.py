@@ -13,29 +13,98 @@ positional embeddings) to the reference's semantics:
   dz = gamma*rstd*(gy - s1/N - xhat*s2/N) with the global N; d(gamma), d(beta) stay LOCAL sums (the
   gradient all-reduce of eda_amd/parallel.py adds them over ranks like every other gradient).
 
-It is written with device-agnostic torch ops (it runs under gloo on CPU in tests/test_parallel_cpu.py
-and under RCCL on the GPUs); the fused single-launch kernels cannot stop in the middle for a
-collective, so this mode trades their fusion for the reference's exact multi-GPU statistics.
+Two implementations:
+
+* the FUSED set-abstraction / feature-propagation calls (eda_sa_fused_fwd/bwd_f32: 16 of the 68 BatchNorm layers, and
+  all of the ones with 10^5..10^6 rows) keep their fusion: `enable()` registers a hook with the library
+  (include/eda_hip.h: eda_set_bn_sync) and the native call hands every layer's packed fp64 sums to
+  `dist.all_reduce` between the kernel that accumulates them and the kernel that finalises them -- one collective per
+  layer and direction on the same stream, no host synchronisation (every rank must hold the same number of rows);
+* the single-launch small-row kernels of the heads / positional embeddings cannot stop in the middle for a collective:
+  those sites run the device-agnostic torch ops below (also what runs under gloo on CPU in
+  tests/test_parallel_cpu.py), one packed collective per BatchNorm and direction, no host synchronisation either.
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
 from torch.autograd import Function
 
 _group = None
 _enabled = False
+_fused_hook = None          # the ctypes callback object (must stay alive while registered)
+_buffers = {}               # id -> tensor: device buffers the native calls may ask to all-reduce parts of
+_reduce = None              # test seam: replaces dist.all_reduce(t, group) in the hook
+
+_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p)
 
 
-def enable(group=None):
-    """Use global-batch statistics in every BN+ReLU site (requires an initialised process group)."""
+def note_buffer(t):
+    """Register a device tensor whose memory a fused native call may hand to the statistics hook."""
+    _buffers[id(t)] = t
+    return t
+
+
+def forget_buffer(t):
+    _buffers.pop(id(t), None)
+
+
+def _hook(user, buf, n, stream):
+    """eda_bn_sync_fn: sum `n` doubles at device address `buf` over the ranks, in place, enqueued on the current stream
+    (the native call launches on torch's current stream, so the collective is ordered between its kernels)."""
+    try:
+        for t in list(_buffers.values()):
+            lo = t.data_ptr()
+            if lo <= buf and buf + 8 * n <= lo + t.numel() * t.element_size():
+                off = buf - lo
+                view = t.view(torch.uint8).reshape(-1)[off:off + 8 * n].view(torch.float64)
+                if _reduce is not None:
+                    _reduce(view)
+                else:
+                    dist.all_reduce(view, group=_group)
+                return 0
+        return 2                      # unknown buffer
+    except Exception:                 # never let an exception cross the C boundary
+        import traceback
+        traceback.print_exc()
+        return 3
+
+
+def install_fused_hook(world):
+    """Register the hook with libeda_hip.so (GPU builds): the fused SA / FP calls then exchange their statistics."""
+    global _fused_hook
+    from . import _lib
+    _fused_hook = _CB(_hook)
+    _lib.check(_lib.lib().eda_set_bn_sync(ctypes.cast(_fused_hook, ctypes.c_void_p), None, int(world)), "eda_set_bn_sync")
+
+
+def remove_fused_hook():
+    global _fused_hook
+    if _fused_hook is not None:
+        from . import _lib
+        _lib.lib().eda_set_bn_sync(None, None, 1)
+        _fused_hook = None
+
+
+def fused_hook_installed():
+    return _fused_hook is not None
+
+
+def enable(group=None, fused=True):
+    """Use global-batch statistics in every BN+ReLU site (requires an initialised process group).  fused=True (and a
+    GPU): the fused SA / FP calls stay fused and exchange their sums through the library hook."""
     global _enabled, _group
     if not dist.is_initialized():
         raise RuntimeError("sync_bn.enable() needs torch.distributed to be initialised")
     _enabled, _group = True, group
+    if fused and torch.cuda.is_available() and dist.get_world_size(group) > 1:
+        install_fused_hook(dist.get_world_size(group))
 
 
 def disable():
     global _enabled, _group
     _enabled, _group = False, None
+    remove_fused_hook()
 
 
 def enabled():
@@ -54,7 +123,7 @@ class _SyncBNReLU(Function):
             mean = packed[:C] / n
             var = (packed[C:2 * C] / n - mean * mean).clamp_min(0.0)
             if running_mean is not None:
-                unbiased = var * (n / (n - 1.0)) if float(n) > 1 else var
+                unbiased = var * (n / (n - 1.0).clamp_min(1.0))          # (on the device: no host synchronisation)
                 running_mean.mul_(1.0 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
                 running_var.mul_(1.0 - momentum).add_(unbiased.to(running_var.dtype), alpha=momentum)
             mean, var = mean.float(), var.float()

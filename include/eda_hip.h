@@ -444,6 +444,15 @@ int eda_linear_ex_f32(const float *x, long ldx, long R, int K, const float *w, l
  * the forward (eda_linear_fwd_f32 on W^T). */
 int eda_transpose_batch_f32(const long long *desc, int count, long long total_tiles, void *stream);
 
+/* Global-batch BatchNorm statistics for the fused set-abstraction / feature-propagation calls: the reference converts
+ * every BatchNorm to SyncBatchNorm when more than one GPU trains (main_utils.py:336-338).  With a hook registered
+ * (fn != NULL, world > 1) eda_sa_fused_fwd_f32 / eda_sa_fused_bwd*_f32 call fn(user, buf, n, stream) once per layer and
+ * direction on a device vector of n fp64 sums that has to be summed over the ranks IN PLACE by work enqueued on
+ * `stream` (no host synchronisation; return 0 on success), and use R * world as the row count.  Every rank must hold
+ * the same number of rows.  fn == NULL restores per-GPU statistics. */
+typedef int (*eda_bn_sync_fn)(void *user, double *buf, long n, void *stream);
+int eda_set_bn_sync(eda_bn_sync_fn fn, void *user, int world);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,89 @@
+"""Global-batch BatchNorm statistics INSIDE the fused set-abstraction / feature-propagation calls (the reference's
+SyncBatchNorm, main_utils.py:336-338; include/eda_hip.h: eda_set_bn_sync; eda_amd/sync_bn.py).  No second GPU is needed
+to check the mechanism:
+  * world = 1 with a hook that reduces nothing: the split path (statistics left un-finalised by the GEMM epilogue, hook,
+    separate finalise kernel) must equal the fused call BIT FOR BIT, forward and backward;
+  * world = 2 emulated with a hook that doubles the sums (two ranks holding the same rows): global statistics equal
+    the local ones, so outputs and gradients must again equal the plain call's (d(gamma), d(beta) = global sums / world);
+  * the hook is called once per layer and direction, with 2 C doubles."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(gather, seed=0):
+    from eda_amd import sa_ops
+    torch.manual_seed(seed)
+    dev = "cuda"
+    chans = [16, 32, 64, 64] if not gather else [3 + 8, 32, 64]
+    L = len(chans) - 1
+    params = []
+    for l in range(L):
+        w = (torch.randn(chans[l + 1], chans[l], device=dev) / chans[l] ** 0.5).requires_grad_(True)
+        g = (torch.rand(chans[l + 1], device=dev) + 0.5).requires_grad_(True)
+        b = (torch.randn(chans[l + 1], device=dev) * 0.1).requires_grad_(True)
+        params += [w, g, b]
+    running = [(torch.zeros(chans[l + 1], device=dev), torch.ones(chans[l + 1], device=dev)) for l in range(L)]
+    if gather:
+        B, N, m, ns = 2, 512, 64, 16
+        xyz = torch.rand(B, N, 3, device=dev)
+        new_xyz = xyz[:, :m].contiguous()
+        feats = torch.randn(B, N, 8, device=dev, requires_grad=True)
+        idx = torch.randint(0, N, (B, m, ns), device=dev, dtype=torch.int32)
+        cfg = dict(gather=True, radius=0.5, normalize_xyz=True, pool=ns, training=True, eps=1e-5, momentum=0.1, running=running)
+        out = sa_ops.FusedMLP.apply(cfg, None, xyz, new_xyz, feats, idx, *params)
+        leaf = feats
+    else:
+        x = torch.randn(4096, chans[0], device=dev, requires_grad=True)
+        cfg = dict(gather=False, radius=1.0, normalize_xyz=False, pool=16, training=True, eps=1e-5, momentum=0.1, running=running)
+        out = sa_ops.FusedMLP.apply(cfg, x, None, None, None, None, *params)
+        leaf = x
+    w = torch.randn_like(out)
+    (out * w).sum().backward()
+    torch.cuda.synchronize()
+    return [out.detach()] + [leaf.grad] + [p.grad for p in params] + [r for pair in running for r in pair]
+
+
+@pytest.mark.parametrize("gather", [False, True])
+def test_split_statistics_path_equals_the_fused_call(gather):
+    from eda_amd import sync_bn
+    plain = _run(gather)
+    calls = []
+    sync_bn._reduce = lambda v: calls.append(v.numel())
+    sync_bn.install_fused_hook(1)
+    try:
+        split = _run(gather)
+    finally:
+        sync_bn.remove_fused_hook()
+        sync_bn._reduce = None
+    L = 3 if not gather else 2
+    assert len(calls) == 2 * L and all(n % 2 == 0 for n in calls), calls       # one per layer and direction
+    for a, b in zip(plain, split):
+        if gather and a.shape == b.shape and a.dim() == 3:
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)             # (scatter-add gradient: fp32 atomics order)
+        else:
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("gather", [False, True])
+def test_two_ranks_with_identical_rows_emulated(gather):
+    from eda_amd import sync_bn
+    plain = _run(gather)
+    sync_bn._reduce = lambda v: v.mul_(2.0)          # what all_reduce gives when the other rank holds the same rows
+    sync_bn.install_fused_hook(2)
+    try:
+        two = _run(gather)
+    finally:
+        sync_bn.remove_fused_hook()
+        sync_bn._reduce = None
+    n_run = len(plain) - 2 * (3 if not gather else 2)
+    for i, (a, b) in enumerate(zip(plain, two)):
+        if i < n_run:
+            # outputs, input gradient, dW, d(gamma), d(beta): global statistics = local ones
+            torch.testing.assert_close(a, b, rtol=2e-6, atol=1e-6)
+    # running variance: unbiased with the GLOBAL count 2R instead of R
+    rows = 4096 if not gather else 2 * 64 * 16
+    rv_plain, rv_two = plain[-1], two[-1]
+    expect = 0.9 + (rv_plain - 0.9) * ((rows - 1) / rows) * (2 * rows / (2 * rows - 1))
+    torch.testing.assert_close(rv_two, expect, rtol=1e-5, atol=1e-6)
