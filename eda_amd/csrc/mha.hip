@@ -861,6 +861,8 @@ bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
 
+int eda_mha_impl() { return mha_impl(); }
+
 #ifdef EDA_MHA_PROFILE
 extern "C" int eda_mha_profile_read(unsigned long long *out8) {
   unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};

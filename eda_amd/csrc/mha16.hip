@@ -21,6 +21,7 @@
 // One barrier pair per 64-row tile, no software pipelining: these variants exist for the 16-bit
 // configurations and their roofline report, not for the fp32 headline.
 #include "eda_common.h"
+#include "mha2.h"
 #include <string.h>
 
 namespace {
@@ -379,6 +380,19 @@ extern "C" int eda_mha_fwd(const float *q, const float *k, const float *v, long 
                            p_drop, seed_ptr, salt, out, lse, stream_);
   hipStream_t stream = (hipStream_t)stream_;
   EDA_CHECK_ARG(dtype == EDA_DTYPE_BF16 || dtype == EDA_DTYPE_F16, "dtype must be EDA_DTYPE_F32 / BF16 / F16");
+  if (eda_mha_impl() != 1 && Lk > 0 && head_dim == HD && B > 0 && Lq > 0) {
+    // the round-3 kernels (mha2.hip) with 16-bit contraction quads; this file's kernels stay behind EDA_MHA_IMPL=1
+    EDA_CHECK_ARG(q && k && v && out && lse, "null pointer");
+    EDA_CHECK_ARG(mult4(q_sb) && mult4(q_sl) && mult4(k_sb) && mult4(k_sl) && mult4(v_sb) && mult4(v_sl),
+                  "strides must be multiples of 4 floats");
+    EDA_CHECK_ARG((long)B * H <= 65535, "B*H too large");
+    Mha2Args m = {};
+    m.q = q; m.k = k; m.v = v; m.q_sb = q_sb; m.q_sl = q_sl; m.k_sb = k_sb; m.k_sl = k_sl; m.v_sb = v_sb; m.v_sl = v_sl;
+    m.o = out; m.o_sb = (long)Lq * H * HD; m.o_sl = (long)H * HD; m.lse = lse; m.mask = key_padding_mask;
+    m.B = B; m.H = H; m.Lq = Lq; m.Lk = Lk; m.scale = scale; m.p_drop = p_drop; m.seed_ptr = seed_ptr; m.salt = salt;
+    m.dtype = dtype;
+    return eda_mha2_fwd_launch(m, (hipStream_t)stream_);
+  }
   EDA_CHECK_ARG(head_dim == HD, "only head_dim 36 (d_model 288 / 8 heads) is built");
   EDA_CHECK_ARG(B >= 0 && H > 0 && Lq >= 0 && Lk >= 0, "bad dimension");
   if (B == 0 || Lq == 0) return 0;
@@ -412,6 +426,21 @@ extern "C" int eda_mha_bwd(const float *q, const float *k, const float *v, long 
                            dk_sl, dv_sb, dv_sl, ws, ws_bytes, stream_);
   hipStream_t stream = (hipStream_t)stream_;
   EDA_CHECK_ARG(dtype == EDA_DTYPE_BF16 || dtype == EDA_DTYPE_F16, "dtype must be EDA_DTYPE_F32 / BF16 / F16");
+  if (eda_mha_impl() != 1 && Lq > 0 && Lk > 0 && head_dim == HD && B > 0) {
+    EDA_CHECK_ARG(q && k && v && out && lse && dout && dq && dk && dv, "null pointer");
+    EDA_CHECK_ARG(mult4(q_sb) && mult4(q_sl) && mult4(k_sb) && mult4(k_sl) && mult4(v_sb) && mult4(v_sl) &&
+                      mult4(do_sb) && mult4(do_sl) && mult4(dq_sb) && mult4(dq_sl) && mult4(dk_sb) && mult4(dk_sl) &&
+                      mult4(dv_sb) && mult4(dv_sl), "strides must be multiples of 4 floats");
+    EDA_CHECK_ARG((long)B * H <= 65535, "B*H too large");
+    Mha2Args m = {};
+    m.q = q; m.k = k; m.v = v; m.q_sb = q_sb; m.q_sl = q_sl; m.k_sb = k_sb; m.k_sl = k_sl; m.v_sb = v_sb; m.v_sl = v_sl;
+    m.o = const_cast<float *>(out); m.o_sb = (long)Lq * H * HD; m.o_sl = (long)H * HD; m.lse = const_cast<float *>(lse);
+    m.mask = key_padding_mask; m.B = B; m.H = H; m.Lq = Lq; m.Lk = Lk; m.scale = scale; m.p_drop = p_drop;
+    m.seed_ptr = seed_ptr; m.salt = salt; m.dout = dout; m.do_sb = do_sb; m.do_sl = do_sl; m.dq = dq; m.dk = dk; m.dv = dv;
+    m.dq_sb = dq_sb; m.dq_sl = dq_sl; m.dk_sb = dk_sb; m.dk_sl = dk_sl; m.dv_sb = dv_sb; m.dv_sl = dv_sl;
+    m.dtype = dtype;
+    return eda_mha2_bwd_launch(m, ws, ws_bytes, (hipStream_t)stream_);
+  }
   EDA_CHECK_ARG(head_dim == HD, "only head_dim 36 (d_model 288 / 8 heads) is built");
   EDA_CHECK_ARG(B >= 0 && H > 0 && Lq >= 0 && Lk >= 0, "bad dimension");
   if (B == 0) return 0;

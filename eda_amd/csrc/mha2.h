@@ -20,7 +20,8 @@ struct Mha2Args {
   int n_kb;          // bwd: key blocks of 16*NW keys        fwd: unused
   int n_qs;          // bwd: query splits                    fwd: query blocks of 16*NQ queries
   int q_per_wg;      // bwd: queries per query split (multiple of the chunk)
-  int prio_mode;     // experiment: 1 = s_setprio by remaining work in phase A
+  int prio_mode;     // 1 = s_setprio by remaining work in phase A (EDA_MHA2_PRIO)
+  int dtype;         // EDA_DTYPE_F32 (exact fp32 MFMA: the parity path) / BF16 / F16 contractions, fp32 accumulate
   float *dq_part;    // bwd: [key block][B][Lq][H*36] dense partials of dQ (n_kb > 1)
   float *dkv_part;   // bwd: [query split][dk | dv][B][Lk][H*36] dense partials (n_qs > 1)
 };
@@ -29,3 +30,5 @@ struct Mha2Args {
 int eda_mha2_fwd_launch(Mha2Args &a, hipStream_t stream);
 int eda_mha2_bwd_launch(Mha2Args &a, void *ws, size_t ws_bytes, hipStream_t stream);
 size_t eda_mha2_bwd_workspace_bytes(int B, int H, int Lq, int Lk);
+// 1 = the round-1/2 kernels (mha.hip / mha16.hip) were selected with EDA_MHA_IMPL=1, else mha2.hip
+int eda_mha_impl();

@@ -78,6 +78,67 @@ __device__ __forceinline__ f32x4 mfma44(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
 
+// Arithmetic of the contractions: exact fp32 (the parity path) or 16-bit operands with fp32 accumulation (BASELINE.json
+// configs[2] / configs[4]).  The 16-bit forms are the SAME kernels: wherever the fp32 code issues four consecutive
+// 16x16x4 steps whose operands a lane holds as four values (a contraction quad), the 16-bit code packs the four values
+// (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32) and issues ONE v_mfma_f32_16x16x16 (one v_mfma_f32_4x4x4 for the 4-dim tile);
+// the 36-deep head-dim contraction (8 + 1 values per lane) becomes three of them, the third carrying one value and three
+// zeros.  Tensors stay fp32 in HBM and LDS; softmax, dS and all accumulators stay fp32.
+typedef unsigned long long u64;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+
+struct ArF32 { static constexpr bool is16 = false; };
+struct ArBf16 {
+  static constexpr bool is16 = true;
+  static __device__ __forceinline__ u64 pk4(float a, float b, float c, float d) {
+    const unsigned lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+    const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{c, d}, bf16x2));
+    return (u64)lo | ((u64)hi << 32);
+  }
+  static __device__ __forceinline__ f32x4 mma16(u64 a, u64 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 mma44(u64 a, u64 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+  }
+};
+struct ArFp16 {
+  static constexpr bool is16 = true;
+  static __device__ __forceinline__ u64 pk4(float a, float b, float c, float d) {
+    const unsigned lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, h16x2));
+    const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{c, d}, h16x2));
+    return (u64)lo | ((u64)hi << 32);
+  }
+  static __device__ __forceinline__ f32x4 mma16(u64 a, u64 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, a), __builtin_bit_cast(h16x4, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 mma44(u64 a, u64 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(h16x4, a), __builtin_bit_cast(h16x4, b), c, 0, 0, 0);
+  }
+};
+
+// a lane's 9 contraction values of a head-dim row as three packed quads (the third: one value + zeros)
+struct Row16 { u64 p[3]; };
+template <class AR>
+__device__ __forceinline__ Row16 pack_row(const float (&r)[9]) {
+  Row16 o;
+  o.p[0] = AR::pk4(r[0], r[1], r[2], r[3]);
+  o.p[1] = AR::pk4(r[4], r[5], r[6], r[7]);
+  o.p[2] = AR::pk4(r[8], 0.f, 0.f, 0.f);
+  return o;
+}
+// acc += sum over the 36 head dims of a-row x b-row (both lanes' 9-value operands)
+template <class AR>
+__device__ __forceinline__ f32x4 dot36(const Row16 &a, const Row16 &b, f32x4 acc) {
+  acc = AR::mma16(a.p[0], b.p[0], acc);
+  acc = AR::mma16(a.p[1], b.p[1], acc);
+  return AR::mma16(a.p[2], b.p[2], acc);
+}
+
 __device__ __forceinline__ unsigned hash32(unsigned x) {     // = mha.hip
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
@@ -162,11 +223,11 @@ __device__ __forceinline__ void dma_rows(float *lds, const float *base, long row
 // ======================================================================================== forward ==========
 // One 64-key tile for one wave (16 queries): NSUB live 16-key sub-tiles (compile time).  Scores arrive in the
 // log2 domain (the query operand carries scale * log2 e).
-template <int NSUB, bool DROP>
+template <int NSUB, bool DROP, class AR>
 __device__ __forceinline__ void fwd_tile(const float *__restrict__ Kt, const float *__restrict__ Vt,
                                          const unsigned *__restrict__ deadw, bool need_mask,
-                                         const float (&qreg)[KSTEPS], int c, int g, int key0, unsigned rowbase,
-                                         const DropCfg &dc, float &m, float &lsum, f32x4 (&o)[3]) {
+                                         const float (&qreg)[KSTEPS], const Row16 &q16, int c, int g, int key0,
+                                         unsigned rowbase, const DropCfg &dc, float &m, float &lsum, f32x4 (&o)[3]) {
   f32x4 st[NSUB];
 #pragma unroll
   for (int j = 0; j < NSUB; ++j) st[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -174,10 +235,15 @@ __device__ __forceinline__ void fwd_tile(const float *__restrict__ Kt, const flo
     float kreg[NSUB][KSTEPS];
 #pragma unroll
     for (int j = 0; j < NSUB; ++j) load_row_operand(kreg[j], Kt + (16 * j + c) * HD, g);
+    if constexpr (AR::is16) {
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s)
+      for (int j = 0; j < NSUB; ++j) st[j] = dot36<AR>(pack_row<AR>(kreg[j]), q16, st[j]);
+    } else {
 #pragma unroll
-      for (int j = 0; j < NSUB; ++j) st[j] = mfma4(kreg[j][s], qreg[s], st[j]);
+      for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j) st[j] = mfma4(kreg[j][s], qreg[s], st[j]);
+    }
   }
   ColOperand va;
   load_col_operand(va, Vt, c, g);
@@ -229,19 +295,26 @@ __device__ __forceinline__ void fwd_tile(const float *__restrict__ Kt, const flo
   for (int j = 0; j < NSUB; ++j) {
     ColOperand vb;
     if (j + 1 < NSUB) load_col_operand(vb, Vt + 16 * (j + 1) * HD, c, g);
+    if constexpr (AR::is16) {
+      const u64 pb = AR::pk4(st[j][0], st[j][1], st[j][2], st[j][3]);
+      o[0] = AR::mma16(AR::pk4(va.v[0][0], va.v[1][0], va.v[2][0], va.v[3][0]), pb, o[0]);
+      o[1] = AR::mma16(AR::pk4(va.v[0][1], va.v[1][1], va.v[2][1], va.v[3][1]), pb, o[1]);
+      o[2] = AR::mma44(AR::pk4(va.v[0][2], va.v[1][2], va.v[2][2], va.v[3][2]), pb, o[2]);
+    } else {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const float pb = st[j][t];
-      o[0] = mfma4(va.v[t][0], pb, o[0]);
-      o[1] = mfma4(va.v[t][1], pb, o[1]);
-      o[2] = mfma44(va.v[t][2], pb, o[2]);       // dims 32..35: per-lane-group partials
+      for (int t = 0; t < 4; ++t) {
+        const float pb = st[j][t];
+        o[0] = mfma4(va.v[t][0], pb, o[0]);
+        o[1] = mfma4(va.v[t][1], pb, o[1]);
+        o[2] = mfma44(va.v[t][2], pb, o[2]);       // dims 32..35: per-lane-group partials
+      }
     }
     if (j + 1 < NSUB) va = vb;
   }
 }
 
 // NQ query sub-tiles x KS key shares = NW waves; CHK keys per LDS chunk, NBUF chunk buffers.
-template <int NQ, int KS, int CHK, int NBUF, bool DROP>
+template <int NQ, int KS, int CHK, int NBUF, bool DROP, class AR>
 __global__ __launch_bounds__(NQ * KS * 64) void mha2_fwd_kernel(const Mha2Args a) {
   constexpr int NW = NQ * KS, NT = NW * 64;
   constexpr int TILES = CHK / 64;
@@ -275,6 +348,8 @@ __global__ __launch_bounds__(NQ * KS * 64) void mha2_fwd_kernel(const Mha2Args a
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) qreg[s] = qvalid ? qreg[s] * sc : 0.f;
   }
+  Row16 q16 = {{0, 0, 0}};
+  if constexpr (AR::is16) q16 = pack_row<AR>(qreg);
   DropCfg dc = {0u, 0u, 1.f};
   if (DROP) dc = drop_cfg(a);
   const unsigned rowbase = ((unsigned)bh * (unsigned)a.Lq + (unsigned)qi) * (unsigned)a.Lk;
@@ -309,10 +384,10 @@ __global__ __launch_bounds__(NQ * KS * 64) void mha2_fwd_kernel(const Mha2Args a
       const bool need_mask = (mrow != nullptr) || (key0 + 64 > a.Lk);
       const float *Kt = Kc + 64 * t * HD, *Vt = Vc + 64 * t * HD;
       const unsigned *dw = dd + 16 * t;
-      if (nsub == 4) fwd_tile<4, DROP>(Kt, Vt, dw, need_mask, qreg, c, g, key0, rowbase, dc, m, lsum, o);
-      else if (nsub == 3) fwd_tile<3, DROP>(Kt, Vt, dw, need_mask, qreg, c, g, key0, rowbase, dc, m, lsum, o);
-      else if (nsub == 2) fwd_tile<2, DROP>(Kt, Vt, dw, need_mask, qreg, c, g, key0, rowbase, dc, m, lsum, o);
-      else fwd_tile<1, DROP>(Kt, Vt, dw, need_mask, qreg, c, g, key0, rowbase, dc, m, lsum, o);
+      if (nsub == 4) fwd_tile<4, DROP, AR>(Kt, Vt, dw, need_mask, qreg, q16, c, g, key0, rowbase, dc, m, lsum, o);
+      else if (nsub == 3) fwd_tile<3, DROP, AR>(Kt, Vt, dw, need_mask, qreg, q16, c, g, key0, rowbase, dc, m, lsum, o);
+      else if (nsub == 2) fwd_tile<2, DROP, AR>(Kt, Vt, dw, need_mask, qreg, q16, c, g, key0, rowbase, dc, m, lsum, o);
+      else fwd_tile<1, DROP, AR>(Kt, Vt, dw, need_mask, qreg, q16, c, g, key0, rowbase, dc, m, lsum, o);
     }
   };
 
@@ -393,7 +468,7 @@ __global__ __launch_bounds__(NQ * KS * 64) void mha2_fwd_kernel(const Mha2Args a
 //            interleaved accumulators; no partial sums, no atomics (ds_add_f32 from 16 waves measured 3x the whole
 //            kernel, scattered global fp32 atomics worse) -- written straight to dQ, or to this key block's partial
 //   barrier
-template <int KSUB, int QG, int QC, int NBUF, bool DROP>
+template <int KSUB, int QG, int QC, int NBUF, bool DROP, class AR>
 __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args a) {
   constexpr int NW = KSUB * QG, NT = NW * 64;
   constexpr int KB = 16 * KSUB;        // keys per block
@@ -458,6 +533,8 @@ __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) { kreg[s] = 0.f; vreg[s] = 0.f; }
   }
+  Row16 k16 = {{0, 0, 0}}, v16 = {{0, 0, 0}};
+  if constexpr (AR::is16) { k16 = pack_row<AR>(kreg); v16 = pack_row<AR>(vreg); }
 
   const int qbeg = qsp * a.q_per_wg;
   const int qend = min(a.Lq, qbeg + a.q_per_wg);
@@ -565,10 +642,15 @@ __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args
         float qa[KSTEPS], da[KSTEPS];
         load_row_operand(qa, Ql + (16 * j + c) * HD, g);
         load_row_operand(da, Dl + (16 * j + c) * HD, g);
+        if constexpr (AR::is16) {
+          sacc = dot36<AR>(pack_row<AR>(qa), k16, sacc);
+          pacc = dot36<AR>(pack_row<AR>(da), v16, pacc);
+        } else {
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-          sacc = mfma4(qa[s], kreg[s], sacc);          // S[query 4g+r][key c]
-          pacc = mfma4(da[s], vreg[s], pacc);          // dP / keep
+          for (int s = 0; s < KSTEPS; ++s) {
+            sacc = mfma4(qa[s], kreg[s], sacc);          // S[query 4g+r][key c]
+            pacc = mfma4(da[s], vreg[s], pacc);          // dP / keep
+          }
         }
       }
       const float4 lse4 = *reinterpret_cast<const float4 *>(lse_l + 16 * j + 4 * g);
@@ -612,23 +694,37 @@ __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args
       {
         ColOperand cd;
         load_col_operand(cd, Dl + 16 * j * HD, c, g);
+        if constexpr (AR::is16) {
+          const u64 pb = AR::pk4(pd[0], pd[1], pd[2], pd[3]);
+          dv[0] = AR::mma16(AR::pk4(cd.v[0][0], cd.v[1][0], cd.v[2][0], cd.v[3][0]), pb, dv[0]);
+          dv[1] = AR::mma16(AR::pk4(cd.v[0][1], cd.v[1][1], cd.v[2][1], cd.v[3][1]), pb, dv[1]);
+          dv[2] = AR::mma44(AR::pk4(cd.v[0][2], cd.v[1][2], cd.v[2][2], cd.v[3][2]), pb, dv[2]);
+        } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const float pb = pd[t];
-          dv[0] = mfma4(cd.v[t][0], pb, dv[0]);
-          dv[1] = mfma4(cd.v[t][1], pb, dv[1]);
-          dv[2] = mfma44(cd.v[t][2], pb, dv[2]);
+          for (int t = 0; t < 4; ++t) {
+            const float pb = pd[t];
+            dv[0] = mfma4(cd.v[t][0], pb, dv[0]);
+            dv[1] = mfma4(cd.v[t][1], pb, dv[1]);
+            dv[2] = mfma44(cd.v[t][2], pb, dv[2]);
+          }
         }
       }
       {
         ColOperand cq;
         load_col_operand(cq, Ql + 16 * j * HD, c, g);
+        if constexpr (AR::is16) {
+          const u64 sb = AR::pk4(ds[0], ds[1], ds[2], ds[3]);
+          dk[0] = AR::mma16(AR::pk4(cq.v[0][0], cq.v[1][0], cq.v[2][0], cq.v[3][0]), sb, dk[0]);
+          dk[1] = AR::mma16(AR::pk4(cq.v[0][1], cq.v[1][1], cq.v[2][1], cq.v[3][1]), sb, dk[1]);
+          dk[2] = AR::mma44(AR::pk4(cq.v[0][2], cq.v[1][2], cq.v[2][2], cq.v[3][2]), sb, dk[2]);
+        } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const float sb = ds[t];
-          dk[0] = mfma4(cq.v[t][0], sb, dk[0]);
-          dk[1] = mfma4(cq.v[t][1], sb, dk[1]);
-          dk[2] = mfma44(cq.v[t][2], sb, dk[2]);
+          for (int t = 0; t < 4; ++t) {
+            const float sb = ds[t];
+            dk[0] = mfma4(cq.v[t][0], sb, dk[0]);
+            dk[1] = mfma4(cq.v[t][1], sb, dk[1]);
+            dk[2] = mfma44(cq.v[t][2], sb, dk[2]);
+          }
         }
       }
     }
@@ -649,7 +745,15 @@ __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args
       const float *dp_ = DS + (16 * j + c) * DSS + 4 * g;      // dS[query c][key 16s + 4g + t]
       f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
       int s = 0;
-      if (full) {
+      if constexpr (AR::is16) {
+        for (; s < nks_live; ++s) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4 *>(dp_ + 16 * s);
+          const float *k0 = kp + 16 * s * HD;
+          const u64 ka = AR::pk4(k0[0], k0[HD], k0[2 * HD], k0[3 * HD]), kb_ = AR::pk4(b0[0], b0[1], b0[2], b0[3]);
+          if (full) { if (s & 1) acc1 = AR::mma16(ka, kb_, acc1); else acc0 = AR::mma16(ka, kb_, acc0); }
+          else { if (s & 1) acc1 = AR::mma44(ka, kb_, acc1); else acc0 = AR::mma44(ka, kb_, acc0); }
+        }
+      } else if (full) {
         for (; s + 1 < nks_live; s += 2) {
           const f32x4 b0 = *reinterpret_cast<const f32x4 *>(dp_ + 16 * s);
           const f32x4 b1 = *reinterpret_cast<const f32x4 *>(dp_ + 16 * s + 16);
@@ -820,10 +924,17 @@ template <int NQ, int KS, int CHK, int NBUF>
 int launch_fwd(Mha2Args &a, hipStream_t stream) {
   a.n_qs = (a.Lq + 16 * NQ - 1) / (16 * NQ);
   const unsigned grid = (unsigned)(a.B * a.H * a.n_qs);
-  if (a.p_drop > 0.f)
-    hipLaunchKernelGGL((mha2_fwd_kernel<NQ, KS, CHK, NBUF, true>), dim3(grid), dim3(NQ * KS * 64), 0, stream, a);
-  else
-    hipLaunchKernelGGL((mha2_fwd_kernel<NQ, KS, CHK, NBUF, false>), dim3(grid), dim3(NQ * KS * 64), 0, stream, a);
+  const dim3 g(grid), b(NQ * KS * 64);
+  const bool drop = a.p_drop > 0.f;
+#define EDA_FWD(AR)                                                                                        \
+  do {                                                                                                     \
+    if (drop) hipLaunchKernelGGL((mha2_fwd_kernel<NQ, KS, CHK, NBUF, true, AR>), g, b, 0, stream, a);      \
+    else hipLaunchKernelGGL((mha2_fwd_kernel<NQ, KS, CHK, NBUF, false, AR>), g, b, 0, stream, a);          \
+  } while (0)
+  if (a.dtype == EDA_DTYPE_BF16) EDA_FWD(ArBf16);
+  else if (a.dtype == EDA_DTYPE_F16) EDA_FWD(ArFp16);
+  else EDA_FWD(ArF32);
+#undef EDA_FWD
   EDA_CHECK_LAUNCH();
   return 0;
 }
@@ -862,10 +973,17 @@ size_t bwd_workspace_floats(const BwdPlan &p, int B, int H, int Lq, int Lk) {
 template <int KSUB, int QG, int QC, int NBUF>
 int launch_bwd(Mha2Args &a, hipStream_t stream) {
   const unsigned grid = (unsigned)(a.B * a.H * a.n_kb * a.n_qs);
-  if (a.p_drop > 0.f)
-    hipLaunchKernelGGL((mha2_bwd_kernel<KSUB, QG, QC, NBUF, true>), dim3(grid), dim3(KSUB * QG * 64), 0, stream, a);
-  else
-    hipLaunchKernelGGL((mha2_bwd_kernel<KSUB, QG, QC, NBUF, false>), dim3(grid), dim3(KSUB * QG * 64), 0, stream, a);
+  const dim3 g(grid), b(KSUB * QG * 64);
+  const bool drop = a.p_drop > 0.f;
+#define EDA_BWD(AR)                                                                                        \
+  do {                                                                                                     \
+    if (drop) hipLaunchKernelGGL((mha2_bwd_kernel<KSUB, QG, QC, NBUF, true, AR>), g, b, 0, stream, a);     \
+    else hipLaunchKernelGGL((mha2_bwd_kernel<KSUB, QG, QC, NBUF, false, AR>), g, b, 0, stream, a);         \
+  } while (0)
+  if (a.dtype == EDA_DTYPE_BF16) EDA_BWD(ArBf16);
+  else if (a.dtype == EDA_DTYPE_F16) EDA_BWD(ArFp16);
+  else EDA_BWD(ArF32);
+#undef EDA_BWD
   EDA_CHECK_LAUNCH();
   return 0;
 }
