@@ -32,7 +32,10 @@ def test_pipelined_graph_replays_around_a_host_sync_keep_training():
     env = dict(os.environ, EDA_BENCH_INGRAPH_HIST="1")
     env.pop("DEBUG_CLR_GRAPH_PACKET_CAPTURE", None)          # bench.py must set it itself
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "5",
-                        "--kernel-steps", "0", "--cpu-scenes", "0", "--gemm-tuning", "shipped"],
+                        "--kernel-steps", "0", "--cpu-scenes", "0", "--gemm-tuning", "shipped",
+                        # one batch: the loss must fall monotonically (with alternating batches it zigzags between the two;
+                        # the batch hand-over itself is tested in tests/test_pipeline_gpu.py)
+                        "--batches", "1", "--in-step-steps", "0"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     m = re.search(r"in-graph loss history \((\d+) steps[^:]*\): ([-0-9. ]+)", p.stderr)
@@ -67,7 +70,7 @@ def test_split_graphs_structure_of_the_multi_gpu_step_trains_like_the_single_gra
         env = dict(os.environ, EDA_BENCH_INGRAPH_HIST="1")
         p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "3",
                             "--kernel-steps", "0", "--cpu-scenes", "0", "--gemm-tuning", "shipped", "--per-gpu", "4",
-                            "--points", "20000"] + extra, env=env, capture_output=True, text=True, timeout=600)
+                            "--points", "20000", "--batches", "1", "--in-step-steps", "0"] + extra, env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         line = json.loads(p.stdout.strip().splitlines()[-1])
         assert line["value"] > 0 and "HIP graph" in p.stderr

@@ -1,22 +1,31 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/r02p
-O=gpurun_out/r02p
+# The evidence run of a round: tests, smoke, PMC traffic, the bench lines of BASELINE.json's single-GPU configurations and
+# one profiled eager run.  usage (on the GPU box): bash tools/final_run.sh <tag>   -> gpurun_out/<tag>/
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+tag=${1:-r03z}
+O=gpurun_out/$tag; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; tail -2 $O/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
 python tools/measure_traffic.py > $O/traffic.txt 2>&1
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
-python bench.py --fps-prefetch 0 > $O/bench_fps_in_step.json 2> $O/bench_fps_in_step.err
+python bench.py --fps-prefetch 0 --in-step-steps 0 > $O/bench_fps_in_step.json 2> $O/bench_fps_in_step.err
 python bench.py --text-stream 0 > $O/bench_one_graph.json 2> $O/bench_one_graph.err
-python bench.py --split-graphs > $O/bench_split_graphs.json 2> $O/bench_split_graphs.err
-python bench.py --tokens 130 > $O/bench_130_tokens.json 2> $O/bench_130_tokens.err
-python bench.py --loss hungarian > $O/bench_hungarian_loss.json 2> $O/bench_hungarian_loss.err
-python bench.py --attn-dtype bf16 > $O/bench_attn_bf16.json 2> $O/bench_attn_bf16.err
-python bench.py --attn-dtype f16 --tokens 130 > $O/bench_attn_f16_130_tokens.json 2> $O/bench_attn_f16_130_tokens.err
+python bench.py --split-graphs --in-step-steps 0 > $O/bench_split_graphs.json 2> $O/bench_split_graphs.err
+python bench.py --tokens 130 --in-step-steps 0 > $O/bench_130_tokens.json 2> $O/bench_130_tokens.err
+python bench.py --loss hungarian --in-step-steps 0 > $O/bench_hungarian_loss.json 2> $O/bench_hungarian_loss.err
+python bench.py --attn-dtype bf16 --in-step-steps 0 > $O/bench_attn_bf16.json 2> $O/bench_attn_bf16.err
+python bench.py --attn-dtype f16 --tokens 130 --in-step-steps 0 > $O/bench_attn_f16_130_tokens.json 2> $O/bench_attn_f16_130_tokens.err
+EDA_FAST_ROBERTA=0 python bench.py --in-step-steps 0 > $O/bench_stock_roberta.json 2> $O/bench_stock_roberta.err
+python bench.py --batches 1 --in-step-steps 0 > $O/bench_one_batch.json 2> $O/bench_one_batch.err
+rm -rf /tmp/pe
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pe -o eager -- python bench.py --steps 20 --warmup 3 --graph 0 --cpu-scenes 0 > $O/bench_eager_under_rocprof.json 2> $O/bench_eager.err
 find /tmp/pe -name "*kernel_stats.csv" -exec cp {} $O/bench_eager_kernel_stats_rocprofv3.csv \;
-python - <<'PY'
-import json,glob
-for f in sorted(glob.glob("gpurun_out/r02p/bench_*.json")):
+python tools/summarize_profile.py $tag 23 $O/bench_eager_kernel_stats_rocprofv3.csv $O/bench_default.json $O/bench_eager_under_rocprof.json > $O/summary.md 2> $O/summary.err
+tools/prof_mha.sh ${tag}_f32 2 > /dev/null 2>&1
+ATTN_DTYPE=bf16 tools/prof_mha.sh ${tag}_bf16 2 > /dev/null 2>&1
+python - "$O" <<'PY'
+import json, glob, sys
+for f in sorted(glob.glob(sys.argv[1] + "/bench_*.json")):
     try:
-        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f.split("/")[-1], d["value"], d["ms_per_step"])
+        d = json.loads(open(f).read().strip().splitlines()[-1]); print(f.split("/")[-1], d["value"], d["ms_per_step"])
     except Exception as e: print(f, "ERR", e)
 PY

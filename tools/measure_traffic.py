@@ -89,9 +89,10 @@ def main():
     def total(pred):
         return sum((2.0 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024.0 for k in set(fetch) | set(write) if pred(k))
     entries = [
-        {"op": "mha_fwd", "dims": [8, 8, 1024, 1024], "bytes_per_launch": total(lambda k: "mha_fwd_kernel" in k)},
+        {"op": "mha_fwd", "dims": [8, 8, 1024, 1024], "bytes_per_launch": total(lambda k: "mha_fwd_kernel" in k or "mha2_fwd_kernel" in k)},
         {"op": "mha_bwd", "dims": [8, 8, 1024, 1024],
-         "bytes_per_launch": total(lambda k: "mha_bwd_dq_kernel" in k or "mha_bwd_dkv_kernel" in k or "mha_part_reduce" in k)},
+         "bytes_per_launch": total(lambda k: "mha_bwd_dq_kernel" in k or "mha_bwd_dkv_kernel" in k or "mha_part_reduce" in k
+                                   or "mha2_bwd_kernel" in k or "mha2_part_reduce" in k)},
         # the fused SA1 forward = one launch per layer + pooling: sum of its kernels' per-launch bytes
         {"op": "sa_fused_fwd", "dims": [1048576, 64, 1, 6, 64, 64, 128], "bytes_per_launch": sum(sa_parts.values()),
          "kernels": {k[:90]: v for k, v in sorted(sa_parts.items())}},
