@@ -366,6 +366,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
+        from eda_amd import parallel as _par
+        _par.reserve_cus_for_collectives(32)        # the prefetched sampling runs next to RCCL's channel workgroups
 
     from eda_amd import ext
     if args.sync_bn and world > 1:

@@ -35,6 +35,7 @@
 namespace {
 
 constexpr int kRecWords = 8;          // u64 words per mailbox record (5 used, 64-byte record)
+int g_fps_cu_reserve = [] { const char *e = getenv("EDA_FPS_CU_RESERVE"); return e ? atoi(e) : 0; }();
 constexpr int kMaxG = 64;             // workgroups per scene (one poll lane each)
 constexpr size_t kStatusBytes = 256;  // status words in front of the mailboxes
 constexpr unsigned kSpinLimit = 1u << 20;   // ~1 s of polling, then give up (status word set, indices zero-filled)
@@ -771,9 +772,11 @@ extern "C" int eda_furthest_point_sampling_f32(const float *xyz, int b, int n, i
   int dev = 0, num_cu = 256;
   EDA_CHECK_HIP(hipGetDevice(&dev));
   EDA_CHECK_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  // Every workgroup of a launch must be co-resident (they spin on each other):
-  // at most one workgroup per CU is assumed.
-  int scenes_per_launch = G == 1 ? b : num_cu / G;
+  // Every workgroup of a launch must be co-resident (they spin on each other): at most one workgroup per CU is
+  // assumed, minus a reserve the host sets aside for other resident spin-kernels (RCCL's channel workgroups at N > 1:
+  // eda_fps_set_cu_reserve / EDA_FPS_CU_RESERVE) -- larger batches are then sampled in more launches.
+  const int avail_cu = num_cu - g_fps_cu_reserve > 16 ? num_cu - g_fps_cu_reserve : 16;
+  int scenes_per_launch = G == 1 ? b : avail_cu / G;
   if (scenes_per_launch < 1) {
     eda_set_error("fps: a cluster of %d workgroups does not fit %d CUs", G, num_cu);
     return EDA_ERR_UNSUPPORTED;
@@ -821,6 +824,12 @@ extern "C" int eda_furthest_point_sampling_f32(const float *xyz, int b, int n, i
   return 0;
 }
 
+
+extern "C" int eda_fps_set_cu_reserve(int cus) {
+  EDA_CHECK_ARG(cus >= 0 && cus <= 240, "reserve must be 0..240 CUs");
+  g_fps_cu_reserve = cus;
+  return 0;
+}
 
 extern "C" size_t eda_fps_prefix_workspace_bytes(int b, int n, int m) {
   const size_t base = (eda_fps_workspace_bytes(b, n, m) + 15) / 16 * 16;

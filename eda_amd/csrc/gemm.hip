@@ -1004,7 +1004,9 @@ bool gemm_vec_ok(const GemmArgs &a, int wmode) {
   if (a.xmode == X_BNRELU && (!al16(a.in_scale) || !al16(a.in_shift))) return false;
   if (wmode == W_NT) return a.ldw % 4 == 0 && al16(a.w);
   if (a.N < 4 || a.N % 4 != 0) return false;
-  return true;
+  // dX form: the kernel reads the (K, N) weight with 16-byte loads along N -- rows must be 16-byte addressable too
+  // (a row-strided view with an odd ld or a misaligned base takes the element-wise kernel instead)
+  return a.ldw % 4 == 0 && al16(a.w);
 }
 
 template <int WR, int WC, bool VEC, int WN = 1, int PF = 1, int KC = G_KC, bool DB = false>

@@ -135,6 +135,10 @@ class ClsAgnosticPredictHead(nn.Module):
         return (_GROUPED_HEADS and not sync_bn.enabled() and rows.is_cuda and rows.shape[0] <= _lib.lib().eda_bn_relu_dropout_max_rows()
                 and self.seed_feat_dim % 16 == 0 and 2 <= len(nets) <= 4
                 and all(n[1].training == bn0.training and n[5].training == bn0.training for n in nets)
+                # the grouped launches take eps / momentum / running-statistics mode / dropout state from sibling 0
+                and all(bn.eps == bn0.eps and bn.momentum == bn0.momentum
+                        and bn.track_running_stats == bn0.track_running_stats for n in nets for bn in (n[1], n[5]))
+                and all(n[3].training == nets[0][3].training and n[7].training == nets[0][3].training for n in nets)
                 and all(n[3].p == nets[0][3].p and n[7].p == nets[0][3].p for n in nets))
 
     def _sibling_mlps_rows(self, rows):

@@ -204,6 +204,15 @@ class FlatParams:
         return norm
 
 
+def reserve_cus_for_collectives(cus=32):
+    """N > 1: keep `cus` CUs out of the furthest point sampler's co-residency plan (include/eda_hip.h:
+    eda_fps_set_cu_reserve) -- RCCL's channel workgroups spin on their peers like the sampler's workgroups spin on each
+    other, and both must be resident at the same time when the sampling of batch i+1 runs underneath step i's
+    all-reduce."""
+    from . import _lib
+    _lib.check(_lib.lib().eda_fps_set_cu_reserve(int(cus)), "eda_fps_set_cu_reserve")
+
+
 def broadcast_parameters(module, src=0):
     """DDP constructor semantics: every rank starts from rank `src`'s weights and buffers."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

@@ -444,6 +444,12 @@ int eda_linear_ex_f32(const float *x, long ldx, long R, int K, const float *w, l
  * the forward (eda_linear_fwd_f32 on W^T). */
 int eda_transpose_batch_f32(const long long *desc, int count, long long total_tiles, void *stream);
 
+/* CUs the multi-workgroup furthest point sampler must leave to other resident spin-kernels (its workgroups poll each
+ * other and have to be co-resident; at N > 1 RCCL's channel workgroups are such kernels): the sampler then plans with
+ * (CUs - reserve) / workgroups-per-scene scenes per launch.  Default 0 (or EDA_FPS_CU_RESERVE).  Replaces nothing in
+ * the reference (its sampler is one workgroup per scene, sampling_gpu.cu:74-178). */
+int eda_fps_set_cu_reserve(int cus);
+
 /* Global-batch BatchNorm statistics for the fused set-abstraction / feature-propagation calls: the reference converts
  * every BatchNorm to SyncBatchNorm when more than one GPU trains (main_utils.py:336-338).  With a hook registered
  * (fn != NULL, world > 1) eda_sa_fused_fwd_f32 / eda_sa_fused_bwd*_f32 call fn(user, buf, n, stream) once per layer and
