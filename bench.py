@@ -379,6 +379,9 @@ def main():
     if args.blas != "default":
         torch.backends.cuda.preferred_blas_library("cublas" if args.blas == "rocblas" else "cublaslt")
     tuning_file, shipped_ok = None, False
+    fast_roberta = os.environ.get("EDA_FAST_ROBERTA", "1") != "0"
+    if fast_roberta:
+        args.gemm_tuning = "off"        # no library GEMM is left in the step (eda_amd/roberta_fast.py): nothing to select
     if args.gemm_tuning != "off":
         from eda_amd import gemm_tuning
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -796,7 +799,8 @@ def main():
                                   if (args.text_stream and not args.overlap) else
                                   "hipGraph replay of the whole step" if world == 1 and not args.split_graphs else
                                   "two hipGraphs (fwd+bwd | clip+AdamW) with the RCCL all-reduce between them"),
-                       "text_encoder": "RoBERTa-base random-init frozen" + (
+                       "text_encoder": "RoBERTa-base random-init frozen, " + (
+                           "forward on own kernels (eda_amd/roberta_fast.py)" if fast_roberta else "stock Hugging Face forward (hipBLASLt / AOTriton)") + (
                            "; runs for the NEXT step's tokens on the second stream" if (args.graph and args.text_stream and not args.overlap
                                                                                       and args.fps_prefetch and args.text_prefetch) else ""),
                        "sa1_sampling": (("furthest point sampling" if args.fps_prefetch == 1 else
@@ -805,7 +809,8 @@ def main():
                                         "current step (once per step; --fps-prefetch 0 puts it back on the critical path)")
                        if (args.graph and args.text_stream and not args.overlap and args.fps_prefetch) else "inside the step",
                        "attention_dtype": args.attn_dtype,
-                       "own_gemms": "every pointwise layer of the model (csrc/gemm.hip); hipBLASLt only inside RoBERTa",
+                       "own_gemms": "every pointwise layer of the model AND of the frozen text encoder (csrc/gemm.hip)" if fast_roberta
+                       else "every pointwise layer of the model (csrc/gemm.hip); hipBLASLt only inside RoBERTa",
                        "roberta_gemm_selection": ("TunableOp (%s; shipped results %s)" % (
                            args.gemm_tuning, "loaded" if shipped_ok else "not used"))
                        if args.gemm_tuning != "off" else "library default"},
