@@ -994,6 +994,246 @@ __global__ __launch_bounds__(256) void gemm_gather3_kernel(const GemmArgs a) {
   if (is_last) bn_finalize(a, tid, 256);
 }
 
+#ifdef EDA_GEMM_PROFILE
+// Section timing of gemm_dma_kernel (experiments only; tools/gemm_dma_profile.py): per-wave s_memtime deltas summed over
+// all waves of all launches since the last read.
+__device__ unsigned long long gemm_prof[64 * 8];
+#define GSTAMP(slot)                                                   \
+  do {                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+    const unsigned long long now__ = __builtin_amdgcn_s_memtime();     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(now__));                 \
+    prof_acc[slot] += now__ - prof_t;                                  \
+    prof_t = now__;                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+  } while (0)
+#else
+#define GSTAMP(slot) do { } while (0)
+#endif
+
+// ---- plain products with DMA staging -------------------------------------------------------------------
+// Y = X W^T (W_NT) / dX = dY W (W_NN) with the plain epilogue, for 32-multiples of the contraction length and 16-byte
+// addressable operands: the linear layers of the encoder / decoder / heads and of the frozen text encoder.  What is
+// different from gemm_rows_kernel: the chunk tiles go from memory to LDS directly (`global_load_lds`, 16 bytes a lane,
+// no staging registers, no ds_write), NST LDS stages in a ring with the DMA NST - 1 chunks ahead and ONE barrier per
+// 32-wide chunk; NWM x NWN waves with (BM/NWM) x (BN/NWN) wave tiles.  96-column tiles divide every width of the path
+// (288, 576, 864, 768, 2304, 3072).  Same products in the same order as gemm_rows_kernel: results are bitwise equal
+// (tools/check_gemm_dma.py).
+// LDS layout: a tile row is the 32 floats of the chunk (8 granules of 16 bytes) with granule g of tile row r stored in
+// slot g ^ ((r >> 1) & 7): the DMA writes whole 1 KB pieces (8 rows) in lane order, so padding the rows is not an
+// option, and with the XOR the MFMA operand reads (16 rows x one granule) touch all 64 banks once.  The W_NN weight
+// tile is [k][BN columns] as it lies in memory, read with ds_read_b32.
+// Measured (profiles/r03c_gemm_dma.md): a global_load_lds costs the issuing wave ~90 cycles wherever it is issued (all
+// at once after the barrier, one between MFMA steps, or from a producer wave -- which then is the bottleneck), so what
+// pays is waves per SIMD, i.e. SMALL tiles (32 x 96, 32 KB of LDS, up to 5 workgroups per CU); 64- and 128-row tiles,
+// 8- and 16-wave workgroups and 3-4 stages all lost on the shapes of the path.
+template <int BM, int BN, int NWM, int NWN, int WMODE, int NST>
+__global__ __launch_bounds__(64 * NWM * NWN) void gemm_dma_kernel(const GemmArgs a) {
+  constexpr int KC = 32, NW = NWM * NWN;
+  constexpr int WR = BM / NWM / 16, WC = BN / NWN / 16;
+  static_assert(WR * 16 * NWM == BM && WC * 16 * NWN == BN, "wave tiles must be multiples of 16");
+  constexpr int XF = BM * KC, WF = BN * KC, STAGE = XF + WF;      // floats
+  constexpr int XP = BM / 8, WP = BN / 8, NP = XP + WP;           // 1 KB pieces of the row / weight tile
+  constexpr int NPW = (NP + NW - 1) / NW, REM = NP % NW;          // pieces per wave (waves >= REM: one less if REM)
+  __shared__ __attribute__((aligned(1024))) float smem[NST * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave / NWN, wave_n = wave % NWN;
+  const int xcd = blockIdx.x & 7;
+  const long q = blockIdx.x >> 3;
+  // tile -> XCD (block b runs on XCD b % 8, each XCD has its own L2).  row_slots == 0: an XCD owns row blocks (all column
+  // tiles of a row block back to back: the row tile is fetched once, every XCD reads the whole weight) -- many rows, small
+  // weight.  row_slots == 1: an XCD owns column tiles (its slice of the weight stays in its L2, every XCD reads all rows)
+  // -- few rows against a large weight (the text encoder's 640 x 768 -> 2304: 60 -> 23 MB fetched, 37.6 -> 28.1 us)
+  int ct;
+  long rb;
+  if (a.row_slots == 0) {
+    ct = (int)(q % a.col_tiles);
+    rb = (q / a.col_tiles) * 8 + xcd;
+  } else {
+    const int ctg = (a.col_tiles + 7) / 8;
+    ct = (int)(q % ctg) * 8 + xcd;
+    rb = q / ctg;
+  }
+  if (rb >= a.row_blocks || ct >= a.col_tiles) return;
+  const long row0 = rb * BM, R = a.R;
+  const int n0 = ct * BN, K = a.K, N = a.N;
+#ifdef EDA_GEMM_PROFILE
+  unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long prof_t = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(prof_t));
+#endif
+
+  // ---- DMA maps: piece p of a stage = 8 tile rows (W_NN weight: 64 granules of the [32][BN/4] granule grid)
+  const float *src[NPW];
+  int dst[NPW];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int p = wave + NW * i;
+    dst[i] = p * 256;
+    src[i] = a.x;
+    if (p < XP) {
+      const int r = 8 * p + (lane >> 3), g = (lane & 7) ^ ((r >> 1) & 7);
+      long row = row0 + r;
+      if (row > R - 1) row = R - 1;
+      src[i] = a.x + row * a.ldx + 4 * g;
+    } else if (p < NP) {
+      if (WMODE == W_NT) {
+        const int r = 8 * (p - XP) + (lane >> 3), g = (lane & 7) ^ ((r >> 1) & 7);
+        int n = n0 + r;
+        if (n > N - 1) n = N - 1;
+        src[i] = a.w + (long)n * a.ldw + 4 * g;
+      } else {
+        const int gi = 64 * (p - XP) + lane, k = gi / (BN / 4), sl = gi - (BN / 4) * k;
+        int n = n0 + 4 * sl;
+        if (n > N - 4) n = N - 4;
+        src[i] = a.w + (long)k * a.ldw + n;
+      }
+    }
+  }
+  auto issue = [&](int kc, int stage) {
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int p = wave + NW * i;
+      if (REM != 0 && i == NPW - 1 && p >= NP) break;            // (wave-uniform)
+      const float *g = (WMODE == W_NN && p >= XP) ? src[i] + (long)kc * a.ldw : src[i] + kc;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                       (__attribute__((address_space(3))) void *)(smem + stage * STAGE + dst[i]), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[WC][WR];
+#pragma unroll
+  for (int j = 0; j < WC; ++j)
+#pragma unroll
+    for (int i = 0; i < WR; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int c = lane & 15, qq = lane >> 4;
+  // operand read offsets (floats) inside a stage for the two half-chunks
+  int xo[WR][2], wo[WC][2];
+#pragma unroll
+  for (int i = 0; i < WR; ++i) {
+    const int r = wave_m * 16 * WR + 16 * i + c, f = (r >> 1) & 7;
+    xo[i][0] = r * KC + 4 * (qq ^ f);
+    xo[i][1] = r * KC + 4 * ((4 + qq) ^ f);
+  }
+#pragma unroll
+  for (int j = 0; j < WC; ++j) {
+    if (WMODE == W_NT) {
+      const int r = wave_n * 16 * WC + 16 * j + c, f = (r >> 1) & 7;
+      wo[j][0] = XF + r * KC + 4 * (qq ^ f);
+      wo[j][1] = XF + r * KC + 4 * ((4 + qq) ^ f);
+    } else {
+      wo[j][0] = XF + (4 * qq) * BN + wave_n * 16 * WC + 16 * j + c;
+      wo[j][1] = wo[j][0] + 16 * BN;
+    }
+  }
+  auto multiply = [&](const float *st) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x4 xv[WR], wv[WC];
+#pragma unroll
+      for (int i = 0; i < WR; ++i) xv[i] = *reinterpret_cast<const f32x4 *>(st + xo[i][h]);
+#pragma unroll
+      for (int j = 0; j < WC; ++j) {
+        if (WMODE == W_NT) wv[j] = *reinterpret_cast<const f32x4 *>(st + wo[j][h]);
+        else {
+          const float *wp = st + wo[j][h];
+          wv[j][0] = wp[0]; wv[j][1] = wp[BN]; wv[j][2] = wp[2 * BN]; wv[j][3] = wp[3 * BN];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < WC; ++j)
+#pragma unroll
+          for (int i = 0; i < WR; ++i)
+            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j][s], xv[i][s], acc[j][i], 0, 0, 0);
+    }
+  };
+
+  // The barrier at the end of chunk ci needs chunk ci + 1 in LDS (every wave waits for its own pieces: loads complete
+  // in order, so "at most the pieces of the NST - 2 youngest chunks still in flight") and releases the stage of chunk
+  // ci to the DMA of chunk ci + NST.  A plain s_barrier: __syncthreads() is also a fence, for which the compiler
+  // drains vmcnt to 0 -- i.e. waits for the prefetch it was meant to overlap.
+  const int nchunks = K / KC;
+  constexpr int AHEAD = NST - 1;
+  constexpr int KEEP_HI = (NST - 2) * NPW, KEEP_LO = (NST - 2) * (NPW - 1);
+  auto wait_keep = [&]() {
+    if (REM != 0 && wave >= REM) __builtin_amdgcn_s_waitcnt((KEEP_LO & 15) | (7 << 4) | (15 << 8) | ((KEEP_LO >> 4) << 14));
+    else __builtin_amdgcn_s_waitcnt((KEEP_HI & 15) | (7 << 4) | (15 << 8) | ((KEEP_HI >> 4) << 14));
+  };
+  constexpr int WAIT_ALL = (7 << 4) | (15 << 8);
+#pragma unroll
+  for (int p = 0; p < AHEAD; ++p)
+    if (p < nchunks) issue(p * KC, p);
+  if (NST > 2 && nchunks >= AHEAD) wait_keep(); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+  __builtin_amdgcn_s_barrier();
+  GSTAMP(0);
+  int st_cur = 0, st_nxt = AHEAD % NST;
+  for (int ci = 0; ci < nchunks; ++ci) {
+    const bool more = ci + AHEAD < nchunks;
+    if (more) issue((ci + AHEAD) * KC, st_nxt);
+    GSTAMP(1);
+    multiply(smem + st_cur * STAGE);
+    GSTAMP(2);
+    if (more && NST > 2) wait_keep(); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+    GSTAMP(3);
+    __builtin_amdgcn_s_barrier();
+    GSTAMP(4);
+    st_cur = st_cur + 1 == NST ? 0 : st_cur + 1;
+    st_nxt = st_nxt + 1 == NST ? 0 : st_nxt + 1;
+  }
+
+  // ---- epilogue (the plain one of gemm_rows_kernel: bias, ReLU / GELU, Dropout, gate) ------------------
+  unsigned dseed = 0, dthresh = 0;
+  float dinv = 1.f;
+  const bool drop = a.drop_p > 0.f;
+  if (drop) {
+    dseed = gemm_hash32((unsigned)(*a.drop_seed) * 0x9E3779B1u + a.drop_salt);
+    dthresh = (unsigned)((double)a.drop_p * 4294967296.0);
+    dinv = 1.f / (1.f - a.drop_p);
+  }
+  const bool gated = a.gate != nullptr;
+#pragma unroll
+  for (int j = 0; j < WC; ++j) {
+    const int col = n0 + 16 * WC * wave_n + 16 * j + 4 * qq;
+    if (col >= N) continue;                                 // (N % 4 == 0: a lane's four columns are in or out together)
+    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) bb = *reinterpret_cast<const float4 *>(a.bias + col);
+    const float b4[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+      const long row = row0 + 16 * WR * wave_m + 16 * i + c;
+      if (row >= R) continue;
+      float o[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        o[u] = acc[j][i][u] + b4[u];
+        if (a.relu == 1) o[u] = fmaxf(o[u], 0.f);
+        else if (a.relu == 2) o[u] = 0.5f * o[u] * (1.f + erff(o[u] * 0.70710678118654752f));
+      }
+      if (drop) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          o[u] = gemm_hash32(dseed ^ (unsigned)(row * N + col + u)) >= dthresh ? o[u] * dinv : 0.f;
+      }
+      if (gated) {
+        const float4 gv = *reinterpret_cast<const float4 *>(a.gate + row * a.ldgate + col);
+        const float g4[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) o[u] = g4[u] > 0.f ? o[u] * a.gate_scale : 0.f;
+      }
+      *reinterpret_cast<float4 *>(a.y + row * a.ldy + col) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+#ifdef EDA_GEMM_PROFILE
+  GSTAMP(5);
+  prof_acc[7] = 1;
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&gemm_prof[((blockIdx.x * NW + wave) & 63) * 8 + i], prof_acc[i]);
+#endif
+}
+
 bool gemm_vec_ok(const GemmArgs &a, int wmode) {
   auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
   if (a.xmode == X_GATHER) {
@@ -1050,6 +1290,62 @@ int launch_cfg(GemmArgs &a, int wmode, hipStream_t stream) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { eda_set_error("gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
   return 0;
+}
+
+// ---- DMA-staged plain products ---------------------------------------------------------------------------
+// EDA_GEMM_DMA=0 switches the kernel off, =<id> forces configuration <id> of the table below for every eligible
+// launch (experiments); EDA_GEMM_DMA_MAP=0/1 forces the tile -> XCD mapping
+int g_dma_mode_v = -2;
+int g_dma_mode() {
+  if (g_dma_mode_v == -2) { const char *e = getenv("EDA_GEMM_DMA"); g_dma_mode_v = e ? atoi(e) : -1; }
+  return g_dma_mode_v;
+}
+
+bool dma_takes(const GemmArgs &a, int wmode) {
+  if (g_dma_mode() == 0) return false;
+  if (a.epi != E_PLAIN || a.xmode != X_PLAIN || a.ngroups > 1) return false;
+  auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  if (a.K % 32 != 0 || a.N % 4 != 0 || a.N < 4) return false;
+  if (a.ldx % 4 != 0 || a.ldw % 4 != 0 || a.ldy % 4 != 0 || !al16(a.x) || !al16(a.w) || !al16(a.y)) return false;
+  if (a.bias && !al16(a.bias)) return false;
+  if (a.gate && (a.ldgate % 4 != 0 || !al16(a.gate))) return false;
+  if (g_dma_mode() > 0) return true;
+  // where it wins inside the step (bench.py's HIP-event table, r03c): >= 400 tiles of 32 x 96 (the 8192-row layers, the
+  // text encoder's 2304- / 3072-wide ones) or a long contraction; the 2048- and 640-row launches of 64-192 tiles stay
+  // with the 32 x 32 tiles of gemm_rows_kernel (more, smaller workgroups)
+  const long tiles = ((a.R + 31) / 32) * ((a.N + 95) / 96);
+  return tiles >= 400 || (a.K >= 2048 && tiles >= 128);
+}
+
+template <int BM, int BN, int NWM, int NWN, int NST>
+int launch_dma1(GemmArgs &a, int wmode, hipStream_t stream) {
+  a.row_blocks = (a.R + BM - 1) / BM;
+  a.col_tiles = (a.N + BN - 1) / BN;
+  static int force_map = -2;
+  if (force_map == -2) { const char *e = getenv("EDA_GEMM_DMA_MAP"); force_map = e ? atoi(e) : -1; }
+  {
+    // bytes an XCD pulls through its L2 under either mapping
+    const double xb = 4.0 * a.R * a.K, wb = 4.0 * a.N * a.K;
+    a.row_slots = force_map >= 0 ? force_map : (xb + wb / 8 < xb / 8 + wb ? 1 : 0);
+  }
+  const long blocks = a.row_slots == 0 ? (a.row_blocks + 7) / 8 * 8 * a.col_tiles
+                                       : (long)((a.col_tiles + 7) / 8) * 8 * a.row_blocks;
+  if (blocks > 0x7fffffffL) { eda_set_error("gemm: grid too large"); return EDA_ERR_INVALID_ARG; }
+  const dim3 grid((unsigned)blocks), block(64 * NWM * NWN);
+  if (wmode == W_NN) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, NWM, NWN, W_NN, NST>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, NWM, NWN, W_NT, NST>), grid, block, 0, stream, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { eda_set_error("gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+
+int launch_dma(GemmArgs &a, int wmode, hipStream_t stream) {
+  switch (g_dma_mode()) {
+    case 2: return launch_dma1<64, 96, 2, 2, 2>(a, wmode, stream);
+    case 3: return launch_dma1<64, 96, 4, 2, 3>(a, wmode, stream);
+    case 4: return launch_dma1<32, 96, 2, 2, 4>(a, wmode, stream);
+    default: return launch_dma1<32, 96, 2, 2, 2>(a, wmode, stream);
+  }
 }
 
 // ---- streaming launches (SA1) ---------------------------------------------------------------------
@@ -1195,6 +1491,7 @@ int eda_gemm_launch(GemmArgs &a, int wmode, hipStream_t stream) {
     if (rc >= 0) return rc;
   }
   if (!gemm_vec_ok(a, wmode)) return launch_cfg<1, 4, false>(a, wmode, stream);
+  if (dma_takes(a, wmode)) return launch_dma(a, wmode, stream);
   // measured on MI355X (tools/bench_gemm.py, profiles/r02a_gemm_tiles.txt): the 64x64 tile at 5-6
   // waves per SIMD beats the 128-row tiles at 2-4 on every shape of the path; 64x128 is a few
   // per cent ahead for the 128-multiples with many rows
@@ -1239,6 +1536,23 @@ int eda_gemm_launch(GemmArgs &a, int wmode, hipStream_t stream) {
     case 6: return launch_cfg<1, 6, true>(a, wmode, stream);
     default: return launch_cfg<1, 8, true>(a, wmode, stream);
   }
+}
+
+#ifdef EDA_GEMM_PROFILE
+extern "C" int eda_gemm_profile_read(unsigned long long *out8) {
+  static unsigned long long all[64 * 8], zero[64 * 8];
+  if (hipMemcpyFromSymbol(all, HIP_SYMBOL(gemm_prof), sizeof(all)) != hipSuccess) return 1;
+  for (int i = 0; i < 8; ++i) out8[i] = 0;
+  for (int s = 0; s < 64; ++s)
+    for (int i = 0; i < 8; ++i) out8[i] += all[s * 8 + i];
+  return hipMemcpyToSymbol(HIP_SYMBOL(gemm_prof), zero, sizeof(zero)) != hipSuccess;
+}
+#endif
+
+extern "C" int eda_gemm_set_dma(int mode) {
+  EDA_CHECK_ARG(mode >= -1 && mode <= 4, "mode: -1 (own selection), 0 (off), 1..4 (configuration for every eligible launch)");
+  g_dma_mode_v = mode;
+  return 0;
 }
 
 // ---- C ABI: plain linear layers ----------------------------------------------------------------

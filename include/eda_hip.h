@@ -450,6 +450,13 @@ int eda_transpose_batch_f32(const long long *desc, int count, long long total_ti
  * the reference (its sampler is one workgroup per scene, sampling_gpu.cu:74-178). */
 int eda_fps_set_cu_reserve(int cus);
 
+/* Kernel selection of the plain row products (eda_linear_fwd_f32 / _ex_f32 / _dgrad_f32): -1 the library's own choice
+ * (the DMA-staged kernel of csrc/gemm.hip for launches of >= 400 tiles of 32 x 96, else the register-staged one), 0 the
+ * DMA-staged kernel off, 1..4 one of its configurations for every eligible launch (tests, experiments).  Process-wide;
+ * default from EDA_GEMM_DMA.  Both kernels form the same products in the same order: the results are bitwise equal.
+ * Replaces nothing in the reference (its linear layers are cuBLAS calls, models/encoder_decoder_layers.py). */
+int eda_gemm_set_dma(int mode);
+
 /* Global-batch BatchNorm statistics for the fused set-abstraction / feature-propagation calls: the reference converts
  * every BatchNorm to SyncBatchNorm when more than one GPU trains (main_utils.py:336-338).  With a hook registered
  * (fn != NULL, world > 1) eda_sa_fused_fwd_f32 / eda_sa_fused_bwd*_f32 call fn(user, buf, n, stream) once per layer and

@@ -57,6 +57,39 @@ def test_linear_dgrad(R, K, N):
     assert bool((err <= tol + 1e-6 * ref.abs()).all()), float(err.max())
 
 
+DMA_SHAPES = [(8192, 288, 576), (640, 768, 2304), (640, 3072, 768), (2048, 288, 288), (2048, 288, 256), (1000, 64, 100),
+              (37, 32, 4), (1040, 288, 864), (8200, 576, 288), (33, 96, 196)]
+
+
+@pytest.mark.parametrize("R,K,N", DMA_SHAPES)
+def test_dma_staged_kernel_equals_register_staged_kernel(R, K, N):
+    """gemm_dma_kernel (global_load_lds staging, every configuration, both tile -> XCD maps come up through the shapes)
+    forms the same products in the same order as gemm_rows_kernel: forward (bias, ReLU / dropout / gate epilogues) and
+    dX agree bit for bit."""
+    from eda_amd import _lib, gemm
+    L = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(R + K + N)
+    x = torch.randn(R, K, device="cuda", generator=g); w = torch.randn(N, K, device="cuda", generator=g)
+    b = torch.randn(N, device="cuda", generator=g); dy = torch.randn(R, N, device="cuda", generator=g)
+    seed = torch.tensor([1234], dtype=torch.int64, device="cuda")
+    gate = torch.randn(R, N, device="cuda", generator=g)
+
+    def run():
+        return (gemm.linear_fwd(x, w, b), gemm.linear_fwd(x, w, None, True), gemm.linear_dgrad(dy, w),
+                gemm.linear_ex(x, w, b, relu=True, drop=(0.1, seed, 7)), gemm.linear_ex(x, w, None, gate=(gate, 1.25)))
+    try:
+        assert L.eda_gemm_set_dma(0) == 0
+        base = run()
+        for mode in (1, 2, 3, 4):
+            assert L.eda_gemm_set_dma(mode) == 0
+            for got, want in zip(run(), base):
+                assert torch.equal(got, want), (mode, float((got - want).abs().max()))
+    finally:
+        L.eda_gemm_set_dma(-1)
+    ref = x.double() @ w.double().t() + b.double()
+    assert float((base[0].double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
 def test_strided_operands_and_outputs():
     """Column views of packed projection buffers (row stride 864) as inputs and outputs."""
     from eda_amd import gemm
