@@ -359,6 +359,15 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a_i
   // the epilogue the loads were a fully exposed HBM round trip per row block)
   const bool yvec = (N % 4 == 0) && (a.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15u) == 0);
   const bool zvec = yvec && (a.ldzm % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.zm) & 15u) == 0);
+  // plain epilogue: the bias is requested before the main loop (loaded in the epilogue it is an exposed memory round
+  // trip at the end of every workgroup -- the small launches are a few microseconds long)
+  float bias_r[WC][4];
+#pragma unroll
+  for (int j = 0; j < WC; ++j) {
+    const int col = n0 + 16 * j + 16 * WC * wave_n + 4 * (lane >> 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bias_r[j][u] = (a.bias && col + u < N) ? a.bias[col + u] : 0.f;
+  }
   float4 zt[WC][WR];
   auto load_z = [&]() {
     if (a.dbg & 8) return;
@@ -471,11 +480,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a_i
 #pragma unroll
     for (int j = 0; j < WC; ++j) {
       const int col = n0 + 16 * j + cq;
-      float bb[4] = {0.f, 0.f, 0.f, 0.f};
-      if (a.bias) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) if (col + u < N) bb[u] = a.bias[col + u];
-      }
+      const float bb[4] = {bias_r[j][0], bias_r[j][1], bias_r[j][2], bias_r[j][3]};
       float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < WR; ++i) {
@@ -1108,6 +1113,14 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_dma_kernel(const GemmArgs
     for (int i = 0; i < WR; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int c = lane & 15, qq = lane >> 4;
+  // the bias is requested now: loaded in the epilogue it is an exposed memory round trip at the end of every workgroup
+  float4 bias_v[WC];
+#pragma unroll
+  for (int j = 0; j < WC; ++j) {
+    const int col = n0 + 16 * WC * wave_n + 16 * j + 4 * qq;
+    bias_v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias && col < N) bias_v[j] = *reinterpret_cast<const float4 *>(a.bias + col);
+  }
   // operand read offsets (floats) inside a stage for the two half-chunks
   int xo[WR][2], wo[WC][2];
 #pragma unroll
@@ -1198,9 +1211,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_dma_kernel(const GemmArgs
   for (int j = 0; j < WC; ++j) {
     const int col = n0 + 16 * WC * wave_n + 16 * j + 4 * qq;
     if (col >= N) continue;                                 // (N % 4 == 0: a lane's four columns are in or out together)
-    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.bias) bb = *reinterpret_cast<const float4 *>(a.bias + col);
-    const float b4[4] = {bb.x, bb.y, bb.z, bb.w};
+    const float b4[4] = {bias_v[j].x, bias_v[j].y, bias_v[j].z, bias_v[j].w};
 #pragma unroll
     for (int i = 0; i < WR; ++i) {
       const long row = row0 + 16 * WR * wave_m + 16 * i + c;
@@ -1344,6 +1355,12 @@ int launch_dma(GemmArgs &a, int wmode, hipStream_t stream) {
     case 2: return launch_dma1<64, 96, 2, 2, 2>(a, wmode, stream);
     case 3: return launch_dma1<64, 96, 4, 2, 3>(a, wmode, stream);
     case 4: return launch_dma1<32, 96, 2, 2, 4>(a, wmode, stream);
+    case 5: return launch_dma1<32, 96, 2, 6, 2>(a, wmode, stream);
+    case 6: return launch_dma1<32, 96, 2, 6, 3>(a, wmode, stream);
+    case 7: return launch_dma1<32, 96, 2, 3, 2>(a, wmode, stream);
+    case 8: return launch_dma1<16, 96, 1, 6, 2>(a, wmode, stream);
+    case 9: return launch_dma1<16, 96, 1, 3, 2>(a, wmode, stream);
+    case 10: return launch_dma1<32, 96, 2, 3, 3>(a, wmode, stream);
     default: return launch_dma1<32, 96, 2, 2, 2>(a, wmode, stream);
   }
 }
@@ -1550,7 +1567,7 @@ extern "C" int eda_gemm_profile_read(unsigned long long *out8) {
 #endif
 
 extern "C" int eda_gemm_set_dma(int mode) {
-  EDA_CHECK_ARG(mode >= -1 && mode <= 4, "mode: -1 (own selection), 0 (off), 1..4 (configuration for every eligible launch)");
+  EDA_CHECK_ARG(mode >= -1 && mode <= 10, "mode: -1 (own selection), 0 (off), 1..10 (configuration for every eligible launch)");
   g_dma_mode_v = mode;
   return 0;
 }

@@ -19,7 +19,7 @@ if len(sys.argv) > 1:
 else:
     import torch
     res = {}
-    for mode in range(0, 5):
+    for mode in range(0, 11):
         env = dict(os.environ, EDA_GEMM_DMA=str(mode))
         f = f"/tmp/gd_{mode}.pt"
         subprocess.check_call([sys.executable, __file__, f], env=env)
