@@ -294,11 +294,17 @@ class MultiheadAttention(nn.Module):
         memo[id(self)] = new
         return new
 
+    def hip_path(self, query):
+        """True when forward() takes the HIP kernels for this query (then skip_out_proj is honoured)."""
+        return query.is_cuda and _core is _hip_core
+
     def forward(self, query, key, value, key_padding_mask=None, need_weights=False,
-                attn_mask=None, batch_first=False, defer_out_bias=False):
+                attn_mask=None, batch_first=False, defer_out_bias=False, skip_out_proj=False):
         """Returns (output, None).  Inputs are (L,B,F) unless batch_first (then (B,L,F)).
         With defer_out_bias the out-projection is applied WITHOUT its bias and (output, bias) is
-        returned: the caller's fused residual+LayerNorm kernel adds it (fused_ln.py)."""
+        returned: the caller's fused residual+LayerNorm kernel adds it (fused_ln.py).
+        With skip_out_proj (HIP path only, see hip_path) the attention output BEFORE the out-projection is
+        returned: the caller's fused kernel applies out_proj together with the residual LayerNorm."""
         if attn_mask is not None:
             raise NotImplementedError("EDA always passes attn_mask=None")
         same_qk, same_kv = query is key, key is value
@@ -319,10 +325,13 @@ class MultiheadAttention(nn.Module):
                 groups, xs = ((0, d), (d, 2 * d), (2 * d, 3 * d)), (query, key, value)
             o = _ProjectedMHA.apply(W, b, key_padding_mask, self.num_heads,
                                     self.dropout if self.training else 0.0, self._salt, groups, *xs)
+            if skip_out_proj:
+                return (o if batch_first else o.transpose(0, 1)), None
             o = linear_rows(o, self.out_proj.weight, None if defer_out_bias else self.out_proj.bias)
             if not batch_first:
                 o = o.transpose(0, 1)
             return o, (self.out_proj.bias if defer_out_bias else None)
+        assert not skip_out_proj, "skip_out_proj: HIP path only (check hip_path(query) first)"
         if query is key and key is value:
             q, k, v = F.linear(query, W, b).split(d, dim=-1)
         elif key is value:

@@ -47,6 +47,10 @@ struct GemmArgs {
   // whose activated output `gate` is, applied to the input gradient that flows into it
   float drop_p; const unsigned long long *drop_seed; unsigned drop_salt;
   const float *gate; long ldgate; float gate_scale;
+  // gemm_dma_kernel<..., LN = true> (eda_linear_add_dropout_ln_fwd_f32): the row block spans all N columns and the
+  // epilogue is  z = resid + Dropout(acc + bias),  out = LayerNorm(z) * gamma + beta  (+ out_pos = out + pos); y is unused
+  const float *ln_resid, *ln_gamma, *ln_beta, *ln_pos; float ln_eps;
+  float *ln_z, *ln_out, *ln_out_pos, *ln_mean, *ln_rstd;
   int defer_finalize;   // E_STATS: the last workgroup only re-arms the ticket; the column sums stay in `sum` / `sumsq`
                         // for a cross-rank all-reduce, a separate kernel finalises (sa_cl.hip, eda_set_bn_sync)
   int dbg;   // EDA_GEMM_DBG timing experiments (results are then wrong): 1 skip park, 2 no grid cap, 4 skip atomics, 8 skip z loads

@@ -1032,7 +1032,10 @@ __device__ unsigned long long gemm_prof[64 * 8];
 // at once after the barrier, one between MFMA steps, or from a producer wave -- which then is the bottleneck), so what
 // pays is waves per SIMD, i.e. SMALL tiles (32 x 96, 32 KB of LDS, up to 5 workgroups per CU); 64- and 128-row tiles,
 // 8- and 16-wave workgroups and 3-4 stages all lost on the shapes of the path.
-template <int BM, int BN, int NWM, int NWN, int WMODE, int NST>
+// LN: the tile spans all N = BN columns of its rows and the epilogue is the residual + Dropout + LayerNorm of the
+// post-norm blocks (csrc/ln.hip's forward kernel folded in: the product itself is never written, only z = the
+// pre-norm sum, which the LayerNorm backward needs) -- see eda_linear_add_dropout_ln_fwd_f32.
+template <int BM, int BN, int NWM, int NWN, int WMODE, int NST, bool LN = false>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_dma_kernel(const GemmArgs a) {
   constexpr int KC = 32, NW = NWM * NWN;
   constexpr int WR = BM / NWM / 16, WC = BN / NWN / 16;
@@ -1121,6 +1124,21 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_dma_kernel(const GemmArgs
     bias_v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.bias && col < N) bias_v[j] = *reinterpret_cast<const float4 *>(a.bias + col);
   }
+  float4 res_v[LN ? WC : 1][LN ? WR : 1], pos_v[LN ? WC : 1][LN ? WR : 1];
+  if (LN) {
+#pragma unroll
+    for (int j = 0; j < WC; ++j) {
+      const int col = 16 * WC * wave_n + 16 * j + 4 * qq;
+#pragma unroll
+      for (int i = 0; i < WR; ++i) {
+        long row = row0 + 16 * WR * wave_m + 16 * i + c;
+        if (row > R - 1) row = R - 1;
+        res_v[j][i] = *reinterpret_cast<const float4 *>(a.ln_resid + row * N + col);
+        pos_v[j][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.ln_pos) pos_v[j][i] = *reinterpret_cast<const float4 *>(a.ln_pos + row * N + col);
+      }
+    }
+  }
   // operand read offsets (floats) inside a stage for the two half-chunks
   int xo[WR][2], wo[WC][2];
 #pragma unroll
@@ -1205,6 +1223,93 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_dma_kernel(const GemmArgs
     dseed = gemm_hash32((unsigned)(*a.drop_seed) * 0x9E3779B1u + a.drop_salt);
     dthresh = (unsigned)((double)a.drop_p * 4294967296.0);
     dinv = 1.f / (1.f - a.drop_p);
+  }
+  if constexpr (LN) {
+    // z = resid + Dropout(acc + bias) (same element hash as ln.hip, so its backward regenerates the mask), then the
+    // two-pass LayerNorm over the N columns of a row: lane (c, qq) holds 4 * WC values of row c of each of its WR row
+    // tiles; row sums = over qq by cross-lane adds, over the NWN waves of the row through LDS
+    float *red = smem;                                       // [NWN][BM] (the stages are free after the last barrier)
+    float t[WC][WR][4];
+    float rs[WR];
+#pragma unroll
+    for (int i = 0; i < WR; ++i) rs[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < WC; ++j) {
+      const int col = 16 * WC * wave_n + 16 * j + 4 * qq;
+      const float b4[4] = {bias_v[j].x, bias_v[j].y, bias_v[j].z, bias_v[j].w};
+#pragma unroll
+      for (int i = 0; i < WR; ++i) {
+        const long row = row0 + 16 * WR * wave_m + 16 * i + c;
+        const float r4[4] = {res_v[j][i].x, res_v[j][i].y, res_v[j][i].z, res_v[j][i].w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float yy = acc[j][i][u] + b4[u];
+          if (drop) yy = gemm_hash32(dseed ^ (unsigned)(row * N + col + u)) >= dthresh ? yy * dinv : 0.f;
+          t[j][i][u] = r4[u] + yy;
+          rs[i] += t[j][i][u];
+        }
+        if (row < R && a.ln_z)
+          *reinterpret_cast<float4 *>(a.ln_z + row * N + col) = make_float4(t[j][i][0], t[j][i][1], t[j][i][2], t[j][i][3]);
+      }
+    }
+    auto row_total = [&](float (&v)[WR]) {
+#pragma unroll
+      for (int i = 0; i < WR; ++i) {
+        v[i] += __shfl_xor(v[i], 16);
+        v[i] += __shfl_xor(v[i], 32);
+        if (qq == 0) red[wave_n * BM + 16 * WR * wave_m + 16 * i + c] = v[i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < WR; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWN; ++w) s += red[w * BM + 16 * WR * wave_m + 16 * i + c];
+        v[i] = s;
+      }
+      __syncthreads();
+    };
+    row_total(rs);
+    float mean[WR], rstd[WR], qs[WR];
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+      mean[i] = rs[i] / (float)N;
+      qs[i] = 0.f;
+#pragma unroll
+      for (int j = 0; j < WC; ++j)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const float dl = t[j][i][u] - mean[i]; qs[i] += dl * dl; }
+    }
+    row_total(qs);
+#pragma unroll
+    for (int i = 0; i < WR; ++i) rstd[i] = 1.f / sqrtf(qs[i] / (float)N + a.ln_eps);
+#pragma unroll
+    for (int j = 0; j < WC; ++j) {
+      const int col = 16 * WC * wave_n + 16 * j + 4 * qq;
+      const float4 g4 = *reinterpret_cast<const float4 *>(a.ln_gamma + col), be4 = *reinterpret_cast<const float4 *>(a.ln_beta + col);
+      const float g[4] = {g4.x, g4.y, g4.z, g4.w}, be[4] = {be4.x, be4.y, be4.z, be4.w};
+#pragma unroll
+      for (int i = 0; i < WR; ++i) {
+        const long row = row0 + 16 * WR * wave_m + 16 * i + c;
+        if (row >= R) continue;
+        float o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) o[u] = (t[j][i][u] - mean[i]) * rstd[i] * g[u] + be[u];
+        *reinterpret_cast<float4 *>(a.ln_out + row * N + col) = make_float4(o[0], o[1], o[2], o[3]);
+        if (a.ln_out_pos) {
+          const float p4[4] = {pos_v[j][i].x, pos_v[j][i].y, pos_v[j][i].z, pos_v[j][i].w};
+          *reinterpret_cast<float4 *>(a.ln_out_pos + row * N + col) = make_float4(o[0] + p4[0], o[1] + p4[1], o[2] + p4[2], o[3] + p4[3]);
+        }
+      }
+    }
+    if (wave_n == 0 && qq == 0) {
+#pragma unroll
+      for (int i = 0; i < WR; ++i) {
+        const long row = row0 + 16 * WR * wave_m + 16 * i + c;
+        if (row < R) { a.ln_mean[row] = mean[i]; a.ln_rstd[row] = rstd[i]; }
+      }
+    }
+    return;
   }
   const bool gated = a.gate != nullptr;
 #pragma unroll
@@ -1555,6 +1660,57 @@ int eda_gemm_launch(GemmArgs &a, int wmode, hipStream_t stream) {
   }
 }
 
+static void gemm_defaults(GemmArgs &a) {
+  memset(&a, 0, sizeof(a));
+}
+
+// ---- C ABI: linear layer + residual + Dropout + LayerNorm in one launch ----------------------------------
+extern "C" int eda_linear_add_dropout_ln_supported(int K, int N) { return N == 288 && K >= 32 && K % 32 == 0; }
+
+extern "C" int eda_linear_add_dropout_ln_fwd_f32(const float *x, long ldx, long R, int K, const float *w, long ldw, int N,
+                                                 const float *bias, const float *resid, const float *gamma,
+                                                 const float *beta, float eps, float drop_p,
+                                                 const unsigned long long *drop_seed, unsigned drop_salt, float *z,
+                                                 float *out, float *mean, float *rstd, const float *pos, float *out_pos,
+                                                 void *stream_) {
+  EDA_CHECK_ARG(R >= 0 && ldx >= K && ldw >= K, "bad dimension");
+  EDA_CHECK_ARG(eda_linear_add_dropout_ln_supported(K, N), "the fused kernel exists for N = 288 and K a multiple of 32");
+  EDA_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || drop_seed), "dropout needs 0 <= p < 1 and a seed");
+  if (R == 0) return 0;
+  EDA_CHECK_ARG(x && w && resid && gamma && beta && out && mean && rstd, "null pointer");
+  EDA_CHECK_ARG((pos == nullptr) == (out_pos == nullptr), "pos and out_pos come together");
+  EDA_CHECK_ARG((long long)R * N < 0x100000000LL || drop_p == 0.f, "dropout: more than 2^32 elements");
+  auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  EDA_CHECK_ARG(ldx % 4 == 0 && ldw % 4 == 0 && al16(x) && al16(w) && al16(resid) && al16(gamma) && al16(beta) && al16(out) &&
+                (!bias || al16(bias)) && (!z || al16(z)) && (!pos || (al16(pos) && al16(out_pos))), "operands must be 16-byte aligned");
+  GemmArgs a;
+  gemm_defaults(a);
+  a.xmode = X_PLAIN; a.epi = E_PLAIN;
+  a.x = x; a.ldx = ldx; a.R = R; a.K = K;
+  a.w = w; a.ldw = ldw; a.N = N; a.bias = bias;
+  a.drop_p = drop_p; a.drop_seed = drop_seed; a.drop_salt = drop_salt;
+  a.ln_resid = resid; a.ln_gamma = gamma; a.ln_beta = beta; a.ln_eps = eps; a.ln_pos = pos;
+  a.ln_z = z; a.ln_out = out; a.ln_out_pos = out_pos; a.ln_mean = mean; a.ln_rstd = rstd;
+  a.col_tiles = 1; a.row_slots = 0;
+  // 16-row blocks (6 waves) below 4096 rows, 32-row blocks (12 waves) from there (EDA_GEMM_LN_BM forces one)
+  static int force_bm = -2;
+  if (force_bm == -2) { const char *e = getenv("EDA_GEMM_LN_BM"); force_bm = e ? atoi(e) : 0; }
+  const int bm = force_bm == 16 || force_bm == 32 ? force_bm : (R >= 4096 ? 32 : 16);
+  hipStream_t stream = (hipStream_t)stream_;
+  if (bm == 32) {
+    a.row_blocks = (R + 31) / 32;
+    const long blocks = (a.row_blocks + 7) / 8 * 8;
+    hipLaunchKernelGGL((gemm_dma_kernel<32, 288, 2, 6, W_NT, 2, true>), dim3((unsigned)blocks), dim3(768), 0, stream, a);
+  } else {
+    a.row_blocks = (R + 15) / 16;
+    const long blocks = (a.row_blocks + 7) / 8 * 8;
+    hipLaunchKernelGGL((gemm_dma_kernel<16, 288, 1, 6, W_NT, 2, true>), dim3((unsigned)blocks), dim3(384), 0, stream, a);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { eda_set_error("linear_add_dropout_ln: launch failed: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+
 #ifdef EDA_GEMM_PROFILE
 extern "C" int eda_gemm_profile_read(unsigned long long *out8) {
   static unsigned long long all[64 * 8], zero[64 * 8];
@@ -1573,9 +1729,6 @@ extern "C" int eda_gemm_set_dma(int mode) {
 }
 
 // ---- C ABI: plain linear layers ----------------------------------------------------------------
-static void gemm_defaults(GemmArgs &a) {
-  memset(&a, 0, sizeof(a));
-}
 
 extern "C" int eda_linear_fwd_f32(const float *x, long ldx, long R, int K, const float *w, long ldw, int N,
                                   const float *bias, int relu, float *y, long ldy, void *stream_) {

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(LN_THREADS) void add_dropout_ln_bwd_kernel(
         const int c = lane + 64 * i;
         const bool ok = live[u] && c < C;
         xv[u][i] = ok ? x[row * C + c] : 0.f;
-        yv[u][i] = ok ? y[row * C + c] : 0.f;
+        yv[u][i] = (ok && y) ? y[row * C + c] : 0.f;
         gv[u][i] = ok ? (EXTRA ? dout[row * C + c] + dout2[row * C + c] : dout[row * C + c]) : 0.f;
       }
     }
@@ -142,6 +142,7 @@ __global__ __launch_bounds__(LN_THREADS) void add_dropout_ln_bwd_kernel(
           keep[i] = ln_hash32(d.seed ^ (unsigned)(row * C + c)) >= d.thresh;
           yy = keep[i] ? yy * d.inv_keep : 0.f;
         }
+        if (!y) yy = 0.f;                      // x already is the pre-norm sum (fused linear + LayerNorm forward)
         const float xhat = c < C ? (xv[u][i] + yy - mean[u]) * rstd[u] : 0.f;
         const float go = gv[u][i];
         dg[i] += go * xhat;
@@ -289,7 +290,7 @@ extern "C" int eda_add_dropout_ln_bwd_f32(const float *dout, const float *x, con
   // grads3 == NULL: leave the per-block partial sums in `ws` (eda_add_dropout_ln_bwd_blocks(R) rows
   // of 3*C floats) for a later eda_ln_reduce_grouped_f32 over many sites
   if (R == 0) return grads3 ? eda_zero_async(grads3, sizeof(float) * 3 * C, stream) : 0;
-  EDA_CHECK_ARG(dout && x && y && gamma && mean && rstd && dx && dy && ws, "null pointer");
+  EDA_CHECK_ARG(dout && x && gamma && mean && rstd && dx && dy && ws, "null pointer");   // y == NULL: x is the pre-norm sum
   if (ws_bytes < eda_add_dropout_ln_bwd_workspace_bytes(R, C)) {
     eda_set_error("add_dropout_ln_bwd: workspace too small");
     return EDA_ERR_WORKSPACE;

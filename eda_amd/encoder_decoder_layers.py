@@ -14,7 +14,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from .attention import MultiheadAttention
-from .fused_ln import add_dropout_layer_norm, fuses_bias, new_salt_base
+from .fused_ln import (_FFNAddDropoutLN, add_dropout_layer_norm, fuses_bias, fuses_linear, linear_add_dropout_layer_norm,
+                       new_salt_base)
 from .nn_utils import Conv1dK1, Linear, bn_relu_rows, linear_rows, mlp_chain, rows_ok
 
 
@@ -30,6 +31,12 @@ def _ffn(d_model, dim_feedforward, dropout):
 def _ffn_residual_norm(x, ffn, norm, training, salt):
     """norm(x + ffn(x)) where ffn = Linear, ReLU, Dropout, Linear, Dropout: the last Dropout is
     applied inside the fused residual+LayerNorm kernel."""
+    if fuses_linear(x, norm, ffn[3].weight.shape[1]) and x.dtype == torch.float32:
+        # the whole block as one autograd node: Linear + ReLU + Dropout | Linear + residual + Dropout + LayerNorm
+        p1 = float(ffn[2].p) if training else 0.0
+        p2 = float(ffn[4].p) if training else 0.0
+        return _FFNAddDropoutLN.apply(x, ffn[0].weight, ffn[0].bias, ffn[3].weight, ffn[3].bias, norm.weight, norm.bias,
+                                      norm.eps, p1, salt + 0x5BD1E995, p2, salt)
     fused = fuses_bias(x, norm)  # second linear's bias (and its gradient) ride in the LN kernels
     # Linear + ReLU + Dropout + Linear as one autograd node, the activations in the GEMM epilogues
     y = mlp_chain(x, [(ffn[0].weight, ffn[0].bias, True, ffn[2].p, salt + 0x5BD1E995),
@@ -40,6 +47,11 @@ def _ffn_residual_norm(x, ffn, norm, training, salt):
 def _attn_residual_norm(attn, x, q, k, v, mask, norm, p_drop, training, salt, batch_first=True, pos=None):
     """norm(x + dropout(attn(q, k, v))): the out-projection bias is deferred to the fused
     residual+LayerNorm kernel whenever that kernel runs.  With `pos`: (out, out + pos)."""
+    if batch_first and attn.hip_path(q) and fuses_linear(x, norm, attn.embed_dim):
+        # the out-projection rides in the residual LayerNorm's launch
+        o, _ = attn(q, k, v, key_padding_mask=mask, batch_first=True, skip_out_proj=True)
+        return linear_add_dropout_layer_norm(o, attn.out_proj.weight, attn.out_proj.bias, x, norm, p_drop, training,
+                                             salt, pos=pos)
     y, y_bias = attn(q, k, v, key_padding_mask=mask, batch_first=batch_first,
                      defer_out_bias=fuses_bias(x, norm))
     return add_dropout_layer_norm(x, y, norm, p_drop, training, salt, y_bias=y_bias, pos=pos)

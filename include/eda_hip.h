@@ -252,12 +252,27 @@ int eda_add_dropout_ln_fwd_f32(const float *x, const float *y, const float *y_bi
                                float *out, float *mean, float *rstd, const float *pos, float *out_pos,
                                void *stream);
 size_t eda_add_dropout_ln_bwd_workspace_bytes(long R, int C);
+/* (y == NULL: x already is the pre-norm sum z of eda_linear_add_dropout_ln_fwd_f32) */
 int eda_add_dropout_ln_bwd_f32(const float *dout, const float *x, const float *y,
                                const float *y_bias, const float *gamma, const float *mean,
                                const float *rstd, long R, int C, float p_drop,
                                const unsigned long long *seed_ptr, unsigned salt, float *dx,
                                float *dy, float *grads3, void *ws, size_t ws_bytes,
                                const float *dout2 /* (R,C) or NULL: added to dout */, void *stream);
+
+/* The post-norm block's linear layer and its residual + Dropout + LayerNorm as ONE launch:
+ *     z = resid + Dropout(x W^T + bias),   out = LayerNorm(z) * gamma + beta   (+ out_pos = out + pos)
+ * for the attention out-projections and the second FFN linear (models/encoder_decoder_layers.py:94-96, 106-122, 154-156,
+ * 184-186, 371-405): x (R,K) with row stride ldx, W (N,K) with row stride ldw, resid / z / out / pos / out_pos dense (R,N),
+ * mean / rstd (R).  The product x W^T is never written; z (may be NULL in inference) is what the backward needs:
+ * eda_add_dropout_ln_bwd_f32 with x = z and y = NULL (dy then is the gradient of the product, dx that of resid), followed
+ * by the linear layer's own eda_linear_dgrad_f32 / weight gradient.  Same Dropout hash as eda_add_dropout_ln_fwd_f32.
+ * Exists for N = 288 (d_model of the path) and K % 32 == 0 (eda_linear_add_dropout_ln_supported); 16-byte aligned operands. */
+int eda_linear_add_dropout_ln_supported(int K, int N);
+int eda_linear_add_dropout_ln_fwd_f32(const float *x, long ldx, long R, int K, const float *w, long ldw, int N,
+                                      const float *bias, const float *resid, const float *gamma, const float *beta,
+                                      float eps, float p_drop, const unsigned long long *seed_ptr, unsigned salt, float *z,
+                                      float *out, float *mean, float *rstd, const float *pos, float *out_pos, void *stream);
 
 /* Deferred form: with grads3 == NULL eda_add_dropout_ln_bwd_f32 leaves its per-block partial sums
  * in `ws` (eda_add_dropout_ln_bwd_blocks(R) rows of 3*C floats); eda_ln_reduce_grouped_f32 then

@@ -191,3 +191,80 @@ def test_add_dropout_layer_norm_with_pos_output(use):
             assert a is None or float(a.abs().max()) == 0.0
         else:
             torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
+
+
+def _close(a, b, tol=2e-5):
+    scale = float(b.abs().max()) + 1e-12
+    return float((a - b).abs().max()) <= tol * scale
+
+
+@pytest.mark.parametrize("R,K", [(2048, 288), (640, 288), (1000, 256), (8192, 288), (37, 32), (4100, 576)])
+@pytest.mark.parametrize("p,with_pos", [(0.0, False), (0.1, True)])
+def test_linear_layer_in_the_layer_norm_launch(R, K, p, with_pos, monkeypatch):
+    """eda_linear_add_dropout_ln_fwd_f32 (the out-projection / second FFN linear inside the residual LayerNorm's launch)
+    against the two-launch composition of the same kernels' siblings: same Dropout mask (same hash), so outputs and every
+    gradient agree to fp32 rounding; and against torch in eval mode."""
+    from eda_amd import fused_ln
+    C = 288
+    g = torch.Generator(device="cuda").manual_seed(R + K)
+    base = dict(inp=torch.randn(R, K, device="cuda", generator=g), W=torch.randn(C, K, device="cuda", generator=g) * K ** -0.5,
+                b=torch.randn(C, device="cuda", generator=g), x=torch.randn(R, C, device="cuda", generator=g),
+                pos=torch.randn(R, C, device="cuda", generator=g))
+    norm0 = torch.nn.LayerNorm(C).cuda()
+    with torch.no_grad():
+        norm0.weight.uniform_(0.5, 1.5, generator=g); norm0.bias.normal_(generator=g)
+    w1, w2 = torch.randn(R, C, device="cuda", generator=g), torch.randn(R, C, device="cuda", generator=g)
+
+    def run(fused):
+        monkeypatch.setenv("EDA_FUSED_LINEAR_LN", "1" if fused else "0")
+        t = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        norm = torch.nn.LayerNorm(C).cuda()
+        norm.load_state_dict(norm0.state_dict())
+        assert fused_ln.fuses_linear(t["x"], norm, K) == fused
+        res = fused_ln.linear_add_dropout_layer_norm(t["inp"], t["W"], t["b"], t["x"], norm, p, True, 77,
+                                                     pos=t["pos"] if with_pos else None)
+        out, out_pos = res if with_pos else (res, None)
+        loss = (out * w1).sum() + ((out_pos * w2).sum() if with_pos else 0.0)
+        loss.backward()
+        grads = {k: v.grad for k, v in t.items() if v.grad is not None}
+        grads["gamma"], grads["beta"] = norm.weight.grad, norm.bias.grad
+        return out.detach(), (out_pos.detach() if with_pos else None), grads
+
+    o1, op1, g1 = run(True)
+    o0, op0, g0 = run(False)
+    assert _close(o1, o0) and (not with_pos or _close(op1, op0))
+    assert set(g1) == set(g0)
+    for k in g0:
+        assert _close(g1[k], g0[k], 5e-5), k
+    if p == 0.0:
+        with torch.no_grad():
+            ref = F.layer_norm(base["x"] + F.linear(base["inp"], base["W"], base["b"]), (C,), norm0.weight, norm0.bias, norm0.eps)
+        assert _close(o1, ref)
+
+
+@pytest.mark.parametrize("R", [2048, 640, 1030])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_ffn_block_as_one_node(R, p, monkeypatch):
+    """_ffn_residual_norm through _FFNAddDropoutLN (two launches) against the mlp_chain + residual LayerNorm path."""
+    from eda_amd import encoder_decoder_layers as EDL
+    C, Fd = 288, 256
+    g = torch.Generator(device="cuda").manual_seed(R)
+    ffn0 = EDL._ffn(C, Fd, p).cuda()
+    norm0 = torch.nn.LayerNorm(C).cuda()
+    x0 = torch.randn(8, R // 8 if R % 8 == 0 else R, C, device="cuda", generator=g) if R % 8 == 0 else torch.randn(1, R, C, device="cuda", generator=g)
+    w = torch.randn_like(x0)
+
+    def run(fused):
+        monkeypatch.setenv("EDA_FUSED_LINEAR_LN", "1" if fused else "0")
+        ffn, norm = EDL._ffn(C, Fd, p).cuda(), torch.nn.LayerNorm(C).cuda()
+        ffn.load_state_dict(ffn0.state_dict()); norm.load_state_dict(norm0.state_dict())
+        x = x0.clone().requires_grad_(True)
+        out = EDL._ffn_residual_norm(x, ffn, norm, True, 4242)
+        (out * w).sum().backward()
+        return out.detach(), [x.grad] + [q.grad for q in ffn.parameters()] + [q.grad for q in norm.parameters()]
+
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    assert _close(o1, o0)
+    for a, b in zip(g1, g0):
+        assert _close(a, b, 5e-5)
