@@ -104,7 +104,7 @@ def algorithmic_flops(name):
     if op == "mha_bwd":
         b, h, lq, lk = d
         return 10.0 * b * h * lq * lk * 36
-    if op in ("gemm_fwd", "gemm_dgrad"):
+    if op in ("gemm_fwd", "gemm_dgrad", "linear_add_dropout_ln_fwd"):
         r, k, n = d
         return 2.0 * r * k * n
     if op in ("gemm_grouped_fwd", "gemm_grouped_dgrad"):
@@ -717,9 +717,10 @@ def main():
         # trace) are bound by launch latency and the ~12 B/clk a CU can ingest, a HIP-event bracket around one of them
         # measures mostly the bracket, and no roof prices them; their family total is `gemm_family_ms_per_step` and
         # `launch_bound_gemm` below
-        mf_all = [k for k in kernels if k["tflops"] and (k["op"].startswith("mha_") or k["op"] in ("gemm_fwd", "gemm_dgrad"))]
+        GEMM_OPS = ("gemm_fwd", "gemm_dgrad", "linear_add_dropout_ln_fwd")   # (the last: product + LayerNorm epilogue)
+        mf_all = [k for k in kernels if k["tflops"] and (k["op"].startswith("mha_") or k["op"] in GEMM_OPS)]
         mf = [k for k in mf_all if k["ms"] >= 0.05]
-        small = [k for k in mf_all if k["ms"] < 0.05 and k["op"] in ("gemm_fwd", "gemm_dgrad")]
+        small = [k for k in mf_all if k["ms"] < 0.05 and k["op"] in GEMM_OPS]
         launch_bound_gemm = None
         if small:
             tsm = max(small, key=lambda k: k["ms"] * k["calls_per_step"])
@@ -730,7 +731,7 @@ def main():
         # the tiled row-GEMM family as a whole (forward + input-gradient products of the linear layers; the streaming
         # kernels of the SA layers are inside sa_fused_*): priced by its dominant shape, family totals alongside
         roofline_gemm = None
-        fam = [k for k in mf_all if k["op"] in ("gemm_fwd", "gemm_dgrad")]
+        fam = [k for k in mf_all if k["op"] in GEMM_OPS]
         if fam:
             topg = max(fam, key=lambda k: k["ms"] * k["calls_per_step"])
             fam_ms = sum(k["ms"] * k["calls_per_step"] for k in fam)
@@ -741,7 +742,7 @@ def main():
                              "alg_flops_per_launch": algorithmic_flops((topg["op"],) + tuple(topg["dims"])),
                              "ms_per_launch": topg["ms"], "calls_per_step": topg["calls_per_step"],
                              "ms_per_step": round(fam_ms, 4),
-                             "family": "own tiled row GEMMs (csrc/gemm.hip gemm_rows_kernel), forward + input gradients",
+                             "family": "own tiled row GEMMs (csrc/gemm.hip gemm_rows_kernel / gemm_dma_kernel), forward + input gradients",
                              "family_tflops": round(fam_fl / (fam_ms * 1e-3) / 1e12, 2) if fam_ms > 0 else None,
                              "family_frac": round(fam_fl / (fam_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4) if fam_ms > 0 else None,
                              "by_shape": [{"kernel": f"{k['op']}{tuple(k['dims'])}", "calls_per_step": k["calls_per_step"],
