@@ -18,7 +18,7 @@ NATIVE = [
     ("native: zero-fill", r"^zero_kernel"),
 ]
 TORCH = [
-    ("library GEMM (hipBLASLt/rocBLAS, fp32; RoBERTa only)", r"^Cijk_|gemm|Gemm"),
+    ("library GEMM (hipBLASLt, fp32: the batched query x token products of the contrastive losses; the text encoder too with EDA_FAST_ROBERTA=0)", r"^Cijk_|gemm|Gemm"),
     ("optimizer / foreach", r"multi_tensor_apply"),
     ("torch reduce", r"reduce_kernel"),
     ("torch layernorm / softmax / attention (RoBERTa)", r"layer_norm|softmax|attn_fwd|LayerNorm"),
