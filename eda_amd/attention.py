@@ -252,6 +252,170 @@ class _ProjectedMHA(Function):
         return (dW, db, None, None, None, None, None, *dxs)
 
 
+class KVSink:
+    """Where the n consumers of a stacked K/V projection (StackedKV) put their dk | dv: side by side in ONE (B, Lk, n*2d)
+    buffer, allocated by the first consumer's backward -- the projection's input gradient then is a single product over
+    the concatenated contraction (no per-layer products, no gradient-accumulation adds)."""
+
+    def __init__(self, n, width):
+        self.n, self.width, self.buf = n, width, None
+
+    def slot(self, i, B, Lk, device):
+        if self.buf is None:
+            self.buf = torch.empty((B, Lk, self.n * self.width), dtype=torch.float32, device=device)
+        return self.buf[..., i * self.width:(i + 1) * self.width]
+
+
+class _StackedKV(Function):
+    """K | V projections of ONE memory tensor for n attention modules (the decoder layers' cross_l / cross_d / cross_v:
+    text, boxes and points are the same for all six layers, encoder_decoder_layers.py:366-401) as one product:
+    y = x [W_0[d:]; W_1[d:]; ...]^T.  `stack` = (Wst, bst): persistent (n*2d, d) / (n*2d) buffers refreshed by the caller
+    (refresh_kv_stacks).  Outputs: n column views (B, Lk, 2d) of y.  Backward: one dX product over the n*2d columns when
+    the consumers wrote their gradients into the sink, the weight / bias gradients per module (queued)."""
+
+    @staticmethod
+    def forward(ctx, x, sink, stack, *wb):
+        n = len(wb) // 2
+        d = x.shape[-1]
+        Wst, bst = stack
+        x2 = x.reshape(-1, d)
+        y = gemm.linear_fwd(x2, Wst, bst).view(*x.shape[:-1], n * 2 * d)
+        ctx.save_for_backward(x2, *wb)
+        ctx.Wst = Wst                     # (persistent buffer, rewritten by the next forward's refresh: not a saved tensor)
+        ctx.sink, ctx.xshape, ctx.n = sink, x.shape, n
+        ctx.set_materialize_grads(False)
+        return tuple(y[..., 2 * d * i:2 * d * (i + 1)] for i in range(n))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x2, Wst = ctx.saved_tensors[0], ctx.Wst
+        wb = ctx.saved_tensors[1:]
+        n, sink = ctx.n, ctx.sink
+        d = x2.shape[1]
+        B, Lk = ctx.xshape[0], ctx.xshape[1]
+        dall = None
+        if sink.buf is not None and all(
+                dy is not None and dy.data_ptr() == sink.buf.data_ptr() + 4 * 2 * d * i and dy.stride() == sink.buf.stride()
+                for i, dy in enumerate(dys)):
+            dall = sink.buf
+        else:                                           # (consumers that did not use the sink: assemble)
+            dall = torch.cat([dy if dy is not None else torch.full((B, Lk, 2 * d), 0.0, device=x2.device) for dy in dys], -1)
+        sink.buf = None
+        dall2 = dall.view(-1, n * 2 * d)
+        dx = gemm.linear_dgrad(dall2, Wst).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        from . import wgrad_queue
+        q = wgrad_queue.active
+        grads = []
+        for i in range(n):
+            W, b = wb[2 * i], wb[2 * i + 1]
+            dyi = dall2[:, 2 * d * i:2 * d * (i + 1)]
+            need_w, need_b = ctx.needs_input_grad[3 + 2 * i], ctx.needs_input_grad[4 + 2 * i]
+            if q is not None and need_w and need_b and q.submit(W[d:], b[d:], dyi, x2):
+                grads += [None, None]
+                continue
+            dW = db = None
+            if need_w:
+                dW = torch.zeros_like(W)
+                db = torch.zeros_like(b) if need_b else None
+                wgrad(dyi.contiguous(), x2, dW=dW[d:], db=db[d:] if db is not None else None, want_db=db is not None)
+            elif need_b:
+                db = torch.zeros_like(b)
+                colsum(dyi.contiguous(), out=db[d:])
+            grads += [dW, db]
+        return (dx, None, None, *grads)
+
+
+def refresh_kv_stacks(stacks, modules_per_stack):
+    """Copy the K | V rows of the modules' in-projection weights / biases into the persistent stacks (one multi-tensor
+    launch for all of them): stacks = [(Wst, bst), ...], modules_per_stack = [[MultiheadAttention, ...], ...]."""
+    dst, src = [], []
+    for (Wst, bst), mods in zip(stacks, modules_per_stack):
+        d = mods[0].embed_dim
+        for i, m in enumerate(mods):
+            dst += [Wst[2 * d * i:2 * d * (i + 1)], bst[2 * d * i:2 * d * (i + 1)]]
+            src += [m.in_proj_weight.detach()[d:], m.in_proj_bias.detach()[d:]]
+    with torch.no_grad():
+        torch._foreach_copy_(dst, src)
+
+
+class _ProjectedMHAPreKV(Function):
+    """q-projection + attention core on K | V that were projected elsewhere (_StackedKV): kv (B, Lk, 2d) column view.
+    Backward: dk | dv go into the sink's slot of this consumer (or a fresh tensor without a sink)."""
+
+    @staticmethod
+    def forward(ctx, W, b, mask, num_heads, p_drop, salt, sink, slot, x, kv):
+        d = W.shape[1]
+        dev = W.device
+        B, Lq = x.shape[0], x.shape[1]
+        x2 = x.reshape(-1, d)
+        q = gemm.linear_fwd(x2, W[:d], b[:d]).view(B, Lq, d)
+        k, v = kv[..., :d], kv[..., d:]
+        Lk = kv.shape[1]
+        hd = d // num_heads
+        out = torch.empty((B, Lq, d), dtype=torch.float32, device=dev)
+        lse = torch.empty((B, num_heads, Lq), dtype=torch.float32, device=dev)
+        m8 = mask.contiguous().view(torch.uint8) if mask is not None else None
+        seed = dropout_state(dev) if p_drop > 0 else None
+        with torch.cuda.device(dev), _timed('mha_fwd', (B, num_heads, Lq, Lk)):
+            rc = _lib.lib().eda_mha_fwd(
+                q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
+                k.stride(1), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else None,
+                B, num_heads, Lq, Lk, hd, hd ** -0.5, float(p_drop),
+                seed.data_ptr() if seed is not None else None, int(salt), out.data_ptr(),
+                lse.data_ptr(), _compute_dtype, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "eda_mha_fwd")
+        ctx.dtype_code = _compute_dtype
+        ctx.save_for_backward(W, b, x2, q, kv, out, lse)
+        ctx.mask8 = m8
+        ctx.cfg = (num_heads, float(p_drop), int(salt), sink, slot, x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        num_heads, p_drop, salt, sink, slot, xshape = ctx.cfg
+        W, bias, x2, q, kv, out, lse = ctx.saved_tensors
+        d = W.shape[1]
+        dev = W.device
+        dout = _rows(dout)
+        k, v = kv[..., :d], kv[..., d:]
+        B, Lq, Lk = q.shape[0], q.shape[1], kv.shape[1]
+        hd = d // num_heads
+        dq = torch.empty_like(q)
+        dkv = sink.slot(slot, B, Lk, dev) if sink is not None else torch.empty((B, Lk, 2 * d), dtype=torch.float32, device=dev)
+        dk, dv = dkv[..., :d], dkv[..., d:]
+        delta = torch.empty((B, num_heads, Lq), dtype=torch.float32, device=dev)
+        m8 = ctx.mask8
+        seed = dropout_state(dev) if p_drop > 0 else None
+        ws_bytes = _lib.lib().eda_mha_bwd_workspace_bytes(B, num_heads, Lq, Lk)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
+        with torch.cuda.device(dev), _timed('mha_bwd', (B, num_heads, Lq, Lk)):
+            rc = _lib.lib().eda_mha_bwd(
+                q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
+                k.stride(1), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else None,
+                B, num_heads, Lq, Lk, hd, hd ** -0.5, p_drop,
+                seed.data_ptr() if seed is not None else None, salt, out.data_ptr(), lse.data_ptr(),
+                dout.data_ptr(), dout.stride(0), dout.stride(1), delta.data_ptr(), dq.data_ptr(),
+                dk.data_ptr(), dv.data_ptr(), dq.stride(0), dq.stride(1), dk.stride(0), dk.stride(1),
+                dv.stride(0), dv.stride(1), ws.data_ptr() if ws is not None else None, ws_bytes,
+                ctx.dtype_code, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "eda_mha_bwd")
+        from . import wgrad_queue
+        qd = wgrad_queue.active
+        dq2 = dq.view(-1, d)
+        dW = db = None
+        need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not (qd is not None and need_w and need_b and qd.submit(W[:d], bias[:d], dq2, x2)):
+            if need_w:
+                dW = torch.zeros_like(W)
+                db = torch.zeros_like(bias) if need_b else None
+                wgrad(dq2, x2, dW=dW[:d], db=db[:d] if db is not None else None, want_db=db is not None)
+            elif need_b:
+                db = torch.zeros_like(bias)
+                colsum(dq2, out=db[:d])
+        dx = gemm.linear_dgrad(dq2, W[:d]).view(xshape) if ctx.needs_input_grad[8] else None
+        return (dW, db, None, None, None, None, None, None, dx, dkv if ctx.needs_input_grad[9] else None)
+
+
 def _hip_core(q, k, v, key_padding_mask, num_heads, dropout_p, salt):
     return _FusedMHA.apply(q, k, v, key_padding_mask, num_heads, dropout_p, salt)
 
@@ -299,7 +463,7 @@ class MultiheadAttention(nn.Module):
         return query.is_cuda and _core is _hip_core
 
     def forward(self, query, key, value, key_padding_mask=None, need_weights=False,
-                attn_mask=None, batch_first=False, defer_out_bias=False, skip_out_proj=False):
+                attn_mask=None, batch_first=False, defer_out_bias=False, skip_out_proj=False, pre_kv=None):
         """Returns (output, None).  Inputs are (L,B,F) unless batch_first (then (B,L,F)).
         With defer_out_bias the out-projection is applied WITHOUT its bias and (output, bias) is
         returned: the caller's fused residual+LayerNorm kernel adds it (fused_ln.py).
@@ -307,6 +471,13 @@ class MultiheadAttention(nn.Module):
         returned: the caller's fused kernel applies out_proj together with the residual LayerNorm."""
         if attn_mask is not None:
             raise NotImplementedError("EDA always passes attn_mask=None")
+        if pre_kv is not None:
+            # K | V of this module were projected together with its siblings' (_StackedKV): q-projection + core only
+            assert batch_first and skip_out_proj and self.hip_path(query)
+            kv, sink, slot = pre_kv
+            o = _ProjectedMHAPreKV.apply(self.in_proj_weight, self.in_proj_bias, key_padding_mask, self.num_heads,
+                                         self.dropout if self.training else 0.0, self._salt, sink, slot, query, kv)
+            return o, None
         same_qk, same_kv = query is key, key is value
         if not batch_first:
             query = query.transpose(0, 1)

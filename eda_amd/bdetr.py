@@ -251,8 +251,10 @@ class BeaUTyDETR(nn.Module):
         projected = [("proposal_", query)]
         center, size = self.proposal_head(cluster_feature, base_xyz=cluster_xyz, end_points=end_points,
                                           prefix="proposal_", features_rows=cluster_rows)
-        base_xyz, base_size = center.detach().clone(), size.detach().clone()
+        # (the reference clones: main_utils-side code never writes into these outputs, the cat below copies them anyway)
+        base_xyz, base_size = center.detach(), size.detach()
 
+        hoisted = self._hoisted_kv(vis, text_feats, detected_feats if self.butd else None)
         for i in range(self.num_decoder_layers):
             prefix = "last_" if i == self.num_decoder_layers - 1 else f"{i}head_"
             if self.self_position_embedding == "none":
@@ -265,17 +267,48 @@ class BeaUTyDETR(nn.Module):
                 raise NotImplementedError
             query = self.decoder[i](query, vis, text_feats, query_pos, None, text_padding_mask,
                                     detected_feats=detected_feats if self.butd else None,
-                                    detected_mask=detected_mask if self.butd else None)
+                                    detected_mask=detected_mask if self.butd else None,
+                                    pre_kv={k: (kvs[i], sink, i) for k, (kvs, sink) in hoisted.items()})
             projected.append((prefix, query))
             center, size = self.prediction_heads[i](query.transpose(1, 2), base_xyz=cluster_xyz,
                                                     end_points=end_points, prefix=prefix,
                                                     features_rows=query)
-            base_xyz, base_size = center.detach().clone(), size.detach().clone()
+            base_xyz, base_size = center.detach(), size.detach()
         if self.contrastive_align_loss:
             proj = _project(self.contrastive_align_projection_image, torch.stack([q for _, q in projected], 0))
             for (prefix, _), p in zip(projected, proj.unbind(0)):
                 end_points[f"{prefix}proj_queries"] = p
         return end_points
+
+    def _hoisted_kv(self, vis, text_feats, detected_feats):
+        """K | V projections of the decoder's three memories for ALL layers in one product each (they are the same tensors
+        for every layer, models/encoder_decoder_layers.py:366-401): {"l" | "d" | "v": ([kv_0 .. kv_5], sink)}, or {} when
+        the fused GPU path does not run (CPU, EDA_HOIST_KV=0, d_model the fused kernels do not cover)."""
+        import os
+        from . import attention as A
+        from .fused_ln import fuses_linear
+        layers = list(self.decoder)
+        if (not vis.is_cuda or os.environ.get("EDA_HOIST_KV", "1") == "0" or not layers
+                or not layers[0].cross_v.hip_path(vis) or not fuses_linear(vis, layers[0].norm_v, vis.shape[-1])):
+            return {}
+        memories = {"l": (text_feats, [L.cross_l for L in layers]), "v": (vis, [L.cross_v for L in layers])}
+        if detected_feats is not None and all(hasattr(L, "cross_d") for L in layers):
+            memories["d"] = (detected_feats, [L.cross_d for L in layers])
+        d, n = vis.shape[-1], len(layers)
+        key = (vis.device, n, d, tuple(memories))
+        if getattr(self, "_kv_stack_key", None) != key:
+            self._kv_stacks = {k: (torch.empty((n * 2 * d, d), dtype=torch.float32, device=vis.device),
+                                   torch.empty((n * 2 * d,), dtype=torch.float32, device=vis.device)) for k in memories}
+            self._kv_stack_key = key
+        A.refresh_kv_stacks([self._kv_stacks[k] for k in memories], [mods for _, mods in memories.values()])
+        out = {}
+        for k, (mem, mods) in memories.items():
+            sink = A.KVSink(n, 2 * d)
+            wb = []
+            for m in mods:
+                wb += [m.in_proj_weight, m.in_proj_bias]
+            out[k] = (A._StackedKV.apply(mem, sink, self._kv_stacks[k], *wb), sink)
+        return out
 
     def init_bn_momentum(self):
         for m in self.modules():

@@ -44,12 +44,13 @@ def _ffn_residual_norm(x, ffn, norm, training, salt):
     return add_dropout_layer_norm(x, y, norm, ffn[4].p, training, salt, y_bias=ffn[3].bias if fused else None)
 
 
-def _attn_residual_norm(attn, x, q, k, v, mask, norm, p_drop, training, salt, batch_first=True, pos=None):
+def _attn_residual_norm(attn, x, q, k, v, mask, norm, p_drop, training, salt, batch_first=True, pos=None, pre_kv=None):
     """norm(x + dropout(attn(q, k, v))): the out-projection bias is deferred to the fused
-    residual+LayerNorm kernel whenever that kernel runs.  With `pos`: (out, out + pos)."""
+    residual+LayerNorm kernel whenever that kernel runs.  With `pos`: (out, out + pos).
+    pre_kv = (kv, sink, slot): K | V of this module already projected (attention.StackedKV); k, v are then not read."""
     if batch_first and attn.hip_path(q) and fuses_linear(x, norm, attn.embed_dim):
         # the out-projection rides in the residual LayerNorm's launch
-        o, _ = attn(q, k, v, key_padding_mask=mask, batch_first=True, skip_out_proj=True)
+        o, _ = attn(q, k, v, key_padding_mask=mask, batch_first=True, skip_out_proj=True, pre_kv=pre_kv)
         return linear_add_dropout_layer_norm(o, attn.out_proj.weight, attn.out_proj.bias, x, norm, p_drop, training,
                                              salt, pos=pos)
     y, y_bias = attn(q, k, v, key_padding_mask=mask, batch_first=batch_first,
@@ -228,7 +229,10 @@ class BiDecoderLayer(nn.Module):
         self._salt = new_salt_base()
 
     def forward(self, query, vis_feats, lang_feats, query_pos, padding_mask, text_key_padding_mask,
-                detected_feats=None, detected_mask=None):
+                detected_feats=None, detected_mask=None, pre_kv=None):
+        """pre_kv: {"l": .., "d": .., "v": ..} -> (kv, sink, slot) per cross-attention whose K | V projection the caller
+        hoisted out of the layer loop (BeaUTyDETR._hoisted_kv); only honoured on the fused GPU path."""
+        pre_kv = pre_kv or {}
         if self.self_posembed is not None:
             pos = self.self_posembed.rows(query_pos)
         else:
@@ -241,14 +245,15 @@ class BiDecoderLayer(nn.Module):
         if detected_feats is not None:
             query, qp = _attn_residual_norm(self.cross_l, query, qp, lang_feats, lang_feats,
                                             text_key_padding_mask, self.norm_l, self.dropout_l.p, tr, sb + 1,
-                                            pos=pos)
+                                            pos=pos, pre_kv=pre_kv.get("l"))
             query, qp = _attn_residual_norm(self.cross_d, query, qp, detected_feats, detected_feats,
-                                            detected_mask, self.norm_d, self.dropout_d.p, tr, sb + 2, pos=pos)
+                                            detected_mask, self.norm_d, self.dropout_d.p, tr, sb + 2, pos=pos,
+                                            pre_kv=pre_kv.get("d"))
         else:
             query, qp = _attn_residual_norm(self.cross_l, query, qp, lang_feats, lang_feats,
                                             text_key_padding_mask, self.norm_l, self.dropout_l.p, tr, sb + 1,
-                                            pos=pos)
+                                            pos=pos, pre_kv=pre_kv.get("l"))
         query = _attn_residual_norm(self.cross_v, query, qp, vis_feats, vis_feats, None,
-                                    self.norm_v, self.dropout_v.p, tr, sb + 3)
+                                    self.norm_v, self.dropout_v.p, tr, sb + 3, pre_kv=pre_kv.get("v"))
         query = _ffn_residual_norm(query, self.ffn, self.norm2, tr, sb + 4)
         return query.contiguous()

@@ -60,3 +60,48 @@ def test_full_model_16bit_attention(dtype, tag):
     assert rep["queries_changed"] <= MAX_QUERIES_CHANGED, rep["queries_changed"]
     for k, use in rep["worst"].items():
         assert use <= K_16BIT.get(k, K_16BIT["default"]), (k, use, top)
+
+
+def test_hoisted_decoder_kv_projections_equal_per_layer_projections(monkeypatch):
+    """The decoder's K | V projections of text / boxes / points for all six layers as one product each
+    (BeaUTyDETR._hoisted_kv) against the per-layer projections, in TRAIN mode with Dropout (same counter, same masks): same
+    outputs, same parameter gradients up to fp32 rounding (the memories' input gradients are one long contraction instead
+    of six products and five additions)."""
+    import torch
+    from eda_amd import attention
+    from eda_amd.bdetr import BeaUTyDETR
+    from tests import model_fixtures as MF
+    dev = "cuda"
+    torch.manual_seed(3)
+    model = BeaUTyDETR(num_queries=64, butd=True)
+    model.text_encoder = MF.small_roberta(1)
+    MF.fill_det_state(model, seed=30)
+    model.train().to(dev)
+    inputs = MF.full_model_inputs(7, max_len=16)
+    inputs = {k: ({kk: vv.to(dev) for kk, vv in v.items()} if isinstance(v, dict) else v.to(dev)) for k, v in inputs.items()}
+    bn_state = {k: v.clone() for k, v in model.state_dict().items()}
+    counter = attention.get_dropout_counter(torch.device(dev))
+    res = {}
+    for hoist in ("1", "0"):
+        monkeypatch.setenv("EDA_HOIST_KV", hoist)
+        model.load_state_dict(bn_state)                      # (running statistics move in train mode)
+        attention.set_dropout_counter(torch.device(dev), counter)
+        torch.manual_seed(11)                                # (anything that draws from torch's generator)
+        model.zero_grad(set_to_none=True)
+        ep = model(inputs)
+        assert bool(model._hoisted_kv.__func__) and (hoist == "0" or getattr(model, "_kv_stacks", None))
+        keys = sorted(k for k, v in ep.items() if torch.is_tensor(v) and v.dtype.is_floating_point and v.requires_grad)
+        loss = sum((ep[k].float() ** 2).mean() for k in keys)
+        loss.backward()
+        res[hoist] = ({k: ep[k].detach().clone() for k in keys},
+                      {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    (o1, g1), (o0, g0) = res["1"], res["0"]
+    assert set(o1) == set(o0) and set(g1) == set(g0) and len(g1) > 300
+    for k in o0:
+        assert float((o1[k] - o0[k]).abs().max()) <= 2e-5 * (float(o0[k].abs().max()) + 1e-12), k
+    # (biases in front of a train-mode BatchNorm have a zero gradient in exact arithmetic: noise of the size of the
+    # rounding errors in both runs -- hence the absolute term, relative to the largest gradient of the model)
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    for k in g0:
+        scale = float(g0[k].abs().max())
+        assert float((g1[k] - g0[k]).abs().max()) <= 2e-3 * scale + 1e-6 * gmax, (k, float((g1[k] - g0[k]).abs().max()), scale, gmax)
