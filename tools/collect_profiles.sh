@@ -1,0 +1,14 @@
+#!/bin/bash
+# Copy the outputs of tools/final_run.sh <tag> (gpurun_out/<tag>/) into profiles/ under the round's names.
+# usage: tools/collect_profiles.sh <tag> <round prefix, e.g. r03>
+cd "$(dirname "$0")/.." || exit 1
+tag=$1; r=$2; O=gpurun_out/$tag
+python tools/summarize_profile.py $r 23 $O/bench_eager_kernel_stats_rocprofv3.csv $O/bench_default.json $O/bench_eager_under_rocprof.json > profiles/${r}_summary.md
+for f in default fps_in_step one_graph split_graphs 130_tokens hungarian_loss attn_bf16 attn_f16_130_tokens stock_roberta one_batch eager_under_rocprof; do
+  cp $O/bench_$f.json profiles/${r}_bench_$f.json
+done
+cp $O/bench_eager_kernel_stats_rocprofv3.csv profiles/${r}_bench_eager_kernel_stats_rocprofv3.csv
+cp gpurun_out/mha_${tag}_f32_new.txt profiles/${r}_mha_f32.txt
+cp gpurun_out/mha_${tag}_bf16_new.txt profiles/${r}_mha_bf16.txt
+cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json
+tail -3 $O/pytest_gpu.txt > profiles/${r}_pytest_gpu_tail.txt
