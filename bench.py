@@ -312,13 +312,14 @@ def main():
                     help="1 (with --graph): the frozen text encoder runs as its own HIP graph on a second stream "
                          "underneath the point backbone's graph (whose furthest point sampling keeps ~100 of the 256 "
                          "CUs busy for 3 ms); the rest of the step is a third graph behind an event.  0: one graph")
-    ap.add_argument("--fps-prefetch", type=int, default=1, choices=[0, 1, 2],
+    ap.add_argument("--fps-prefetch", type=int, default=2, choices=[0, 1, 2],
                     help="1 (with --text-stream): the furthest point sampling of SA1 -- a function of the input coordinates "
                          "only, 3 ms of dependent rounds on ~100 CUs -- runs for the NEXT step's batch on the second stream "
                          "while the current step trains (an input pipeline has batch i+1 resident by then) and is handed to "
                          "the model through the reference's own `inds` argument; one sampling per timed step either way.  "
-                         "2: everything the backbone derives from the coordinates alone (the four samplings, four ball "
-                         "queries, two 3-NN searches: Pointnet2Backbone.geometry) for the next batch on the second stream.  "
+                         "2 (default): everything the backbone derives from the coordinates alone (the four samplings, four "
+                         "ball queries, two 3-NN searches: Pointnet2Backbone.geometry; handed over through the backbone's "
+                         "optional `geometry` argument) for the next batch on the second stream, once per timed step.  "
                          "0: all of it inside the step, on its critical path")
     ap.add_argument("--text-prefetch", type=int, default=1,
                     help="1 (with --fps-prefetch): the frozen text encoder runs for the NEXT step's tokens, behind the sampling on "

@@ -57,8 +57,8 @@ def test_deferred_weight_gradients_match_immediate_on_the_full_model():
 
 def test_split_graphs_structure_of_the_multi_gpu_step_trains_like_the_single_graph():
     """The step structures of bench.py on one GPU: (a) ONE graph (`--text-stream 0`); (b) the default: three graphs
-    on two streams (frozen text encoder underneath the point backbone, next batch's furthest point sampling
-    underneath the rest of the step); (c) the N > 1 structure: (b) + eager slot of the RCCL all-reduce + clip/AdamW
+    on two streams (next batch's coordinate-only geometry and text encoding underneath the step; `--fps-prefetch 1`:
+    only SA1's sampling is prefetched); (c) the N > 1 structure: (b) + eager slot of the RCCL all-reduce + clip/AdamW
     graph (`--split-graphs`).  All must train alike (same in-graph loss history up to fp32-atomics noise) and
     report no furthest-point-sampling give-up."""
     import json
@@ -66,7 +66,8 @@ def test_split_graphs_structure_of_the_multi_gpu_step_trains_like_the_single_gra
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hists = []
-    for extra in (["--text-stream", "0"], [], ["--split-graphs"], ["--text-prefetch", "0", "--fps-prefetch", "2"]):
+    for extra in (["--text-stream", "0"], [], ["--split-graphs"], ["--fps-prefetch", "1"],
+                  ["--text-prefetch", "0", "--fps-prefetch", "2"]):
         env = dict(os.environ, EDA_BENCH_INGRAPH_HIST="1")
         p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "3",
                             "--kernel-steps", "0", "--cpu-scenes", "0", "--gemm-tuning", "shipped", "--per-gpu", "4",

@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.." || exit 1
 tag=$1; r=$2; O=gpurun_out/$tag
 python tools/summarize_profile.py $r 23 $O/bench_eager_kernel_stats_rocprofv3.csv $O/bench_default.json $O/bench_eager_under_rocprof.json > profiles/${r}_summary.md
-for f in default fps_in_step one_graph split_graphs 130_tokens hungarian_loss attn_bf16 attn_f16_130_tokens stock_roberta one_batch eager_under_rocprof; do
+for f in default fps_in_step sa1_prefetch_only one_graph split_graphs 130_tokens hungarian_loss attn_bf16 attn_f16_130_tokens stock_roberta one_batch eager_under_rocprof; do
   cp $O/bench_$f.json profiles/${r}_bench_$f.json
 done
 cp $O/bench_eager_kernel_stats_rocprofv3.csv profiles/${r}_bench_eager_kernel_stats_rocprofv3.csv

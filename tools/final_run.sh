@@ -8,6 +8,7 @@ python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke
 python tools/measure_traffic.py > $O/traffic.txt 2>&1
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --fps-prefetch 0 --in-step-steps 0 > $O/bench_fps_in_step.json 2> $O/bench_fps_in_step.err
+python bench.py --fps-prefetch 1 --in-step-steps 0 > $O/bench_sa1_prefetch_only.json 2> $O/bench_sa1_prefetch_only.err
 python bench.py --text-stream 0 > $O/bench_one_graph.json 2> $O/bench_one_graph.err
 python bench.py --split-graphs --in-step-steps 0 > $O/bench_split_graphs.json 2> $O/bench_split_graphs.err
 python bench.py --tokens 130 --in-step-steps 0 > $O/bench_130_tokens.json 2> $O/bench_130_tokens.err
