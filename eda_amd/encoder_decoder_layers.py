@@ -28,20 +28,21 @@ def _ffn(d_model, dim_feedforward, dropout):
                          Linear(dim_feedforward, d_model), nn.Dropout(dropout))
 
 
-def _ffn_residual_norm(x, ffn, norm, training, salt):
+def _ffn_residual_norm(x, ffn, norm, training, salt, pos=None):
     """norm(x + ffn(x)) where ffn = Linear, ReLU, Dropout, Linear, Dropout: the last Dropout is
-    applied inside the fused residual+LayerNorm kernel."""
+    applied inside the fused residual+LayerNorm kernel.  With `pos`: (out, out + pos)."""
     if fuses_linear(x, norm, ffn[3].weight.shape[1]) and x.dtype == torch.float32:
         # the whole block as one autograd node: Linear + ReLU + Dropout | Linear + residual + Dropout + LayerNorm
         p1 = float(ffn[2].p) if training else 0.0
         p2 = float(ffn[4].p) if training else 0.0
-        return _FFNAddDropoutLN.apply(x, ffn[0].weight, ffn[0].bias, ffn[3].weight, ffn[3].bias, norm.weight, norm.bias,
-                                      norm.eps, p1, salt + 0x5BD1E995, p2, salt)
+        args = (x, ffn[0].weight, ffn[0].bias, ffn[3].weight, ffn[3].bias, norm.weight, norm.bias,
+                norm.eps, p1, salt + 0x5BD1E995, p2, salt)
+        return _FFNAddDropoutLN.apply(*args, pos) if pos is not None else _FFNAddDropoutLN.apply(*args)
     fused = fuses_bias(x, norm)  # second linear's bias (and its gradient) ride in the LN kernels
     # Linear + ReLU + Dropout + Linear as one autograd node, the activations in the GEMM epilogues
     y = mlp_chain(x, [(ffn[0].weight, ffn[0].bias, True, ffn[2].p, salt + 0x5BD1E995),
                       (ffn[3].weight, None if fused else ffn[3].bias, False, 0.0, 0)], training)
-    return add_dropout_layer_norm(x, y, norm, ffn[4].p, training, salt, y_bias=ffn[3].bias if fused else None)
+    return add_dropout_layer_norm(x, y, norm, ffn[4].p, training, salt, y_bias=ffn[3].bias if fused else None, pos=pos)
 
 
 def _attn_residual_norm(attn, x, q, k, v, mask, norm, p_drop, training, salt, batch_first=True, pos=None, pre_kv=None):
@@ -111,19 +112,24 @@ class CrossAttentionLayer(nn.Module):
         self._salt = new_salt_base()
 
     def forward(self, vis_feats, vis_key_padding_mask, text_feats, text_key_padding_mask,
-                pos_feats, detected_feats=None, detected_mask=None):
+                pos_feats, detected_feats=None, detected_mask=None, vis_query=None, emit_pos=False):
+        """vis_query: vis_feats + pos_feats when the caller already has it (the producing LayerNorm launch emits it);
+        emit_pos: return (vis, text, vis + pos_feats) -- the next encoder layer's self-attention query / key."""
         # text attends to points: no positional term on the keys (:80-93)
         tr, sb = self.training, self._salt
         text_out = _attn_residual_norm(self.cross_lv, text_feats, text_feats, vis_feats, vis_feats,
                                        vis_key_padding_mask, self.norm_lv, self.dropout_lv.p, tr, sb)
         text_out = _ffn_residual_norm(text_out, self.ffn_lv, self.norm_lv2, tr, sb + 1)
         # points attend to the ORIGINAL text (:99-105), position added to the query only
-        vis = _attn_residual_norm(self.cross_vl, vis_feats, vis_feats + pos_feats, text_feats,
-                                  text_feats, text_key_padding_mask, self.norm_vl, self.dropout_vl.p,
+        vis = _attn_residual_norm(self.cross_vl, vis_feats, vis_query if vis_query is not None else vis_feats + pos_feats,
+                                  text_feats, text_feats, text_key_padding_mask, self.norm_vl, self.dropout_vl.p,
                                   tr, sb + 2)
         if detected_feats is not None and self.use_butd_enc_attn:
             vis = _attn_residual_norm(self.cross_d, vis, vis, detected_feats, detected_feats,
                                       detected_mask, self.norm_d, self.dropout_d.p, tr, sb + 3)
+        if emit_pos:
+            vis, vis_q = _ffn_residual_norm(vis, self.ffn_vl, self.norm_vl2, tr, sb + 4, pos=pos_feats)
+            return vis, text_out, vis_q
         vis = _ffn_residual_norm(vis, self.ffn_vl, self.norm_vl2, tr, sb + 4)
         return vis, text_out
 
@@ -147,11 +153,14 @@ class TransformerEncoderLayerNoFFN(nn.Module):
 class PosTransformerEncoderLayerNoFFN(TransformerEncoderLayerNoFFN):
     """Same, with the positional embedding added to query and key (not value)."""
 
-    def forward(self, src, pos, src_mask=None, src_key_padding_mask=None, batch_first=False):
-        qk = src + pos
+    def forward(self, src, pos, src_mask=None, src_key_padding_mask=None, batch_first=False, qk=None, emit_pos=False):
+        """qk: src + pos when the caller already has it; emit_pos (batch_first only): return (out, out + pos)."""
+        if qk is None:
+            qk = src + pos
         assert src_mask is None, "EDA always passes attn_mask=None"
         return _attn_residual_norm(self.self_attn, src, qk, qk, src, src_key_padding_mask,
-                                   self.norm1, self.dropout1.p, self.training, self._salt, batch_first)
+                                   self.norm1, self.dropout1.p, self.training, self._salt, batch_first,
+                                   pos=pos if emit_pos else None)
 
 
 class BiEncoderLayer(nn.Module):
@@ -166,17 +175,22 @@ class BiEncoderLayer(nn.Module):
                                                use_butd_enc_attn)
 
     def forward(self, vis_feats, pos_feats, padding_mask, text_feats, text_padding_mask,
-                end_points={}, detected_feats=None, detected_mask=None):
+                end_points={}, detected_feats=None, detected_mask=None, vis_query=None, emit_pos=False):
+        """vis_query / emit_pos: `vis_feats + pos_feats` handed from layer to layer -- every residual LayerNorm whose
+        output is next used with the positional term added emits that sum in the same launch (BiEncoder.forward)."""
+        vis_q = None
         if self.self_attention_visual is not None:
-            vis_feats = self.self_attention_visual(vis_feats, pos_feats,
-                                                   src_key_padding_mask=padding_mask, batch_first=True)
+            vis_feats, vis_q = self.self_attention_visual(vis_feats, pos_feats, src_key_padding_mask=padding_mask,
+                                                          batch_first=True, qk=vis_query, emit_pos=True)
+        elif vis_query is not None:
+            vis_q = vis_query
         if self.self_attention_lang is not None:
             text_feats = self.self_attention_lang(text_feats, src_key_padding_mask=text_padding_mask,
                                                   batch_first=True)
         return self.cross_layer(vis_feats=vis_feats, vis_key_padding_mask=padding_mask,
                                 text_feats=text_feats, text_key_padding_mask=text_padding_mask,
                                 pos_feats=pos_feats, detected_feats=detected_feats,
-                                detected_mask=detected_mask)
+                                detected_mask=detected_mask, vis_query=vis_q, emit_pos=emit_pos)
 
 
 class BiEncoder(nn.Module):
@@ -192,10 +206,13 @@ class BiEncoder(nn.Module):
 
     def forward(self, vis_feats, pos_feats, padding_mask, text_feats, text_padding_mask,
                 end_points={}, detected_feats=None, detected_mask=None):
-        for layer in self.layers:
-            vis_feats, text_feats = layer(vis_feats, pos_feats, padding_mask, text_feats,
-                                          text_padding_mask, end_points,
-                                          detected_feats=detected_feats, detected_mask=detected_mask)
+        vis_q = None
+        for i, layer in enumerate(self.layers):
+            last = i == len(self.layers) - 1
+            out = layer(vis_feats, pos_feats, padding_mask, text_feats, text_padding_mask, end_points,
+                        detected_feats=detected_feats, detected_mask=detected_mask, vis_query=vis_q, emit_pos=not last)
+            vis_feats, text_feats = out[0], out[1]
+            vis_q = out[2] if not last else None
         return vis_feats, text_feats
 
 

@@ -213,26 +213,32 @@ class _FFNAddDropoutLN(Function):
     the first layer's dX; weight gradients queued."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2, gamma, beta, eps, p1, salt1, p2, salt2):
+    def forward(ctx, x, W1, b1, W2, b2, gamma, beta, eps, p1, salt1, p2, salt2, pos=None):
         from . import gemm
         shape = x.shape
         C = shape[-1]
         x2 = x.reshape(-1, C).contiguous()
+        pos2 = pos.reshape(-1, C).contiguous() if pos is not None else None
         seed = dropout_state(x.device) if p1 > 0 else None
         h = gemm.linear_ex(x2, W1, b1, True, drop=(p1, seed, salt1) if p1 > 0 else None)
-        out, _, z, stats = _linear_ln_forward(h, W2, b2, x2, gamma, beta, eps, p2, salt2, None)
+        out, out_pos, z, stats = _linear_ln_forward(h, W2, b2, x2, gamma, beta, eps, p2, salt2, pos2)
         ctx.save_for_backward(x2, h, W1, b1, W2, b2, z, gamma, stats)
         ctx.beta_ref = beta
         ctx.cfg = (float(p1), float(p2), int(salt2), shape)
+        ctx.with_pos = pos is not None
+        ctx.set_materialize_grads(False)
+        if pos is not None:
+            return out.view(shape), out_pos.view(shape)
         return out.view(shape)
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dout_pos=None):
         from . import gemm, wgrad_queue
         from .nn_utils import colsum, wgrad
         x2, h, W1, b1, W2, b2, z, gamma, stats = ctx.saved_tensors
         p1, p2, salt2, shape = ctx.cfg
-        dx, dy, g3 = _ln_backward(z.device, dout, None, False, z, None, b2, gamma, ctx.beta_ref, stats, p2, salt2)
+        dx, dy, g3 = _ln_backward(z.device, dout, dout_pos, ctx.with_pos, z, None, b2, gamma, ctx.beta_ref, stats, p2, salt2)
+        dpos = (dout_pos.reshape(shape) if dout_pos is not None else None) if ctx.with_pos else None
         q = wgrad_queue.active
         grads = {}
         if ctx.needs_input_grad[3] and not (q is not None and q.submit(W2, None, dy, h)):
@@ -250,9 +256,9 @@ class _FFNAddDropoutLN(Function):
         if ctx.needs_input_grad[0]:
             dxin = gemm.linear_dgrad(dh, W1).add_(dx).view(shape)
         if g3 is None:
-            return (dxin, grads.get("W1"), grads.get("b1"), grads.get("W2"), None, None, None, None, None, None, None, None)
+            return (dxin, grads.get("W1"), grads.get("b1"), grads.get("W2"), None, None, None, None, None, None, None, None, dpos)
         return (dxin, grads.get("W1"), grads.get("b1"), grads.get("W2"), g3[2] if b2 is not None else None, g3[0], g3[1],
-                None, None, None, None, None)
+                None, None, None, None, None, dpos)
 
 
 def fuses_linear(x, norm, K):
