@@ -24,24 +24,46 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-def _stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [
-        os.path.join(HERE, "..", "include", "eda_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+def _deps():
+    return glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "eda_hip.h")]
 
 
-def build(force=False, verbose=False):
-    """Compile every .hip source into one shared library.  Returns its path."""
-    if not force and not _stale():
-        return LIB
+def _compile_objects(objdir, extra_flags, force, verbose):
+    """One object per source (hipcc -c), in parallel; an object is rebuilt when its source or any header is newer."""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(objdir, exist_ok=True)
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + HIPCC_FLAGS + sources() + ["-o", LIB]
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags)
+    hdr_t = max(os.path.getmtime(d) for d in _deps())
+    jobs, objs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
+    if jobs:
+        if verbose:
+            for j in jobs:
+                print(" ".join(j))
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(subprocess.check_call, jobs))
+    return objs, bool(jobs)
+
+
+def _link(objs, out, verbose):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+
+
+def build(force=False, verbose=False):
+    """Compile every .hip source (one object each, in parallel, only what is out of date) and link the shared
+    library.  Returns its path."""
+    objs, rebuilt = _compile_objects(os.path.join(CSRC, "_obj"), [], force, verbose)
+    if rebuilt or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        _link(objs, LIB, verbose)
     return LIB
 
 
@@ -49,11 +71,8 @@ def build_variant(name, extra_flags, verbose=False):
     """An experiment build of the same sources with extra -D flags -> csrc/libeda_hip_<name>.so (select it with
     EDA_HIP_LIB=<path>; tools/mha2_phase_profile.py uses -DEDA_MHA2_PROFILE)."""
     out = os.path.join(CSRC, f"libeda_hip_{name}.so")
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + sources() + ["-o", out]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    objs, _ = _compile_objects(os.path.join(CSRC, "_obj_" + name), extra_flags, False, verbose)
+    _link(objs, out, verbose)
     return out
 
 
