@@ -334,7 +334,7 @@ def main():
                          "report them under `in_step` of the same line; 0 = skip")
     ap.add_argument("--attn-dtype", choices=["f32", "bf16", "f16"], default="f32",
                     help="arithmetic of the attention QK^T / PV contractions: f32 = the headline / parity path; bf16 / "
-                         "f16 = 16-bit MFMA with fp32 accumulation (csrc/mha16.hip, BASELINE.json configs[2] / [4]) -- "
+                         "f16 = 16-bit MFMA with fp32 accumulation (csrc/mha2.hip with packed 16-bit quads, BASELINE.json configs[2] / [4]) -- "
                          "a SEPARATE bench line, never the headline")
     ap.add_argument("--sync-bn", action="store_true",
                     help="N > 1: global-batch BatchNorm statistics like the reference's SyncBatchNorm "

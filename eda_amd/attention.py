@@ -7,9 +7,9 @@ masks, attention-probability dropout 0.1).
 298,306,314,319) and checkpoints must load -- but works batch-first: no
 (B,N,F)<->(N,B,F) transposes, one packed projection GEMM when q/k/v share their
 input, and the QK^T-softmax-dropout-PV core is ONE fused HIP kernel
-(csrc/mha.hip, fp32 MFMA) that reads the heads in place from the (B,L,288)
+(csrc/mha2.hip, fp32 MFMA) that reads the heads in place from the (B,L,288)
 projection outputs and never materialises the (B*8,Lq,Lk) probabilities; its
-backward is two more kernels (dQ; dK+dV) that recompute the probabilities.
+backward is one more kernel (dQ, dK, dV in one pass) that recomputes them.
 
 ``attention_core`` has no CPU path (the HIP library is the product); the torch
 restatement used by CPU-side tests lives in oracle/attention_ref.py.
@@ -31,7 +31,7 @@ _compute_dtype = 0       # arithmetic of the QK^T / PV contractions (include/eda
 
 def set_compute_dtype(name):
     """"f32" (default: the parity path, fp32 MFMA), "bf16" or "f16" (16-bit MFMA contractions with fp32
-    accumulation and softmax, csrc/mha16.hip -- BASELINE.json configs[2] / configs[4]).  Tensors stay fp32."""
+    accumulation and softmax, the same kernels of csrc/mha2.hip -- BASELINE.json configs[2] / configs[4]).  Tensors stay fp32."""
     global _compute_dtype
     _compute_dtype = _DTYPES[name]
 
@@ -281,7 +281,9 @@ class _StackedKV(Function):
         x2 = x.reshape(-1, d)
         y = gemm.linear_fwd(x2, Wst, bst).view(*x.shape[:-1], n * 2 * d)
         ctx.save_for_backward(x2, *wb)
-        ctx.Wst = Wst                     # (persistent buffer, rewritten by the next forward's refresh: not a saved tensor)
+        # (persistent buffer, rewritten in place by the next forward's refresh: not a saved tensor; the backward
+        # re-assembles the stack from the saved parameters if it was rewritten in between)
+        ctx.Wst, ctx.Wst_version = Wst, Wst._version
         ctx.sink, ctx.xshape, ctx.n = sink, x.shape, n
         ctx.set_materialize_grads(False)
         return tuple(y[..., 2 * d * i:2 * d * (i + 1)] for i in range(n))
@@ -292,6 +294,8 @@ class _StackedKV(Function):
         wb = ctx.saved_tensors[1:]
         n, sink = ctx.n, ctx.sink
         d = x2.shape[1]
+        if Wst._version != ctx.Wst_version:
+            Wst = torch.cat([wb[2 * i][d:] for i in range(n)], 0)
         B, Lk = ctx.xshape[0], ctx.xshape[1]
         dall = None
         if sink.buf is not None and all(

@@ -28,6 +28,24 @@ def _deps():
     return glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "eda_hip.h")]
 
 
+def _dep_time(depfile, fallback):
+    """Newest mtime among the repo headers a previous compile recorded (-MD); every header's if there is no record."""
+    try:
+        words = open(depfile).read().replace("\\\n", " ").split()
+    except OSError:
+        return fallback
+    root = os.path.abspath(os.path.join(HERE, ".."))
+    t = 0.0
+    for w in words[1:]:
+        a = os.path.abspath(w)
+        if a.startswith(root):
+            try:
+                t = max(t, os.path.getmtime(a))
+            except OSError:
+                return fallback
+    return t
+
+
 def _compile_objects(objdir, extra_flags, force, verbose):
     """One object per source (hipcc -c), in parallel; an object is rebuilt when its source or any header is newer."""
     from concurrent.futures import ThreadPoolExecutor
@@ -39,8 +57,9 @@ def _compile_objects(objdir, extra_flags, force, verbose):
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
-            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
+        newest = max(os.path.getmtime(src), _dep_time(obj + ".d", hdr_t))
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
+            jobs.append([hipcc] + flags + ["-MD", "-MF", obj + ".d", "-c", src, "-o", obj])
     if jobs:
         if verbose:
             for j in jobs:

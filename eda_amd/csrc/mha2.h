@@ -1,5 +1,4 @@
-// mha2.h -- launch interface of the round-3 attention kernels (csrc/mha2.hip); the C ABI stays
-// eda_mha_fwd_f32 / eda_mha_bwd_f32 (csrc/mha.hip), which dispatch here.
+// mha2.h -- launch interface of the attention kernels (csrc/mha2.hip) under the C ABI eda_mha_fwd / eda_mha_bwd.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -30,5 +29,3 @@ struct Mha2Args {
 int eda_mha2_fwd_launch(Mha2Args &a, hipStream_t stream);
 int eda_mha2_bwd_launch(Mha2Args &a, void *ws, size_t ws_bytes, hipStream_t stream);
 size_t eda_mha2_bwd_workspace_bytes(int B, int H, int Lq, int Lk);
-// 1 = the round-1/2 kernels (mha.hip / mha16.hip) were selected with EDA_MHA_IMPL=1, else mha2.hip
-int eda_mha_impl();

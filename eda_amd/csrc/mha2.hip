@@ -1,37 +1,32 @@
-// mha2.hip -- round-3 fused multi-head attention for gfx950 (fp32 MFMA), forward and ONE-PASS backward.
+// mha2.hip -- fused multi-head attention for gfx950 (fp32 MFMA, or 16-bit contraction quads), forward and ONE-PASS
+// backward, and the C entry points eda_mha_fwd/bwd(_f32) (include/eda_hip.h).
 //
-// Replaces the 64-row-tile kernels of mha.hip (kept behind EDA_MHA_IMPL=1) for the attention the reference runs
-// through torch.nn.MultiheadAttention (models/encoder_decoder_layers.py:87-117, 149-153, 179-183, 366-401 ->
-// F.multi_head_attention_forward: q*scale, bmm QK^T, -inf key-padding fill, softmax, dropout(0.1), bmm PV).
+// The attention the reference runs through torch.nn.MultiheadAttention (models/encoder_decoder_layers.py:87-117,
+// 149-153, 179-183, 366-401 -> F.multi_head_attention_forward: q*scale, bmm QK^T, -inf key-padding fill, softmax,
+// dropout(0.1), bmm PV).  (The round-1/2 kernels -- 4-wave workgroups on 64-row tiles, two-kernel backward,
+// mha.hip / mha16.hip -- were removed in round 4; profiles/r01k_mha_pmc.md is their record.)
 //
-// What was wrong with the old structure (profiles/r01k_mha_pmc.md): 4-wave workgroups that stage a 64-row tile,
-// meet at a barrier and do ~2700 cycles of MFMA per 7700-cycle tile; 168 registers -> 3 waves per SIMD, so the
-// 1024 workgroups of a 1024 x 1024 launch run as 768 + 256; and the backward computed S and dP twice (dQ kernel
-// and dK/dV kernel: 72 MFMAs per 16 x 16 pair for 45 useful).
-//
-// Structure here (both kernels): ONE big workgroup per CU (up to 16 waves = 4 per SIMD, <= 128 registers), the
-// streamed operand arrives in LARGE chunks (128 query rows / 256 key rows) by LDS-DMA (global_load_lds_dwordx4:
-// no staging registers, no LDS store pass) into a double buffer, and between two chunk barriers every wave works
-// through its 4-16 sixteen-row sub-tiles on its own -- the waves of a SIMD drift apart and one wave's
-// softmax / exp / dropout VALU runs under another's MFMAs.
+// Structure (both kernels): ONE big workgroup per CU (up to 16 waves = 4 per SIMD, <= 128 registers), the
+// streamed operand arrives in LARGE chunks (64-96 query rows / 192-256 key rows) by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no LDS store pass) into a double buffer, and between two chunk
+// barriers every wave works through its 4-16 sixteen-row sub-tiles on its own -- the waves of a SIMD drift apart
+// and one wave's softmax / exp / dropout VALU runs under another's MFMAs.
 //
 //   forward   wave = 16 queries (x a share of the key tiles when Lq is short: the partial (m, l, O) of the KS
 //             key shares are merged through LDS at the end); S^T = K Q^T so that a query's softmax statistics
-//             are lane-local (as in mha.hip), exp2 with log2(e) folded into the query scale, 1/(1-p) folded
-//             into the final 1/l.
+//             are lane-local, exp2 with log2(e) folded into the query scale, 1/(1-p) folded into the final 1/l.
 //   backward  wave = 16 keys: K, V rows in registers for the lifetime of the workgroup, dK^T / dV^T
-//             accumulators in registers.  Per 16-query sub-tile: S = Q K^T and dP = dO V^T (9 + 9 MFMA),
-//             P = exp2(S - lse), dS = P o (dP - delta); dV^T += dO^T P, dK^T += Q^T dS (12 + 12); dS is
-//             TRANSPOSED through a wave-private LDS scratch (4 ds_write_b32 + 1 ds_read_b128; an in-wave LDS
-//             write -> read needs no barrier) and dQ^T = K^T dS^T (12) is added into a per-chunk LDS
-//             accumulator with ds_add_f32 (the 16 waves own different keys of the same queries); the chunk's
-//             dQ is flushed one chunk later -- a plain store when the workgroup owns all keys of its (scene,
-//             head), fp32 atomics when the key range is split over workgroups (then an up-front zero launch).
-//             54 MFMAs per pair, 45 useful (head_dim 36 = 9 k-steps in the contraction, 3 x 16 rows as output).
-//             delta = rowsum(dO o O) is computed while a chunk is staged.
+//             accumulators in registers.  Phase A, per 16-query sub-tile: S = Q K^T and dP = dO V^T (9 + 9 MFMA),
+//             P = exp2(S - lse), dS = P o (dP - delta); dV^T += dO^T P, dK^T += Q^T dS (8 + 8 + 2 x 4 small); dS
+//             goes to the block's LDS tile DS[query][key].  Barrier.  Phase B: work item = one 16-dim x 16-query
+//             tile of dQ^T = K^T dS^T contracted over ALL keys of the block (K rows of the block in LDS), written
+//             straight to dQ, or to this key block's dense partial when Lk > 256 (summed in split order by
+//             mha2_part_reduce_kernel).  45 MFMAs issued per 16 x 16 pair = 45 useful: the last four of the 36
+//             head dims run on v_mfma_f32_4x4x1 (see mfma44 below).  delta = rowsum(dO o O) is computed while a
+//             chunk is staged.  No atomics anywhere: ds_add_f32 and global fp32 atomics were measured 3x slower
+//             (DESIGN.md section 4).
 //
-// Dropout: the counter hash of mha.hip (one 32-bit hash per two keys, 16 bits each) -- the masks of the two
-// implementations are identical, so either forward pairs with either backward.
+// Dropout: counter hash (one 32-bit hash per two keys, 16 bits each), regenerated in the backward.
 #include "eda_common.h"
 #include "mha2.h"
 
@@ -139,7 +134,7 @@ __device__ __forceinline__ f32x4 dot36(const Row16 &a, const Row16 &b, f32x4 acc
   return AR::mma16(a.p[2], b.p[2], acc);
 }
 
-__device__ __forceinline__ unsigned hash32(unsigned x) {     // = mha.hip
+__device__ __forceinline__ unsigned hash32(unsigned x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
@@ -166,7 +161,7 @@ __device__ __forceinline__ f32x4 grp_sum4(f32x4 v) {
 
 // A lane's 9 contraction values of one 36-float row: MFMA k-step s of lane group g contracts head dim 8g+s
 // (s < 8) and 32+g (s = 8) -- any permutation is fine as long as both operands use it -- so the first eight are
-// two 16-byte reads (mha.hip "LDS operand layouts"; row stride 36 is conflict-free for them).
+// two 16-byte reads (row stride 36 is conflict-free for them).
 __device__ __forceinline__ void load_row_operand(float (&r)[KSTEPS], const float *row, int g) {
   const float4 x = *reinterpret_cast<const float4 *>(row + 8 * g);
   const float4 y = *reinterpret_cast<const float4 *>(row + 8 * g + 4);
@@ -658,7 +653,7 @@ __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args
       const float lse_r[4] = {lse4.x, lse4.y, lse4.z, lse4.w};
       const float del_r[4] = {del4.x, del4.y, del4.z, del4.w};
       // dropout bits: lanes c and c^1 (keys 2m, 2m+1) need the same four pair hashes (one per query r);
-      // each computes two of them and they swap through a quad-permute DPP move (= mha.hip)
+      // each computes two of them and they swap through a quad-permute DPP move
       unsigned h16[4] = {0xffffu, 0xffffu, 0xffffu, 0xffffu};
       if (DROP) {
         const int odd = c & 1;
@@ -1060,4 +1055,123 @@ int eda_mha2_bwd_launch(Mha2Args &a, void *ws, size_t ws_bytes, hipStream_t stre
     EDA_CHECK_LAUNCH();
   }
   return 0;
+}
+
+// ---------------------------------------------------------------------------------------- C entry points ----
+namespace {
+
+bool mult4(long v) { return (v & 3) == 0; }
+bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// rows x D floats = value (degenerate shapes: no keys / no queries)
+__global__ __launch_bounds__(256) void mha2_fill_rows_kernel(float *__restrict__ o, long sb, long sl, int B, int L, int D,
+                                                             float value) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * L * D) return;
+  const long row = i / D;
+  const int col = (int)(i - row * D);
+  const long bb = row / L, l = row - bb * L;
+  o[bb * sb + l * sl + col] = value;
+}
+int fill_rows(float *o, long sb, long sl, int B, int L, int D, float value, hipStream_t stream) {
+  const long n = (long)B * L * D;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(mha2_fill_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, o, sb, sl, B, L, D, value);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int eda_mha_fwd(const float *q, const float *k, const float *v, long q_sb, long q_sl, long k_sb, long k_sl,
+                           long v_sb, long v_sl, const unsigned char *key_padding_mask, int B, int H, int Lq, int Lk,
+                           int head_dim, float scale, float p_drop, const unsigned long long *seed_ptr, unsigned salt,
+                           float *out, float *lse, int dtype, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(dtype == EDA_DTYPE_F32 || dtype == EDA_DTYPE_BF16 || dtype == EDA_DTYPE_F16,
+                "dtype must be EDA_DTYPE_F32 / BF16 / F16");
+  EDA_CHECK_ARG(head_dim == HD, "only head_dim 36 (d_model 288 / 8 heads) is built");
+  EDA_CHECK_ARG(B >= 0 && H > 0 && Lq >= 0 && Lk >= 0, "bad dimension");
+  if (B == 0 || Lq == 0) return 0;
+  EDA_CHECK_ARG(q && k && v && out && lse, "null pointer");
+  EDA_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed_ptr), "bad dropout arguments");
+  EDA_CHECK_ARG(mult4(q_sb) && mult4(q_sl) && mult4(k_sb) && mult4(k_sl) && mult4(v_sb) && mult4(v_sl) &&
+                    al16(q) && al16(k) && al16(v) && al16(out),
+                "rows must be 16-byte aligned");
+  EDA_CHECK_ARG((long)B * H <= 65535, "B*H too large");
+  if (Lk == 0) {            // no keys: P V is an empty sum (torch: bmm over a zero-length dimension = 0)
+    if (int rc = fill_rows(out, (long)Lq * H * HD, (long)H * HD, B, Lq, H * HD, 0.f, stream)) return rc;
+    return fill_rows(lse, (long)H * Lq, (long)Lq, B, H, Lq, -INFINITY, stream);
+  }
+  Mha2Args m = {};
+  m.q = q; m.k = k; m.v = v; m.q_sb = q_sb; m.q_sl = q_sl; m.k_sb = k_sb; m.k_sl = k_sl;
+  m.v_sb = v_sb; m.v_sl = v_sl; m.o = out; m.o_sb = (long)Lq * H * HD; m.o_sl = (long)H * HD;
+  m.lse = lse; m.mask = key_padding_mask; m.B = B; m.H = H; m.Lq = Lq; m.Lk = Lk; m.scale = scale;
+  m.p_drop = p_drop; m.seed_ptr = seed_ptr; m.salt = salt; m.dtype = dtype;
+  return eda_mha2_fwd_launch(m, stream);
+}
+
+extern "C" int eda_mha_fwd_f32(const float *q, const float *k, const float *v, long q_sb, long q_sl,
+                               long k_sb, long k_sl, long v_sb, long v_sl,
+                               const unsigned char *key_padding_mask, int B, int H, int Lq, int Lk,
+                               int head_dim, float scale, float p_drop,
+                               const unsigned long long *seed_ptr, unsigned salt, float *out,
+                               float *lse, void *stream_) {
+  return eda_mha_fwd(q, k, v, q_sb, q_sl, k_sb, k_sl, v_sb, v_sl, key_padding_mask, B, H, Lq, Lk, head_dim, scale,
+                     p_drop, seed_ptr, salt, out, lse, EDA_DTYPE_F32, stream_);
+}
+
+extern "C" size_t eda_mha_bwd_workspace_bytes(int B, int H, int Lq, int Lk) {
+  return eda_mha2_bwd_workspace_bytes(B, H, Lq, Lk);
+}
+
+// delta_ws: unused since round 3 (delta = rowsum(dO o O) is formed while a chunk is staged); may be NULL.
+extern "C" int eda_mha_bwd(const float *q, const float *k, const float *v, long q_sb, long q_sl, long k_sb, long k_sl,
+                           long v_sb, long v_sl, const unsigned char *key_padding_mask, int B, int H, int Lq, int Lk,
+                           int head_dim, float scale, float p_drop, const unsigned long long *seed_ptr, unsigned salt,
+                           const float *out, const float *lse, const float *dout, long do_sb, long do_sl,
+                           float *delta_ws, float *dq, float *dk, float *dv, long dq_sb, long dq_sl, long dk_sb,
+                           long dk_sl, long dv_sb, long dv_sl, void *ws, size_t ws_bytes, int dtype, void *stream_) {
+  (void)delta_ws;
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(dtype == EDA_DTYPE_F32 || dtype == EDA_DTYPE_BF16 || dtype == EDA_DTYPE_F16,
+                "dtype must be EDA_DTYPE_F32 / BF16 / F16");
+  EDA_CHECK_ARG(head_dim == HD, "only head_dim 36 (d_model 288 / 8 heads) is built");
+  EDA_CHECK_ARG(B >= 0 && H > 0 && Lq >= 0 && Lk >= 0, "bad dimension");
+  if (B == 0) return 0;
+  EDA_CHECK_ARG(q && k && v && out && lse && dout && dq && dk && dv, "null pointer");
+  EDA_CHECK_ARG(mult4(q_sb) && mult4(q_sl) && mult4(k_sb) && mult4(k_sl) && mult4(v_sb) && mult4(v_sl) &&
+                    mult4(do_sb) && mult4(do_sl) && mult4(dq_sb) && mult4(dq_sl) && mult4(dk_sb) &&
+                    mult4(dk_sl) && mult4(dv_sb) && mult4(dv_sl) && al16(q) && al16(k) && al16(v) && al16(out) &&
+                    al16(dout) && al16(dq) && al16(dk) && al16(dv),
+                "rows must be 16-byte aligned");
+  EDA_CHECK_ARG((long)B * H <= 65535, "B*H too large");
+  if (Lq == 0 || Lk == 0) {      // empty sums: every gradient that has rows is zero
+    if (int rc = fill_rows(dq, dq_sb, dq_sl, B, Lq, H * HD, 0.f, stream)) return rc;
+    if (int rc = fill_rows(dk, dk_sb, dk_sl, B, Lk, H * HD, 0.f, stream)) return rc;
+    return fill_rows(dv, dv_sb, dv_sl, B, Lk, H * HD, 0.f, stream);
+  }
+  Mha2Args m = {};
+  m.q = q; m.k = k; m.v = v; m.q_sb = q_sb; m.q_sl = q_sl; m.k_sb = k_sb; m.k_sl = k_sl;
+  m.v_sb = v_sb; m.v_sl = v_sl; m.o = const_cast<float *>(out); m.o_sb = (long)Lq * H * HD; m.o_sl = (long)H * HD;
+  m.lse = const_cast<float *>(lse); m.mask = key_padding_mask; m.B = B; m.H = H; m.Lq = Lq; m.Lk = Lk;
+  m.scale = scale; m.p_drop = p_drop; m.seed_ptr = seed_ptr; m.salt = salt;
+  m.dout = dout; m.do_sb = do_sb; m.do_sl = do_sl; m.dq = dq; m.dk = dk; m.dv = dv;
+  m.dq_sb = dq_sb; m.dq_sl = dq_sl; m.dk_sb = dk_sb; m.dk_sl = dk_sl; m.dv_sb = dv_sb; m.dv_sl = dv_sl;
+  m.dtype = dtype;
+  return eda_mha2_bwd_launch(m, ws, ws_bytes, stream);
+}
+
+extern "C" int eda_mha_bwd_f32(const float *q, const float *k, const float *v, long q_sb, long q_sl,
+                               long k_sb, long k_sl, long v_sb, long v_sl,
+                               const unsigned char *key_padding_mask, int B, int H, int Lq, int Lk,
+                               int head_dim, float scale, float p_drop,
+                               const unsigned long long *seed_ptr, unsigned salt, const float *out,
+                               const float *lse, const float *dout, long do_sb, long do_sl,
+                               float *delta_ws, float *dq, float *dk, float *dv, long dq_sb,
+                               long dq_sl, long dk_sb, long dk_sl, long dv_sb, long dv_sl,
+                               void *ws, size_t ws_bytes, void *stream_) {
+  return eda_mha_bwd(q, k, v, q_sb, q_sl, k_sb, k_sl, v_sb, v_sl, key_padding_mask, B, H, Lq, Lk, head_dim, scale, p_drop,
+                     seed_ptr, salt, out, lse, dout, do_sb, do_sl, delta_ws, dq, dk, dv, dq_sb, dq_sl, dk_sb, dk_sl, dv_sb,
+                     dv_sl, ws, ws_bytes, EDA_DTYPE_F32, stream_);
 }

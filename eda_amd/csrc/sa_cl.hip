@@ -6,16 +6,21 @@
 // round-trips a (B, C, npoint, nsample) tensor through HBM -- group xyz, subtract
 // centre, divide, group features, concat, conv out, BN out, ReLU, pool.
 //
-// Here a position (scene, centre j, neighbour k) is a ROW of a (B*m*ns, C) matrix:
-//  * group_concat: one pass writes [ (xyz[idx]-centre)*(1/r) | feats[idx] ] rows,
-//    reading features as contiguous C-float rows of a (B,N,C) channels-last tensor
-//    (coalesced gather instead of a stride-N scatter);
-//  * the three 1x1 convolutions are plain row-major GEMMs Z = A W^T (library GEMM);
-//  * batch-norm statistics: column sums in fp32 per slab, merged in fp64 atomics;
-//  * BN + ReLU (+ max-pool over the ns consecutive rows of a centre, with arg-max
-//    kept for the backward) in one pass over Z;
-//  * backward: one pass for the two BN reductions (sum dY, sum dY*xhat), one pass
-//    that writes dZ; dW / dA are library GEMMs again.
+// Here a position (scene, centre j, neighbour k) is a ROW of a (B*m*ns, C) matrix.  On the training path
+// (eda_sa_fused_fwd/bwd_f32 below) one native call per direction runs the whole module body on this repo's own
+// MFMA kernels (csrc/gemm.hip, csrc/wgrad.hip -- no library GEMM):
+//  * layer 0 gathers [ (xyz[idx]-centre)*(1/r) | feats[idx] ] rows straight into the product's operand staging
+//    (gemm_gather3_kernel / the gather prologue of gemm_stream_kernel): the grouped tensor never exists;
+//  * layers >= 1 apply the previous layer's BatchNorm + ReLU while staging; every layer's BatchNorm statistics
+//    (column sums of y, y^2) come out of its accumulators (fp64 atomics once per workgroup, last one finalises);
+//  * BN + ReLU + max-pool over the ns consecutive rows of a centre (arg-max kept for the backward) in one pass
+//    over the last layer's pre-activations (bn_relu_pool_kernel);
+//  * backward: weight gradients with the forward's prologue recomputed while staging (wgrad_x_kernel), input
+//    gradients as products against W^T with the ReLU mask + BN-backward reductions in the epilogue, one
+//    element-wise pass dz = A*gy + B*z + D (bn_relu_bwd_apply_kernel), the pooled last layer's dz formed while
+//    staging; layer 0's input gradient is scattered straight into d(features).
+// The stand-alone kernels of this file (group_concat_cl, bn_stats / bn_relu_apply, bn_relu_bwd_*) serve the
+// generic op API and the EDA_SA_FUSED=0 path.
 // Results equal the reference's to fp32 rounding (tested against goldens generated
 // by the reference's own modules, tests/golden/model_sa_*).
 #include "eda_common.h"

@@ -163,8 +163,20 @@ class FlatParams:
         if self._prefilled:
             # deferred_wgrad() zeroed the buffer and its flush wrote the queued gradients; a
             # parameter that ALSO got a gradient from autograd (used outside the queue) adds to it
-            both = [(v, g) for v, g in have if v.data_ptr() in self._deferred_ptrs]
-            have = [(v, g) for v, g in have if v.data_ptr() not in self._deferred_ptrs]
+            # (range test, not pointer equality: the queue may have written only a ROW RANGE of a packed parameter --
+            # the K | V rows of an in-projection whose q rows went through autograd -- and the autograd tensor then
+            # holds zeros there; a copy would wipe the queued rows)
+            import bisect
+            spans = sorted(self._deferred_ptrs)
+            starts = [s_ for s_, _ in spans]
+
+            def overlaps(v):
+                lo, hi = v.data_ptr(), v.data_ptr() + v.numel() * 4
+                i = bisect.bisect_left(starts, hi) - 1      # last span starting below hi (spans are disjoint views)
+                return i >= 0 and spans[i][0] + spans[i][1] > lo
+            flags = [overlaps(v) for v, _ in have]
+            both = [vg for vg, f in zip(have, flags) if f]
+            have = [vg for vg, f in zip(have, flags) if not f]
             if both:
                 torch._foreach_add_([v for v, _ in both], [g for _, g in both])
             self._prefilled = False

@@ -114,14 +114,15 @@ class WgradQueue:
         return sum(len(t[4]) for t in self._targets.values()) + len(self._ln)
 
     def touched(self):
-        """data_ptr of every gradient view (weights and biases) that flush() will write."""
+        """(data_ptr, bytes) of every gradient view (weights and biases) that flush() will write.  A view may be a ROW
+        RANGE of a parameter's gradient (packed in-projections: q rows and K | V rows are queued independently)."""
         out = set()
         for gW, gb, *_ in self._targets.values():
-            out.add(gW.data_ptr())
+            out.add((gW.data_ptr(), gW.numel() * 4))
             if gb is not None:
-                out.add(gb.data_ptr())
+                out.add((gb.data_ptr(), gb.numel() * 4))
         for _, _, _, gg, gb, gy in self._ln.values():
-            out.update(t.data_ptr() for t in (gg, gb, gy) if t is not None)
+            out.update((t.data_ptr(), t.numel() * 4) for t in (gg, gb, gy) if t is not None)
         return out
 
     # ------------------------------------------------------------------- flush

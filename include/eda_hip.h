@@ -177,7 +177,7 @@ size_t eda_mha_bwd_workspace_bytes(int B, int H, int Lq, int Lk);
  * (SURVEY.md 8b "dtype enum"; BASELINE.json configs[2] bf16, configs[4] fp16).  Tensors stay fp32 at
  * the boundary; F32 forwards to the fp32 kernels above (v_mfma_f32_16x16x4_f32, the parity path);
  * BF16 / F16 convert the operands on the fly and run v_mfma_f32_16x16x16_{bf16,f16} with fp32
- * accumulation and fp32 softmax (csrc/mha16.hip; head_dim 36 padded to 48, padding not counted as
+ * accumulation and fp32 softmax (the same kernels of csrc/mha2.hip with packed contraction quads; nothing padded, only
  * useful FLOPs).  The 16-bit kernels ignore ws.                                                 */
 #define EDA_DTYPE_F32  0
 #define EDA_DTYPE_BF16 1

@@ -89,3 +89,62 @@ def test_decoder_layer_flat_grads_match_immediate_path():
     scale = g0.abs().max().item()
     assert (g0 - g1).abs().max().item() <= 2e-4 * scale, ((g0 - g1).abs().max().item(), scale)
     assert g0.abs().sum().item() > 0
+
+
+def _stacked_kv_step(mode, monkeypatch):
+    """Two attention modules reading one memory through the hoisted K | V projection (_StackedKV + pre_kv).
+    mode: "immediate" | "deferred" | "mixed" (the queue refuses the q rows of every packed in-projection, so the q half
+    comes back through autograd as a full-size tensor with zeros in the K | V rows while the K | V half is queued)."""
+    from eda_amd import attention as A, wgrad_queue
+    from eda_amd.parallel import FlatParams
+    torch.manual_seed(5)
+    d, B, Lq, Lk = 288, 2, 64, 48
+    mods = torch.nn.ModuleList([A.MultiheadAttention(d, 8, dropout=0.0) for _ in range(2)]).cuda().train()
+    for m in mods:
+        torch.nn.init.normal_(m.in_proj_bias, std=0.1)
+    flat = FlatParams(mods)
+    torch.manual_seed(6)
+    mem = torch.randn(B, Lk, d, device="cuda", requires_grad=True)
+    xs = [torch.randn(B, Lq, d, device="cuda", requires_grad=True) for _ in mods]
+    stack = (torch.empty(2 * 2 * d, d, device="cuda"), torch.empty(2 * 2 * d, device="cuda"))
+    A.refresh_kv_stacks([stack], [list(mods)])
+    sink = A.KVSink(2, 2 * d)
+    wb = []
+    for m in mods:
+        wb += [m.in_proj_weight, m.in_proj_bias]
+    kvs = A._StackedKV.apply(mem, sink, stack, *wb)
+    loss = 0.0
+    for i, m in enumerate(mods):
+        o, _ = m(xs[i], None, None, batch_first=True, skip_out_proj=True, pre_kv=(kvs[i], sink, i))
+        loss = loss + (o * torch.randn_like(o)).sum()
+    if mode == "immediate":
+        loss.backward()
+    else:
+        if mode == "mixed":
+            plan0 = wgrad_queue.WgradQueue.plan
+            bases = {m.in_proj_weight.data_ptr() for m in mods}
+
+            def plan(self, W, b, dy2, x2):
+                return None if W.data_ptr() in bases else plan0(self, W, b, dy2, x2)      # q rows start at the base
+            monkeypatch.setattr(wgrad_queue.WgradQueue, "plan", plan)
+        with flat.deferred_wgrad() as q:
+            loss.backward()
+            assert len(q) == (2 if mode == "mixed" else 4)
+    flat.collect_grads()
+    return flat.flat_grad.clone(), mem.grad.clone()
+
+
+def test_packed_in_projection_with_only_the_kv_rows_queued_keeps_them(monkeypatch):
+    """q rows through autograd (full-size dW with zeros in the K | V rows) + K | V rows through the
+    queue must ADD in collect_grads(), not overwrite the queued rows."""
+    g0, dm0 = _stacked_kv_step("immediate", monkeypatch)
+    g1, dm1 = _stacked_kv_step("deferred", monkeypatch)
+    g2, dm2 = _stacked_kv_step("mixed", monkeypatch)
+    assert torch.equal(dm0, dm1) and torch.equal(dm0, dm2)
+    scale = g0.abs().max().item()
+    assert g0.abs().sum().item() > 0
+    assert (g0 - g1).abs().max().item() <= 2e-4 * scale
+    assert (g0 - g2).abs().max().item() <= 2e-4 * scale
+    d = 288
+    kv_rows = g2[d * d:3 * d * d]                     # K | V rows of the first module's in_proj_weight
+    assert kv_rows.abs().max().item() > 1e-3 * scale
