@@ -341,6 +341,15 @@ def main():
                          "(eda_amd/sync_bn.py: one packed statistics all-reduce per BN layer and direction; the fused SA / FP "
                          "calls stay fused and exchange their sums through eda_set_bn_sync, the single-launch small-row BN "
                          "kernels are replaced by torch ops).  Default: per-GPU statistics (DESIGN.md §5)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="N > 1: nccl (= RCCL over xGMI, the measured configuration) or gloo on device tensors (debugging)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="N > 1 on a ONE-GPU box: every rank uses device 0 and the collectives go through gloo -- exercises "
+                         "the multi-rank step structure end to end; the line it prints says so and is not a measurement")
+    ap.add_argument("--overlap-allreduce", type=int, default=1,
+                    help="N > 1: 1 = all-reduce the first half of the flat gradient buffer underneath the grouped "
+                         "weight-gradient kernel of the second half (FlatParams.flush_and_reduce); 0 = one all-reduce "
+                         "after the whole backward")
     ap.add_argument("--split-graphs", action="store_true",
                     help="use the N>1 graph structure (two graphs, eager all-reduce slot) even at N=1")
     ap.add_argument("--kernel-steps", type=int, default=3,
@@ -355,6 +364,14 @@ def main():
         return
 
     t_start = time.perf_counter()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)
+        import socket
+        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print("[bench] --gpus %d without WORLD_SIZE: re-launching as %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+        os.execv(sys.executable, cmd)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -362,11 +379,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path is HIP-only (no CPU fallback)")
+    if args.share_gpu:
+        local_rank = 0                  # functional test of the N > 1 structure on a one-GPU box (never a measurement)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.share_gpu or args.dist_backend == "gloo":
+            dist.init_process_group("gloo")         # (RCCL refuses two ranks on one device)
+        else:
+            dist.init_process_group("nccl", device_id=device)
         from eda_amd import parallel as _par
         _par.reserve_cus_for_collectives(32)        # the prefetched sampling runs next to RCCL's channel workgroups
 
@@ -452,13 +474,43 @@ def main():
     if os.environ.get("EDA_BENCH_INGRAPH_HIST") == "1":
         ingraph_hist = (torch.full((4096,), 0.0, device=device), torch.full((1,), 0, dtype=torch.long, device=device))
 
+    # N > 1: the flat gradient is reduced in two ranges, the first one's all-reduce in flight underneath the second
+    # range's grouped weight-gradient kernel (DDP overlaps its buckets with the backward, main_utils.py:343-346; here
+    # everything the collective needs is produced at the very end of the backward)
+    overlap_ar = world > 1 and bool(args.overlap_allreduce) and bool(args.defer_wgrad)
+    ar_mid, ar_total, ar_works = flat.split_offset(0.5), flat.flat_grad.numel(), []
+
     def backward(loss):
+        if overlap_ar:
+            with flat.deferred_wgrad(flush=False):
+                loss.backward()
+            flat.flush_range(0, ar_mid)              # range A complete: its collective can start
+            return
         if args.defer_wgrad:
             with flat.deferred_wgrad():              # weight gradients: one grouped kernel after the backward
                 loss.backward()
         else:
             loss.backward()
         flat.collect_grads()
+
+    def reduce_a():
+        ar_works.append(dist.all_reduce(flat.flat_grad[:ar_mid], async_op=True))
+
+    def stage_b():
+        flat.flush_range(ar_mid, ar_total)
+        flat.finish_ranges()
+
+    def reduce_b():
+        ar_works.append(dist.all_reduce(flat.flat_grad[ar_mid:], async_op=True))
+        for w_ in ar_works:
+            w_.wait()
+        ar_works.clear()                             # (the 1/world rides in the clip's multiplication, update())
+
+    def all_reduce():
+        if overlap_ar:
+            reduce_a(); stage_b(); reduce_b()
+        elif world > 1:
+            dist.all_reduce(flat.flat_grad)
 
     def record_loss(loss):
         if ingraph_hist is not None:                 # debugging aid: loss history written by the graph itself
@@ -473,12 +525,12 @@ def main():
         return loss
 
     def update():
-        flat.clip_grad_norm_(0.1)                    # main_utils.py:483-486
+        flat.clip_grad_norm_(0.1, pre_scale=1.0 / world)      # main_utils.py:483-486 (on the mean over ranks)
         opt.step()
 
     def core_step():
         loss = fwd_bwd()
-        flat.all_reduce_mean(world)
+        all_reduce()
         update()
         return loss
 
@@ -516,7 +568,8 @@ def main():
                 # second stream underneath [point backbone | rest of the forward, loss, backward (, clip + AdamW at N = 1)]
                 pipe = pipeline.PipelinedTrainStep(
                     model, batches[0], loss_fn, backward, update, stream=side,
-                    all_reduce=(lambda: flat.all_reduce_mean(world)) if world > 1 else None,
+                    all_reduce=all_reduce if (world > 1 and not overlap_ar) else None,
+                    post_stages=[(None, reduce_a), (stage_b, reduce_b)] if overlap_ar else None,
                     split_update=(world > 1 or args.split_graphs),
                     prefetch={0: None, 1: "sa1", 2: "geometry"}[args.fps_prefetch],
                     text_prefetch=bool(args.text_prefetch), after_loss=record_loss)
@@ -547,7 +600,7 @@ def main():
                 def step():
                     load_batch()
                     g_fb.replay()
-                    flat.all_reduce_mean(world)
+                    all_reduce()
                     g_up.replay()
                     return static_loss
             log("step captured in HIP graph(s)")
@@ -793,7 +846,13 @@ def main():
                            not args.no_butd, args.loss),
                        "scenes_per_gpu": args.per_gpu, "global_batch": args.per_gpu * world,
                        "points": args.points, "queries": args.queries, "tokens": args.tokens,
-                       "parallelism": f"dp{world}", "batchnorm": "global-batch statistics (sync_bn)" if (args.sync_bn and world > 1) else "per-GPU statistics",
+                       "parallelism": f"dp{world}" + (" (ALL RANKS ON ONE GPU, gloo collectives: functional run of the N > 1 "
+                                                       "structure, not a measurement)" if args.share_gpu else ""),
+                       "gradient_allreduce": (None if world == 1 else
+                                              "two ranges of the flat fp32 buffer, the first in flight underneath the second "
+                                              "range's grouped weight-gradient kernel" if overlap_ar else
+                                              "one all-reduce of the flat fp32 buffer after the backward"),
+                       "batchnorm": "global-batch statistics (sync_bn)" if (args.sync_bn and world > 1) else "per-GPU statistics",
                        "launch": ("eager" if not args.graph else
                                   ("three hipGraphs on two streams (frozen text encoder underneath the point backbone | "
                                    "rest of the step)" + ("" if world == 1 and not args.split_graphs else

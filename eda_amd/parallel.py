@@ -132,11 +132,12 @@ class FlatParams:
         return self.flat_grad[off:off + t.numel()].view(t.shape)
 
     @contextlib.contextmanager
-    def deferred_wgrad(self):
+    def deferred_wgrad(self, flush=True):
         """Run the backward pass inside this context: the weight / bias gradients of the
         pointwise linear layers are queued (eda_amd/wgrad_queue.py) and written into the flat
         gradient buffer by ONE grouped kernel when the context exits; collect_grads() then only
-        gathers what autograd still produced itself."""
+        gathers what autograd still produced itself.  flush=False leaves the queue full: the caller
+        continues with flush_and_reduce() (range-wise flush with the all-reduce underneath)."""
         from . import wgrad_queue, wt_shadow
         self.flat_grad.fill_(0.0)          # (a kernel, not a memset node: see DESIGN.md on graphs)
         prev, wgrad_queue.active = wgrad_queue.active, self.queue
@@ -152,14 +153,23 @@ class FlatParams:
             wgrad_queue.active = prev
             wt_shadow.active = prev_shadow
             self._deferred_ptrs = self.queue.touched()
-            self.queue.flush()
+            if flush:
+                self.queue.flush()
             self._prefilled = True
 
-    def collect_grads(self):
+    def collect_grads(self, lo=None, hi=None):
         """Gather the gradients autograd produced this step into the flat buffer
         (multi-tensor copy) and release them, so the next backward again ASSIGNS
-        instead of accumulating."""
-        have = [(v, p.grad) for v, p in zip(self._grad_views, self.params) if p.grad is not None]
+        instead of accumulating.  lo / hi (element offsets at parameter boundaries, deferred mode only): just the
+        parameters inside [lo, hi) -- flush_and_reduce() gathers range by range."""
+        ranged = lo is not None
+        if ranged:
+            assert self._prefilled, "range-wise gather: only after deferred_wgrad()"
+            base = self.flat_grad.data_ptr()
+            sel = [base + 4 * lo <= v.data_ptr() < base + 4 * hi for v in self._grad_views]
+            have = [(v, p.grad) for v, p, s_ in zip(self._grad_views, self.params, sel) if s_ and p.grad is not None]
+        else:
+            have = [(v, p.grad) for v, p in zip(self._grad_views, self.params) if p.grad is not None]
         if self._prefilled:
             # deferred_wgrad() zeroed the buffer and its flush wrote the queued gradients; a
             # parameter that ALSO got a gradient from autograd (used outside the queue) adds to it
@@ -179,14 +189,84 @@ class FlatParams:
             have = [vg for vg, f in zip(have, flags) if not f]
             if both:
                 torch._foreach_add_([v for v, _ in both], [g for _, g in both])
-            self._prefilled = False
-            self._deferred_ptrs = set()
+            if not ranged:
+                self._prefilled = False
+                self._deferred_ptrs = set()
         elif len(have) != len(self.params):
             self.flat_grad.fill_(0.0)          # (a fill kernel rather than a memset node)
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        if ranged:
+            for p, s_ in zip(self.params, sel):
+                if s_:
+                    p.grad = None
+            return
         for p in self.params:
             p.grad = None
+
+    def split_offset(self, frac=0.5):
+        """Element offset of the parameter boundary closest to `frac` of the flat buffer."""
+        total = self.flat_grad.numel()
+        best = min((off for _, _, off, _ in self.layout), key=lambda o: abs(o - frac * total))
+        return int(best)
+
+    def flush_range(self, lo, hi):
+        """Second half of a deferred backward for the buffer range [lo, hi): the grouped weight-gradient kernel over the
+        queued entries that write into the range (an entry with ANY output inside it -- the LayerNorm reductions also
+        write the bias of the linear in front, which may lie in another range -- runs now; later ranges only store
+        into their own entries), then the gather of what autograd produced for the range's parameters.  Capturable."""
+        base = self.flat_grad.data_ptr()
+        a, b = base + 4 * lo, base + 4 * hi
+        self.queue.flush(select=lambda views: any(a <= v.data_ptr() < b for v in views))
+        self.collect_grads(lo, hi)
+
+    def finish_ranges(self):
+        """After the last flush_range(): anything still queued (nothing, if the ranges cover the buffer), state reset."""
+        self.queue.flush()
+        self._prefilled = False
+        self._deferred_ptrs = set()
+
+    def flush_and_reduce(self, world=None, group=None, frac=0.5):
+        """Continue a backward that ran under deferred_wgrad(flush=False): the all-reduce of the first part of the flat
+        buffer runs UNDERNEATH the grouped weight-gradient kernel of the second part (DDP overlaps its buckets with
+        the backward, main_utils.py:343-346; here everything the collective needs is produced at the very end of
+        the backward, so the overlap is between the two halves of that tail).  Returns a handle; wait() completes
+        both collectives and applies 1/world (the global-norm clip needs the complete reduced gradient, so the
+        optimizer cannot start earlier).  world <= 1: flushes, gathers, returns a no-op handle."""
+        if world is None:
+            world = dist.get_world_size(group) if dist.is_initialized() else 1
+        total = self.flat_grad.numel()
+        flat = self.flat_grad
+
+        class _Done:
+            def __init__(self, works):
+                self.works = works
+
+            def wait(self):
+                for w in self.works:
+                    w.wait()
+                if world > 1:
+                    flat.mul_(1.0 / world)
+                return True
+        if world <= 1:
+            self.flush_range(0, total)
+            self.finish_ranges()
+            return _Done([])
+        mid = self.split_offset(frac)
+        works = []
+        for lo, hi in ((0, mid), (mid, total)):
+            if hi > lo:
+                self.flush_range(lo, hi)
+                works.append(dist.all_reduce(self.flat_grad[lo:hi], group=group, async_op=True))
+        self.finish_ranges()
+        return _Done(works)
+
+    def backward_overlapped(self, loss, world=None, group=None):
+        """loss.backward() with the weight gradients deferred and the gradient all-reduce overlapped with their
+        computation; returns the handle of flush_and_reduce()."""
+        with self.deferred_wgrad(flush=False):
+            loss.backward()
+        return self.flush_and_reduce(world, group)
 
     def all_reduce_mean(self, world=None, async_op=False):
         """Mean of the flat gradient over the ranks (DDP semantics): one all-reduce of the whole buffer, then 1/world.
@@ -209,10 +289,14 @@ class FlatParams:
                 return True
         return _MeanWork()
 
-    def clip_grad_norm_(self, max_norm):
-        """torch.nn.utils.clip_grad_norm_ over all parameters (main_utils.py:483-486) on the flat buffer."""
+    def clip_grad_norm_(self, max_norm, pre_scale=1.0):
+        """torch.nn.utils.clip_grad_norm_ over all parameters (main_utils.py:483-486) on the flat buffer.
+        pre_scale: the buffer still holds the SUM over ranks (the all-reduce's 1/world has not been applied): the
+        mean's norm is pre_scale * |sum| and both factors go into the one multiplication."""
         norm = torch.linalg.vector_norm(self.flat_grad)
-        self.flat_grad.mul_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
+        if pre_scale != 1.0:
+            norm = norm * pre_scale
+        self.flat_grad.mul_(torch.clamp(max_norm / (norm + 1e-6), max=1.0) * pre_scale)
         return norm
 
 

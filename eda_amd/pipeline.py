@@ -45,11 +45,16 @@ def _clone(batch):
 
 class PipelinedTrainStep:
     def __init__(self, model, first_batch, loss_fn, backward_fn, update_fn, *, stream=None, all_reduce=None,
-                 split_update=False, prefetch="sa1", text_prefetch=True, after_loss=None, sa1_samples=2048):
+                 split_update=False, prefetch="sa1", text_prefetch=True, after_loss=None, sa1_samples=2048,
+                 post_stages=None):
         """model: BeaUTyDETR (train mode, text encoder frozen).  first_batch: dict of DEVICE tensors (the layout of
         every later batch; extra tensors, e.g. loss targets, ride along).  loss_fn(end_points, batch) -> scalar.  backward_fn(loss): backward + gradient gather (e.g. under
         FlatParams.deferred_wgrad()).  update_fn(): clip + optimizer step (capturable).  all_reduce(): eager
         collective between the backward graph and the update graph (N > 1; implies split_update).
+        post_stages: instead of all_reduce, a list of (capturable_fn or None, eager_fn or None) pairs executed in order
+        between the backward graph and the update graph -- each capturable_fn becomes its own small graph, each eager_fn
+        is called on the host after it (bench.py: [(None, start all-reduce of range A), (flush + gather of range B, start
+        all-reduce of range B and wait for both)]: the first collective runs underneath the second weight-gradient kernel).
         prefetch: "sa1" (SA1's sampling for the next batch), "geometry" (everything the backbone derives from the
         coordinates alone: Pointnet2Backbone.geometry) or None (sampling inside the step; then the text encoder runs for
         the CURRENT batch underneath the point backbone).  text_prefetch: the text encoder, too, works for the next batch.
@@ -58,7 +63,8 @@ class PipelinedTrainStep:
         text_prefetch = bool(text_prefetch) and prefetch is not None
         self.model, self.loss_fn = model, loss_fn
         self.all_reduce = all_reduce
-        split_update = split_update or all_reduce is not None
+        split_update = split_update or all_reduce is not None or bool(post_stages)
+        assert all_reduce is None or not post_stages, "all_reduce and post_stages are alternatives"
         dev = first_batch["point_clouds"].device
         self.main = stream or torch.cuda.current_stream()
         self.side = torch.cuda.Stream()
@@ -129,6 +135,14 @@ class PipelinedTrainStep:
                 after_loss(self.loss)
             if self.g_up is None:
                 update_fn()
+        self.post = []
+        for cap_fn, eager_fn in (post_stages or []):
+            g = None
+            if cap_fn is not None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, stream=self.main, **mode):
+                    cap_fn()
+            self.post.append((g, eager_fn))
         if self.g_up is not None:
             with torch.cuda.graph(self.g_up, pool=pool, stream=self.main, **mode):
                 update_fn()
@@ -138,12 +152,20 @@ class PipelinedTrainStep:
 
     def _feed(self, batch):
         """Copy `batch` (same layout as the first one) into the nxt buffers, on the side stream."""
-        torch._foreach_copy_(self._nxt_flat, _flat(batch))
+        src = _flat(batch)
+        torch._foreach_copy_(self._nxt_flat, src)
+        for t in src:                       # the copy runs on the side stream: keep the caller's memory alive until it is done
+            t.record_stream(self.side)
 
     def step(self, next_batch=None):
         """Train on the batch fed by the previous call (the first batch initially); start the sampling / text encoding
         of `next_batch` underneath.  Returns the (static) loss tensor of this step."""
-        cur = torch.cuda.current_stream()
+        if torch.cuda.current_stream() != self.main:
+            # the graphs were captured on self.main and the events order against it: replay there whatever the caller's
+            # current stream is (ADVICE r03)
+            with torch.cuda.stream(self.main):
+                return self.step(next_batch)
+        cur = self.main
         # the point graph first: a replay call returns when its last node has been queued, which for the long graph is
         # close to its end on the GPU -- whatever the host issues before the point graph is time the main queue idles
         cur.wait_event(self.ev_fps)                # this batch's sampling / hidden states / data are in the nxt buffers
@@ -170,6 +192,11 @@ class PipelinedTrainStep:
         if self.g_up is not None:
             if self.all_reduce is not None:
                 self.all_reduce()
+            for g, eager_fn in self.post:
+                if g is not None:
+                    g.replay()
+                if eager_fn is not None:
+                    eager_fn()
             self.g_up.replay()
         return self.loss
 

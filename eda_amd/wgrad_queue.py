@@ -126,13 +126,21 @@ class WgradQueue:
         return out
 
     # ------------------------------------------------------------------- flush
-    def flush(self, accumulate=False):
+    def flush(self, accumulate=False, select=None):
         """Launch the grouped kernel for everything queued (stores, or adds with accumulate=True)
-        and drop the references to the queued activations."""
-        lns = list(self._ln.values())
-        self._ln = {}
-        targets = list(self._targets.values())
-        self._targets = {}
+        and drop the references to the queued activations.  select(views) -> bool restricts the flush to the entries
+        it accepts (views = the gradient views the entry writes); the others stay queued (FlatParams.flush_and_reduce
+        flushes the buffer range by range so that a range's all-reduce runs underneath the next range's kernel)."""
+        if select is None:
+            lns = list(self._ln.values())
+            self._ln = {}
+            targets = list(self._targets.values())
+            self._targets = {}
+        else:
+            ln_keys = [k for k, e in self._ln.items() if select([t for t in e[3:6] if t is not None])]
+            lns = [self._ln.pop(k) for k in ln_keys]
+            t_keys = [k for k, t in self._targets.items() if select([v for v in t[0:2] if v is not None])]
+            targets = [self._targets.pop(k) for k in t_keys]
         if lns:
             self._flush_ln(lns)
         if not targets:

@@ -50,17 +50,31 @@ def _worker(rank, world, port, out_dir):
         q = dec(f.transpose(1, 2).contiguous(), f.transpose(1, 2).contiguous(), lang, new_xyz, None, mask)
         return q.pow(2).mean()
 
-    for it in range(2):
-        local_loss().backward()
-        grads.collect_grads()
+    for it in range(3):
+        if it == 2:
+            # the overlapped form (FlatParams.backward_overlapped: range-wise flush + gather with the first range's
+            # all-reduce in flight underneath the second range): same reduced gradient as the plain path
+            with grads.deferred_wgrad():
+                local_loss().backward()
+            grads.collect_grads()
+            local = grads.flat_grad.clone()
+            mid = grads.split_offset(0.5)
+            assert 0 < mid < local.numel()
+            grads.backward_overlapped(local_loss(), world).wait()
+            gathered = [torch.zeros_like(local) for _ in range(world)]
+            dist.all_gather(gathered, local)
+        else:
+            local_loss().backward()
+            grads.collect_grads()
+            assert all(p.grad is None for p in grads.params)
+            local = grads.flat_grad.clone()
+            gathered = [torch.zeros_like(local) for _ in range(world)]
+            dist.all_gather(gathered, local)
+            if it == 0:
+                grads.all_reduce_mean(world)
+            else:                                           # the asynchronous form: a mean only after wait()
+                grads.all_reduce_mean(world, async_op=True).wait()
         assert all(p.grad is None for p in grads.params)
-        local = grads.flat_grad.clone()
-        gathered = [torch.zeros_like(local) for _ in range(world)]
-        dist.all_gather(gathered, local)
-        if it == 0:
-            grads.all_reduce_mean(world)
-        else:                                           # the asynchronous form: a mean only after wait()
-            grads.all_reduce_mean(world, async_op=True).wait()
         expect = sum(gathered) / world
         assert torch.allclose(grads.flat_grad, expect, rtol=1e-6, atol=1e-7), "all-reduce != mean of rank grads"
         assert not torch.equal(gathered[0], gathered[1]), "ranks saw the same scenes"

@@ -21,8 +21,8 @@ rm -rf /tmp/pe
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pe -o eager -- python bench.py --steps 20 --warmup 3 --graph 0 --cpu-scenes 0 > $O/bench_eager_under_rocprof.json 2> $O/bench_eager.err
 find /tmp/pe -name "*kernel_stats.csv" -exec cp {} $O/bench_eager_kernel_stats_rocprofv3.csv \;
 python tools/summarize_profile.py $tag 23 $O/bench_eager_kernel_stats_rocprofv3.csv $O/bench_default.json $O/bench_eager_under_rocprof.json > $O/summary.md 2> $O/summary.err
-tools/prof_mha.sh ${tag}_f32 2 > /dev/null 2>&1
-ATTN_DTYPE=bf16 tools/prof_mha.sh ${tag}_bf16 2 > /dev/null 2>&1
+tools/prof_mha.sh ${tag}_f32 > /dev/null 2>&1
+ATTN_DTYPE=bf16 tools/prof_mha.sh ${tag}_bf16 > /dev/null 2>&1
 python - "$O" <<'PY'
 import json, glob, sys
 for f in sorted(glob.glob(sys.argv[1] + "/bench_*.json")):
