@@ -391,6 +391,10 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         from eda_amd import parallel as _par
         _par.reserve_cus_for_collectives(32)        # the prefetched sampling runs next to RCCL's channel workgroups
+        if os.environ.get("EDA_FPS_BUCKET") is None:
+            # ... and on the sampler whose workgroups never wait for each other (5 ms on 8 CUs of the second stream instead
+            # of 3 ms on 104: hidden under the step either way, 20.73 vs 20.64 ms/step at N = 1)
+            _par.sampler_without_co_residency()
 
     from eda_amd import ext
     if args.sync_bn and world > 1:
@@ -690,6 +694,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
 
+    fps_repaired = ext.fps_repaired(device)
+    if fps_repaired:
+        log(f"furthest point sampling: {fps_repaired} cluster launch(es) were not co-resident and were repaired on the device "
+            "by the bucket sampler (indices exact; each cost its spin limit)")
     fps_giveups = ext.fps_status(device)
     if fps_giveups:
         raise SystemExit(f"furthest point sampling gave up its inter-workgroup spin in {fps_giveups} workspace(s): "

@@ -29,8 +29,10 @@
 // in the reference; here it carries the constant candidate (-1.0f, k = 0), which
 // is exactly what a reference thread without a valid point contributes.
 #include "eda_common.h"
+#include "fps_bucket.h"
 
 #include <limits.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -38,7 +40,27 @@ constexpr int kRecWords = 8;          // u64 words per mailbox record (5 used, 6
 int g_fps_cu_reserve = [] { const char *e = getenv("EDA_FPS_CU_RESERVE"); return e ? atoi(e) : 0; }();
 constexpr int kMaxG = 64;             // workgroups per scene (one poll lane each)
 constexpr size_t kStatusBytes = 256;  // status words in front of the mailboxes
-constexpr unsigned kSpinLimit = 1u << 20;   // ~1 s of polling, then give up (status word set, indices zero-filled)
+constexpr unsigned kSpinLimit = 1u << 20;   // ~1 s of polling, then give up (per-call flag set, indices zero-filled)
+// Status block (64 ints in front of the mailboxes).  int 0: STICKY, some call gave up and nothing recovered it (only
+// scenes the bucket sampler cannot take: > 65536 points); int 2: STICKY count of give-ups the bucket sampler recovered;
+// int 3: duration of the last launch (10 ns ticks); ints 4..59: diagnostics; int 60 (kFailInt): give-up flag of the
+// CURRENT call (zeroed per call with ints 4..63, set by the cluster kernels, consumed by the launches behind them).
+constexpr int kFailInt = 60;
+int g_fps_policy = [] {                      // EDA_FPS_AUTO / CLUSTER / BUCKET (include/eda_hip.h); EDA_FPS_BUCKET=0|1 overrides
+  const char *e = getenv("EDA_FPS_BUCKET");
+  return (e && *e) ? (atoi(e) != 0 ? EDA_FPS_BUCKET : EDA_FPS_CLUSTER) : EDA_FPS_AUTO;
+}();
+
+// a give-up that nothing can recover becomes sticky
+__global__ void fps_fail_latch_kernel(int *status) {
+  if (status[kFailInt] != 0) status[0] = 1;
+}
+// test hook (EDA_FPS_TEST_GIVEUP=1): what a cluster launch that was not co-resident leaves behind -- the call's give-up
+// flag set, zero indices -- without waiting for the spin limit
+__global__ void fps_fake_giveup_kernel(int *status, int *idx, long count) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) idx[i] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) status[kFailInt] = 1;
+}
 
 typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
@@ -212,7 +234,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz_al
         __builtin_amdgcn_s_sleep(1);
       }
       if (failed) {
-        if (lane == 0) { sh->fail = 1; atomicExch(status, 1); }
+        if (lane == 0) { sh->fail = 1; atomicExch(status + kFailInt, 1); }
       } else {
         const int gb = lane < G ? (int)v0 : INT_MIN;
         const int gm = eda_wave_max_i32(gb);
@@ -474,7 +496,7 @@ __global__ __launch_bounds__(T) void fps_spec_kernel(const float *__restrict__ x
       }
       FPS_MARK(4);
       if (failed) {
-        if (lane == 0) { sh->fail = 1; atomicExch(status, 1); }
+        if (lane == 0) { sh->fail = 1; atomicExch(status + kFailInt, 1); }
       } else {
         // ---- 5. global top-K of the G*K gathered keys (one per lane) --------------------------
         const u64 mine = (poller && (int)v0 != INT_MIN) ? fps_key((int)v0, v1, p_log2) : 0ull;
@@ -710,10 +732,17 @@ int env_int(const char *name, int dflt) {
 
 }  // namespace
 
-extern "C" size_t eda_fps_workspace_bytes(int b, int n, int m) {
-  (void)n; (void)m;
+// status block + mailboxes of the cluster kernels (zeroed per call), then the sorted points of the bucket sampler
+static size_t fps_mail_bytes(int b) {
   if (b < 0) b = 0;
   return kStatusBytes + (size_t)b * 2 * kMaxG * kRecWords * sizeof(u64);
+}
+
+extern "C" size_t eda_fps_workspace_bytes(int b, int n, int m) {
+  (void)m;
+  size_t bytes = fps_mail_bytes(b);
+  if (eda_fps_bucket_supports(n)) bytes += eda_fps_bucket_workspace_bytes(b, n);
+  return bytes;
 }
 
 // cuda_utils.h:20-24: 2^floor(log2 n) clamped to [1, 512]; only its log2 is needed.
@@ -738,6 +767,23 @@ extern "C" int eda_furthest_point_sampling_f32(const float *xyz, int b, int n, i
     return EDA_ERR_WORKSPACE;
   }
   const int p_log2 = fps_block_log2(n);
+
+  // Scenes of 8193..65536 points have TWO samplers with identical results: the cluster kernels below (13 workgroups per
+  // scene spinning on each other: 3.1 ms for 8 x 50 000 -> 2048, but every workgroup of a launch must be co-resident)
+  // and the single-workgroup bucket sampler (csrc/fps_bucket.hip: no co-residency requirement, no spin, 8 CUs; 5.3 ms).
+  // Policy (eda_fps_set_policy; the environment variable EDA_FPS_BUCKET=0|1 is read at every call and overrides it):
+  //   AUTO     cluster kernels, and behind them the bucket sampler GATED on this call's give-up flag: a cluster that
+  //            was not co-resident costs its spin limit plus 5 ms, never a wrong index
+  //   CLUSTER  cluster kernels only (a give-up becomes the sticky status word)
+  //   BUCKET   bucket sampler only (what a data-parallel job next to RCCL's spinning channel kernels should use)
+  int policy = g_fps_policy;
+  { const char *e = getenv("EDA_FPS_BUCKET"); if (e && *e) policy = atoi(e) != 0 ? EDA_FPS_BUCKET : EDA_FPS_CLUSTER; }
+  const bool bucket_ok = eda_fps_bucket_supports(n);
+  if (bucket_ok && policy == EDA_FPS_BUCKET) {
+    { const int zrc__ = eda_zero_async(reinterpret_cast<unsigned char *>(ws) + 16, kStatusBytes - 16, stream); if (zrc__) return zrc__; }
+    return eda_fps_bucket_launch(xyz, b, n, m, idx, p_log2, reinterpret_cast<unsigned char *>(ws) + fps_mail_bytes(b),
+                                 reinterpret_cast<int *>(ws), nullptr, g_eda_fma_mode, stream);
+  }
 
   // ---- geometry: T threads, P points per thread, G workgroups per scene ----
   int T, P, G;
@@ -784,7 +830,7 @@ extern "C" int eda_furthest_point_sampling_f32(const float *xyz, int b, int n, i
 
   // ints 0..3 of the workspace are a STICKY status block (int 0 != 0: some call on this workspace gave
   // up); everything behind them (diagnostics, mailboxes) is zeroed per call
-  { const int zrc__ = eda_zero_async(reinterpret_cast<unsigned char *>(ws) + 16, eda_fps_workspace_bytes(b, n, m) - 16, stream); if (zrc__) return zrc__; }
+  { const int zrc__ = eda_zero_async(reinterpret_cast<unsigned char *>(ws) + 16, fps_mail_bytes(b) - 16, stream); if (zrc__) return zrc__; }
   int *status = reinterpret_cast<int *>(ws);
   u64 *mail = reinterpret_cast<u64 *>(reinterpret_cast<unsigned char *>(ws) + kStatusBytes);
 
@@ -792,7 +838,12 @@ extern "C" int eda_furthest_point_sampling_f32(const float *xyz, int b, int n, i
   // clusters of the default geometry run the speculative K=4 kernel (EDA_FPS_SPEC=0: one sample
   // per hand-off, the kernel above)
   const bool use_spec = G > 1 && G <= kSpecMaxG && T == 512 && (P == 16 || P == 8) && env_int("EDA_FPS_SPEC", 1) != 0;
-  for (int s0 = 0; s0 < b; s0 += scenes_per_launch) {
+  const bool fake_giveup = G > 1 && env_int("EDA_FPS_TEST_GIVEUP", 0) != 0;
+  if (fake_giveup) {
+    hipLaunchKernelGGL(fps_fake_giveup_kernel, dim3(64), dim3(256), 0, stream, status, idx, (long)b * m);
+    EDA_CHECK_LAUNCH();
+  }
+  for (int s0 = 0; s0 < b && !fake_giveup; s0 += scenes_per_launch) {
     const int S = (b - s0) < scenes_per_launch ? (b - s0) : scenes_per_launch;
     const float *x = xyz + (size_t)s0 * n * 3;
     int *o = idx + (size_t)s0 * m;
@@ -821,9 +872,21 @@ extern "C" int eda_furthest_point_sampling_f32(const float *xyz, int b, int n, i
     }
     if (rc) return rc;
   }
+  if (G > 1) {          // (single-workgroup scenes cannot give up)
+    if (bucket_ok && policy == EDA_FPS_AUTO)
+      return eda_fps_bucket_launch(xyz, b, n, m, idx, p_log2, reinterpret_cast<unsigned char *>(ws) + fps_mail_bytes(b),
+                                   status, status + kFailInt, g_eda_fma_mode, stream);
+    hipLaunchKernelGGL(fps_fail_latch_kernel, dim3(1), dim3(1), 0, stream, status);
+    EDA_CHECK_LAUNCH();
+  }
   return 0;
 }
 
+extern "C" int eda_fps_set_policy(int policy) {
+  EDA_CHECK_ARG(policy == EDA_FPS_AUTO || policy == EDA_FPS_CLUSTER || policy == EDA_FPS_BUCKET, "policy must be EDA_FPS_AUTO / CLUSTER / BUCKET");
+  g_fps_policy = policy;
+  return 0;
+}
 
 extern "C" int eda_fps_set_cu_reserve(int cus) {
   EDA_CHECK_ARG(cus >= 0 && cus <= 240, "reserve must be 0..240 CUs");

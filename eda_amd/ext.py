@@ -133,6 +133,23 @@ def fps_status(device=None, reset=False):
     return bad
 
 
+def fps_repaired(device=None):
+    """How many furthest-point-sampling calls so far gave up their inter-workgroup spin (the cluster kernels were not
+    co-resident) and were REPAIRED on the device by the single-workgroup bucket sampler (int 2 of the status block;
+    include/eda_hip.h eda_fps_set_policy).  Their indices are correct; the number says how often ~1 s was lost.
+    Synchronises."""
+    total = 0
+    for (dev, _), ws in _fps_ws.items():
+        if device is None or torch.device(device) == dev:
+            total += int(ws[:16].view(torch.int32)[2].item())
+    return total
+
+
+def fps_set_policy(name):
+    """"auto" (cluster kernels + gated bucket-sampler repair), "cluster", "bucket": include/eda_hip.h eda_fps_set_policy."""
+    _lib.check(_lib.lib().eda_fps_set_policy({"auto": 0, "cluster": 1, "bucket": 2}[name]), "eda_fps_set_policy")
+
+
 def fps_last_duration_ms(device=None):
     """Wall time the multi-workgroup sampler last took on the device (its own 100 MHz clock reads, int 3 of the
     workspace's status block), per workspace: a diagnostic for runs that replay graphs, where no host-side event can

@@ -309,6 +309,15 @@ def reserve_cus_for_collectives(cus=32):
     _lib.check(_lib.lib().eda_fps_set_cu_reserve(int(cus)), "eda_fps_set_cu_reserve")
 
 
+def sampler_without_co_residency():
+    """N > 1: furthest point sampling of the large scenes on the single-workgroup bucket sampler (include/eda_hip.h:
+    eda_fps_set_policy(EDA_FPS_BUCKET)) -- no workgroup of this library then waits for another one, whatever RCCL's
+    channel kernels occupy.  (The default policy repairs a cluster launch that was not co-resident, but only after its
+    spin limit: ~1 s.)"""
+    from . import _lib
+    _lib.check(_lib.lib().eda_fps_set_policy(2), "eda_fps_set_policy")
+
+
 def broadcast_parameters(module, src=0):
     """DDP constructor semantics: every rank starts from rank `src`'s weights and buffers."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

@@ -465,6 +465,22 @@ int eda_transpose_batch_f32(const long long *desc, int count, long long total_ti
  * the reference (its sampler is one workgroup per scene, sampling_gpu.cu:74-178). */
 int eda_fps_set_cu_reserve(int cus);
 
+/* Which sampler eda_furthest_point_sampling_f32 runs for scenes of 8193..65536 points (csrc/fps.hip, csrc/fps_bucket.hip;
+ * identical indices either way; replaces nothing in the reference, whose sampler is one workgroup per scene,
+ * sampling_gpu.cu:74-178):
+ *   EDA_FPS_AUTO    (default) the cluster kernels (workgroups of a scene hand candidates to each other: fast, but all of
+ *                   a launch's workgroups must be co-resident) and, behind them, the single-workgroup bucket sampler
+ *                   gated on the call's give-up flag: a launch that was not co-resident is REPAIRED on the device;
+ *                   int 2 of the workspace's status block counts such repairs, int 0 stays 0
+ *   EDA_FPS_CLUSTER the cluster kernels only; a give-up sets the sticky int 0 of the status block
+ *   EDA_FPS_BUCKET  the bucket sampler only: one workgroup per scene, no inter-workgroup communication (use it next to
+ *                   other resident spin-kernels, e.g. RCCL's channel kernels at N > 1)
+ * Process-wide; the environment variable EDA_FPS_BUCKET=0|1 (read at every call) overrides it with CLUSTER | BUCKET. */
+#define EDA_FPS_AUTO    0
+#define EDA_FPS_CLUSTER 1
+#define EDA_FPS_BUCKET  2
+int eda_fps_set_policy(int policy);
+
 /* Kernel selection of the plain row products (eda_linear_fwd_f32 / _ex_f32 / _dgrad_f32): -1 the library's own choice
  * (the DMA-staged kernel of csrc/gemm.hip for launches of >= 400 tiles of 32 x 96, else the register-staged one), 0 the
  * DMA-staged kernel off, 1..4 one of its configurations for every eligible launch (tests, experiments).  Process-wide;

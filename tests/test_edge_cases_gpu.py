@@ -110,3 +110,37 @@ def test_fps_is_exact_and_reports_status_while_another_stream_keeps_the_cus_busy
     for o in outs:
         assert (o.cpu() == want).all()
     assert bool(((outs[0] >= 0) & (outs[0] < 50000)).all())
+
+
+def test_fps_give_up_is_repaired_on_the_device(oracle, monkeypatch):
+    """Default policy (EDA_FPS_AUTO): behind the cluster kernels runs the bucket sampler, gated on the call's give-up
+    flag.  A cluster launch that was not co-resident (simulated: EDA_FPS_TEST_GIVEUP=1 leaves what such a launch leaves
+    -- flag set, zero indices -- without the ~1 s spin limit) is repaired before the call's stream work ends: exact
+    indices, sticky status still clear, the repair counted.  Without a give-up the gated launch is a no-op; with the
+    cluster-only policy the give-up is reported through the sticky status word as before."""
+    import torch
+    from eda_amd import ext, synthetic
+    pc = synthetic.batch([31, 32], 30000)
+    xyz_c = torch.from_numpy(pc[:, :, :3].copy())
+    xyz = xyz_c.cuda()
+    want = oracle.furthest_point_sampling(xyz_c, 256)
+    ext.fps_status(reset=True)
+    r0 = ext.fps_repaired()
+    assert (ext.furthest_point_sampling(xyz, 256).cpu() == want).all() and ext.fps_repaired() == r0      # no give-up: no repair
+    monkeypatch.setenv("EDA_FPS_TEST_GIVEUP", "1")
+    got = ext.furthest_point_sampling(xyz, 256)
+    assert (got.cpu() == want).all()
+    assert ext.fps_status() == 0 and ext.fps_repaired() == r0 + 1
+    ext.fps_set_policy("cluster")
+    try:
+        got = ext.furthest_point_sampling(xyz, 256)
+        assert int(got.abs().sum()) == 0 and ext.fps_status() == 1          # reported, valid (zero) indices
+    finally:
+        ext.fps_set_policy("auto")
+        ext.fps_status(reset=True)
+    monkeypatch.delenv("EDA_FPS_TEST_GIVEUP")
+    ext.fps_set_policy("bucket")
+    try:
+        assert (ext.furthest_point_sampling(xyz, 256).cpu() == want).all()
+    finally:
+        ext.fps_set_policy("auto")

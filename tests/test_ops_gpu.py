@@ -264,3 +264,77 @@ def test_fps_prefix_verification_equals_oracle_on_every_kind_of_input(oracle, fm
         assert ext.fps_status() == 0
     finally:
         L.eda_set_fma_mode(0); oracle.set_fma_mode(0)
+
+
+# ---- the single-workgroup bucket sampler (csrc/fps_bucket.hip: scenes of 8193..65536 points) -----------------------
+def _bucket_cases():
+    rng = np.random.default_rng(2024)
+    c = {}
+    c["uniform_65536"] = (_cloud(rng, 1, 65536), 1500)
+    c["min_size_8193"] = (_cloud(rng, 2, 8193), 700)
+    p = _cloud(rng, 1, 30000); p[..., 2] = 0.25                          # planar: a degenerate scene box
+    c["planar"] = (p, 900)
+    p = _cloud(rng, 1, 20000); p[0, :, 1:] = 0.5                          # a line
+    c["line"] = (p, 400)
+    p = _cloud(rng, 1, 12000, dup=0.9)                                    # almost every point duplicated: exact ties
+    c["mostly_duplicates"] = (p, 3000)
+    p = np.repeat(_cloud(rng, 1, 40), 250, axis=1)                        # 40 distinct points x 250: m > distinct points
+    c["forty_distinct_points"] = (np.ascontiguousarray(p[:, rng.permutation(10000)]), 120)
+    p = _cloud(rng, 1, 9000); p[:] = p[:, :1]                             # one point, 9000 times
+    c["one_point"] = (p, 50)
+    c["quantised_coarse"] = (_cloud(rng, 1, 25000, quant=2), 600)         # 9^3 lattice: massive distance ties
+    c["quantised_fine"] = (_cloud(rng, 2, 50000, quant=64, origin=0.002), 1200)
+    p = _cloud(rng, 1, 10000, origin=0.3); p[0, 0] = (0.01, 0.0, 0.01)    # first point and 30 % inside the origin ball
+    c["origin_ball"] = (p, 800)
+    p = (_cloud(rng, 1, 9000) * 0.005).astype(np.float32)                 # EVERY point inside the ball: all indices 0
+    c["all_in_origin_ball"] = (p, 30)
+    p = _cloud(rng, 1, 16000); p[0, 8000:] += 50.0                        # two far-apart clusters
+    c["two_clusters"] = (p, 1000)
+    p = _cloud(rng, 1, 9000)                                              # sample EVERY point (m = n)
+    c["all_points"] = (p, 9000)
+    return c
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("name", sorted(_bucket_cases()))
+def test_fps_bucket_sampler_vs_oracle(ext, oracle, mode, name, monkeypatch):
+    monkeypatch.setenv("EDA_FPS_BUCKET", "1")        # (default policy: the cluster kernels, repaired by this sampler)
+    p, m = _bucket_cases()[name]
+    oracle.set_fma_mode(mode); ext.set_fma_mode(mode)
+    oracle.set_threads(os.cpu_count() or 1)
+    try:
+        exp = oracle.furthest_point_sampling(t(p), m, mt=True).numpy()
+        got = ext.furthest_point_sampling(dev(p), m).cpu().numpy()
+    finally:
+        oracle.set_fma_mode(0); ext.set_fma_mode(0); oracle.set_threads(1)
+    bad = np.argwhere(got != exp)
+    assert bad.size == 0, (name, mode, bad[:5], got[got != exp][:5], exp[got != exp][:5])
+    assert ext.fps_status() == 0
+
+
+def test_fps_bucket_sampler_equals_the_cluster_kernels_and_needs_no_co_residency(ext, oracle, monkeypatch):
+    """Bench geometry (8 x 50 000 -> 2048, synthetic rooms): the bucket sampler, the round-3 cluster kernels
+    (EDA_FPS_BUCKET=0) and the oracle agree; the bucket sampler also while another stream keeps every CU busy (the
+    cluster kernels need ~100 co-resident workgroups and give up without them)."""
+    from eda_amd import synthetic
+    xyz = torch.from_numpy(synthetic.batch(range(40, 48), 50000)[:, :, :3].copy()).cuda()
+    monkeypatch.setenv("EDA_FPS_BUCKET", "1")
+    got = ext.furthest_point_sampling(xyz, 2048)
+    monkeypatch.setenv("EDA_FPS_BUCKET", "0")
+    old = ext.furthest_point_sampling(xyz, 2048)
+    monkeypatch.setenv("EDA_FPS_BUCKET", "1")
+    assert torch.equal(got, old)
+    oracle.set_threads(os.cpu_count() or 1)
+    try:
+        exp = oracle.furthest_point_sampling(xyz[:2].cpu(), 2048, mt=True)
+    finally:
+        oracle.set_threads(1)
+    assert torch.equal(got[:2].cpu(), exp)
+    busy = torch.cuda.Stream()
+    a = torch.randn(8192, 8192, device="cuda")
+    with torch.cuda.stream(busy):
+        for _ in range(6):
+            a = (a @ a).clamp_(-1, 1)
+    again = ext.furthest_point_sampling(xyz, 2048)
+    torch.cuda.synchronize()
+    assert torch.equal(again, got) and ext.fps_status() == 0

@@ -45,6 +45,7 @@ def main():
         sync_bn.enable()
         assert sync_bn.fused_hook_installed()
         parallel.reserve_cus_for_collectives(32)
+        parallel.sampler_without_co_residency()
 
     torch.manual_seed(0)
     model = BeaUTyDETR(num_queries=64, num_decoder_layers=2, butd=True)

@@ -37,6 +37,10 @@ def main():
     prof = ws[:256].view(torch.int32)[16:23].tolist()
     if any(prof):
         names = ["update+lists", "wave top-K", "barrier1", "wg rank+publish", "poll", "global rank+accept", "barrier2"]
+        if L.eda_fps_workspace_bytes(B, N, M) > 256 + B * 2 * 64 * 8 * 8 and os.environ.get("EDA_FPS_BUCKET", "1") != "0":
+            names = ["candidates", "flag pass", "dense rounds", "load", "round update", "round barrier", "arg-max"]
+            extra = ws[:256].view(torch.int32)[24:28].tolist()
+            print("   bucket sampler, scene 0: dense rounds %d, register rounds %d (unsafe %d), groups loaded %d" % tuple(extra))
         tot = sum(prof)
         print("   cycle shares (wave 0 of workgroup 0, scene 0): " +
               ", ".join(f"{n} {100 * v / tot:.0f}%" for n, v in zip(names, prof)) +
