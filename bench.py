@@ -101,6 +101,9 @@ def algorithmic_flops(name):
     if op == "mha_fwd":
         b, h, lq, lk = d
         return 4.0 * b * h * lq * lk * 36
+    if op == "mha_qproj_fwd":                 # q-projection (2 * rows * 288 * 288) + QK^T + PV in one launch
+        b, h, lq, lk = d
+        return 4.0 * b * h * lq * lk * 36 + 2.0 * b * lq * (h * 36) * (h * 36)
     if op == "mha_bwd":
         b, h, lq, lk = d
         return 10.0 * b * h * lq * lk * 36
@@ -350,6 +353,10 @@ def main():
                     help="N > 1: 1 = all-reduce the first half of the flat gradient buffer underneath the grouped "
                          "weight-gradient kernel of the second half (FlatParams.flush_and_reduce); 0 = one all-reduce "
                          "after the whole backward")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1: initialise a ONE-rank RCCL process group and run the step exactly as at N > 1 (bucket sampler "
+                         "policy, split graphs, the two-range all-reduce through RCCL between them, optional --sync-bn "
+                         "collectives inside the captured graphs): the multi-GPU code path on the one GPU a test box has")
     ap.add_argument("--split-graphs", action="store_true",
                     help="use the N>1 graph structure (two graphs, eager all-reduce slot) even at N=1")
     ap.add_argument("--kernel-steps", type=int, default=3,
@@ -383,8 +390,13 @@ def main():
         local_rank = 0                  # functional test of the N > 1 structure on a one-GPU box (never a measurement)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist       # the step has collectives in it
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); os.environ.setdefault("MASTER_PORT", str(s_.getsockname()[1])); s_.close()
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.share_gpu or args.dist_backend == "gloo":
             dist.init_process_group("gloo")         # (RCCL refuses two ranks on one device)
         else:
@@ -397,9 +409,13 @@ def main():
             _par.sampler_without_co_residency()
 
     from eda_amd import ext
-    if args.sync_bn and world > 1:
+    if args.sync_bn and dist_on:
         from eda_amd import sync_bn
-        sync_bn.enable()        # fused SA / FP calls keep their fusion (library hook); no host synchronisation anywhere, so the
+        if dist.get_backend() == "gloo" and args.graph:
+            log_early = lambda m: print("[bench] " + m, file=sys.stderr, flush=True)
+            log_early("gloo collectives cannot be captured in a HIP graph: --sync-bn with gloo runs eager (--graph 0)")
+            args.graph = 0
+        sync_bn.enable(single_rank_too=(world == 1))        # fused SA / FP calls keep their fusion (library hook); no host synchronisation anywhere, so the
         # step is captured like the default one (a capture failure falls back to eager launches below)
     from eda_amd.bdetr import BeaUTyDETR
     from eda_amd.parallel import FlatParams, reference_lr_groups
@@ -481,7 +497,7 @@ def main():
     # N > 1: the flat gradient is reduced in two ranges, the first one's all-reduce in flight underneath the second
     # range's grouped weight-gradient kernel (DDP overlaps its buckets with the backward, main_utils.py:343-346; here
     # everything the collective needs is produced at the very end of the backward)
-    overlap_ar = world > 1 and bool(args.overlap_allreduce) and bool(args.defer_wgrad)
+    overlap_ar = dist_on and bool(args.overlap_allreduce) and bool(args.defer_wgrad)
     ar_mid, ar_total, ar_works = flat.split_offset(0.5), flat.flat_grad.numel(), []
 
     def backward(loss):
@@ -513,7 +529,7 @@ def main():
     def all_reduce():
         if overlap_ar:
             reduce_a(); stage_b(); reduce_b()
-        elif world > 1:
+        elif dist_on:
             dist.all_reduce(flat.flat_grad)
 
     def record_loss(loss):
@@ -560,7 +576,7 @@ def main():
             for _ in range(2):
                 eager_step()
         torch.cuda.current_stream().wait_stream(side)
-        barrier_sync = (lambda: (dist.barrier() if world > 1 else None, torch.cuda.synchronize()))
+        barrier_sync = (lambda: (dist.barrier() if dist_on else None, torch.cuda.synchronize()))
         barrier_sync()
         # thread-local capture mode: calls from other threads (RCCL's watchdog) must not
         # invalidate the capture.
@@ -572,9 +588,9 @@ def main():
                 # second stream underneath [point backbone | rest of the forward, loss, backward (, clip + AdamW at N = 1)]
                 pipe = pipeline.PipelinedTrainStep(
                     model, batches[0], loss_fn, backward, update, stream=side,
-                    all_reduce=all_reduce if (world > 1 and not overlap_ar) else None,
+                    all_reduce=all_reduce if (dist_on and not overlap_ar) else None,
                     post_stages=[(None, reduce_a), (stage_b, reduce_b)] if overlap_ar else None,
-                    split_update=(world > 1 or args.split_graphs),
+                    split_update=(dist_on or args.split_graphs),
                     prefetch={0: None, 1: "sa1", 2: "geometry"}[args.fps_prefetch],
                     text_prefetch=bool(args.text_prefetch), after_loss=record_loss)
                 static_loss = pipe.loss
@@ -584,7 +600,7 @@ def main():
                     pcount[0] += 1
                     return pipe.step(next_batch=batches[pcount[0] % nb] if nb > 1 else None)
 
-            elif world == 1 and not args.split_graphs:
+            elif not dist_on and not args.split_graphs:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=side, **mode):
                     static_loss = core_step()
@@ -665,7 +681,7 @@ def main():
     # trained inside it (the reference's loop structure) -- timed in the same run so that both schedules are on the
     # driver's clock
     in_step = None
-    if args.graph and world == 1 and args.text_stream and not args.overlap and not args.split_graphs and args.in_step_steps > 0:
+    if args.graph and not dist_on and args.text_stream and not args.overlap and not args.split_graphs and args.in_step_steps > 0:
         try:
             g_one = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
@@ -854,9 +870,9 @@ def main():
                            not args.no_butd, args.loss),
                        "scenes_per_gpu": args.per_gpu, "global_batch": args.per_gpu * world,
                        "points": args.points, "queries": args.queries, "tokens": args.tokens,
-                       "parallelism": f"dp{world}" + (" (ALL RANKS ON ONE GPU, gloo collectives: functional run of the N > 1 "
+                       "parallelism": f"dp{world}" + (" (--force-dist: one-rank RCCL group, the N > 1 step structure)" if (args.force_dist and world == 1) else "") + (" (ALL RANKS ON ONE GPU, gloo collectives: functional run of the N > 1 "
                                                        "structure, not a measurement)" if args.share_gpu else ""),
-                       "gradient_allreduce": (None if world == 1 else
+                       "gradient_allreduce": (None if not dist_on else
                                               "two ranges of the flat fp32 buffer, the first in flight underneath the second "
                                               "range's grouped weight-gradient kernel" if overlap_ar else
                                               "one all-reduce of the flat fp32 buffer after the backward"),
@@ -903,7 +919,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = run_cpu_baseline(args)
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

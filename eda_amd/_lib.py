@@ -62,6 +62,9 @@ SIGNATURES = {
     "eda_mha_fwd_hd64_f32": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _l, _p, _i, _i, _i, _i, _f, _p, _p]),
     "eda_mha_fwd": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _l, _p, _i, _i, _i, _i, _i, _f, _f,
                         _p, _u, _p, _p, _i, _p]),
+    "eda_mha_qproj_supported": (_i, [_i, _i, _i]),
+    "eda_mha_qproj_fwd": (_i, [_p, _l, _l, _p, _l, _p, _p, _p, _l, _l, _l, _l, _p, _i, _i, _i, _i, _i, _f, _f, _p, _u,
+                              _p, _l, _l, _p, _p, _i, _p]),
     "eda_mha_bwd": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _l, _p, _i, _i, _i, _i, _i, _f, _f,
                         _p, _u, _p, _p, _p, _l, _l, _p, _p, _p, _p, _l, _l, _l, _l, _l, _l, _p, _sz, _i, _p]),
     "eda_wgrad_workspace_bytes": (_sz, [_l, _i, _i]),

@@ -151,6 +151,46 @@ class _FusedMHA(Function):
         return dq, dk, dv, None, None, None, None
 
 
+def _qproj_fused_ok(d, num_heads, Lk, *tensors):
+    """The fused [q-projection | attention core] launch (include/eda_hip.h eda_mha_qproj_fwd) takes this site.
+    Measured (tools/time_qproj_site.py, graph replay, B = 8): 256 queries x 80 / 132 keys 15.3 / 17.0 us against 18.5 /
+    19.4 us for the two launches (one workgroup of 64 queries x 1 head per CU, one round); 1024 queries: 62 / 71 us against
+    36 / 42 us (four rounds of 106 KB workgroups) -- so the default takes the launch only while it is ONE round of the
+    chip (EDA_MHA_QPROJ=1 forces it, =0 switches it off)."""
+    import os
+    mode = os.environ.get("EDA_MHA_QPROJ", "auto")
+    if mode == "0" or d % num_heads or not all(t.is_cuda and t.dtype == torch.float32 for t in tensors):
+        return False
+    if not _lib.lib().eda_mha_qproj_supported(num_heads, d // num_heads, int(Lk)):
+        return False
+    x = tensors[0]
+    one_round = x.shape[0] * num_heads * ((x.shape[1] + 63) // 64) <= 256
+    return mode == "1" or one_round
+
+
+def _qproj_core_fwd(x, Wq, bq, k, v, m8, num_heads, p_drop, salt):
+    """q = x Wq^T + bq and softmax(q k^T / sqrt(hd) + mask) v in ONE launch.  Returns (q, out, lse)."""
+    x = _rows(x)
+    B, Lq, d = x.shape
+    Lk = k.shape[1]
+    hd = d // num_heads
+    dev = x.device
+    q = torch.empty((B, Lq, d), dtype=torch.float32, device=dev)
+    out = torch.empty((B, Lq, d), dtype=torch.float32, device=dev)
+    lse = torch.empty((B, num_heads, Lq), dtype=torch.float32, device=dev)
+    Wq = gemm._rows2d(Wq)
+    seed = dropout_state(dev) if p_drop > 0 else None
+    with torch.cuda.device(dev), _timed('mha_qproj_fwd', (B, num_heads, Lq, Lk)):
+        rc = _lib.lib().eda_mha_qproj_fwd(
+            x.data_ptr(), x.stride(0), x.stride(1), Wq.data_ptr(), gemm._ld(Wq), bq.data_ptr() if bq is not None else None,
+            k.data_ptr(), v.data_ptr(), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+            m8.data_ptr() if m8 is not None else None, B, num_heads, Lq, Lk, hd, hd ** -0.5, float(p_drop),
+            seed.data_ptr() if seed is not None else None, int(salt), q.data_ptr(), q.stride(0), q.stride(1),
+            out.data_ptr(), lse.data_ptr(), _compute_dtype, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "eda_mha_qproj_fwd")
+    return q, out, lse
+
+
 class _ProjectedMHA(Function):
     """In-projection + attention core as ONE autograd node (GPU training path of
     MultiheadAttention).  `groups` lists, per distinct input tensor, the row range [lo, hi) of
@@ -168,28 +208,36 @@ class _ProjectedMHA(Function):
         dev = W.device
         B = xs[0].shape[0]
         x2s, Ps, cols = [], [], {}
-        for x, (lo, hi) in zip(xs, groups):
+        m8 = mask.contiguous().view(torch.uint8) if mask is not None else None
+        # a query projected on its own (cross-attention) over a short key set: the projection rides in the attention launch
+        fuse_q = (groups[0] == (0, d) and len(groups) > 1 and b is not None
+                  and _qproj_fused_ok(d, num_heads, xs[1].shape[1], *xs))
+        for gi, (x, (lo, hi)) in enumerate(zip(xs, groups)):
             x2 = x.reshape(-1, d)
-            P = gemm.linear_fwd(x2, W[lo:hi], b[lo:hi]).view(B, -1, hi - lo)
+            P = None if (fuse_q and gi == 0) else gemm.linear_fwd(x2, W[lo:hi], b[lo:hi]).view(B, -1, hi - lo)
             x2s.append(x2)
             Ps.append(P)
             for j in range(lo // d, hi // d):
                 cols[j] = (len(Ps) - 1, j * d - lo)
-        q, k, v = (Ps[g][..., c:c + d] for g, c in (cols[0], cols[1], cols[2]))
-        Lq, Lk = q.shape[1], k.shape[1]
-        hd = d // num_heads
-        out = torch.empty((B, Lq, d), dtype=torch.float32, device=dev)
-        lse = torch.empty((B, num_heads, Lq), dtype=torch.float32, device=dev)
-        m8 = mask.contiguous().view(torch.uint8) if mask is not None else None
-        seed = dropout_state(dev) if p_drop > 0 else None
-        with torch.cuda.device(dev), _timed('mha_fwd', (B, num_heads, Lq, Lk)):
-            rc = _lib.lib().eda_mha_fwd(
-                q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
-                k.stride(1), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else None,
-                B, num_heads, Lq, Lk, hd, hd ** -0.5, float(p_drop),
-                seed.data_ptr() if seed is not None else None, int(salt), out.data_ptr(),
-                lse.data_ptr(), _compute_dtype, torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "eda_mha_fwd")
+        if fuse_q:
+            k, v = (Ps[g][..., c:c + d] for g, c in (cols[1], cols[2]))
+            q, out, lse = _qproj_core_fwd(xs[0], W[:d], b[:d], k, v, m8, num_heads, p_drop, salt)
+            Ps[0] = q
+        else:
+            q, k, v = (Ps[g][..., c:c + d] for g, c in (cols[0], cols[1], cols[2]))
+            Lq, Lk = q.shape[1], k.shape[1]
+            hd = d // num_heads
+            out = torch.empty((B, Lq, d), dtype=torch.float32, device=dev)
+            lse = torch.empty((B, num_heads, Lq), dtype=torch.float32, device=dev)
+            seed = dropout_state(dev) if p_drop > 0 else None
+            with torch.cuda.device(dev), _timed('mha_fwd', (B, num_heads, Lq, Lk)):
+                rc = _lib.lib().eda_mha_fwd(
+                    q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
+                    k.stride(1), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else None,
+                    B, num_heads, Lq, Lk, hd, hd ** -0.5, float(p_drop),
+                    seed.data_ptr() if seed is not None else None, int(salt), out.data_ptr(),
+                    lse.data_ptr(), _compute_dtype, torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "eda_mha_fwd")
         ctx.dtype_code = _compute_dtype
         ctx.save_for_backward(W, out, lse, b, *x2s, *Ps)
         ctx.mask8 = m8
@@ -352,22 +400,26 @@ class _ProjectedMHAPreKV(Function):
         dev = W.device
         B, Lq = x.shape[0], x.shape[1]
         x2 = x.reshape(-1, d)
-        q = gemm.linear_fwd(x2, W[:d], b[:d]).view(B, Lq, d)
         k, v = kv[..., :d], kv[..., d:]
         Lk = kv.shape[1]
         hd = d // num_heads
-        out = torch.empty((B, Lq, d), dtype=torch.float32, device=dev)
-        lse = torch.empty((B, num_heads, Lq), dtype=torch.float32, device=dev)
         m8 = mask.contiguous().view(torch.uint8) if mask is not None else None
-        seed = dropout_state(dev) if p_drop > 0 else None
-        with torch.cuda.device(dev), _timed('mha_fwd', (B, num_heads, Lq, Lk)):
-            rc = _lib.lib().eda_mha_fwd(
-                q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
-                k.stride(1), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else None,
-                B, num_heads, Lq, Lk, hd, hd ** -0.5, float(p_drop),
-                seed.data_ptr() if seed is not None else None, int(salt), out.data_ptr(),
-                lse.data_ptr(), _compute_dtype, torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "eda_mha_fwd")
+        if b is not None and _qproj_fused_ok(d, num_heads, Lk, x, kv):
+            # short key set (text tokens, detected boxes): the q-projection rides in the attention launch
+            q, out, lse = _qproj_core_fwd(x, W[:d], b[:d], k, v, m8, num_heads, p_drop, salt)
+        else:
+            q = gemm.linear_fwd(x2, W[:d], b[:d]).view(B, Lq, d)
+            out = torch.empty((B, Lq, d), dtype=torch.float32, device=dev)
+            lse = torch.empty((B, num_heads, Lq), dtype=torch.float32, device=dev)
+            seed = dropout_state(dev) if p_drop > 0 else None
+            with torch.cuda.device(dev), _timed('mha_fwd', (B, num_heads, Lq, Lk)):
+                rc = _lib.lib().eda_mha_fwd(
+                    q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
+                    k.stride(1), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else None,
+                    B, num_heads, Lq, Lk, hd, hd ** -0.5, float(p_drop),
+                    seed.data_ptr() if seed is not None else None, int(salt), out.data_ptr(),
+                    lse.data_ptr(), _compute_dtype, torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "eda_mha_fwd")
         ctx.dtype_code = _compute_dtype
         ctx.save_for_backward(W, b, x2, q, kv, out, lse)
         ctx.mask8 = m8

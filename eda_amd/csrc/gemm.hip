@@ -1704,7 +1704,13 @@ extern "C" int eda_linear_add_dropout_ln_fwd_f32(const float *x, long ldx, long 
   } else {
     a.row_blocks = (R + 15) / 16;
     const long blocks = (a.row_blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL((gemm_dma_kernel<16, 288, 1, 6, W_NT, 2, true>), dim3((unsigned)blocks), dim3(384), 0, stream, a);
+    // experiment switch (tools/bench_linear_ln.py): ring depth x waves of the 16-row variant
+    static const int var = [] { const char *e = getenv("EDA_GEMM_LN_VAR"); return e ? atoi(e) : 0; }();
+    if (var == 63) hipLaunchKernelGGL((gemm_dma_kernel<16, 288, 1, 6, W_NT, 3, true>), dim3((unsigned)blocks), dim3(384), 0, stream, a);
+    else if (var == 64) hipLaunchKernelGGL((gemm_dma_kernel<16, 288, 1, 6, W_NT, 4, true>), dim3((unsigned)blocks), dim3(384), 0, stream, a);
+    else if (var == 92) hipLaunchKernelGGL((gemm_dma_kernel<16, 288, 1, 9, W_NT, 2, true>), dim3((unsigned)blocks), dim3(576), 0, stream, a);
+    else if (var == 94) hipLaunchKernelGGL((gemm_dma_kernel<16, 288, 1, 9, W_NT, 4, true>), dim3((unsigned)blocks), dim3(576), 0, stream, a);
+    else hipLaunchKernelGGL((gemm_dma_kernel<16, 288, 1, 6, W_NT, 2, true>), dim3((unsigned)blocks), dim3(384), 0, stream, a);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { eda_set_error("linear_add_dropout_ln: launch failed: %s", hipGetErrorString(e)); return (int)e; }

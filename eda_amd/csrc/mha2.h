@@ -23,9 +23,16 @@ struct Mha2Args {
   int dtype;         // EDA_DTYPE_F32 (exact fp32 MFMA: the parity path) / BF16 / F16 contractions, fp32 accumulate
   float *dq_part;    // bwd: [key block][B][Lq][H*36] dense partials of dQ (n_kb > 1)
   float *dkv_part;   // bwd: [query split][dk | dv][B][Lk][H*36] dense partials (n_qs > 1)
+  // q-projection fused in front of the forward (eda_mha_qproj_fwd): q = xq Wq^T + bq is computed per (query block, head)
+  // inside the attention launch and WRITTEN to q_out (the backward reads it like any projected q)
+  const float *xq; long xq_sb, xq_sl;         // (B, Lq, H*36) input rows of the q-projection
+  const float *wq; long ldwq;                 // (H*36, H*36) weight, row-major (row = output column)
+  const float *bq;                            // (H*36) bias or null
+  float *q_out; long qo_sb, qo_sl;
 };
 
 // 0 = launched, EDA_ERR_* otherwise.  Both enqueue on `stream` only, allocate nothing, never synchronise.
 int eda_mha2_fwd_launch(Mha2Args &a, hipStream_t stream);
+int eda_mha2_qproj_fwd_launch(Mha2Args &a, hipStream_t stream);      // Lk <= 192
 int eda_mha2_bwd_launch(Mha2Args &a, void *ws, size_t ws_bytes, hipStream_t stream);
 size_t eda_mha2_bwd_workspace_bytes(int B, int H, int Lq, int Lk);

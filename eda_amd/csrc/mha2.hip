@@ -453,6 +453,151 @@ __global__ __launch_bounds__(NQ * KS * 64) void mha2_fwd_kernel(const Mha2Args a
   }
 }
 
+// ============================================================ forward with the q-projection fused in front ==
+// One launch for [q = x Wq^T + bq | softmax(q K^T) V] of an attention site whose key set is short (Lk <= 192: the text
+// tokens and detected boxes of models/encoder_decoder_layers.py:99-117, 375-391) -- for those sites the attention
+// core alone is a 10 us launch at ~10 % of the MFMA peak, most of it the launch floor, with an 11 us projection
+// launch in front of it.  Workgroup = 4 waves = 64 queries of one (scene, head): every head computes ITS 36 columns
+// of q (no redundant product), so the fused launch does the work of both at one launch floor.
+//   * the wave's 16 input rows go straight from memory into registers as MFMA operand fragments (lane (c, g) holds
+//     x[query c][16 j + 4 g .. + 3], j < 18: all 18 loads in flight at once; the contraction order is a permutation of
+//     the input index, which a dot product does not care about);
+//   * the head's 36 weight rows (41 KB) are staged once per workgroup into LDS with row stride 292 (conflict-free
+//     16-byte operand reads), K and V of the (scene, head) by LDS-DMA as in the plain forward;
+//   * q^T[dim][query] accumulates in three 16-row tiles (216 MFMAs), gets its bias, is written to memory (the backward
+//     needs it) and, through a wave-private LDS strip, becomes the query operand of the unchanged forward tiles.
+constexpr int QP_W = 292;          // LDS row stride of the weight rows
+constexpr int QP_D = 288;          // input width of the projection (= 8 heads x 36)
+template <bool DROP, class AR>
+__global__ __launch_bounds__(256) void mha2_qproj_fwd_kernel(const Mha2Args a) {
+  constexpr int CHK = 192, NQ = 4;
+  __shared__ __attribute__((aligned(16))) float Ks0[CHK * HD];
+  __shared__ __attribute__((aligned(16))) float Vs0[CHK * HD];
+  __shared__ __attribute__((aligned(16))) float Ws[HD * QP_W];
+  __shared__ __attribute__((aligned(16))) float Qs[NQ][16 * HD];
+  __shared__ unsigned dead_s[CHK / 4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int BH = a.B * a.H;
+  const int bh = (int)(blockIdx.x % (unsigned)BH), qb = (int)(blockIdx.x / (unsigned)BH);
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int qi = qb * (16 * NQ) + 16 * wave + c;
+  const bool qvalid = qi < a.Lq;
+  const bool wave_live = qb * (16 * NQ) + 16 * wave < a.Lq;
+
+  // this lane's fragments of its input row (clamped row: no predicate on the loads)
+  float4 xf[18];
+  {
+    const float *xr = a.xq + (long)b * a.xq_sb + (long)min(qi, a.Lq - 1) * a.xq_sl + 4 * g;
+#pragma unroll
+    for (int j = 0; j < 18; ++j) xf[j] = *reinterpret_cast<const float4 *>(xr + 16 * j);
+  }
+  // K, V of the (scene, head) by DMA; dead-key flags; the head's weight rows through registers (padded rows)
+  const float *kbase = a.k + (long)b * a.k_sb + h * HD;
+  const float *vbase = a.v + (long)b * a.v_sb + h * HD;
+  const unsigned char *mrow = a.mask ? a.mask + (long)b * a.Lk : nullptr;
+  for (int w = tid; w < CHK / 4; w += 256) {
+    unsigned word = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = 4 * w + r;
+      unsigned dead = key >= a.Lk ? 1u : 0u;
+      if (key < a.Lk && mrow) dead = mrow[key] ? 1u : 0u;
+      word |= dead << (8 * r);
+    }
+    dead_s[w] = word;
+  }
+  dma_rows<CHK>(Ks0, kbase, a.k_sl, 0, a.Lk, wave, NQ, lane, 0);
+  dma_rows<CHK>(Vs0, vbase, a.v_sl, 0, a.Lk, wave, NQ, lane, CHK * 9 / 64);
+  {
+    const float *wb = a.wq + (long)(h * HD) * a.ldwq;
+    for (int i = tid; i < HD * (QP_D / 4); i += 256) {
+      const int row = i / (QP_D / 4), c4 = i - row * (QP_D / 4);
+      *reinterpret_cast<float4 *>(Ws + row * QP_W + 4 * c4) = *reinterpret_cast<const float4 *>(wb + (long)row * a.ldwq + 4 * c4);
+    }
+  }
+  __syncthreads();
+
+  // q^T[dim 16 t + 4 g + i][query c] = sum_k W[dim][k] x[query][k]
+  f32x4 qa[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  {
+    const float *w0 = Ws + c * QP_W + 4 * g, *w1 = w0 + 16 * QP_W, *w2 = Ws + min(32 + c, HD - 1) * QP_W + 4 * g;
+#pragma unroll
+    for (int j = 0; j < 18; ++j) {
+      const float4 a0 = *reinterpret_cast<const float4 *>(w0 + 16 * j);
+      const float4 a1 = *reinterpret_cast<const float4 *>(w1 + 16 * j);
+      const float4 a2 = *reinterpret_cast<const float4 *>(w2 + 16 * j);
+      const float xs[4] = {xf[j].x, xf[j].y, xf[j].z, xf[j].w};
+      const float s0[4] = {a0.x, a0.y, a0.z, a0.w}, s1[4] = {a1.x, a1.y, a1.z, a1.w}, s2[4] = {a2.x, a2.y, a2.z, a2.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        qa[0] = mfma4(s0[i], xs[i], qa[0]);
+        qa[1] = mfma4(s1[i], xs[i], qa[1]);
+        qa[2] = mfma4(s2[i], xs[i], qa[2]);
+      }
+    }
+  }
+  {
+    // bias, memory (for the backward), LDS strip (-> operand layout of the forward tiles)
+    float *qrow = a.q_out + (long)b * a.qo_sb + (long)(qvalid ? qi : 0) * a.qo_sl + h * HD;
+    float *qs = Qs[wave] + c * HD;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      if (t == 2 && g != 0) break;                       // dims 32..35 live in lane group 0 of the third tile
+      float4 v = make_float4(qa[t][0], qa[t][1], qa[t][2], qa[t][3]);
+      if (a.bq) {
+        const float4 bb = *reinterpret_cast<const float4 *>(a.bq + h * HD + 16 * t + 4 * g);
+        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+      }
+      *reinterpret_cast<float4 *>(qs + 16 * t + 4 * g) = v;
+      if (qvalid) *reinterpret_cast<float4 *>(qrow + 16 * t + 4 * g) = v;
+    }
+  }
+  float qreg[KSTEPS];
+  load_row_operand(qreg, Qs[wave] + c * HD, g);           // (same wave wrote it: LDS is in order per wave)
+  {
+    const float sc = a.scale * LOG2E;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) qreg[s] = qvalid ? qreg[s] * sc : 0.f;
+  }
+  Row16 q16 = {{0, 0, 0}};
+  if constexpr (AR::is16) q16 = pack_row<AR>(qreg);
+  DropCfg dc = {0u, 0u, 1.f};
+  if (DROP) dc = drop_cfg(a);
+  const unsigned rowbase = ((unsigned)bh * (unsigned)a.Lq + (unsigned)qi) * (unsigned)a.Lk;
+
+  float m = -INFINITY, lsum = 0.f;
+  f32x4 o[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  if (wave_live) {
+#pragma unroll 1
+    for (int t = 0; t < CHK / 64; ++t) {
+      const int key0 = 64 * t;
+      if (key0 >= a.Lk) break;
+      const int nsub = min(4, (a.Lk - key0 + 15) >> 4);
+      const bool need_mask = (mrow != nullptr) || (key0 + 64 > a.Lk);
+      const float *Kt = Ks0 + 64 * t * HD, *Vt = Vs0 + 64 * t * HD;
+      const unsigned *dw = dead_s + 16 * t;
+      if (nsub == 4) fwd_tile<4, DROP, AR>(Kt, Vt, dw, need_mask, qreg, q16, c, g, key0, rowbase, dc, m, lsum, o);
+      else if (nsub == 3) fwd_tile<3, DROP, AR>(Kt, Vt, dw, need_mask, qreg, q16, c, g, key0, rowbase, dc, m, lsum, o);
+      else if (nsub == 2) fwd_tile<2, DROP, AR>(Kt, Vt, dw, need_mask, qreg, q16, c, g, key0, rowbase, dc, m, lsum, o);
+      else fwd_tile<1, DROP, AR>(Kt, Vt, dw, need_mask, qreg, q16, c, g, key0, rowbase, dc, m, lsum, o);
+    }
+  }
+  lsum = grp_sum(lsum);
+  o[2] = grp_sum4(o[2]);
+  if (qvalid) {
+    const float inv = dc.inv_keep / lsum;          // all keys masked -> NaN, like the reference
+    float *orow = a.o + (long)b * a.o_sb + (long)qi * a.o_sl + h * HD;
+    *reinterpret_cast<float4 *>(orow + 4 * g) = make_float4(o[0][0] * inv, o[0][1] * inv, o[0][2] * inv, o[0][3] * inv);
+    *reinterpret_cast<float4 *>(orow + 16 + 4 * g) = make_float4(o[1][0] * inv, o[1][1] * inv, o[1][2] * inv, o[1][3] * inv);
+    if (g == 0) {
+      *reinterpret_cast<float4 *>(orow + 32) = make_float4(o[2][0] * inv, o[2][1] * inv, o[2][2] * inv, o[2][3] * inv);
+      a.lse[(long)bh * a.Lq + qi] = (m + __builtin_amdgcn_logf(lsum)) * LN2;
+    }
+  }
+}
+
 // ======================================================================================= backward ==========
 // KSUB key sub-tiles (16 keys each) x QG query groups = NW waves; QC queries per chunk, NBUF chunk buffers.
 //   phase A  wave (ks, qg): for the chunk's 16-query sub-tiles j = qg, qg + QG, ...: S = Q K^T, dP = dO V^T (18 MFMA),
@@ -1007,6 +1152,23 @@ int eda_mha2_fwd_launch(Mha2Args &a, hipStream_t stream) {
   return launch_fwd<16, 1, 256, 2>(a, stream);
 }
 
+int eda_mha2_qproj_fwd_launch(Mha2Args &a, hipStream_t stream) {
+  if (a.B == 0 || a.Lq == 0) return 0;
+  const dim3 g((unsigned)(a.B * a.H * ((a.Lq + 63) / 64))), b(256);
+  const bool drop = a.p_drop > 0.f;
+#define EDA_QP(AR)                                                                                   \
+  do {                                                                                               \
+    if (drop) hipLaunchKernelGGL((mha2_qproj_fwd_kernel<true, AR>), g, b, 0, stream, a);             \
+    else hipLaunchKernelGGL((mha2_qproj_fwd_kernel<false, AR>), g, b, 0, stream, a);                 \
+  } while (0)
+  if (a.dtype == EDA_DTYPE_BF16) EDA_QP(ArBf16);
+  else if (a.dtype == EDA_DTYPE_F16) EDA_QP(ArFp16);
+  else EDA_QP(ArF32);
+#undef EDA_QP
+  EDA_CHECK_LAUNCH();
+  return 0;
+}
+
 #ifdef EDA_MHA2_PROFILE
 extern "C" int eda_mha2_profile_read(unsigned long long *out16) {
   static unsigned long long all[64 * 8], zero[64 * 8];
@@ -1109,6 +1271,37 @@ extern "C" int eda_mha_fwd(const float *q, const float *k, const float *v, long 
   m.lse = lse; m.mask = key_padding_mask; m.B = B; m.H = H; m.Lq = Lq; m.Lk = Lk; m.scale = scale;
   m.p_drop = p_drop; m.seed_ptr = seed_ptr; m.salt = salt; m.dtype = dtype;
   return eda_mha2_fwd_launch(m, stream);
+}
+
+extern "C" int eda_mha_qproj_supported(int H, int head_dim, int Lk) { return H * head_dim == QP_D && head_dim == HD && Lk >= 1 && Lk <= 192; }
+
+extern "C" int eda_mha_qproj_fwd(const float *x, long x_sb, long x_sl, const float *wq, long ldwq, const float *bq,
+                                 const float *k, const float *v, long k_sb, long k_sl, long v_sb, long v_sl,
+                                 const unsigned char *key_padding_mask, int B, int H, int Lq, int Lk, int head_dim, float scale,
+                                 float p_drop, const unsigned long long *seed_ptr, unsigned salt, float *q_out, long q_sb,
+                                 long q_sl, float *out, float *lse, int dtype, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(dtype == EDA_DTYPE_F32 || dtype == EDA_DTYPE_BF16 || dtype == EDA_DTYPE_F16,
+                "dtype must be EDA_DTYPE_F32 / BF16 / F16");
+  EDA_CHECK_ARG(B >= 0 && H > 0 && Lq >= 0, "bad dimension");
+  EDA_CHECK_ARG(eda_mha_qproj_supported(H, head_dim, Lk), "the fused launch exists for 8 heads x 36 and 1..192 keys");
+  if (B == 0 || Lq == 0) return 0;
+  EDA_CHECK_ARG(x && wq && k && v && q_out && out && lse, "null pointer");
+  EDA_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed_ptr), "bad dropout arguments");
+  EDA_CHECK_ARG(mult4(x_sb) && mult4(x_sl) && mult4(ldwq) && mult4(k_sb) && mult4(k_sl) && mult4(v_sb) && mult4(v_sl) &&
+                    mult4(q_sb) && mult4(q_sl) && al16(x) && al16(wq) && al16(k) && al16(v) && al16(q_out) && al16(out) &&
+                    (!bq || al16(bq)),
+                "rows must be 16-byte aligned");
+  EDA_CHECK_ARG((long)B * H <= 65535, "B*H too large");
+  Mha2Args m = {};
+  m.q = q_out; m.q_sb = q_sb; m.q_sl = q_sl;
+  m.k = k; m.v = v; m.k_sb = k_sb; m.k_sl = k_sl; m.v_sb = v_sb; m.v_sl = v_sl;
+  m.o = out; m.o_sb = (long)Lq * H * HD; m.o_sl = (long)H * HD; m.lse = lse; m.mask = key_padding_mask;
+  m.B = B; m.H = H; m.Lq = Lq; m.Lk = Lk; m.scale = scale; m.p_drop = p_drop; m.seed_ptr = seed_ptr; m.salt = salt;
+  m.dtype = dtype;
+  m.xq = x; m.xq_sb = x_sb; m.xq_sl = x_sl; m.wq = wq; m.ldwq = ldwq; m.bq = bq;
+  m.q_out = q_out; m.qo_sb = q_sb; m.qo_sl = q_sl;
+  return eda_mha2_qproj_fwd_launch(m, stream);
 }
 
 extern "C" int eda_mha_fwd_f32(const float *q, const float *k, const float *v, long q_sb, long q_sl,

@@ -35,6 +35,7 @@ _enabled = False
 _fused_hook = None          # the ctypes callback object (must stay alive while registered)
 _buffers = {}               # id -> tensor: device buffers the native calls may ask to all-reduce parts of
 _reduce = None              # test seam: replaces dist.all_reduce(t, group) in the hook
+_single_rank_too = False    # run the exchange even in a ONE-rank group (bench.py --force-dist: the N > 1 code path on one GPU)
 
 _CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p)
 
@@ -90,25 +91,26 @@ def fused_hook_installed():
     return _fused_hook is not None
 
 
-def enable(group=None, fused=True):
+def enable(group=None, fused=True, single_rank_too=False):
     """Use global-batch statistics in every BN+ReLU site (requires an initialised process group).  fused=True (and a
-    GPU): the fused SA / FP calls stay fused and exchange their sums through the library hook."""
-    global _enabled, _group
+    GPU): the fused SA / FP calls stay fused and exchange their sums through the library hook.  single_rank_too: also
+    in a one-rank group (same results as without; exercises the collectives' code path on a one-GPU box)."""
+    global _enabled, _group, _single_rank_too
     if not dist.is_initialized():
         raise RuntimeError("sync_bn.enable() needs torch.distributed to be initialised")
-    _enabled, _group = True, group
-    if fused and torch.cuda.is_available() and dist.get_world_size(group) > 1:
+    _enabled, _group, _single_rank_too = True, group, bool(single_rank_too)
+    if fused and torch.cuda.is_available() and (dist.get_world_size(group) > 1 or single_rank_too):
         install_fused_hook(dist.get_world_size(group))
 
 
 def disable():
-    global _enabled, _group
-    _enabled, _group = False, None
+    global _enabled, _group, _single_rank_too
+    _enabled, _group, _single_rank_too = False, None, False
     remove_fused_hook()
 
 
 def enabled():
-    return _enabled and dist.is_initialized() and dist.get_world_size(_group) > 1
+    return _enabled and dist.is_initialized() and (dist.get_world_size(_group) > 1 or _single_rank_too)
 
 
 class _SyncBNReLU(Function):

@@ -193,6 +193,21 @@ int eda_mha_bwd(const float *q, const float *k, const float *v, long q_sb, long 
                 float *delta_ws, float *dq, float *dk, float *dv, long dq_sb, long dq_sl, long dk_sb,
                 long dk_sl, long dv_sb, long dv_sl, void *ws, size_t ws_bytes, int dtype, void *stream);
 
+/* The q-projection fused in front of the forward (csrc/mha2.hip, mha2_qproj_fwd_kernel): one launch computes
+ * q = x Wq^T + bq for a site whose key set is short (1 <= Lk <= 192: the text tokens / detected boxes of
+ * models/encoder_decoder_layers.py:99-117, 375-391 -> nn.MultiheadAttention's in-projection of the query followed by
+ * the attention core) and runs eda_mha_fwd's arithmetic on it.  x (B,Lq,H*36) with element strides (x_sb, x_sl); wq
+ * (H*36, H*36) row-major = rows [0, d) of in_proj_weight, leading dimension ldwq; bq (H*36) or NULL; k, v, mask, scale,
+ * dropout, out, lse, dtype as in eda_mha_fwd.  q_out (B,Lq,H*36) with strides (q_sb, q_sl) receives the projected,
+ * UNSCALED q: eda_mha_bwd takes it as its `q`.  eda_mha_qproj_supported(H, head_dim, Lk) != 0 says whether the launch
+ * exists for a shape. */
+int eda_mha_qproj_supported(int H, int head_dim, int Lk);
+int eda_mha_qproj_fwd(const float *x, long x_sb, long x_sl, const float *wq, long ldwq, const float *bq,
+                      const float *k, const float *v, long k_sb, long k_sl, long v_sb, long v_sl,
+                      const unsigned char *key_padding_mask, int B, int H, int Lq, int Lk, int head_dim, float scale,
+                      float p_drop, const unsigned long long *seed_ptr, unsigned salt, float *q_out, long q_sb, long q_sl,
+                      float *out, float *lse, int dtype, void *stream);
+
 /* ---- set-abstraction grouped MLP, channels-last pipeline -----------------
  * Rows are positions (scene, centre j, neighbour k) of a (b*m*ns, C) matrix.
  *

@@ -285,3 +285,59 @@ def test_16bit_attention_dropout_consistency(dtype):
     tot_out = o1.detach().view(B, Lq, 8, 36)[..., 0].sum(1)           # (B, 8)
     tot_dv = ones.grad.view(B, Lk, 8, 36)[..., 0].sum(1)
     torch.testing.assert_close(tot_out, tot_dv, rtol=2e-2, atol=1e-2)
+
+
+# ---------------------------------------------- fused [q-projection | attention core] launch (short key sets) ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Lq,Lk,masked,p", [
+    (8, 256, 80, True, 0.1), (8, 256, 132, True, 0.1), (2, 1024, 80, True, 0.0), (2, 1024, 132, True, 0.1),
+    (2, 100, 130, True, 0.0), (1, 17, 1, False, 0.0), (3, 64, 192, False, 0.1), (2, 65, 17, True, 0.1), (2, 256, 64, False, 0.0)])
+def test_qproj_fused_site_equals_projection_launch_plus_core_launch(B, Lq, Lk, masked, p, monkeypatch):
+    """eda_mha_qproj_fwd (csrc/mha2.hip mha2_qproj_fwd_kernel: q = x Wq^T + bq and the attention core in ONE launch,
+    the sites of encoder_decoder_layers.py:99-117, 375-391) against the two-launch composition it replaces, through the
+    module: projected q, attention output, log-sum-exp and -- because the backward is shared and the Dropout hash is the
+    same -- every gradient.  Then against the fp64 restatement directly (the q the kernel wrote, its output)."""
+    from eda_amd import attention
+    torch.manual_seed(Lq * 7 + Lk)
+    dev = "cuda"
+    mha = attention.MultiheadAttention(288, 8, dropout=p).to(dev).train()
+    with torch.no_grad():
+        mha.in_proj_bias.normal_(0, 0.2)
+    x = torch.randn(B, Lq, 288, device=dev)
+    mem = torch.randn(B, Lk, 288, device=dev)
+    mask = _mask(B, Lk, 3).to(dev) if masked else None
+    w = torch.randn(B, Lq, 288, device=dev)
+    counter = attention.get_dropout_counter(torch.device(dev, 0))
+    res = {}
+    for fused in ("1", "0"):                  # (1 forces the fused launch for every supported shape; the default takes
+        monkeypatch.setenv("EDA_MHA_QPROJ", fused)    # it only while it is one round of workgroups)
+        attention.set_dropout_counter(torch.device(dev, 0), counter)
+        xq = x.clone().requires_grad_(True)
+        mm = mem.clone().requires_grad_(True)
+        mha.zero_grad(set_to_none=True)
+        timer_names = []
+        from eda_amd import ext
+        ext.op_timer = ext.OpTimer()
+        try:
+            o, _ = mha(xq, mm, mm, key_padding_mask=mask, batch_first=True, skip_out_proj=True)
+            torch.cuda.synchronize()
+            timer_names = [k[0] for k in ext.op_timer.summary()]
+        finally:
+            ext.op_timer = None
+        (o * w).sum().backward()
+        res[fused] = (o.detach(), xq.grad, mm.grad, mha.in_proj_weight.grad.clone(), mha.in_proj_bias.grad.clone(), timer_names)
+    assert "mha_qproj_fwd" in res["1"][5] and "mha_fwd" not in res["1"][5]          # the fused launch really ran
+    assert "mha_fwd" in res["0"][5] and "mha_qproj_fwd" not in res["0"][5]
+    for a, b_, name in zip(res["1"][:5], res["0"][:5], ["out", "dx", "dmem", "dW", "db"]):
+        scale = float(b_.abs().max()) + 1e-12
+        assert float((a - b_).abs().max()) <= 2e-5 * scale, (name, float((a - b_).abs().max()), scale)
+    if p == 0.0:
+        # against the fp64 restatement (oracle/attention_ref.py) on the module's own parameters
+        W, bb = mha.in_proj_weight.detach().double(), mha.in_proj_bias.detach().double()
+        q64 = x.double() @ W[:288].t() + bb[:288]
+        k64 = mem.double() @ W[288:576].t() + bb[288:576]
+        v64 = mem.double() @ W[576:].t() + bb[576:]
+        exp = attention_ref.attention_core(q64, k64, v64, mask, 8, 0.0, 0)
+        got = res["1"][0].double()
+        err = (got - exp).abs()
+        assert float((err - 1e-4 * exp.abs()).max()) <= 4e-6 * float(exp.abs().max())

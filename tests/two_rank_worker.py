@@ -99,11 +99,12 @@ def main():
             flat.all_reduce_mean(a.world)
         if step == 0:
             grad0 = flat.flat_grad.detach().cpu().clone()
+            # (running statistics after ONE forward: later steps see parameters that two correct runs have moved apart)
+            bn = {k: v.detach().cpu().clone() for k, v in model.state_dict().items() if "running_" in k and "backbone_net.sa1" in k}
         flat.clip_grad_norm_(0.1)
         opt.step()
         losses.append(loss.detach().cpu())
     torch.cuda.synchronize()
-    bn = {k: v.detach().cpu() for k, v in model.state_dict().items() if "running_" in k and "backbone_net.sa1" in k}
     torch.save({"losses": torch.stack(losses), "grad0": grad0, "param": flat.flat_param.detach().cpu(), "bn": bn, "param0": param0,
                 "fused_hook_calls": hooks[0]}, a.out)
     if a.world > 1:
