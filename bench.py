@@ -349,7 +349,7 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="N > 1 on a ONE-GPU box: every rank uses device 0 and the collectives go through gloo -- exercises "
                          "the multi-rank step structure end to end; the line it prints says so and is not a measurement")
-    ap.add_argument("--overlap-allreduce", type=int, default=1,
+    ap.add_argument("--overlap-allreduce", type=int, default=0,
                     help="N > 1: 1 = all-reduce the first half of the flat gradient buffer underneath the grouped "
                          "weight-gradient kernel of the second half (FlatParams.flush_and_reduce); 0 = one all-reduce "
                          "after the whole backward")
