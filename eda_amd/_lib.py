@@ -58,6 +58,7 @@ SIGNATURES = {
     "eda_set_bn_sync": (_i, [_p, _p, _i]),
     "eda_fps_set_cu_reserve": (_i, [_i]),
     "eda_fps_set_policy": (_i, [_i]),
+    "eda_add_n_f32": (_i, [_p, _i, _sz, _p, _p]),
     "eda_gemm_set_dma": (_i, [_i]),
     "eda_mha_fwd_hd64_f32": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _l, _p, _i, _i, _i, _i, _f, _p, _p]),
     "eda_mha_fwd": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _l, _p, _i, _i, _i, _i, _i, _f, _f,

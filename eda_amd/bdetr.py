@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from .backbone_module import Pointnet2Backbone
 from .encoder_decoder_layers import BiDecoderLayer, BiEncoder, BiEncoderLayer, PositionEmbeddingLearned
-from .nn_utils import Conv1dK1, Linear, deferred_bn_counters, embedding_rows, l2_normalize, mlp_chain
+from .nn_utils import Conv1dK1, Linear, deferred_bn_counters, embedding_rows, fan_out, l2_normalize, mlp_chain
 from .modules import ClsAgnosticPredictHead, GeneralSamplingModule, PointsObjClsModule
 
 
@@ -49,7 +49,6 @@ def _load_text_stack(data_path):
     cfg = RobertaConfig(vocab_size=50265, max_position_embeddings=514, type_vocab_size=1,
                         pad_token_id=1)       # roberta-base geometry, random init
     return None, RobertaModel(cfg)
-
 
 class BeaUTyDETR(nn.Module):
     def __init__(self, num_class=256, num_obj_class=485, input_feature_dim=3, num_queries=256,
@@ -269,10 +268,13 @@ class BeaUTyDETR(nn.Module):
                                     detected_feats=detected_feats if self.butd else None,
                                     detected_mask=detected_mask if self.butd else None,
                                     pre_kv={k: (kvs[i], sink, i) for k, (kvs, sink) in hoisted.items()})
-            projected.append((prefix, query))
-            center, size = self.prediction_heads[i](query.transpose(1, 2), base_xyz=cluster_xyz,
+            # three consumers (the next layer, this layer's prediction head, the contrastive projection): one alias each,
+            # their gradients are then summed in one launch (nn_utils.fan_out)
+            query, q_head, q_proj = fan_out(query, 3)
+            projected.append((prefix, q_proj))
+            center, size = self.prediction_heads[i](q_head.transpose(1, 2), base_xyz=cluster_xyz,
                                                     end_points=end_points, prefix=prefix,
-                                                    features_rows=query)
+                                                    features_rows=q_head)
             base_xyz, base_size = center.detach(), size.detach()
         if self.contrastive_align_loss:
             proj = _project(self.contrastive_align_projection_image, torch.stack([q for _, q in projected], 0))

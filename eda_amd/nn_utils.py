@@ -404,3 +404,48 @@ def l2_normalize(x, eps=1e-12):
     if x.is_cuda and x.dtype == torch.float32 and 0 < x.shape[-1] <= 1024:
         return _L2NormalizeRows.apply(x, eps)
     return torch.nn.functional.normalize(x, p=2, dim=-1, eps=eps)
+
+
+class _FanOut(Function):
+    """n aliases of one tensor, one per consumer: the gradients the consumers send back are summed in ONE launch
+    (include/eda_hip.h eda_add_n_f32) instead of n - 1 accumulation launches of the autograd engine."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g for g in grads if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        g0 = gs[0]
+        ok = (g0.is_cuda and g0.dtype == torch.float32 and g0.numel() % 4 == 0 and len(gs) <= 8
+              and all(g.shape == g0.shape and g.dtype == torch.float32 for g in gs))
+        if not ok:
+            out = gs[0] + gs[1]
+            for g in gs[2:]:
+                out = out + g
+            return out, None
+        gs = [g if (g.is_contiguous() and g.data_ptr() % 16 == 0) else g.contiguous() for g in gs]
+        out = torch.empty_like(gs[0])
+        import ctypes
+        from . import _lib
+        from .ext import _timed
+        arr = (ctypes.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
+        with torch.cuda.device(g0.device), _timed("add_n", (len(gs), g0.numel())):
+            rc = _lib.lib().eda_add_n_f32(arr, len(gs), g0.numel(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "eda_add_n_f32")
+        return out, None
+
+
+def fan_out(x, n):
+    """`n` aliases of `x` for n consumers (training on the GPU: their gradients are then added in one launch); a plain
+    tuple of the same tensor where that buys nothing (no gradient, CPU, n < 3: two consumers cost the engine one add
+    either way)."""
+    if n < 3 or not (torch.is_grad_enabled() and x.requires_grad and x.is_cuda):
+        return (x,) * n
+    return _FanOut.apply(x, n)

@@ -367,6 +367,13 @@ int eda_l2norm_rows_bwd_f32(const float *dy, const float *y, const float *norm, 
  * HBM rate next to the 8 TB/s nominal peak.  Replaces nothing in the reference.          */
 int eda_device_copy_f32(const float *src, float *dst, size_t n, void *stream);
 
+/* out[0..count) = srcs[0] + srcs[1] + ... + srcs[n-1] (1 <= n <= 8 device pointers in a HOST array; count a multiple
+ * of 4, everything 16-byte aligned; out may alias srcs[0]).  The backward of a tensor with several consumers: the
+ * reference leaves the n - 1 accumulations to the autograd engine (one at::add launch per incoming gradient, e.g. the
+ * residual stream / positional term of models/encoder_decoder_layers.py:366-405); eda_amd.nn_utils.fan_out sums them in
+ * one launch. */
+int eda_add_n_f32(const float *const *srcs, int n, size_t count, float *out, void *stream);
+
 /* ---- row GEMMs of the pointwise layers (csrc/gemm.hip, fp32 MFMA) ---------------------------
  * eda_linear_fwd_f32 replaces the cuBLAS/cuDNN call behind every nn.Linear / Conv1d(k=1) /
  * Conv2d(1x1) of the path (pointnet2/pytorch_utils.py:88-120; models/encoder_decoder_layers.py:
