@@ -829,6 +829,42 @@ def main():
                              "timing": "HIP events around each launch in eager runs (for the < 20 us launches ~30 % above "
                                        "the rocprofv3 kernel durations in profiles/)",
                              "dtype": "f32 in / f32 accumulate MFMA"}
+        # the dominant tiled product once more, the way the step actually runs it: 50 launches back to back in a replayed
+        # hipGraph (a HIP-event bracket around ONE eager launch of a ~10 us kernel measures the bracket too: ~+35 %; the
+        # rocprofv3 average in profiles/*_summary.md is the third view of the same kernel)
+        if roofline_gemm and topg["op"] in ("gemm_fwd", "gemm_dgrad"):
+            try:
+                from eda_amd import gemm as _g
+                r_, k_, n_ = topg["dims"]
+                x_ = torch.randn(r_, k_, device=device)
+                w_ = torch.randn((n_, k_) if topg["op"] == "gemm_fwd" else (k_, n_), device=device) * 0.05
+                fn_ = (lambda: _g.linear_fwd(x_, w_)) if topg["op"] == "gemm_fwd" else (lambda: _g.linear_dgrad(x_, w_))
+                gs_ = torch.cuda.Stream()
+                gg_ = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(gs_), torch.no_grad():
+                    for _ in range(3):
+                        fn_()
+                    torch.cuda.synchronize()
+                    with torch.cuda.graph(gg_, stream=gs_, capture_error_mode="thread_local"):
+                        for _ in range(50):
+                            fn_()
+                for _ in range(3):
+                    gg_.replay()
+                torch.cuda.synchronize()
+                ge0, ge1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ge0.record()
+                for _ in range(20):
+                    gg_.replay()
+                ge1.record()
+                torch.cuda.synchronize()
+                t_ = ge0.elapsed_time(ge1) / (20 * 50)             # ms per launch
+                fl_ = roofline_gemm["alg_flops_per_launch"]
+                roofline_gemm["ms_per_launch_graph_replay"] = round(t_, 5)
+                roofline_gemm["achieved_graph_replay"] = round(fl_ / (t_ * 1e-3) / 1e12, 2)
+                roofline_gemm["frac_graph_replay"] = round(fl_ / (t_ * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
+                del gg_
+            except Exception as exc:      # a measurement aid: never lose the line to it
+                roofline_gemm["graph_replay_error"] = f"{type(exc).__name__}: {exc}"[:200]
         peak16 = 2500.0                    # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA
         roofline_mfma = None
         if mf:

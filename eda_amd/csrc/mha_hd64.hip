@@ -173,12 +173,10 @@ extern "C" int eda_mha_fwd_hd64_f32(const float *q, const float *k, const float 
   a.o = out; a.o_sb = (long)Lq * H * HD64; a.o_sl = (long)H * HD64; a.mask = key_padding_mask;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale;
   const size_t lds = sizeof(float) * 2 * (size_t)Lk * LDK + (size_t)((Lk + 15) & ~15);
-  static bool attr_set = false;
-  if (!attr_set) {           // dynamic LDS above 64 KB needs the opt-in (once per process)
+  {           // dynamic LDS above 64 KB needs the opt-in; the attribute is per DEVICE and cheap: set on every launch
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mha_hd64_fwd_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * 2 * MAXLK * LDK + 256));
     if (e != hipSuccess) { eda_set_error("eda_mha_fwd_hd64_f32: %s", hipGetErrorString(e)); return (int)e; }
-    attr_set = true;
   }
   hipLaunchKernelGGL(mha_hd64_fwd_kernel, dim3((unsigned)(B * H), (unsigned)((Lq + 63) / 64)), dim3(256), lds, stream, a);
   EDA_CHECK_LAUNCH();

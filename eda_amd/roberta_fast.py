@@ -126,16 +126,17 @@ def _gelu_linear(x2, w, bias):
     return out
 
 
-_cache = {}
-
-
 def encode(hf_model, input_ids, attention_mask):
-    """last_hidden_state of `hf_model` through the fast path (built and cached per module; rebuilt when its parameters
-    were written in place since)."""
-    key = id(hf_model)
-    fast = _cache.get(key)
+    """last_hidden_state of `hf_model` through the fast path.  The packed weights live ON the module (`_eda_fast`: freed
+    with it, no process-wide table keyed by id()); rebuilt when its parameters were written in place since -- but never
+    inside a stream capture (the packed copies would come from the graph's private pool)."""
+    fast = hf_model.__dict__.get("_eda_fast")
     if fast is None or fast.m is not hf_model or fast.stale():
-        fast = _cache[key] = FrozenRobertaFast(hf_model)
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("roberta_fast: the packed weights must be built before a HIP graph is captured "
+                               "(run one eager encode_text_frozen first)")
+        fast = FrozenRobertaFast(hf_model)
+        object.__setattr__(hf_model, "_eda_fast", fast)       # (not a sub-module / parameter: a plain attribute)
     return fast(input_ids, attention_mask)
 
 

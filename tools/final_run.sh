@@ -1,7 +1,7 @@
 # The evidence run of a round: tests, smoke, PMC traffic, the bench lines of BASELINE.json's single-GPU configurations and
 # one profiled eager run.  usage (on the GPU box): bash tools/final_run.sh <tag>   -> gpurun_out/<tag>/
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-tag=${1:-r03z}
+tag=${1:-r04z}
 O=gpurun_out/$tag; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; tail -2 $O/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
@@ -17,6 +17,17 @@ python bench.py --attn-dtype bf16 --in-step-steps 0 > $O/bench_attn_bf16.json 2>
 python bench.py --attn-dtype f16 --tokens 130 --in-step-steps 0 > $O/bench_attn_f16_130_tokens.json 2> $O/bench_attn_f16_130_tokens.err
 EDA_FAST_ROBERTA=0 python bench.py --in-step-steps 0 > $O/bench_stock_roberta.json 2> $O/bench_stock_roberta.err
 python bench.py --batches 1 --in-step-steps 0 > $O/bench_one_batch.json 2> $O/bench_one_batch.err
+# round 4: the sampler policies, the N > 1 step structure through a one-rank RCCL group, the fused q-projection sites
+EDA_FPS_BUCKET=1 python bench.py --in-step-steps 0 > $O/bench_fps_bucket.json 2> $O/bench_fps_bucket.err
+EDA_FPS_BUCKET=1 python bench.py --fps-prefetch 0 --in-step-steps 0 > $O/bench_fps_bucket_in_step.json 2> $O/bench_fps_bucket_in_step.err
+python bench.py --force-dist --in-step-steps 0 > $O/bench_force_dist.json 2> $O/bench_force_dist.err
+python bench.py --force-dist --overlap-allreduce 1 --in-step-steps 0 > $O/bench_force_dist_overlap.json 2> $O/bench_force_dist_overlap.err
+python bench.py --force-dist --sync-bn --in-step-steps 0 > $O/bench_force_dist_sync_bn.json 2> $O/bench_force_dist_sync_bn.err
+EDA_MHA_QPROJ=0 python bench.py --in-step-steps 0 > $O/bench_qproj_off.json 2> $O/bench_qproj_off.err
+python tools/time_qproj_site.py > $O/qproj_site.txt 2>&1
+python tools/time_linear_ln.py 2048 288 > $O/linear_ln.txt 2>&1
+python tools/fps_handoffs.py 8 50000 2048 > $O/fps_cluster.txt 2>&1
+EDA_FPS_BUCKET=1 python tools/fps_handoffs.py 8 50000 2048 > $O/fps_bucket.txt 2>&1
 rm -rf /tmp/pe
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pe -o eager -- python bench.py --steps 20 --warmup 3 --graph 0 --cpu-scenes 0 > $O/bench_eager_under_rocprof.json 2> $O/bench_eager.err
 find /tmp/pe -name "*kernel_stats.csv" -exec cp {} $O/bench_eager_kernel_stats_rocprofv3.csv \;
