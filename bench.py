@@ -954,6 +954,9 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = run_cpu_baseline(args)
+        if os.environ.get("EDA_BENCH_KERNELS_FILE"):       # the complete per-op table (the line carries the first 40 rows)
+            with open(os.environ["EDA_BENCH_KERNELS_FILE"], "w") as f:
+                json.dump(kernels, f)
         print(json.dumps(out))
     if dist_on:
         dist.barrier()

@@ -71,6 +71,7 @@ SIGNATURES = {
     "eda_wgrad_workspace_bytes": (_sz, [_l, _i, _i]),
     "eda_wgrad_f32": (_i, [_p, _l, _p, _l, _l, _i, _i, _p, _p, _p, _sz, _p]),
     "eda_wgrad_grouped_f32": (_i, [_p, _i, _p, _p, _p]),
+    "eda_wgrad_set_arith": (_i, [_i]),
     "eda_lsa_f32": (_i, [_p, _l, _l, _l, _i, _i, _i, _p, _p, _p]),
     "eda_wcolsum_workspace_bytes": (_sz, [_l, _i, _i]),
     "eda_wcolsum_f32": (_i, [_p, _l, _i, _l, _p, _l, _i, _p, _p, _p, _sz, _p, _p]),

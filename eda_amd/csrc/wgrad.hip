@@ -17,6 +17,7 @@
 // their dY chunk's columns from LDS: d(bias) costs no extra pass over dY.
 #include "eda_common.h"
 #include "gemm.h"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -288,14 +289,262 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
   if (do_db && m0 + tid < M) db[m0 + tid] = accumulate ? db[m0 + tid] + dbsum : dbsum;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The grouped kernel on the bf16 matrix pipe with fp32-level accuracy ("bf16 x 3").
+//
+// gfx950 runs v_mfma_f32_16x16x32_bf16 at 16x the rate of v_mfma_f32_16x16x4_f32 per contraction step, and the fp32
+// kernel above is bound by the matrix pipe (MI355X_MICROARCH.md: 157 TFLOP/s fp32 vs 2.5 PFLOP/s bf16).  Every fp32
+// operand value is split EXACTLY into three bf16 terms, v = h + m + l (h = bf16(v), m = bf16(v - h), l = bf16(v - h - m):
+// 3 x 8 significant bits cover fp32's 24; the subtractions are exact), and a product a b is evaluated as the six
+// terms of weight >= 2^-16:  ah bh + ah bm + am bh + am bm + ah bl + al bh  -- every bf16 x bf16 product is exact in
+// fp32, the accumulators are fp32, and the three dropped terms (am bl, al bm, al bl) are <= 2^-23 |a b|: the error of
+// a contraction is that of an fp32 evaluation (measured in tests/test_wgrad_gpu.py against fp64, same bound as the
+// fp32 kernel).  Six 16-cycle instructions per 32 contraction steps instead of eight 32-cycle ones: 2.7x less time
+// on the matrix pipe.
+//
+// What it costs is the split (11 VALU operations per two values) and 16-bit operand tiles: each value is split ONCE,
+// by the thread that stages it, and the three planes of a tile lie in LDS contraction-minor ([96 rows of the output
+// tile][64 k] bf16, 128-byte rows) because a lane of the bf16 MFMA holds EIGHT consecutive contraction values of one
+// row.  The staging thread therefore owns a 4 (k) x 4 (columns) block -- four 16-byte row loads, as coalesced as the
+// fp32 kernel's -- and writes, per column and plane, its four k values as one 8-byte store.  16-byte granule g of row
+// r is kept in slot g ^ ((r >> 1) & 7): with the lane -> block map below both the 8-byte stores (16-lane groups, 32
+// banks) and the operand reads (ds_read_b128 service groups, 64 banks) are conflict-free.
+typedef __bf16 wb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wb_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float wb_f32x2 __attribute__((ext_vector_type(2)));
+#define WB_PLANE_BYTES (WG_T * WG_KC * 2)        // one bf16 plane of a 96 x 64 operand tile
+
+__device__ __forceinline__ unsigned wb_pk(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(wb_f32x2{a, b}, wb_bf16x2));
+}
+// (a, b) -> packed bf16 pairs of the three terms
+__device__ __forceinline__ void wb_split(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
+  h = wb_pk(a, b);
+  a -= __uint_as_float(h << 16); b -= __uint_as_float(h & 0xffff0000u);
+  m = wb_pk(a, b);
+  a -= __uint_as_float(m << 16); b -= __uint_as_float(m & 0xffff0000u);
+  l = wb_pk(a, b);
+}
+__device__ __forceinline__ f32x4 wb_mma(const uint4 &a, const uint4 &b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wb_bf16x8, a), __builtin_bit_cast(wb_bf16x8, b), c, 0, 0, 0);
+}
+
+// Workgroup = 4 waves (one per SIMD), wave = 48 x 48 of the 96 x 96 tile (three row strips x three column tiles: 18
+// operand reads feed 54 MFMAs per K step), two workgroups per CU by LDS (2 x 72 KB) = two waves per SIMD with up to 256
+// registers each: while one workgroup splits and stages its next chunk (VALU, LDS stores) the other multiplies.
+// Measured on the way (profiles/r04_experiments.md): the fp32 kernel's 12 waves x 16 x 48 under its 80-register cap
+// spilled the address registers (every reload waited for the prefetch: 1.63 ms against 1.38 fp32); 6 waves x 32 x 48
+// at 140-168 registers ran ONE workgroup per CU (six waves land 2 + 2 + 1 + 1 on the SIMDs from a varying start and a
+// SIMD holding two such waves cannot take two more; SQ_WAVE_CYCLES: 5.3 waves per CU on average): 1.31 ms.
+#define WB_THREADS 256
+#define WB_ITEMS 3                                 // 4 x 4 blocks per thread and chunk (2 x 384 blocks / 256 threads)
+__global__ __launch_bounds__(WB_THREADS, 2) void wgrad_grouped_bf16x3_kernel(
+    const long long *__restrict__ tasks, const long long *__restrict__ targets, const long long *__restrict__ jobs) {
+  // planes: dY h, m, l | X h, m, l
+  __shared__ __attribute__((aligned(16))) unsigned char lds[6 * WB_PLANE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wh = w & 1;
+  const long long *tk = tasks + (long)blockIdx.x * 4;
+  if (tk[0] < 0) return;
+  const long long *tg = targets + tk[0] * 8;
+  const int tm = (int)tk[1], tn = (int)tk[2];
+  float *dW = reinterpret_cast<float *>(tg[0]);
+  float *db = reinterpret_cast<float *>(tg[1]);
+  const int M = (int)tg[2], N = (int)tg[3];
+  const int job0 = (int)tg[4], njobs = (int)tg[5];
+  const bool accumulate = tg[6] != 0;
+  const int m0 = tm * WG_T, n0 = tn * WG_T;
+
+  // staging: block j = tid + 256 q of the chunk's 768 4 (k) x 4 (columns) blocks -- 0..383 of dY, 384..767 of X (the
+  // operand of a (thread, q) is wave-uniform); block (rq, cq) = rows 4 rq.. of the chunk x columns 4 cq.. of the tile,
+  // the 16 lanes of a store group span 4 rq x 4 cq
+  int rq[WB_ITEMS], gcol[WB_ITEMS], soff[WB_ITEMS][4];
+  bool isb[WB_ITEMS], cok[WB_ITEMS];
+#pragma unroll
+  for (int q = 0; q < WB_ITEMS; ++q) {
+    const int item = tid + WB_THREADS * q;
+    isb[q] = item >= 384;
+    const int it = item - (isb[q] ? 384 : 0), lq = it & 15, blk = it >> 4;
+    rq[q] = 4 * (blk / 6) + (lq & 3);
+    const int cq = 4 * (blk % 6) + (lq >> 2);
+    const int c0 = (isb[q] ? n0 : m0) + 4 * cq, lim = isb[q] ? N : M;
+    cok[q] = c0 < lim;
+    gcol[q] = cok[q] ? c0 : lim - 4;               // loads are unconditional: clamped here, zeroed when staged
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = 4 * cq + u;
+      soff[q][u] = (isb[q] ? 3 * WB_PLANE_BYTES : 0) + r * 128 + 16 * ((rq[q] >> 1) ^ ((r >> 1) & 7)) + 8 * (rq[q] & 1);
+    }
+  }
+  const bool edge_tile = (m0 + WG_T > M) || (n0 + WG_T > N);                        // (uniform)
+  // operand reads: lane (i, kg) holds row i of a 16-row strip, granule 4 s + kg of K step s (s = 1: offset ^ 64)
+  const int li = lane & 15, kg = lane >> 4;
+  int aoff[3], boff[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int ra_ = 48 * wm + 16 * t + li, rb_ = 48 * wh + 16 * t + li;
+    aoff[t] = ra_ * 128 + 16 * (kg ^ ((ra_ >> 1) & 7));
+    boff[t] = 3 * WB_PLANE_BYTES + rb_ * 128 + 16 * (kg ^ ((rb_ >> 1) & 7));
+  }
+
+  f32x4 acc[3][3];
+#pragma unroll
+  for (int a_ = 0; a_ < 3; ++a_)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[a_][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool active = (m0 + 48 * wm < M) && (n0 + 48 * wh < N);
+  const bool do_db = db != nullptr && tn == 0;
+  float dbp[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};       // (blocks q = 0 and, for threads < 128, q = 1 are dY's)
+  f32x4 rv[WB_ITEMS][4];
+  typedef const __attribute__((address_space(1))) unsigned char *gbytes;
+  typedef const __attribute__((address_space(1))) f32x4 *gf4;
+
+  for (int jb = 0; jb < njobs; ++jb) {
+    const long long *jd = jobs + (long)(job0 + jb) * 8;
+    const gbytes srca = reinterpret_cast<gbytes>(jd[0]), srcb = reinterpret_cast<gbytes>(jd[2]);
+    const unsigned lda = 4u * (unsigned)jd[1], ldbb = 4u * (unsigned)jd[3];          // row strides in bytes (K * ld * 4 < 2^32)
+    const int K = (int)jd[4];
+    if (K <= 0) continue;
+    // unconditional loads at 32-bit byte offsets from the (uniform) operand bases; rows beyond K are clamped to the
+    // last one (zeroed when staged), so a prefetch past the end is harmless and no load sits behind a branch
+    auto fetch = [&](int k0) {
+#pragma unroll
+      for (int q = 0; q < WB_ITEMS; ++q) {
+        const gbytes src = isb[q] ? srcb : srca;
+        const unsigned ld = isb[q] ? ldbb : lda;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const unsigned r = (unsigned)min(k0 + 4 * rq[q] + i, K - 1);
+          rv[q][i] = *reinterpret_cast<gf4>(src + (r * ld + 4u * (unsigned)gcol[q]));
+        }
+      }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += WG_KC) {
+#pragma unroll
+      for (int q = 0; q < WB_ITEMS; ++q) {
+        if (edge_tile || k0 + WG_KC > K) {                              // (uniform branch)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (!cok[q] || k0 + 4 * rq[q] + i >= K) rv[q][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          unsigned h0, m0_, l0, h1, m1, l1;
+          wb_split(rv[q][0][u], rv[q][1][u], h0, m0_, l0);
+          wb_split(rv[q][2][u], rv[q][3][u], h1, m1, l1);
+          *reinterpret_cast<uint2 *>(lds + soff[q][u]) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2 *>(lds + WB_PLANE_BYTES + soff[q][u]) = make_uint2(m0_, m1);
+          *reinterpret_cast<uint2 *>(lds + 2 * WB_PLANE_BYTES + soff[q][u]) = make_uint2(l0, l1);
+          if (q < 2 && do_db && !isb[q]) dbp[q][u] += (rv[q][0][u] + rv[q][1][u]) + (rv[q][2][u] + rv[q][3][u]);
+        }
+      }
+      __syncthreads();
+      fetch(k0 + WG_KC);
+      if (active) {
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+          const int x_ = s_ * 64;
+          uint4 ah[3], am[3], al[3], b[3];
+#pragma unroll
+          for (int a_ = 0; a_ < 3; ++a_) {
+            ah[a_] = *reinterpret_cast<const uint4 *>(lds + (aoff[a_] ^ x_));
+            am[a_] = *reinterpret_cast<const uint4 *>(lds + WB_PLANE_BYTES + (aoff[a_] ^ x_));
+            al[a_] = *reinterpret_cast<const uint4 *>(lds + 2 * WB_PLANE_BYTES + (aoff[a_] ^ x_));
+          }
+#pragma unroll
+          for (int t = 0; t < 3; ++t) b[t] = *reinterpret_cast<const uint4 *>(lds + (boff[t] ^ x_));                           // X h
+#pragma unroll
+          for (int a_ = 0; a_ < 3; ++a_)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[a_][t] = wb_mma(al[a_], b[t], acc[a_][t]);
+#pragma unroll
+          for (int a_ = 0; a_ < 3; ++a_)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[a_][t] = wb_mma(am[a_], b[t], acc[a_][t]);
+#pragma unroll
+          for (int a_ = 0; a_ < 3; ++a_)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[a_][t] = wb_mma(ah[a_], b[t], acc[a_][t]);
+#pragma unroll
+          for (int t = 0; t < 3; ++t) b[t] = *reinterpret_cast<const uint4 *>(lds + WB_PLANE_BYTES + (boff[t] ^ x_));          // X m
+#pragma unroll
+          for (int a_ = 0; a_ < 3; ++a_)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[a_][t] = wb_mma(am[a_], b[t], acc[a_][t]);
+#pragma unroll
+          for (int a_ = 0; a_ < 3; ++a_)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[a_][t] = wb_mma(ah[a_], b[t], acc[a_][t]);
+#pragma unroll
+          for (int t = 0; t < 3; ++t) b[t] = *reinterpret_cast<const uint4 *>(lds + 2 * WB_PLANE_BYTES + (boff[t] ^ x_));      // X l
+#pragma unroll
+          for (int a_ = 0; a_ < 3; ++a_)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[a_][t] = wb_mma(ah[a_], b[t], acc[a_][t]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int a_ = 0; a_ < 3; ++a_)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int col = n0 + 48 * wh + 16 * t + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + 48 * wm + 16 * a_ + 4 * (lane >> 4) + r;
+          if (row < M && col < N) {
+            float *o = dW + (long)row * N + col;
+            *o = accumulate ? *o + acc[a_][t][r] : acc[a_][t][r];
+          }
+        }
+      }
+  }
+  if (do_db) {
+    // column sums: 16 row-quad partials per column, added in row order (the planes are dead: LDS is the scratch)
+    float *red = reinterpret_cast<float *>(lds);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (!isb[q]) {
+        const int it = tid + WB_THREADS * q, lq = it & 15, blk = it >> 4, cq = 4 * (blk % 6) + (lq >> 2);
+        *reinterpret_cast<float4 *>(red + rq[q] * WG_T + 4 * cq) = make_float4(dbp[q][0], dbp[q][1], dbp[q][2], dbp[q][3]);
+      }
+    __syncthreads();
+    if (tid < WG_T && m0 + tid < M) {
+      float t_ = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t_ += red[r * WG_T + tid];
+      db[m0 + tid] = accumulate ? db[m0 + tid] + t_ : t_;
+    }
+  }
+}
+
+// arithmetic of eda_wgrad_grouped_f32: 0 = fp32 MFMA (wgrad_grouped_kernel), 1 = bf16 x 3 (wgrad_grouped_bf16x3_kernel);
+// default from EDA_WGRAD_BF16X3
+static int g_wgrad_arith = -1;
+static int wgrad_arith() {
+  if (g_wgrad_arith < 0) { const char *e = getenv("EDA_WGRAD_BF16X3"); g_wgrad_arith = e ? (atoi(e) != 0) : 1; }
+  return g_wgrad_arith;
+}
+extern "C" int eda_wgrad_set_arith(int mode) {
+  if (mode < -1 || mode > 1) { eda_set_error("eda_wgrad_set_arith: mode must be -1 (default), 0 (fp32 MFMA) or 1 (bf16 x 3)"); return EDA_ERR_INVALID_ARG; }
+  g_wgrad_arith = mode;
+  return 0;
+}
+
 extern "C" int eda_wgrad_grouped_f32(const long long *tasks, int ntasks, const long long *targets,
                                      const long long *jobs, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EDA_CHECK_ARG(ntasks >= 0, "bad dimension");
   if (ntasks == 0) return 0;
   EDA_CHECK_ARG(tasks && targets && jobs, "null pointer");
-  hipLaunchKernelGGL(wgrad_grouped_kernel, dim3((unsigned)ntasks), dim3(WG_THREADS), 0, stream, tasks, targets,
-                     jobs);
+  if (wgrad_arith() == 1)
+    hipLaunchKernelGGL(wgrad_grouped_bf16x3_kernel, dim3((unsigned)ntasks), dim3(WB_THREADS), 0, stream, tasks, targets, jobs);
+  else
+    hipLaunchKernelGGL(wgrad_grouped_kernel, dim3((unsigned)ntasks), dim3(WG_THREADS), 0, stream, tasks, targets, jobs);
   EDA_CHECK_LAUNCH();
   return 0;
 }

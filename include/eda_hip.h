@@ -306,6 +306,14 @@ int eda_ln_reduce_grouped_f32(const long long *desc, int nsites, int max_c, void
 int eda_wgrad_grouped_f32(const long long *tasks, int ntasks, const long long *targets,
                           const long long *jobs, void *stream);
 
+/* Arithmetic of eda_wgrad_grouped_f32's contractions: 0 = v_mfma_f32_16x16x4_f32 on fp32 operands; 1 = "bf16 x 3": every
+ * fp32 operand value split exactly into three bf16 terms while it is staged, six v_mfma_f32_16x16x32_bf16 products of
+ * weight >= 2^-16 per contraction step, fp32 accumulators -- the dropped terms are <= 2^-23 of a product, the result
+ * is an fp32-accurate dW (same test bound against fp64) at 2.7x less time on the matrix pipe (csrc/wgrad.hip); -1 = the
+ * default again (EDA_WGRAD_BF16X3, on unless set to 0).  Process-wide.  Replaces nothing in the reference (its weight
+ * gradients are cuBLAS calls issued by autograd for nn.Linear / nn.Conv1d, models/encoder_decoder_layers.py). */
+int eda_wgrad_set_arith(int mode);
+
 /* ---- column sums (bias gradients) ------------------------------------------
  * out[c] = sum_r x[r*ld + c] for a row-major (R,C) matrix: d(bias) of every pointwise linear
  * layer on the path (what autograd's AddmmBackward / the reference's nn.Linear, nn.Conv1d(k=1)
