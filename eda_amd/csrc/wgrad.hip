@@ -325,6 +325,9 @@ __device__ __forceinline__ void wb_split(float a, float b, unsigned &h, unsigned
   a -= __uint_as_float(m << 16); b -= __uint_as_float(m & 0xffff0000u);
   l = wb_pk(a, b);
 }
+// workgroup barrier for LDS hand-overs that leaves the global prefetch in flight (__syncthreads() is also a fence, for
+// which the compiler may drain vmcnt to 0, i.e. wait for the very loads the barrier should overlap)
+__device__ __forceinline__ void wb_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ f32x4 wb_mma(const uint4 &a, const uint4 &b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wb_bf16x8, a), __builtin_bit_cast(wb_bf16x8, b), c, 0, 0, 0);
 }
@@ -335,7 +338,11 @@ __device__ __forceinline__ f32x4 wb_mma(const uint4 &a, const uint4 &b, f32x4 c)
 // Measured on the way (profiles/r04_experiments.md): the fp32 kernel's 12 waves x 16 x 48 under its 80-register cap
 // spilled the address registers (every reload waited for the prefetch: 1.63 ms against 1.38 fp32); 6 waves x 32 x 48
 // at 140-168 registers ran ONE workgroup per CU (six waves land 2 + 2 + 1 + 1 on the SIMDs from a varying start and a
-// SIMD holding two such waves cannot take two more; SQ_WAVE_CYCLES: 5.3 waves per CU on average): 1.31 ms.
+// SIMD holding two such waves cannot take two more; SQ_WAVE_CYCLES: 5.3 waves per CU on average): 1.31 ms.  Tried on
+// top of this form and measured equal (0.79-0.83 ms on tools/bench_wgrad_grouped.py's 95.6 GFLOP against 0.84): a second
+// chunk of register prefetch, and 8-wave workgroups with staging / multiplying ROLES over a double-buffered LDS (one
+// workgroup per CU) -- what bounds it is not latency: the staging waves ingest ~10 bytes per clock and CU, the
+// beyond-L2 rate of MI355X_MICROARCH.md, with the matrix pipe 34 % and the VALU 40 % busy.
 #define WB_THREADS 256
 #define WB_ITEMS 3                                 // 4 x 4 blocks per thread and chunk (2 x 384 blocks / 256 threads)
 __global__ __launch_bounds__(WB_THREADS, 2) void wgrad_grouped_bf16x3_kernel(
@@ -407,19 +414,17 @@ __global__ __launch_bounds__(WB_THREADS, 2) void wgrad_grouped_bf16x3_kernel(
     if (K <= 0) continue;
     // unconditional loads at 32-bit byte offsets from the (uniform) operand bases; rows beyond K are clamped to the
     // last one (zeroed when staged), so a prefetch past the end is harmless and no load sits behind a branch
-    auto fetch = [&](int k0) {
+    auto fetch = [&](int q, int k0) {
+      const gbytes src = isb[q] ? srcb : srca;
+      const unsigned ld = isb[q] ? ldbb : lda;
 #pragma unroll
-      for (int q = 0; q < WB_ITEMS; ++q) {
-        const gbytes src = isb[q] ? srcb : srca;
-        const unsigned ld = isb[q] ? ldbb : lda;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const unsigned r = (unsigned)min(k0 + 4 * rq[q] + i, K - 1);
-          rv[q][i] = *reinterpret_cast<gf4>(src + (r * ld + 4u * (unsigned)gcol[q]));
-        }
+      for (int i = 0; i < 4; ++i) {
+        const unsigned r = (unsigned)min(k0 + 4 * rq[q] + i, K - 1);
+        rv[q][i] = *reinterpret_cast<gf4>(src + (r * ld + 4u * (unsigned)gcol[q]));
       }
     };
-    fetch(0);
+#pragma unroll
+    for (int q = 0; q < WB_ITEMS; ++q) fetch(q, 0);
     for (int k0 = 0; k0 < K; k0 += WG_KC) {
 #pragma unroll
       for (int q = 0; q < WB_ITEMS; ++q) {
@@ -438,9 +443,11 @@ __global__ __launch_bounds__(WB_THREADS, 2) void wgrad_grouped_bf16x3_kernel(
           *reinterpret_cast<uint2 *>(lds + 2 * WB_PLANE_BYTES + soff[q][u]) = make_uint2(l0, l1);
           if (q < 2 && do_db && !isb[q]) dbp[q][u] += (rv[q][0][u] + rv[q][1][u]) + (rv[q][2][u] + rv[q][3][u]);
         }
+        // the block's rows of the NEXT chunk are requested as soon as its registers are free: in flight for the rest of
+        // the staging and the whole multiply phase
+        fetch(q, k0 + WG_KC);
       }
-      __syncthreads();
-      fetch(k0 + WG_KC);
+      wb_barrier();
       if (active) {
 #pragma unroll
         for (int s_ = 0; s_ < 2; ++s_) {
@@ -484,7 +491,7 @@ __global__ __launch_bounds__(WB_THREADS, 2) void wgrad_grouped_bf16x3_kernel(
             for (int t = 0; t < 3; ++t) acc[a_][t] = wb_mma(ah[a_], b[t], acc[a_][t]);
         }
       }
-      __syncthreads();
+      wb_barrier();
     }
   }
   if (active) {
