@@ -272,48 +272,15 @@ class BeaUTyDETR(nn.Module):
             # their gradients are then summed in one launch (nn_utils.fan_out)
             query, q_head, q_proj = fan_out(query, 3)
             projected.append((prefix, q_proj))
-            hs = self._head_stream(query)
-            if hs is None:
-                center, size = self.prediction_heads[i](q_head.transpose(1, 2), base_xyz=cluster_xyz,
-                                                        end_points=end_points, prefix=prefix,
-                                                        features_rows=q_head)
-            else:
-                # EDA_HEAD_STREAM=1: the head's nodes live on a second stream.  The forward gains nothing (the next
-                # layer's positional term needs this head's boxes: fork, five launches, join), the BACKWARD does: a head's
-                # backward depends on the loss alone, so in the captured step all head backwards form a branch next to
-                # the decoder's backward chain and meet it at each layer's fan_out.
-                cur = torch.cuda.current_stream()
-                hs.wait_stream(cur)
-                with torch.cuda.stream(hs):
-                    ep_h = {}
-                    center, size = self.prediction_heads[i](q_head.transpose(1, 2), base_xyz=cluster_xyz,
-                                                            end_points=ep_h, prefix=prefix, features_rows=q_head)
-                cur.wait_stream(hs)
-                q_head.record_stream(hs)
-                for v in list(ep_h.values()) + [center, size]:
-                    if torch.is_tensor(v):
-                        v.record_stream(cur)
-                end_points.update(ep_h)
+            center, size = self.prediction_heads[i](q_head.transpose(1, 2), base_xyz=cluster_xyz,
+                                                    end_points=end_points, prefix=prefix,
+                                                    features_rows=q_head)
             base_xyz, base_size = center.detach(), size.detach()
         if self.contrastive_align_loss:
             proj = _project(self.contrastive_align_projection_image, torch.stack([q for _, q in projected], 0))
             for (prefix, _), p in zip(projected, proj.unbind(0)):
                 end_points[f"{prefix}proj_queries"] = p
         return end_points
-
-    def _head_stream(self, t):
-        """The prediction heads' side stream (EDA_HEAD_STREAM=1, GPU, training), created on first use OUTSIDE any capture."""
-        import os
-        if os.environ.get("EDA_HEAD_STREAM", "0") != "1" or not t.is_cuda or not (self.training and torch.is_grad_enabled()):
-            return None
-        hs = getattr(self, "_hs", None)
-        if hs is None:
-            if torch.cuda.is_current_stream_capturing():
-                return None
-            from . import nn_utils
-            hs = self._hs = torch.cuda.Stream(device=t.device)
-            nn_utils.side_streams.append(hs)
-        return hs
 
     def _hoisted_kv(self, vis, text_feats, detected_feats):
         """K | V projections of the decoder's three memories for ALL layers in one product each (they are the same tensors

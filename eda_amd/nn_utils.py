@@ -442,21 +442,6 @@ class _FanOut(Function):
         return out, None
 
 
-# Side streams that forward code put autograd nodes on (BeaUTyDETR's prediction heads with EDA_HEAD_STREAM=1): the backward
-# of such a node runs on ITS stream (torch's stream semantics of backward passes), possibly after the last engine-made
-# join -- whoever reads deferred results of the backward on the current stream (FlatParams.deferred_wgrad's flush reads
-# the queued dY of the heads' layers) waits for them first.
-side_streams = []
-
-
-def join_side_streams():
-    if side_streams and torch.cuda.is_available():
-        cur = torch.cuda.current_stream()
-        for s_ in side_streams:
-            if s_ != cur:
-                cur.wait_stream(s_)
-
-
 def fan_out(x, n):
     """`n` aliases of `x` for n consumers (training on the GPU: their gradients are then added in one launch); a plain
     tuple of the same tensor where that buys nothing (no gradient, CPU, n < 3: two consumers cost the engine one add

@@ -153,8 +153,6 @@ class FlatParams:
             wgrad_queue.active = prev
             wt_shadow.active = prev_shadow
             self._deferred_ptrs = self.queue.touched()
-            from .nn_utils import join_side_streams
-            join_side_streams()            # (queued dY produced by backward nodes on a side stream)
             if flush:
                 self.queue.flush()
             self._prefilled = True
