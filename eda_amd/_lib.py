@@ -88,6 +88,9 @@ SIGNATURES = {
     "eda_linear_grouped_dgrad_f32": (_i, [_i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p]),
     "eda_bn_relu_grouped_fwd_f32": (_i, [_p, _l, _i, _i, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p]),
     "eda_bn_relu_grouped_bwd_f32": (_i, [_p, _p, _l, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _f, _p, _p, _p]),
+    "eda_tiny_out_bwd_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i]),
+    "eda_tiny_out_bwd_multi_f32": (_i, [_i, _l, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p]),
+    "eda_bn_relu_grouped_bwd_multi_f32": (_i, [_i, _p, _p, _l, _i, _i, _p, _p, _i, _p, _p, _f, _p, _p, _p]),
     "eda_sa_fused_fwd_f32": (_i, [_p, _l, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _l, _i, _p, _p, _p, _p, _p, _p,
                                  _f, _f, _i, _i, _p, _p, _p, _p, _p, _p]),
     "eda_sa_fused_bwd_workspace_bytes": (_sz, [_l, _i, _p, _i]),

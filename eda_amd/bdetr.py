@@ -248,8 +248,16 @@ class BeaUTyDETR(nn.Module):
         # MLP on 7 independent inputs that nothing in the forward reads: applied once on the 7 stacked
         # (bdetr.py:262-264, 316-320 of the reference apply it layer by layer; same numbers)
         projected = [("proposal_", query)]
-        center, size = self.proposal_head(cluster_feature, base_xyz=cluster_xyz, end_points=end_points,
-                                          prefix="proposal_", features_rows=cluster_rows)
+        # the seven heads' backward passes as one set of launches (eda_amd/heads_batched.py) where the grouped GPU path runs
+        from .heads_batched import HeadsBatch
+        B_, Q_ = cluster_rows.shape[0], cluster_rows.shape[1]
+        rows0 = cluster_rows.reshape(B_ * Q_, -1)
+        hb = HeadsBatch() if (self.training and HeadsBatch.usable([self.proposal_head] + list(self.prediction_heads), rows0)) else None
+        if hb is not None:
+            center, size = hb.add(self.proposal_head, rows0, cluster_xyz, end_points, "proposal_", B_, Q_)
+        else:
+            center, size = self.proposal_head(cluster_feature, base_xyz=cluster_xyz, end_points=end_points,
+                                              prefix="proposal_", features_rows=cluster_rows)
         # (the reference clones: main_utils-side code never writes into these outputs, the cat below copies them anyway)
         base_xyz, base_size = center.detach(), size.detach()
 
@@ -272,10 +280,16 @@ class BeaUTyDETR(nn.Module):
             # their gradients are then summed in one launch (nn_utils.fan_out)
             query, q_head, q_proj = fan_out(query, 3)
             projected.append((prefix, q_proj))
-            center, size = self.prediction_heads[i](q_head.transpose(1, 2), base_xyz=cluster_xyz,
-                                                    end_points=end_points, prefix=prefix,
-                                                    features_rows=q_head)
+            if hb is not None:
+                center, size = hb.add(self.prediction_heads[i], q_head.reshape(B_ * Q_, -1), cluster_xyz, end_points, prefix,
+                                      B_, Q_)
+            else:
+                center, size = self.prediction_heads[i](q_head.transpose(1, 2), base_xyz=cluster_xyz,
+                                                        end_points=end_points, prefix=prefix,
+                                                        features_rows=q_head)
             base_xyz, base_size = center.detach(), size.detach()
+        if hb is not None:
+            hb.finalize()
         if self.contrastive_align_loss:
             proj = _project(self.contrastive_align_projection_image, torch.stack([q for _, q in projected], 0))
             for (prefix, _), p in zip(projected, proj.unbind(0)):

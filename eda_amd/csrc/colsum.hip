@@ -13,6 +13,7 @@
 // counter array only has to be zero once, at allocation.  Kernels sharing one counter array must
 // be ordered (same stream / same graph branch).
 #include "eda_common.h"
+#include <string.h>
 
 #define CS_THREADS 256
 #define CS_MAX_SLABS 32      // the last block walks this many partial rows: keep it short
@@ -308,6 +309,137 @@ extern "C" int eda_wcolsum_f32(const float *x, long R, int C, long ld, const flo
     default: WCS_LAUNCH(4); break;
   }
 #undef WCS_LAUNCH
+  EDA_CHECK_LAUNCH();
+  return 0;
+}
+
+
+// ---- the whole backward of 1-4-output-channel layers, several layers in one launch ------------------------------
+// The last layers of the prediction heads' box stacks (centre / size: 288 -> 3, models/modules.py:66-86, 150-175) have
+// outputs too narrow for the GEMM kernels: per layer the input gradient da = dY W ran as an element-wise product launch
+// and dW = dY^T a, db = colsum(dY) as a wcolsum launch -- two launches per layer, two such layers per head, seven
+// heads whose backward passes are issued together (eda_amd/heads_batched.py).  Here ONE streaming pass per layer reads
+// a and dY, writes da and accumulates dW / db, for up to TO_MAXG layers of one shape in one launch (blockIdx.z = layer,
+// blockIdx.y = row slab); a second small launch adds the slabs in order (deterministic, no atomics).
+constexpr int TO_MAXG = 16;
+constexpr int TO_SLABS = 4;
+struct TinyOutArgs {
+  const float *dy[TO_MAXG], *w[TO_MAXG], *a[TO_MAXG];
+  float *da[TO_MAXG], *dW[TO_MAXG], *db[TO_MAXG];
+  long lda[TO_MAXG], ldda[TO_MAXG];
+};
+template <int MW>
+__global__ __launch_bounds__(256) void tiny_out_bwd_kernel(const TinyOutArgs A, int R, int C, float *__restrict__ partial) {
+  __shared__ float red[MW][16][65];
+  __shared__ float wred[MW][16];
+  const int tid = threadIdx.x, g = blockIdx.z, slab = blockIdx.y, cg = blockIdx.x;
+  const int cl = tid & 15, rl = tid >> 4;
+  const int c = cg * 64 + 4 * cl;
+  const int rps = (R + TO_SLABS - 1) / TO_SLABS;
+  const int r0 = slab * rps, r1 = min(R, r0 + rps);
+  const float *dy = A.dy[g], *a = A.a[g];
+  float *da = A.da[g];
+  const long lda = A.lda[g], ldda = A.ldda[g];
+  float4 wv[MW], acc[MW];
+  float ws[MW];
+#pragma unroll
+  for (int m = 0; m < MW; ++m) {
+    wv[m] = c < C ? *reinterpret_cast<const float4 *>(A.w[g] + (long)m * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    acc[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ws[m] = 0.f;
+  }
+  if (c < C) {
+#pragma unroll 2
+    for (int r = r0 + rl; r < r1; r += 16) {
+      const float4 v = *reinterpret_cast<const float4 *>(a + (long)r * lda + c);
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int m = 0; m < MW; ++m) {
+        const float d = dy[(long)r * MW + m];
+        o.x = fmaf(d, wv[m].x, o.x); o.y = fmaf(d, wv[m].y, o.y); o.z = fmaf(d, wv[m].z, o.z); o.w = fmaf(d, wv[m].w, o.w);
+        acc[m].x = fmaf(d, v.x, acc[m].x); acc[m].y = fmaf(d, v.y, acc[m].y);
+        acc[m].z = fmaf(d, v.z, acc[m].z); acc[m].w = fmaf(d, v.w, acc[m].w);
+        ws[m] += d;
+      }
+      *reinterpret_cast<float4 *>(da + (long)r * ldda + c) = o;
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MW; ++m) {
+    red[m][rl][4 * cl + 0] = acc[m].x; red[m][rl][4 * cl + 1] = acc[m].y;
+    red[m][rl][4 * cl + 2] = acc[m].z; red[m][rl][4 * cl + 3] = acc[m].w;
+    if (cl == 0) wred[m][rl] = ws[m];
+  }
+  __syncthreads();
+  // partial: [layer][slab][MW][C + 1] (the last entry of a row: the slab's sum of dY column m)
+  float *p = partial + ((long)g * TO_SLABS + slab) * MW * (C + 1);
+  if (tid < 64 && cg * 64 + tid < C) {
+#pragma unroll
+    for (int m = 0; m < MW; ++m) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += red[m][k][tid];
+      p[(long)m * (C + 1) + cg * 64 + tid] = t;
+    }
+  }
+  if (cg == 0 && tid < MW) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += wred[tid][k];
+    p[(long)tid * (C + 1) + C] = t;
+  }
+}
+template <int MW>
+__global__ __launch_bounds__(256) void tiny_out_reduce_kernel(const TinyOutArgs A, int C, const float *__restrict__ partial) {
+  const int g = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;            // element of the (MW, C + 1) table
+  if (e >= MW * (C + 1)) return;
+  float t = 0.f;
+#pragma unroll
+  for (int s = 0; s < TO_SLABS; ++s) t += partial[((long)g * TO_SLABS + s) * MW * (C + 1) + e];
+  const int m = e / (C + 1), c = e - m * (C + 1);
+  if (c < C) A.dW[g][(long)m * C + c] = t;
+  else if (A.db[g]) A.db[g][m] = t;
+}
+
+extern "C" size_t eda_tiny_out_bwd_workspace_bytes(int ngroups, int C, int MW) {
+  if (ngroups <= 0 || C <= 0 || MW <= 0) return 0;
+  return sizeof(float) * (size_t)ngroups * TO_SLABS * (size_t)MW * ((size_t)C + 1);
+}
+
+extern "C" int eda_tiny_out_bwd_multi_f32(int ngroups, long R, int C, int MW, const float *const *dy, const float *const *w,
+                                          const float *const *a, const long *lda, float *const *da, const long *ldda,
+                                          float *const *dW, float *const *db, void *ws, size_t ws_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(ngroups >= 1 && ngroups <= TO_MAXG && R > 0 && R < 0x7fffffffL && C > 0 && C % 4 == 0 && MW >= 1 && MW <= 4,
+                "1..16 layers, 1..4 output channels, C a multiple of 4");
+  EDA_CHECK_ARG(dy && w && a && lda && da && ldda && dW && db, "null pointer");
+  if (!ws || ws_bytes < eda_tiny_out_bwd_workspace_bytes(ngroups, C, MW)) {
+    eda_set_error("tiny_out_bwd: workspace too small");
+    return EDA_ERR_WORKSPACE;
+  }
+  TinyOutArgs A;
+  memset(&A, 0, sizeof(A));
+  for (int g = 0; g < ngroups; ++g) {
+    EDA_CHECK_ARG(dy[g] && w[g] && a[g] && da[g] && dW[g] && lda[g] >= C && ldda[g] >= C && lda[g] % 4 == 0 && ldda[g] % 4 == 0 &&
+                      ((uintptr_t)a[g] % 16 == 0) && ((uintptr_t)da[g] % 16 == 0) && ((uintptr_t)w[g] % 16 == 0),
+                  "bad group (16-byte addressable rows)");
+    A.dy[g] = dy[g]; A.w[g] = w[g]; A.a[g] = a[g]; A.da[g] = da[g]; A.dW[g] = dW[g]; A.db[g] = db[g];
+    A.lda[g] = lda[g]; A.ldda[g] = ldda[g];
+  }
+  float *partial = reinterpret_cast<float *>(ws);
+  const dim3 grid((unsigned)((C + 63) / 64), TO_SLABS, (unsigned)ngroups);
+  const dim3 rgrid((unsigned)((MW * (C + 1) + 255) / 256), (unsigned)ngroups);
+#define TO_LAUNCH(MWC)                                                                                     \
+  hipLaunchKernelGGL(tiny_out_bwd_kernel<MWC>, grid, dim3(256), 0, stream, A, (int)R, C, partial);        \
+  hipLaunchKernelGGL(tiny_out_reduce_kernel<MWC>, rgrid, dim3(256), 0, stream, A, C, (const float *)partial)
+  switch (MW) {
+    case 1: TO_LAUNCH(1); break;
+    case 2: TO_LAUNCH(2); break;
+    case 3: TO_LAUNCH(3); break;
+    default: TO_LAUNCH(4); break;
+  }
+#undef TO_LAUNCH
   EDA_CHECK_LAUNCH();
   return 0;
 }

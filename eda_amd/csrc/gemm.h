@@ -12,7 +12,7 @@ enum { E_PLAIN = 0, E_STATS = 1, E_MASK = 2, E_SCATTER = 3 };
 
 // one problem of a grouped launch: same row count, own operands / widths (plain rows, plain epilogue)
 struct GemmGroup { const float *x; long ldx; const float *w; long ldw; const float *bias; float *y; long ldy; int K, N, ct0; };
-constexpr int G_MAXGROUPS = 4;
+constexpr int G_MAXGROUPS = 24;     // (the seven prediction heads' 3 x 7 sibling stacks in one backward launch: eda_amd/heads_batched.py)
 
 struct GemmArgs {
   int xmode, epi;

@@ -1809,7 +1809,7 @@ extern "C" int eda_linear_grouped_fwd_f32(int ngroups, const float *const *x, co
                                           const float *const *w, const long *ldw, const int *N,
                                           const float *const *bias, int relu, float *const *y, const long *ldy,
                                           void *stream_) {
-  EDA_CHECK_ARG(ngroups >= 1 && ngroups <= G_MAXGROUPS && R >= 0, "1..4 groups");
+  EDA_CHECK_ARG(ngroups >= 1 && ngroups <= G_MAXGROUPS && R >= 0, "1..24 groups");
   if (R == 0) return 0;
   EDA_CHECK_ARG(x && ldx && K && w && ldw && N && y && ldy, "null pointer");
   GemmArgs a;
@@ -1831,7 +1831,7 @@ extern "C" int eda_linear_grouped_fwd_f32(int ngroups, const float *const *x, co
 extern "C" int eda_linear_grouped_dgrad_f32(int ngroups, const float *const *dy, const long *lddy, long R, const int *N,
                                             const float *const *w, const long *ldw, const int *K, float *const *dx,
                                             const long *lddx, void *stream_) {
-  EDA_CHECK_ARG(ngroups >= 1 && ngroups <= G_MAXGROUPS && R >= 0, "1..4 groups");
+  EDA_CHECK_ARG(ngroups >= 1 && ngroups <= G_MAXGROUPS && R >= 0, "1..24 groups");
   if (R == 0) return 0;
   EDA_CHECK_ARG(dy && lddy && K && w && ldw && N && dx && lddx, "null pointer");
   GemmArgs a;

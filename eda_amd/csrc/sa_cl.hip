@@ -589,12 +589,48 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_fwd_kernel(
 }
 
 template <int CQ>
+__device__ __forceinline__ void bn_relu_small_bwd_body(
+    const float *__restrict__ da, const float *__restrict__ z, int R, int C,
+    const BnGrp &G, const float *__restrict__ mean, const float *__restrict__ rstd,
+    const float *__restrict__ scale, const float *__restrict__ shift, int train,
+    float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dz, float p_drop,
+    const unsigned long long *seed_ptr);
+
+template <int CQ>
 __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_bwd_kernel(
     const float *__restrict__ da, const float *__restrict__ z, int R, int C,
     const BnGrp G, const float *__restrict__ mean, const float *__restrict__ rstd,
     const float *__restrict__ scale, const float *__restrict__ shift, int train,
     double *__restrict__ s1_out, double *__restrict__ s2_out, float *__restrict__ dgamma,
     float *__restrict__ dbeta, float *__restrict__ dz, float p_drop, const unsigned long long *seed_ptr) {
+  bn_relu_small_bwd_body<CQ>(da, z, R, C, G, mean, rstd, scale, shift, train, dgamma, dbeta, dz, p_drop, seed_ptr);
+}
+
+// The same backward for up to BN_MAXMAT packed matrices of one shape in ONE launch (blockIdx.y = matrix): the seven
+// prediction heads' BatchNorm+ReLU+Dropout backward passes depend on the loss alone and are issued together
+// (eda_amd/heads_batched.py).
+constexpr int BN_MAXMAT = 8;
+struct BnMulti {
+  const float *da[BN_MAXMAT], *z[BN_MAXMAT], *stats[BN_MAXMAT];   // stats: (4, C) rows mean | rstd | scale | shift
+  float *dgb[BN_MAXMAT], *dz[BN_MAXMAT];                           // dgb: (2, C) rows dgamma | dbeta
+  BnGrp grp[BN_MAXMAT];
+};
+template <int CQ>
+__global__ __launch_bounds__(SM_THREADS) void bn_relu_small_bwd_multi_kernel(const BnMulti M, int R, int C, int train, float p_drop,
+                                                                             const unsigned long long *seed_ptr) {
+  const int m = blockIdx.y;
+  const float *st = M.stats[m];
+  bn_relu_small_bwd_body<CQ>(M.da[m], M.z[m], R, C, M.grp[m], st, st + C, st + 2 * C, st + 3 * C, train, M.dgb[m], M.dgb[m] + C,
+                             M.dz[m], p_drop, seed_ptr);
+}
+
+template <int CQ>
+__device__ __forceinline__ void bn_relu_small_bwd_body(
+    const float *__restrict__ da, const float *__restrict__ z, int R, int C,
+    const BnGrp &G, const float *__restrict__ mean, const float *__restrict__ rstd,
+    const float *__restrict__ scale, const float *__restrict__ shift, int train,
+    float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dz, float p_drop,
+    const unsigned long long *seed_ptr) {
   constexpr int RL = SM_THREADS / CQ;              // row lanes (see the forward kernel)
   __shared__ float red[8][CQ][SM_WAVES];
   __shared__ float ka_l[4 * CQ], kb_l[4 * CQ], kd_l[4 * CQ];
@@ -1366,6 +1402,35 @@ extern "C" int eda_bn_relu_grouped_bwd_f32(const float *dout, const float *z, lo
   for (int g = 0; g < ngroups; ++g) { EDA_CHECK_ARG(gamma[g], "null pointer"); G.gamma[g] = gamma[g]; G.salt[g] = salts ? salts[g] : 0u; }
   hipLaunchKernelGGL(bn_relu_small_bwd_kernel<4>, dim3(C / 16), dim3(SM_THREADS), 0, stream, dout, z, (int)R, C, G, mean,
                      rstd, scale, shift, training, nullptr, nullptr, dgamma, dbeta, dz, p_drop, seed_ptr);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int eda_bn_relu_grouped_bwd_multi_f32(int nmat, const float *const *dout, const float *const *z, long R, int ngroups,
+                                                 int cpg, const float *const *gamma, const float *const *stats, int training,
+                                                 float *const *dgb, float *const *dz, float p_drop,
+                                                 const unsigned long long *seed_ptr, const unsigned *salts, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EDA_CHECK_ARG(nmat >= 1 && nmat <= BN_MAXMAT, "1..8 matrices");
+  EDA_CHECK_ARG(ngroups >= 1 && ngroups <= 4 && cpg > 0 && cpg % 16 == 0, "1..4 groups of a multiple of 16 channels");
+  EDA_CHECK_ARG(R > 0 && R <= SMALL_ROWS, "row count beyond the single-launch kernels");
+  EDA_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || (seed_ptr && salts)), "bad dropout arguments");
+  EDA_CHECK_ARG(dout && z && gamma && stats && dgb && dz, "null pointer");
+  const int C = ngroups * cpg;
+  BnMulti M;
+  memset(&M, 0, sizeof(M));
+  for (int m = 0; m < nmat; ++m) {
+    EDA_CHECK_ARG(dout[m] && z[m] && stats[m] && dgb[m] && dz[m], "null pointer");
+    M.da[m] = dout[m]; M.z[m] = z[m]; M.stats[m] = stats[m]; M.dgb[m] = dgb[m]; M.dz[m] = dz[m];
+    M.grp[m].cpg = cpg;
+    for (int g = 0; g < ngroups; ++g) {
+      EDA_CHECK_ARG(gamma[m * ngroups + g], "null pointer");
+      M.grp[m].gamma[g] = gamma[m * ngroups + g];
+      M.grp[m].salt[g] = salts ? salts[m * ngroups + g] : 0u;
+    }
+  }
+  hipLaunchKernelGGL(bn_relu_small_bwd_multi_kernel<4>, dim3(C / 16, nmat), dim3(SM_THREADS), 0, stream, M, (int)R, C, training,
+                     p_drop, seed_ptr);
   EDA_CHECK_LAUNCH();
   return 0;
 }

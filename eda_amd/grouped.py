@@ -205,29 +205,36 @@ class _BlockLinear(Function):
         return (dxp, None, None, *grads)
 
 
+def bn_relu_fwd_raw(zp, cfg, gammas, betas):
+    """The grouped BatchNorm+ReLU(+Dropout) forward launch: (out, stats (4, G*C) rows mean | rstd | scale | shift)."""
+    G, C, training, eps, momentum, p_drop, salts, running = cfg
+    zp = zp.contiguous()
+    R = zp.shape[0]
+    dev = zp.device
+    stats = torch.empty((4, G * C), dtype=torch.float32, device=dev)
+    out = torch.empty_like(zp)
+    seed = None
+    if p_drop > 0:
+        from .attention import dropout_state
+        seed = dropout_state(dev)
+    salt_arr = (ctypes.c_uint * G)(*[int(s) & 0xFFFFFFFF for s in salts])
+    with torch.cuda.device(dev), _timed("bn_relu_grouped_fwd", (R, G, C, int(training))):
+        rc = _lib.lib().eda_bn_relu_grouped_fwd_f32(
+            zp.data_ptr(), R, G, C, _parr(gammas), _parr(betas), _parr([r[0] for r in running]),
+            _parr([r[1] for r in running]), float(eps), float(momentum), int(bool(training)),
+            stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), out.data_ptr(),
+            float(p_drop), seed.data_ptr() if seed is not None else None, salt_arr, _stream())
+    _lib.check(rc, "eda_bn_relu_grouped_fwd_f32")
+    return zp, out, stats
+
+
 class _GroupedBNReLU(Function):
     @staticmethod
     def forward(ctx, zp, cfg, *params):
         """cfg = (G, C, training, eps, momentum, p_drop, salts, running=[(rm, rv), ...]); params = gamma_0, beta_0, ..."""
         G, C, training, eps, momentum, p_drop, salts, running = cfg
         gammas, betas = list(params[0::2]), list(params[1::2])
-        zp = zp.contiguous()
-        R = zp.shape[0]
-        dev = zp.device
-        stats = torch.empty((4, G * C), dtype=torch.float32, device=dev)
-        out = torch.empty_like(zp)
-        seed = None
-        if p_drop > 0:
-            from .attention import dropout_state
-            seed = dropout_state(dev)
-        salt_arr = (ctypes.c_uint * G)(*[int(s) & 0xFFFFFFFF for s in salts])
-        with torch.cuda.device(dev), _timed("bn_relu_grouped_fwd", (R, G, C, int(training))):
-            rc = _lib.lib().eda_bn_relu_grouped_fwd_f32(
-                zp.data_ptr(), R, G, C, _parr(gammas), _parr(betas), _parr([r[0] for r in running]),
-                _parr([r[1] for r in running]), float(eps), float(momentum), int(bool(training)),
-                stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), out.data_ptr(),
-                float(p_drop), seed.data_ptr() if seed is not None else None, salt_arr, _stream())
-        _lib.check(rc, "eda_bn_relu_grouped_fwd_f32")
+        zp, out, stats = bn_relu_fwd_raw(zp, cfg, gammas, betas)
         ctx.save_for_backward(zp, stats, *gammas)
         ctx.cfg = (G, C, bool(training), float(p_drop), [int(s) & 0xFFFFFFFF for s in salts])
         return out
@@ -271,9 +278,9 @@ def block_linear(xp, weights, biases, pack_out, relu=False):
     return _BlockLinear.apply(xp, pack_out, relu, *params)
 
 
-def grouped_bn_relu(zp, bns, dropouts=None):
-    """relu(BatchNorm bns[g](zp[:, g*C:(g+1)*C])) (+ the heads' Dropout, fused, in training)."""
-    from .nn_utils import _bn_drop_salts, bump_batches_tracked
+def bn_relu_cfg(zp, bns, dropouts=None):
+    """cfg tuple of the grouped BatchNorm+ReLU(+Dropout) launch for modules `bns` / `dropouts` on packed rows zp."""
+    from .nn_utils import _bn_drop_salts
     G = len(bns)
     C = zp.shape[1] // G
     training = bns[0].training
@@ -287,13 +294,19 @@ def grouped_bn_relu(zp, bns, dropouts=None):
                 from .fused_ln import new_salt_base
                 s = _bn_drop_salts[id(d)] = new_salt_base() + 7
             salts[g] = s
-    cfg = (G, C, training or not bns[0].track_running_stats, bns[0].eps, bns[0].momentum, p, salts,
-           [(bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None) for bn in bns])
+    return (G, C, training or not bns[0].track_running_stats, bns[0].eps, bns[0].momentum, p, salts,
+            [(bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None) for bn in bns])
+
+
+def grouped_bn_relu(zp, bns, dropouts=None):
+    """relu(BatchNorm bns[g](zp[:, g*C:(g+1)*C])) (+ the heads' Dropout, fused, in training)."""
+    from .nn_utils import bump_batches_tracked
+    cfg = bn_relu_cfg(zp, bns, dropouts)
     params = []
     for bn in bns:
         params += [bn.weight, bn.bias]
     out = _GroupedBNReLU.apply(zp, cfg, *params)
-    if training:
+    if bns[0].training:
         for bn in bns:
             if bn.track_running_stats:
                 bump_batches_tracked(bn)

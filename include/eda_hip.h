@@ -348,6 +348,18 @@ int eda_wcolsum_f32(const float *x, long R, int C, long ld, const float *w, long
                     float *out, float *wsum, void *ws, size_t ws_bytes, unsigned *counters,
                     void *stream);
 
+/* The whole backward of pointwise layers with 1-4 output channels (MW), for up to 16 layers of one shape in one pass
+ * (the box-centre / size stacks' last layers of all seven prediction heads, models/modules.py:66-86, 150-175; their
+ * backward passes are issued together, eda_amd/heads_batched.py): per layer g
+ *   da[g] (R, C; ldda) = dy[g] (R, MW contiguous) w[g] (MW, C)     dW[g] (MW, C) = dy[g]^T a[g] (R, C; lda)
+ *   db[g] (MW) = column sums of dy[g] (db[g] may be NULL)
+ * One streaming launch over (64-column groups, 4 row slabs, layers) + one small launch that adds the slabs in order
+ * (deterministic).  ws: eda_tiny_out_bwd_workspace_bytes(ngroups, C, MW) bytes of scratch. */
+size_t eda_tiny_out_bwd_workspace_bytes(int ngroups, int C, int MW);
+int eda_tiny_out_bwd_multi_f32(int ngroups, long R, int C, int MW, const float *const *dy, const float *const *w,
+                               const float *const *a, const long *lda, float *const *da, const long *ldda,
+                               float *const *dW, float *const *db, void *ws, size_t ws_bytes, void *stream);
+
 /* ---- Hungarian matching on the device -----------------------
  * Replaces `scipy.optimize.linear_sum_assignment(C[b])` per scene in HungarianMatcher.forward
  * (models/losses.py:319-329): cost is (B, Q, G) with element strides sb, sq, st; the first
@@ -448,9 +460,14 @@ int eda_sa_fused_bwd_wt_f32(const float *dout, const unsigned char *argmax, cons
  * The three ThreeLayerMLPs of a ClsAgnosticPredictHead (models/modules.py:111-178: centre, size,
  * semantic scores) are independent stacks of the same shape; the reference runs them one layer at
  * a time (15 small cuDNN/cuBLAS launches per head, 7 heads).  Here layer l of all siblings is ONE
- * launch: a grouped GEMM (up to 4 problems with the same row count, own operands and widths; host
+ * launch: a grouped GEMM (up to 24 problems with the same row count, own operands and widths; host
  * arrays of device pointers / strides / dims) and a grouped BatchNorm+ReLU+Dropout over column
- * blocks of one (R, ngroups*cpg) matrix (single-launch kernels: R <= eda_bn_relu_dropout_max_rows()). */
+ * blocks of one (R, ngroups*cpg) matrix (single-launch kernels: R <= eda_bn_relu_dropout_max_rows()).
+ * The BACKWARD passes of the seven heads depend on the loss alone (what a head hands to the next decoder layer is
+ * detached, models/bdetr.py:262-316), so they are issued together (eda_amd/heads_batched.py): grouped input gradients
+ * over 3 x 7 = 21 problems and eda_bn_relu_grouped_bwd_multi_f32 = the grouped BatchNorm backward for up to 8
+ * matrices of one shape in one launch (dout / z / dz / stats = (4, C) rows mean | rstd | scale | shift / dgb = (2, C)
+ * rows dgamma | dbeta per matrix; gamma, salts: nmat * ngroups entries, matrix-major). */
 int eda_linear_grouped_fwd_f32(int ngroups, const float *const *x, const long *ldx, long R, const int *K,
                                const float *const *w, const long *ldw, const int *N,
                                const float *const *bias, int relu, float *const *y, const long *ldy,
@@ -469,6 +486,10 @@ int eda_bn_relu_grouped_bwd_f32(const float *dout, const float *z, long R, int n
                                 const float *scale, const float *shift, int training, float *dgamma,
                                 float *dbeta, float *dz, float p_drop, const unsigned long long *seed_ptr,
                                 const unsigned *salts, void *stream);
+int eda_bn_relu_grouped_bwd_multi_f32(int nmat, const float *const *dout, const float *const *z, long R, int ngroups,
+                                      int cpg, const float *const *gamma, const float *const *stats, int training,
+                                      float *const *dgb, float *const *dz, float p_drop,
+                                      const unsigned long long *seed_ptr, const unsigned *salts, void *stream);
 
 /* eda_linear_fwd_f32 with two more things in its epilogue, for chains Linear -> ReLU -> Dropout -> Linear (the FFNs of
  * models/encoder_decoder_layers.py:88-96,120-122,403-405 and the contrastive projection MLPs of models/bdetr.py:127-139):
