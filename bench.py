@@ -409,6 +409,14 @@ def main():
             _par.sampler_without_co_residency()
 
     from eda_amd import ext
+    if args.sync_bn and dist_on and args.graph:
+        # SyncBN puts collectives INSIDE the step; a captured collective's events are queried by RCCL's watchdog thread on this
+        # torch / ROCm ("operation not permitted on an event last recorded in a capturing stream": the process aborts), so this
+        # configuration runs with eager launches.  The default N > 1 step (per-GPU statistics) keeps its graphs: its one
+        # all-reduce is launched between them.
+        print("[bench] --sync-bn with a process group: eager launches (collectives inside a captured step abort RCCL's watchdog)",
+              file=sys.stderr, flush=True)
+        args.graph = 0
     if args.sync_bn and dist_on:
         from eda_amd import sync_bn
         if dist.get_backend() == "gloo" and args.graph:
@@ -832,7 +840,9 @@ def main():
         # the dominant tiled product once more, the way the step actually runs it: 50 launches back to back in a replayed
         # hipGraph (a HIP-event bracket around ONE eager launch of a ~10 us kernel measures the bracket too: ~+35 %; the
         # rocprofv3 average in profiles/*_summary.md is the third view of the same kernel)
-        if roofline_gemm and topg["op"] in ("gemm_fwd", "gemm_dgrad"):
+        # (not under a live process group: RCCL's watchdog thread queries its events while this thread captures -- "operation
+        # not permitted on an event last recorded in a capturing stream" ended a --force-dist run after the line was printed)
+        if roofline_gemm and topg["op"] in ("gemm_fwd", "gemm_dgrad") and not dist_on:
             try:
                 from eda_amd import gemm as _g
                 r_, k_, n_ = topg["dims"]
@@ -957,7 +967,7 @@ def main():
         if os.environ.get("EDA_BENCH_KERNELS_FILE"):       # the complete per-op table (the line carries the first 40 rows)
             with open(os.environ["EDA_BENCH_KERNELS_FILE"], "w") as f:
                 json.dump(kernels, f)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

@@ -262,6 +262,12 @@ class BeaUTyDETR(nn.Module):
         base_xyz, base_size = center.detach(), size.detach()
 
         hoisted = self._hoisted_kv(vis, text_feats, detected_feats if self.butd else None)
+        from .posembed_batched import PosEmbedBatch
+        pb = None
+        if self.training and self.self_position_embedding == "loc_learned" and self.num_decoder_layers > 1:
+            probe = torch.cat([base_xyz, base_size], -1)
+            if all(PosEmbedBatch.usable(getattr(L, "self_posembed", None), probe) for L in self.decoder):
+                pb = PosEmbedBatch()
         for i in range(self.num_decoder_layers):
             prefix = "last_" if i == self.num_decoder_layers - 1 else f"{i}head_"
             if self.self_position_embedding == "none":
@@ -275,7 +281,7 @@ class BeaUTyDETR(nn.Module):
             query = self.decoder[i](query, vis, text_feats, query_pos, None, text_padding_mask,
                                     detected_feats=detected_feats if self.butd else None,
                                     detected_mask=detected_mask if self.butd else None,
-                                    pre_kv={k: (kvs[i], sink, i) for k, (kvs, sink) in hoisted.items()})
+                                    pre_kv={k: (kvs[i], sink, i) for k, (kvs, sink) in hoisted.items()}, pos_batch=pb)
             # three consumers (the next layer, this layer's prediction head, the contrastive projection): one alias each,
             # their gradients are then summed in one launch (nn_utils.fan_out)
             query, q_head, q_proj = fan_out(query, 3)

@@ -246,12 +246,14 @@ class BiDecoderLayer(nn.Module):
         self._salt = new_salt_base()
 
     def forward(self, query, vis_feats, lang_feats, query_pos, padding_mask, text_key_padding_mask,
-                detected_feats=None, detected_mask=None, pre_kv=None):
+                detected_feats=None, detected_mask=None, pre_kv=None, pos_batch=None):
         """pre_kv: {"l": .., "d": .., "v": ..} -> (kv, sink, slot) per cross-attention whose K | V projection the caller
         hoisted out of the layer loop (BeaUTyDETR._hoisted_kv); only honoured on the fused GPU path."""
         pre_kv = pre_kv or {}
         if self.self_posembed is not None:
-            pos = self.self_posembed.rows(query_pos)
+            # pos_batch: the embedding's backward is issued with the other layers' at the end of the backward pass
+            # (eda_amd/posembed_batched.py)
+            pos = pos_batch.add(self.self_posembed, query_pos) if pos_batch is not None else self.self_posembed.rows(query_pos)
         else:
             pos = torch.full_like(query, 0.0)
         # the incoming query feeds the sum below, the residual and the value of the self-attention; the positional term

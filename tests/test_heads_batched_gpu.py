@@ -9,13 +9,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(batched, defer):
+def _run(batched, defer, what="EDA_BATCHED_HEADS"):
     from eda_amd import synthetic
     from eda_amd.bdetr import BeaUTyDETR
     from eda_amd.parallel import FlatParams
     import itertools
     from eda_amd import attention, fused_ln, nn_utils
-    os.environ["EDA_BATCHED_HEADS"] = "1" if batched else "0"
+    os.environ[what] = "1" if batched else "0"
     try:
         # the same dropout streams in both runs: call-site salts are drawn from process-wide counters at construction
         attention._salt_counter = itertools.count(1)
@@ -46,7 +46,7 @@ def _run(batched, defer):
             flat.collect_grads()
         return {k: ep[k].detach().clone() for k in keys}, flat.flat_grad.clone(), float(loss)
     finally:
-        os.environ.pop("EDA_BATCHED_HEADS", None)
+        os.environ.pop(what, None)
 
 
 @pytest.mark.parametrize("defer", [False, True])
@@ -63,3 +63,17 @@ def test_batched_heads_backward_equals_per_head_nodes(defer):
     # the heads' own parameters saw gradients on the batched path
     nz = (g_b != 0).float().mean().item()
     assert abs(nz - (g_p != 0).float().mean().item()) < 1e-3
+
+
+@pytest.mark.parametrize("defer", [False, True])
+def test_batched_posembed_backward_equals_per_layer_nodes(defer):
+    """The decoder layers' positional embeddings: backward at the end of the pass, all layers together
+    (eda_amd/posembed_batched.py), against the per-layer autograd nodes."""
+    out_b, g_b, l_b = _run(True, defer, "EDA_BATCHED_POSEMBED")
+    out_p, g_p, l_p = _run(False, defer, "EDA_BATCHED_POSEMBED")
+    for k in out_b:
+        torch.testing.assert_close(out_b[k], out_p[k], rtol=1e-5, atol=1e-6)
+    scale = g_p.abs().max().item()
+    assert torch.isfinite(g_b).all()
+    assert (g_b - g_p).abs().max().item() <= 2e-5 * scale
+    assert abs((g_b != 0).float().mean().item() - (g_p != 0).float().mean().item()) < 1e-3

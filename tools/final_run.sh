@@ -24,6 +24,9 @@ python bench.py --force-dist --in-step-steps 0 > $O/bench_force_dist.json 2> $O/
 python bench.py --force-dist --overlap-allreduce 1 --in-step-steps 0 > $O/bench_force_dist_overlap.json 2> $O/bench_force_dist_overlap.err
 python bench.py --force-dist --sync-bn --in-step-steps 0 > $O/bench_force_dist_sync_bn.json 2> $O/bench_force_dist_sync_bn.err
 EDA_MHA_QPROJ=0 python bench.py --in-step-steps 0 > $O/bench_qproj_off.json 2> $O/bench_qproj_off.err
+EDA_WGRAD_BF16X3=0 python bench.py --in-step-steps 0 > $O/bench_wgrad_fp32_mfma.json 2> $O/bench_wgrad_fp32_mfma.err
+EDA_BATCHED_HEADS=0 python bench.py --in-step-steps 0 > $O/bench_heads_per_head.json 2> $O/bench_heads_per_head.err
+python tools/bench_wgrad_grouped.py > $O/wgrad_grouped.txt 2>&1
 python tools/time_qproj_site.py > $O/qproj_site.txt 2>&1
 python tools/time_linear_ln.py 2048 288 > $O/linear_ln.txt 2>&1
 python tools/fps_handoffs.py 8 50000 2048 > $O/fps_cluster.txt 2>&1
