@@ -586,6 +586,14 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         barrier_sync = (lambda: (dist.barrier() if dist_on else None, torch.cuda.synchronize()))
         barrier_sync()
+        if dist_on:
+            # RCCL's watchdog thread polls the events of the collectives issued so far (the barrier just now) every ~100 ms
+            # until it has seen them complete.  Synchronous collectives record those events on the CURRENT stream -- the
+            # stream the capture below starts on -- and on this ROCm an event query on a stream that has since entered capture
+            # fails with "operation not permitted on an event last recorded in a capturing stream", which ABORTS the process
+            # from the watchdog thread (seen in 2 of 6 --force-dist runs).  Everything is complete on the GPU here: give the
+            # watchdog one poll interval to retire it before any stream starts capturing.
+            time.sleep(1.0)
         # thread-local capture mode: calls from other threads (RCCL's watchdog) must not
         # invalidate the capture.
         mode = dict(capture_error_mode="thread_local")
