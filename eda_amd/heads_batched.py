@@ -182,7 +182,6 @@ class _HeadsBatched(Function):
             grads += [dgb2[h][0][s * C:(s + 1) * C] for s in range(S)] + [dgb2[h][1][s * C:(s + 1) * C] for s in range(S)]
             grads += [dW3[k + s].view(nets[s][8].weight.shape) if dW3[k + s] is not None else None for s in range(S)]
             grads += [db3[k + s] for s in range(S)]
-        ctx.recs = None
         return tuple(grads)
 
 

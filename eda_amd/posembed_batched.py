@@ -90,8 +90,8 @@ class PosEmbedBatch:
             Variable._execution_engine.queue_callback(self._run)
 
     def _run(self):
-        recs = [r for r in self.recs if r.dpos is not None]
-        self.recs, self._queued = [], False
+        recs = [r for r in self.recs if r.dpos is not None]      # (the records live as long as the graph: a second backward
+        self._queued = False                                     #  over a retained graph stores new gradients and comes here again)
         if not recs:
             return
         G = len(recs)
@@ -114,8 +114,12 @@ class PosEmbedBatch:
             x_all = torch.stack([r.x for r in recs], 0)
             dW1 = torch.bmm(dz1_all.transpose(1, 2), x_all)                 # (G, 288, 6)
             db1 = dz1_all.sum(1)
+            for r in recs:
+                r.dpos = None
             for g, h in enumerate(heads):
-                _acc(h[3].weight, dW2[g]); _acc(h[3].bias, db2[g]) if h[3].bias is not None else None
+                _acc(h[3].weight, dW2[g])
+                if h[3].bias is not None:
+                    _acc(h[3].bias, db2[g])
                 _acc(h[1].weight, dgb[g][0]); _acc(h[1].bias, dgb[g][1])
                 _acc(h[0].weight, dW1[g])
                 if h[0].bias is not None:
