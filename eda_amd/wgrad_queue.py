@@ -63,6 +63,9 @@ class WgradQueue:
             return None
         if not (self._operand_ok(dy2, M) and self._operand_ok(x2, N)):
             return None
+        # the bf16 x 3 kernel addresses operand rows with 32-bit byte offsets from the operand's base
+        if K > 1 and max(dy2.stride(0), x2.stride(0)) * 4 * K >= (1 << 32):
+            return None
         gW = self.locate(W)
         if gW is None:
             return None
