@@ -77,6 +77,14 @@ struct WgradXArgs {
   // dy_pool > 0: dy is not stored; it is the dz of GemmArgs::X_BNBWDPOOL, formed from dyz (= z, R x M), dy_argmax,
   // dy_dout (R/pool x M) and dy_consts (5 x M) while staging (xmode must be X_BNRELU)
   const float *dyz; const unsigned char *dy_argmax; const float *dy_dout; const float *dy_consts; int dy_pool;
+  // dy_bn: dy is the MASKED gradient g of a non-pooled layer's output and the layer's dz = ka*g + kb*z + kd is formed while
+  // staging (z = dyz (R x M), {., ., ka, kb, kd} = dy_consts (5 x M)): bn_relu_bwd_apply_kernel's pass is not run
+  int dy_bn;
+  // dx_out != NULL (sa_layer_bwd_kernel: xmode X_BNRELU, M and N in {64, 128}, ld_x = N): the layer's input gradient in the
+  // same launch -- g_prev = (dz W) where the input's ReLU was open -> dx_out (R x N), its BatchNorm-backward column sums
+  // (sum g_prev, sum g_prev * xhat) -> dx_s1 / dx_s2 (fp64 atomics); dx_w = the layer's (M, N) weight
+  const float *dx_w; long dx_ldw; float *dx_out; const float *dx_mean, *dx_rstd; double *dx_s1, *dx_s2;
 };
+bool eda_wgrad_x_fuses_dx(int M, int N);
 size_t eda_wgrad_x_workspace_bytes(long R, int M, int N);
 int eda_wgrad_x_launch(const WgradXArgs &a, hipStream_t stream);

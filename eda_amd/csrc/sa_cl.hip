@@ -1132,8 +1132,8 @@ extern "C" size_t eda_sa_fused_bwd_workspace_bytes(long R, int nlayers, const in
     const size_t n = (size_t)channels[l] * channels[l + 1];
     if (n > wt) wt = n;
   }
-  // red (one region of 2 x cmax doubles per layer, all zeroed by ONE launch) | transposed weight | constants of the fused pooled BatchNorm backward (5 x cmax floats) | slabs
-  return sizeof(double) * 2 * (size_t)cmax * nlayers + sizeof(float) * ((wt + 3) / 4 * 4) + sizeof(float) * 5 * (size_t)((cmax + 3) / 4 * 4) + slabs;
+  // red (one region of 2 x cmax doubles per layer, all zeroed by ONE launch) | transposed weight | per layer: constants of a BatchNorm backward formed in its consumers (5 x cmax floats) | slabs
+  return sizeof(double) * 2 * (size_t)cmax * nlayers + sizeof(float) * ((wt + 3) / 4 * 4) + sizeof(float) * 5 * (size_t)((cmax + 3) / 4 * 4) * nlayers + slabs;
 }
 
 // weight_t: optional per-layer pointers to W^T ((cin, cout) row-major, contiguous), e.g. from the caller's W^T shadow
@@ -1184,9 +1184,17 @@ static int sa_fused_bwd_impl(const float *dout, const unsigned char *argmax, con
   { const int zrc = eda_zero_async(red_all, sizeof(double) * 2 * (size_t)cmax * nlayers, stream); if (zrc) return zrc; }
   float *wt = reinterpret_cast<float *>(red_all + 2 * (size_t)cmax * nlayers);
   const size_t const_floats = 5 * (size_t)((cmax + 3) / 4 * 4);
-  float *pool_consts = wt + wt_floats;
-  float *slabs = pool_consts + const_floats;
-  const size_t slab_bytes = ws_bytes - sizeof(double) * 2 * (size_t)cmax * nlayers - sizeof(float) * (wt_floats + const_floats);
+  float *consts_all = wt + wt_floats;                     // layer l: consts_all + l * const_floats
+  float *pool_consts = consts_all + const_floats * (size_t)(nlayers - 1);
+  float *slabs = consts_all + const_floats * (size_t)nlayers;
+  const size_t slab_bytes = ws_bytes - sizeof(double) * 2 * (size_t)cmax * nlayers - sizeof(float) * (wt_floats + const_floats * (size_t)nlayers);
+  // One launch per layer (wgrad.hip, sa_layer_bwd_kernel: weight gradient + masked input gradient + its BatchNorm-backward sums
+  // from one pass over dz) where the layer's dW is one tile; and a non-pooled layer's dz = ka*g + kb*z + kd is formed by
+  // its consumer(s) while staging instead of by bn_relu_bwd_apply_kernel whenever all of them can (`pending`).
+  bool layer_fuse = training != 0;
+  { const char *e = getenv("EDA_SA_LAYER_FUSE"); if (e && atoi(e) == 0) layer_fuse = false; }
+  const bool need_dx0 = g.gather ? (dfeats_cl && c_feat > 0) : dx != nullptr;
+  bool pending = false;
   // Pooled last layer in training mode: its dz = ka*d + kb*z + kd need not be written and read back -- the two kernels
   // that consume it (weight gradient, input gradient) form it while staging z, when the input gradient is a launch
   // of the streaming kernels (gemm.hip X_BNBWDPOOL); otherwise bn_relu_bwd_apply_kernel<true> materialises it.
@@ -1240,6 +1248,7 @@ static int sa_fused_bwd_impl(const float *dout, const unsigned char *argmax, con
   float *cur = scratch_a, *other = scratch_b;
   for (int l = nlayers - 1; l >= 0; --l) {
     const int cin = channels[l], cout = channels[l + 1];
+    const bool fl = layer_fuse && l >= 1 && eda_wgrad_x_fuses_dx(cout, cin);
     // ---- weight gradient: dW_l = dz_l^T (row operand of the forward GEMM, recomputed while staging)
     {
       WgradXArgs wa;
@@ -1259,6 +1268,14 @@ static int sa_fused_bwd_impl(const float *dout, const unsigned char *argmax, con
       wa.dW = dW[l]; wa.ws = slabs; wa.ws_bytes = slab_bytes;
       if (fuse_pool && l == nlayers - 1) {
         wa.dy = nullptr; wa.dy_pool = pool; wa.dyz = z[l]; wa.dy_argmax = argmax; wa.dy_dout = dout; wa.dy_consts = pool_consts;
+      } else if (pending) {
+        wa.dy_bn = 1; wa.dyz = z[l]; wa.dy_consts = consts_all + const_floats * (size_t)l;
+      }
+      if (fl) {
+        const float *st = stats[l - 1];
+        double *red = red_all + 2 * (size_t)cmax * (l - 1);
+        wa.dx_w = weight[l]; wa.dx_ldw = cin; wa.dx_out = other;
+        wa.dx_mean = st; wa.dx_rstd = st + cin; wa.dx_s1 = red; wa.dx_s2 = red + cin;
       }
       const int rc = eda_wgrad_x_launch(wa, stream);
       if (rc) return rc;
@@ -1273,7 +1290,7 @@ static int sa_fused_bwd_impl(const float *dout, const unsigned char *argmax, con
     }
     // dX = dz W as an NT product with W^T (output columns x cout), transposed into the workspace
     const int wcols = (l == 0 && g.gather) ? c_feat : cin, wc0 = (l == 0 && g.gather) ? 3 : 0;
-    const bool need_dx = l > 0 || (g.gather ? (dfeats_cl && c_feat > 0) : dx != nullptr);
+    const bool need_dx = !fl && (l > 0 || need_dx0);         // (fl: the input gradient rides in the weight-gradient launch)
     const float *wt_l = wt;
     if (need_dx && weight_t && weight_t[l] && (reinterpret_cast<uintptr_t>(weight_t[l]) & 15u) == 0 && cout % 4 == 0) {
       wt_l = weight_t[l] + (size_t)wc0 * cout;              // rows wc0.. of W^T: the feature columns of a gather layer
@@ -1286,21 +1303,31 @@ static int sa_fused_bwd_impl(const float *dout, const unsigned char *argmax, con
     if (l > 0) {
       const float *st = stats[l - 1];
       double *red = red_all + 2 * (size_t)cmax * (l - 1);
-      a.N = cin; a.y = other; a.ldy = cin;
-      a.epi = E_MASK;
-      a.zm = z[l - 1]; a.ldzm = cin;
-      a.m_mean = st; a.m_rstd = st + cin; a.m_scale = st + 2 * cin; a.m_shift = st + 3 * cin;
-      a.s1 = red; a.s2 = red + cin;
-      const int rc = eda_gemm_launch(a, W_NT, stream);
-      if (rc) return rc;
+      if (!fl) {
+        a.N = cin; a.y = other; a.ldy = cin;
+        a.epi = E_MASK;
+        a.zm = z[l - 1]; a.ldzm = cin;
+        a.m_mean = st; a.m_rstd = st + cin; a.m_scale = st + 2 * cin; a.m_shift = st + 3 * cin;
+        a.s1 = red; a.s2 = red + cin;
+        const int rc = eda_gemm_launch(a, W_NT, stream);
+        if (rc) return rc;
+      }
       if (sync) {
         const int src = g_sync_fn(g_sync_user, red, 2L * cin, stream_);
         if (src) { eda_set_error("eda_sa_fused_bwd_f32: the BatchNorm statistics hook failed (%d)", src); return EDA_ERR_UNSUPPORTED; }
       }
-      // dz_{l-1} = A*gy + B*z + D, in place (gy is already masked: the kernel's mask is idempotent)
-      hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<false>, dim3(grid_for(R * (cin / 4))), dim3(CL_THREADS), 0, stream,
-                         other, nullptr, z[l - 1], R, cin, 1, st, st + cin, st + 2 * cin, st + 3 * cin, gamma[l - 1],
-                         red, red + cin, training, dgamma[l - 1], dbeta[l - 1], other, inv_n, gscale);
+      // dz_{l-1} = A*gy + B*z + D: in place (gy is already masked: the kernel's mask is idempotent), or -- when every
+      // consumer of dz_{l-1} forms it while staging -- only the five column constants (and d(gamma), d(beta))
+      const bool next_fl = layer_fuse && l - 1 >= 1 && eda_wgrad_x_fuses_dx(cin, channels[l - 1]);
+      pending = layer_fuse && cin % 4 == 0 && (next_fl || (l - 1 == 0 && !need_dx0));
+      if (pending)
+        hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3((cin + 255) / 256), dim3(256), 0, stream, st, st + cin, st + 2 * cin,
+                           st + 3 * cin, gamma[l - 1], red, red + cin, inv_n, gscale, cin, dgamma[l - 1], dbeta[l - 1],
+                           consts_all + const_floats * (size_t)(l - 1));
+      else
+        hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<false>, dim3(grid_for(R * (cin / 4))), dim3(CL_THREADS), 0, stream,
+                           other, nullptr, z[l - 1], R, cin, 1, st, st + cin, st + 2 * cin, st + 3 * cin, gamma[l - 1],
+                           red, red + cin, training, dgamma[l - 1], dbeta[l - 1], other, inv_n, gscale);
       EDA_CHECK_LAUNCH();
       float *t = cur; cur = other; other = t;
     } else if (g.gather) {

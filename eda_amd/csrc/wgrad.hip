@@ -644,7 +644,9 @@ extern "C" int eda_wgrad_f32(const float *dy, long ld_dy, const float *x, long l
 // A operand read each k step).
 // DYP: the dY operand is not stored; it is the dz of a pooled last SharedMLP layer, formed from the layer's
 // pre-activation, the pooling arg-max and the pooled gradient while staging (gemm.h: WgradXArgs::dy_pool)
-template <int TM, int TN, int XMODE, bool DYP = false>
+// DYM = 2: dY is the masked gradient of a non-pooled layer's output, dz = ka*g + kb*z + kd formed while staging
+// (WgradXArgs::dy_bn: the element-wise BatchNorm-backward pass is not run).
+template <int TM, int TN, int XMODE, int DYM = 0>
 __global__ __launch_bounds__(TM * 8) void wgrad_x_kernel(const WgradXArgs a, int chunks_per_split, int tiles_n,
                                                          int ntiles, int nsplits) {
   constexpr int THREADS = TM * 8;                  // (TM/16) x 2 waves
@@ -693,10 +695,21 @@ __global__ __launch_bounds__(TM * 8) void wgrad_x_kernel(const WgradXArgs a, int
       bsh[i] = *reinterpret_cast<const float4 *>(a.in_shift + c);
     }
   }
-  float4 qsc[DYP ? LDA : 1], qsh[DYP ? LDA : 1], qka[DYP ? LDA : 1], qkb[DYP ? LDA : 1], qkd[DYP ? LDA : 1];
+  constexpr bool DYP = DYM == 1, DYB = DYM == 2;
+  float4 qsc[DYP ? LDA : 1], qsh[DYP ? LDA : 1], qka[DYM ? LDA : 1], qkb[DYM ? LDA : 1], qkd[DYM ? LDA : 1];
   unsigned ram[DYP ? LDA : 1];
-  float4 rdo[DYP ? LDA : 1];
+  float4 rdo[DYM ? LDA : 1];           // DYP: the pooled gradient of the row's group; DYB: the row's pre-activation
   int rrp[DYP ? LDA : 1];
+  if (DYB) {
+#pragma unroll
+    for (int i = 0; i < LDA; ++i) {
+      const int mc = m0 + acol[i] < M ? m0 + acol[i] : M - 4;
+      const float *c = a.dy_consts + mc;
+      qka[i] = *reinterpret_cast<const float4 *>(c + 2 * M);
+      qkb[i] = *reinterpret_cast<const float4 *>(c + 3 * M);
+      qkd[i] = *reinterpret_cast<const float4 *>(c + 4 * M);
+    }
+  }
   if (DYP) {
 #pragma unroll
     for (int i = 0; i < LDA; ++i) {
@@ -739,6 +752,7 @@ __global__ __launch_bounds__(TM * 8) void wgrad_x_kernel(const WgradXArgs a, int
         rdo[i] = *reinterpret_cast<const float4 *>(a.dy_dout + grp * M + mc);
       } else {
         ra[i] = *reinterpret_cast<const float4 *>(a.dy + k * a.ld_dy + mc);
+        if (DYB) rdo[i] = *reinterpret_cast<const float4 *>(a.dyz + k * M + mc);
       }
     }
 #pragma unroll
@@ -790,6 +804,10 @@ __global__ __launch_bounds__(TM * 8) void wgrad_x_kernel(const WgradXArgs a, int
           const float dw_ = (am >> 24) == rp && va.w * qsc[i].w + qsh[i].w > 0.f ? rdo[i].w : 0.f;
           va.x = qka[i].x * dx_ + qkb[i].x * va.x + qkd[i].x; va.y = qka[i].y * dy_ + qkb[i].y * va.y + qkd[i].y;
           va.z = qka[i].z * dz_ + qkb[i].z * va.z + qkd[i].z; va.w = qka[i].w * dw_ + qkb[i].w * va.w + qkd[i].w;
+        }
+        if (DYB) {
+          va.x = qka[i].x * va.x + qkb[i].x * rdo[i].x + qkd[i].x; va.y = qka[i].y * va.y + qkb[i].y * rdo[i].y + qkd[i].y;
+          va.z = qka[i].z * va.z + qkb[i].z * rdo[i].z + qkd[i].z; va.w = qka[i].w * va.w + qkb[i].w * rdo[i].w + qkd[i].w;
         }
         if (k0 + arow[i] >= kend || m0 + acol[i] >= M) va = make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4 *>(&As[arow[i]][acol[i]]) = va;
@@ -907,6 +925,274 @@ __global__ __launch_bounds__(256) void wgrad_x_reduce_kernel(const float *__rest
   dW[(long)m * (N - 1) + (n < 3 ? n : n - 1)] = t;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// A SharedMLP layer's WHOLE backward in one pass over its dz (the SA layers whose dW is one tile: M, N in {64, 128}).
+// wgrad_x_kernel and the streaming input-gradient kernel (gemm.hip) each read dz -- 0.25-0.5 GB per SA1 layer -- and, for a
+// non-pooled layer, an element-wise kernel wrote it first.  Here a workgroup of 16 waves owns a range of rows and walks it in
+// 64-row chunks: the chunk's dz (formed while staging: DYM as in wgrad_x_kernel) and the layer input's pre-activation z_in
+// are staged ONCE;
+//   waves 0-7   dW += dz^T relu(bn(z_in))     (rows are the contraction: operand fragments as in wgrad_x_kernel; the
+//                                              BatchNorm+ReLU of the input is applied to the B fragments as they are read)
+//   waves 8-15  g_in = (dz W) masked by the input's ReLU -> HBM, and the input BatchNorm's backward sums (sum g_in,
+//               sum g_in * xhat) -- the epilogue of the streaming kernel's E_MASK.  Transposed product: A = the wave's
+//               16 columns of W (from an LDS copy of the weight), B = dz rows read from LDS with ds_read_b128 (one read feeds
+//               four k steps: k slot g of step j is output channel 16 kq + 4 g + j), D = four consecutive input channels of a row.
+// Each SIMD gets two waves of either kind, both kinds issue the same number of MFMAs (the two products have the same FLOPs).
+// LDS row strides are = 4 (mod 32): the dW fragments of a k step take rows r, r + 4, r + 8, r + 12 (conflict-free b32 reads),
+// the b128 reads of the transposed product are within one extra cycle per lane group of conflict-free.
+// Partial dW tiles go to the slabs of wgrad_x_kernel (wgrad_x_reduce_kernel adds them).
+// Measured (SA1, 1 048 576 rows, profiles/r04_sa_layer_bwd.md): 128 <- 64 pooled 442 us where the two kernels took 277 + 254;
+// 64 <- 64 239 us (1 GB: the HBM ceiling) where element-wise pass + two kernels took 155 + 168 + 141.  With every global
+// access removed the 128 <- 64 launch still takes 389 us: it is bound by the fp32 MFMA pipe (34.4 GFLOP = 218 us at the
+// peak) plus 73 us of staging arithmetic that does not hide under it, not by memory.
+template <int TM, int TN, int DYM>
+__global__ __launch_bounds__(1024) void sa_layer_bwd_kernel(const WgradXArgs a, int chunks_per_split, int nsplits) {
+  constexpr int THREADS = 1024;
+  constexpr int SA = TM + 4, SB = TN + 4;
+  constexpr int LDA = 64 * (TM / 4) / THREADS, LDB = 64 * (TN / 4) / THREADS;      // float4 per thread and chunk: 1 or 2
+  constexpr int MS = TM / 16, NCT = TN / 16;
+  constexpr int WT = MS * NCT / 8;                 // dW tiles of a wave of the first kind: one row strip, WT column tiles
+  constexpr int RG = 8 / NCT, DT = 4 / RG;         // second kind: column tile v % NCT, row tiles v / NCT + RG * i
+  constexpr bool DYP = DYM == 1, DYB = DYM == 2;
+  static_assert(LDA >= 1 && LDB >= 1 && WT >= 1 && RG >= 1, "tile");
+  // LDS (dynamic: sa_layer_bwd_lds_bytes): As[2][64][SA] | Bs[2][64][SB] | ctab[4][TN] | qtab[5][TM] | red[2][8][16]
+  extern __shared__ __attribute__((aligned(16))) float slb_smem[];
+  float *As = slb_smem, *Bs = As + 2 * 64 * SA;
+  float *ctab = Bs + 2 * 64 * SB;                  // scale | shift | mean | rstd of the input's BatchNorm
+  float *qtab = ctab + 4 * TN;                     // sc | sh | ka | kb | kd of the layer's own BatchNorm backward
+  float *red = qtab + 5 * TM;
+  float *Ws = red + 256;                           // the layer's weight, [TM][TN + 4]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int s = xcd + 8 * j;
+  if (s >= nsplits) return;
+  const long K = a.R;
+  const long kbeg = (long)s * chunks_per_split * 64;
+  long kend = kbeg + (long)chunks_per_split * 64;
+  if (kend > K) kend = K;
+  if (kbeg >= kend) return;
+  if (tid < TN) {
+    ctab[tid] = a.in_scale[tid]; ctab[TN + tid] = a.in_shift[tid];
+    ctab[2 * TN + tid] = a.dx_mean[tid]; ctab[3 * TN + tid] = a.dx_rstd[tid];
+  }
+  if (DYM) for (int e = tid; e < 5 * TM; e += THREADS) qtab[e] = a.dy_consts[e];
+  for (int e = tid; e < TM * (TN / 4); e += THREADS) {
+    const int r = e / (TN / 4), c = (e % (TN / 4)) * 4;
+    *reinterpret_cast<float4 *>(&Ws[r * SB + c]) = *reinterpret_cast<const float4 *>(a.dx_w + (long)r * a.dx_ldw + c);
+  }
+  __syncthreads();
+
+  // ---- staging maps (a thread's column never changes: its LDA / LDB rows are 32 apart)
+  const int acol = (tid % (TM / 4)) * 4, arow0 = tid / (TM / 4);
+  const int bcol = (tid % (TN / 4)) * 4, brow0 = tid / (TN / 4);
+  constexpr int ARS = THREADS / (TM / 4), BRS = THREADS / (TN / 4);
+  float4 ra[LDA], rb[LDB], rdo[DYM ? LDA : 1];
+  unsigned ram[DYP ? LDA : 1];
+  int rrp[DYP ? LDA : 1];
+  // (32-bit row and element offsets against uniform base pointers: the launcher checks R * 128 < 2^31)
+  const int kend_i = (int)kend, ld_dy = (int)a.ld_dy, ld_x = (int)a.ld_x;
+  auto fetch = [&](long k0_) {
+    const int k0 = (int)k0_;
+#pragma unroll
+    for (int i = 0; i < LDA; ++i) {
+      int k = k0 + arow0 + ARS * i;
+      if (k >= kend_i) k = kend_i - 1;                   // clamped: zeroed when staged
+      if (DYP) {
+        ra[i] = *reinterpret_cast<const float4 *>(a.dyz + (unsigned)(k * TM + acol));
+        const unsigned grp = (unsigned)k / (unsigned)a.dy_pool;
+        rrp[i] = (int)((unsigned)k - grp * (unsigned)a.dy_pool);
+        ram[i] = *reinterpret_cast<const unsigned *>(a.dy_argmax + (grp * TM + acol));
+        rdo[i] = *reinterpret_cast<const float4 *>(a.dy_dout + (grp * TM + acol));
+      } else {
+        ra[i] = *reinterpret_cast<const float4 *>(a.dy + (unsigned)(k * ld_dy + acol));
+        if (DYB) rdo[i] = *reinterpret_cast<const float4 *>(a.dyz + (unsigned)(k * TM + acol));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < LDB; ++i) {
+      int k = k0 + brow0 + BRS * i;
+      if (k >= kend_i) k = kend_i - 1;
+      rb[i] = *reinterpret_cast<const float4 *>(a.x + (unsigned)(k * ld_x + bcol));
+    }
+  };
+  auto stage = [&](long k0, int buf) {
+    float4 qsc, qsh, qka, qkb, qkd;          // (from LDS every chunk: 20 registers less across the MFMA phase)
+    if (DYP) { qsc = *reinterpret_cast<const float4 *>(&qtab[acol]); qsh = *reinterpret_cast<const float4 *>(&qtab[TM + acol]); }
+    if (DYM) {
+      qka = *reinterpret_cast<const float4 *>(&qtab[2 * TM + acol]); qkb = *reinterpret_cast<const float4 *>(&qtab[3 * TM + acol]);
+      qkd = *reinterpret_cast<const float4 *>(&qtab[4 * TM + acol]);
+    }
+#pragma unroll
+    for (int i = 0; i < LDA; ++i) {
+      float4 va = ra[i];
+      if (DYP) {
+        const unsigned rp = (unsigned)rrp[i], am = ram[i];
+        const float dx_ = (am & 0xffu) == rp && va.x * qsc.x + qsh.x > 0.f ? rdo[i].x : 0.f;
+        const float dy_ = ((am >> 8) & 0xffu) == rp && va.y * qsc.y + qsh.y > 0.f ? rdo[i].y : 0.f;
+        const float dz_ = ((am >> 16) & 0xffu) == rp && va.z * qsc.z + qsh.z > 0.f ? rdo[i].z : 0.f;
+        const float dw_ = (am >> 24) == rp && va.w * qsc.w + qsh.w > 0.f ? rdo[i].w : 0.f;
+        va.x = qka.x * dx_ + qkb.x * va.x + qkd.x; va.y = qka.y * dy_ + qkb.y * va.y + qkd.y;
+        va.z = qka.z * dz_ + qkb.z * va.z + qkd.z; va.w = qka.w * dw_ + qkb.w * va.w + qkd.w;
+      }
+      if (DYB) {
+        va.x = qka.x * va.x + qkb.x * rdo[i].x + qkd.x; va.y = qka.y * va.y + qkb.y * rdo[i].y + qkd.y;
+        va.z = qka.z * va.z + qkb.z * rdo[i].z + qkd.z; va.w = qka.w * va.w + qkb.w * rdo[i].w + qkd.w;
+      }
+      if (k0 + arow0 + ARS * i >= kend) va = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4 *>(&As[(buf * 64 + arow0 + ARS * i) * SA + acol]) = va;
+    }
+#pragma unroll
+    for (int i = 0; i < LDB; ++i)                        // raw (rows past the end: a real row's values against zero dz rows)
+      *reinterpret_cast<float4 *>(&Bs[(buf * 64 + brow0 + BRS * i) * SB + bcol]) = rb[i];
+  };
+
+  // ---- first kind: dW tiles.  One register file for both kinds: U = the accumulators of the first, the column sums of the second
+  const int wm = w % MS, wq = (w & 7) / MS;              // (TM = 64: two waves per row strip, half of the column tiles each)
+  constexpr int NU = WT > 2 ? WT : 2;
+  f32x4 U[NU];
+#define SLB_ACC(t) U[t]
+#define SLB_T1 U[0]
+#define SLB_T2 U[1]
+  // ---- second kind: input-gradient tiles
+  const int v = w & 7, ct = v % NCT, rg = v / NCT;
+#pragma unroll
+  for (int t = 0; t < NU; ++t) U[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float *ap = &As[4 * g * SA + 16 * wm + li];
+  const float *bp = &Bs[4 * g * SB + 16 * wq * WT + li];
+  const float *dp = &As[li * SA + 4 * g];
+  const float *zp = &Bs[li * SB + 16 * ct + 4 * g];
+  const float *wp = &Ws[4 * g * SB + 16 * ct + li];      // k slot g of step jj of part kq: output channel 16 kq + 4 g + jj
+
+  auto dw_tiles = [&](int buf) {
+    const float *ab = ap + buf * 64 * SA, *bb = bp + buf * 64 * SB;
+    float bsc[WT], bsh[WT];                              // (from LDS every chunk, like the staging constants)
+#pragma unroll
+    for (int t = 0; t < WT; ++t) { bsc[t] = ctab[16 * (wq * WT + t) + li]; bsh[t] = ctab[TN + 16 * (wq * WT + t) + li]; }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {                        // 8 rows of the chunk: k step kk takes rows 16 (q / 2) + 2 (q % 2) + kk + 4 g
+      float av[2], bv[WT][2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int r = 16 * (q >> 1) + 2 * (q & 1) + kk;
+        av[kk] = ab[r * SA];
+#pragma unroll
+        for (int t = 0; t < WT; ++t) bv[t][kk] = fmaxf(bb[r * SB + 16 * t] * bsc[t] + bsh[t], 0.f);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int t = 0; t < WT; ++t)
+          SLB_ACC(t) = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv[t][kk], SLB_ACC(t), 0, 0, 0);
+      }
+    }
+  };
+  f32x4 og[DT];                                          // the chunk's masked input-gradient tiles, stored one phase later
+  auto dx_tiles = [&](int buf) {
+    const float *db = dp + buf * 64 * SA, *zb = zp + buf * 64 * SB;
+    f32x4 dacc[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) dacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kq = 0; kq < MS; ++kq) {
+      float wv[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) wv[jj] = wp[(16 * kq + jj) * SB];
+#pragma unroll
+      for (int i = 0; i < DT; ++i) {
+        const f32x4 dz = *reinterpret_cast<const f32x4 *>(db + 16 * (rg + RG * i) * SA + 16 * kq);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          dacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[jj], dz[jj], dacc[i], 0, 0, 0);
+      }
+    }
+    const f32x4 csc = *reinterpret_cast<const f32x4 *>(&ctab[16 * ct + 4 * g]);
+    const f32x4 csh = *reinterpret_cast<const f32x4 *>(&ctab[TN + 16 * ct + 4 * g]);
+    const f32x4 cmu = *reinterpret_cast<const f32x4 *>(&ctab[2 * TN + 16 * ct + 4 * g]);
+    const f32x4 crs = *reinterpret_cast<const f32x4 *>(&ctab[3 * TN + 16 * ct + 4 * g]);
+#pragma unroll
+    for (int i = 0; i < DT; ++i) {
+      const f32x4 zz = *reinterpret_cast<const f32x4 *>(zb + 16 * (rg + RG * i) * SB);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float o = zz[u] * csc[u] + csh[u] > 0.f ? dacc[i][u] : 0.f;
+        og[i][u] = o;
+        SLB_T1[u] += o;
+        SLB_T2[u] += o * (zz[u] - cmu[u]) * crs[u];
+      }
+    }
+  };
+  auto dx_store = [&](long k0) {
+#pragma unroll
+    for (int i = 0; i < DT; ++i) {
+      const int row = (int)k0 + 16 * (rg + RG * i) + li;
+      if (row < kend_i) *reinterpret_cast<f32x4 *>(a.dx_out + (unsigned)(row * TN + 16 * ct + 4 * g)) = og[i];
+    }
+  };
+
+  // Two LDS images, one barrier per chunk: chunk k + 1 is staged into the other image in the same phase in which chunk k is
+  // multiplied -- the waves of the first kind stage first, those of the second kind multiply first, so that on every SIMD
+  // the staging arithmetic of two waves runs under the MFMAs of the other two.  The second kind stores its tiles AFTER it
+  // has staged the next chunk and BEFORE it requests the one after: loads and stores share one in-order counter (vmcnt), so
+  // a wait for the next chunk's loads also waits for every store issued before them -- this way those stores are a whole
+  // phase old by then (stores issued right after the MFMAs exposed their full write latency once per chunk).
+  fetch(kbeg);
+  stage(kbeg, 0);
+  if (kbeg + 64 < kend) fetch(kbeg + 64);
+  __syncthreads();
+  int buf = 0;
+  for (long k0 = kbeg; k0 < kend; k0 += 64, buf ^= 1) {
+    const bool more = k0 + 64 < kend;
+    if (w < 8) {
+      if (more) { stage(k0 + 64, buf ^ 1); if (k0 + 128 < kend) fetch(k0 + 128); }
+      dw_tiles(buf);
+    } else {
+      dx_tiles(buf);
+      if (more) {                                        // (one block: the compiler then knows that nothing but the stores is pending at the fetch)
+        stage(k0 + 64, buf ^ 1);
+        dx_store(k0);
+        if (k0 + 128 < kend) fetch(k0 + 128);
+      } else {
+        dx_store(k0);
+      }
+    }
+    __syncthreads();
+  }
+  // partial dW tile of split s -> slab s of the workspace (TM x TN floats)
+  if (w < 8) {
+    float *o = a.ws + (long)s * TM * TN;
+#pragma unroll
+    for (int t = 0; t < WT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[(long)(16 * wm + 4 * g + r) * TN + 16 * (wq * WT + t) + li] = SLB_ACC(t)[r];
+  } else {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float t1 = SLB_T1[u], t2 = SLB_T2[u];
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) { t1 += __shfl_xor(t1, m, 64); t2 += __shfl_xor(t2, m, 64); }
+      if (li == 0) { red[v * 16 + 4 * g + u] = t1; red[128 + v * 16 + 4 * g + u] = t2; }
+    }
+  }
+  __syncthreads();
+  if (tid < TN) {
+    const int c = tid >> 4, e = tid & 15;
+    double c1 = 0.0, c2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < RG; ++r) { c1 += (double)red[(c + NCT * r) * 16 + e]; c2 += (double)red[128 + (c + NCT * r) * 16 + e]; }
+    const double o1 = atomicAdd(a.dx_s1 + tid, c1);
+    const double o2 = atomicAdd(a.dx_s2 + tid, c2);
+    asm volatile("" ::"v"(o1), "v"(o2));
+  }
+#undef SLB_ACC
+#undef SLB_T1
+#undef SLB_T2
+}
+
+template <int TM, int TN>
+constexpr size_t sa_layer_bwd_lds_bytes() { return sizeof(float) * (2 * 64 * (TM + 4 + TN + 4) + 4 * TN + 5 * TM + 256 + TM * (TN + 4)); }
+
 namespace {
 struct WgxPlan { int TM, TN, tiles_m, tiles_n, splits, cps; };
 WgxPlan wgx_plan(long R, int M, int N, bool gather) {
@@ -939,16 +1225,24 @@ template <int TM, int TN>
 void wgx_launch(const WgradXArgs &a, const WgxPlan &p, hipStream_t stream) {
   const int ntiles = p.tiles_m * p.tiles_n;
   const dim3 grid((unsigned)(8 * ntiles * ((p.splits + 7) / 8))), block(TM * 8);
-  if (a.xmode == X_PLAIN)
+  if (a.xmode == X_PLAIN && a.dy_bn)
+    hipLaunchKernelGGL((wgrad_x_kernel<TM, TN, X_PLAIN, 2>), grid, block, 0, stream, a, p.cps, p.tiles_n, ntiles, p.splits);
+  else if (a.xmode == X_PLAIN)
     hipLaunchKernelGGL((wgrad_x_kernel<TM, TN, X_PLAIN>), grid, block, 0, stream, a, p.cps, p.tiles_n, ntiles, p.splits);
   else if (a.xmode == X_BNRELU && a.dy_pool > 0)
-    hipLaunchKernelGGL((wgrad_x_kernel<TM, TN, X_BNRELU, true>), grid, block, 0, stream, a, p.cps, p.tiles_n, ntiles, p.splits);
+    hipLaunchKernelGGL((wgrad_x_kernel<TM, TN, X_BNRELU, 1>), grid, block, 0, stream, a, p.cps, p.tiles_n, ntiles, p.splits);
+  else if (a.xmode == X_BNRELU && a.dy_bn)
+    hipLaunchKernelGGL((wgrad_x_kernel<TM, TN, X_BNRELU, 2>), grid, block, 0, stream, a, p.cps, p.tiles_n, ntiles, p.splits);
   else if (a.xmode == X_BNRELU)
     hipLaunchKernelGGL((wgrad_x_kernel<TM, TN, X_BNRELU>), grid, block, 0, stream, a, p.cps, p.tiles_n, ntiles, p.splits);
+  else if (a.dy_bn)
+    hipLaunchKernelGGL((wgrad_x_kernel<TM, TN, X_GATHER, 2>), grid, block, 0, stream, a, p.cps, p.tiles_n, ntiles, p.splits);
   else
     hipLaunchKernelGGL((wgrad_x_kernel<TM, TN, X_GATHER>), grid, block, 0, stream, a, p.cps, p.tiles_n, ntiles, p.splits);
 }
 }  // namespace
+
+bool eda_wgrad_x_fuses_dx(int M, int N) { return (M == 128 || M == 64) && N == 64; }
 
 size_t eda_wgrad_x_workspace_bytes(long R, int M, int N) {
   if (R <= 0 || M <= 0 || N <= 0) return 0;
@@ -978,10 +1272,43 @@ int eda_wgrad_x_launch(const WgradXArgs &a, hipStream_t stream) {
     eda_set_error("wgrad_x: BN+ReLU rows must be 16-byte addressable");
     return EDA_ERR_INVALID_ARG;
   }
+  if (a.dy_bn && (a.dy_pool > 0 || !a.dyz || !a.dy_consts ||
+                  ((reinterpret_cast<uintptr_t>(a.dyz) | reinterpret_cast<uintptr_t>(a.dy_consts)) & 15u))) {
+    eda_set_error("wgrad_x: bad operands for the BatchNorm-backward dY prologue");
+    return EDA_ERR_INVALID_ARG;
+  }
   const WgxPlan p = wgx_plan(a.R, a.M, a.N, a.xmode == X_GATHER);
   if (!a.ws || a.ws_bytes < sizeof(float) * (size_t)p.splits * a.M * a.N) {
     eda_set_error("wgrad_x: workspace too small");
     return EDA_ERR_WORKSPACE;
+  }
+  if (a.dx_out) {
+    // the layer's input gradient in the same launch (sa_layer_bwd_kernel)
+    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    if (a.xmode != X_BNRELU || !eda_wgrad_x_fuses_dx(a.M, a.N) || a.ld_x != a.N || a.R * 128 >= 0x7fffffffL || a.ld_dy > 128 || !a.dx_w || !a.dx_mean || !a.dx_rstd ||
+        !a.dx_s1 || !a.dx_s2 || !al16(a.dx_out) || !al16(a.in_scale) || !al16(a.in_shift) || p.tiles_m * p.tiles_n != 1) {
+      eda_set_error("wgrad_x: bad operands for the fused input gradient");
+      return EDA_ERR_INVALID_ARG;
+    }
+    const dim3 grid((unsigned)(8 * ((p.splits + 7) / 8))), block(1024);
+    const int dym = a.dy_pool > 0 ? 1 : a.dy_bn ? 2 : 0;
+#define EDA_SLB(TM_, TN_)                                                                                                   \
+    do {                                                                                                                    \
+      const size_t lds = sa_layer_bwd_lds_bytes<TM_, TN_>();                                                                \
+      void (*kern)(const WgradXArgs, int, int) = dym == 1 ? sa_layer_bwd_kernel<TM_, TN_, 1>                                 \
+                                               : dym == 2 ? sa_layer_bwd_kernel<TM_, TN_, 2> : sa_layer_bwd_kernel<TM_, TN_, 0>; \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) { eda_set_error("wgrad_x: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }           \
+      hipLaunchKernelGGL(kern, grid, block, lds, stream, a, p.cps, p.splits);                                               \
+    } while (0)
+    if (a.M == 128) EDA_SLB(128, 64); else EDA_SLB(64, 64);
+#undef EDA_SLB
+    EDA_CHECK_LAUNCH();
+    const long MN = (long)a.M * a.N;
+    hipLaunchKernelGGL(wgrad_x_reduce_kernel, dim3((unsigned)((MN + 31) / 32)), dim3(256), 0, stream, a.ws, p.splits,
+                       a.M, a.N, 0, a.dW);
+    EDA_CHECK_LAUNCH();
+    return 0;
   }
   if (p.TN == 64) {
     if (p.TM == 128) wgx_launch<128, 64>(a, p, stream); else if (p.TM == 96) wgx_launch<96, 64>(a, p, stream); else wgx_launch<64, 64>(a, p, stream);

@@ -255,3 +255,45 @@ def test_full_size_gradients_vs_fp64_backward_on_the_same_relu_and_argmax_decisi
         scale = float(e_.abs().max()) + 1e-30
         err = float((g_.double() - e_).abs().max())
         assert err <= 2e-4 * scale, (level, n, err, scale)
+
+
+# ---- one launch per layer (wgrad.hip: sa_layer_bwd_kernel) against the separate weight-gradient / input-gradient / BN kernels ----
+@pytest.mark.parametrize("B,N,m,ns,C,chans,feats_grad", [
+    (2, 3000, 128, 16, 3, [64, 64, 128], False),       # SA1's stack: pooled last layer formed while staging, all three layers
+    (2, 3000, 128, 16, 3, [64, 64, 128], True),        # d(features) wanted: the first layer keeps the element-wise pass
+    (3, 1500, 61, 7, 3, [64, 64, 128], False),         # pool not a multiple of 16: the last layer's dz is materialised
+    (2, 4000, 300, 64, 3, [64, 64, 128], False),       # one pooling group per 64-row chunk
+    (2, 1024, 100, 32, 0, [64, 64, 64, 128], False),   # no features at all, four layers
+    (1, 900, 37, 16, 3, [128, 64, 64], False),         # 64 <- 128 is not a fused shape, 64 <- 64 is
+])
+def test_layer_backward_in_one_launch_matches_the_separate_kernels(B, N, m, ns, C, chans, feats_grad, monkeypatch):
+    from eda_amd import pointnet2_utils as PU
+    dev = "cuda"
+    rng = np.random.default_rng(N + ns)
+    xyz = torch.from_numpy(rng.uniform(-2, 2, (B, N, 3)).astype(np.float32)).to(dev)
+    new_xyz = xyz[:, :m].contiguous()
+    idx = PU.ball_query(0.7, ns, xyz, new_xyz)
+    chans = [3 + C] + chans
+    Ws, gammas, betas, running = _build(chans, dev, N + ns + 1)
+    feats_cl = torch.randn(B, N, C, device=dev) if C else None
+    leaves = ([feats_cl] if C and feats_grad else []) + Ws + gammas + betas
+    for t in leaves:
+        t.requires_grad_(True)
+    w = None
+
+    def run(fuse):
+        nonlocal w
+        monkeypatch.setenv("EDA_SA_LAYER_FUSE", "1" if fuse else "0")
+        out = _run_fused(dict(radius=0.7, normalize_xyz=True), Ws, gammas, betas, [(a.clone(), b.clone()) for a, b in running],
+                         True, ns, xyz=xyz, new_xyz=new_xyz, feats_cl=feats_cl, idx=idx)
+        if w is None:
+            w = torch.randn_like(out)
+        return torch.autograd.grad((out * w).sum(), leaves)
+
+    got, exp = run(True), run(False)
+    for i, (g_, e_) in enumerate(zip(got, exp)):
+        scale = float(e_.abs().max()) + 1e-30
+        assert float((g_ - e_).abs().max()) <= 3e-5 * scale, (i, float((g_ - e_).abs().max()), scale)
+    again = run(True)
+    for g_, e_ in zip(again[:len(Ws) + (1 if C and feats_grad else 0)], got):
+        assert float((g_ - e_).abs().max()) <= 1e-5 * (float(e_.abs().max()) + 1e-30)     # (fp64 atomics: order-dependent sums only)
