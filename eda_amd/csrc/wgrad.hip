@@ -946,7 +946,8 @@ __global__ __launch_bounds__(256) void wgrad_x_reduce_kernel(const float *__rest
 // 64 <- 64 239 us (1 GB: the HBM ceiling) where element-wise pass + two kernels took 155 + 168 + 141.  With every global
 // access removed the 128 <- 64 launch still takes 389 us: it is bound by the fp32 MFMA pipe (34.4 GFLOP = 218 us at the
 // peak) plus 73 us of staging arithmetic that does not hide under it, not by memory.
-template <int TM, int TN, int DYM>
+// NBUF = 1 (128 <- 128: two images and the weight do not fit): one LDS image, two barriers per chunk.
+template <int TM, int TN, int DYM, int NBUF>
 __global__ __launch_bounds__(1024) void sa_layer_bwd_kernel(const WgradXArgs a, int chunks_per_split, int nsplits) {
   constexpr int THREADS = 1024;
   constexpr int SA = TM + 4, SB = TN + 4;
@@ -956,10 +957,10 @@ __global__ __launch_bounds__(1024) void sa_layer_bwd_kernel(const WgradXArgs a, 
   constexpr int RG = 8 / NCT, DT = 4 / RG;         // second kind: column tile v % NCT, row tiles v / NCT + RG * i
   constexpr bool DYP = DYM == 1, DYB = DYM == 2;
   static_assert(LDA >= 1 && LDB >= 1 && WT >= 1 && RG >= 1, "tile");
-  // LDS (dynamic: sa_layer_bwd_lds_bytes): As[2][64][SA] | Bs[2][64][SB] | ctab[4][TN] | qtab[5][TM] | red[2][8][16]
+  // LDS (dynamic: sa_layer_bwd_lds_bytes): As[NBUF][64][SA] | Bs[NBUF][64][SB] | ctab[4][TN] | qtab[5][TM] | red[2][8][16] | Ws
   extern __shared__ __attribute__((aligned(16))) float slb_smem[];
-  float *As = slb_smem, *Bs = As + 2 * 64 * SA;
-  float *ctab = Bs + 2 * 64 * SB;                  // scale | shift | mean | rstd of the input's BatchNorm
+  float *As = slb_smem, *Bs = As + NBUF * 64 * SA;
+  float *ctab = Bs + NBUF * 64 * SB;                  // scale | shift | mean | rstd of the input's BatchNorm
   float *qtab = ctab + 4 * TN;                     // sc | sh | ka | kb | kd of the layer's own BatchNorm backward
   float *red = qtab + 5 * TM;
   float *Ws = red + 256;                           // the layer's weight, [TM][TN + 4]
@@ -1070,18 +1071,19 @@ __global__ __launch_bounds__(1024) void sa_layer_bwd_kernel(const WgradXArgs a, 
     float bsc[WT], bsh[WT];                              // (from LDS every chunk, like the staging constants)
 #pragma unroll
     for (int t = 0; t < WT; ++t) { bsc[t] = ctab[16 * (wq * WT + t) + li]; bsh[t] = ctab[TN + 16 * (wq * WT + t) + li]; }
+    constexpr int KB = WT >= 8 ? 1 : 2;                  // k steps whose operands are read together (registers: WT * KB B values)
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {                        // 8 rows of the chunk: k step kk takes rows 16 (q / 2) + 2 (q % 2) + kk + 4 g
-      float av[2], bv[WT][2];
+    for (int q = 0; q < 16 / KB; ++q) {                  // k step kk takes rows 16 (r / 4) + (r % 4) + 4 g, r = KB q + kk
+      float av[KB], bv[WT][KB];
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int r = 16 * (q >> 1) + 2 * (q & 1) + kk;
+      for (int kk = 0; kk < KB; ++kk) {
+        const int r = 16 * ((KB * q + kk) >> 2) + ((KB * q + kk) & 3);
         av[kk] = ab[r * SA];
 #pragma unroll
         for (int t = 0; t < WT; ++t) bv[t][kk] = fmaxf(bb[r * SB + 16 * t] * bsc[t] + bsh[t], 0.f);
       }
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
+      for (int kk = 0; kk < KB; ++kk) {
 #pragma unroll
         for (int t = 0; t < WT; ++t)
           SLB_ACC(t) = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv[t][kk], SLB_ACC(t), 0, 0, 0);
@@ -1137,27 +1139,42 @@ __global__ __launch_bounds__(1024) void sa_layer_bwd_kernel(const WgradXArgs a, 
   // has staged the next chunk and BEFORE it requests the one after: loads and stores share one in-order counter (vmcnt), so
   // a wait for the next chunk's loads also waits for every store issued before them -- this way those stores are a whole
   // phase old by then (stores issued right after the MFMAs exposed their full write latency once per chunk).
-  fetch(kbeg);
-  stage(kbeg, 0);
-  if (kbeg + 64 < kend) fetch(kbeg + 64);
-  __syncthreads();
-  int buf = 0;
-  for (long k0 = kbeg; k0 < kend; k0 += 64, buf ^= 1) {
-    const bool more = k0 + 64 < kend;
-    if (w < 8) {
-      if (more) { stage(k0 + 64, buf ^ 1); if (k0 + 128 < kend) fetch(k0 + 128); }
-      dw_tiles(buf);
-    } else {
-      dx_tiles(buf);
-      if (more) {                                        // (one block: the compiler then knows that nothing but the stores is pending at the fetch)
-        stage(k0 + 64, buf ^ 1);
-        dx_store(k0);
-        if (k0 + 128 < kend) fetch(k0 + 128);
-      } else {
-        dx_store(k0);
-      }
-    }
+  if (NBUF == 2) {
+    fetch(kbeg);
+    stage(kbeg, 0);
+    if (kbeg + 64 < kend) fetch(kbeg + 64);
     __syncthreads();
+    int buf = 0;
+    for (long k0 = kbeg; k0 < kend; k0 += 64, buf ^= 1) {
+      const bool more = k0 + 64 < kend;
+      if (w < 8) {
+        if (more) { stage(k0 + 64, buf ^ 1); if (k0 + 128 < kend) fetch(k0 + 128); }
+        dw_tiles(buf);
+      } else {
+        dx_tiles(buf);
+        if (more) {                                      // (one block: the compiler then knows that nothing but the stores is pending at the fetch)
+          stage(k0 + 64, buf ^ 1);
+          dx_store(k0);
+          if (k0 + 128 < kend) fetch(k0 + 128);
+        } else {
+          dx_store(k0);
+        }
+      }
+      __syncthreads();
+    }
+  } else {
+    // one image: stage | barrier | request the next chunk, multiply | barrier; a chunk's tiles are stored after the NEXT chunk is staged
+    fetch(kbeg);
+    long k0 = kbeg;
+    for (; k0 < kend; k0 += 64) {
+      stage(k0, 0);
+      if (w >= 8 && k0 > kbeg) dx_store(k0 - 64);
+      __syncthreads();
+      if (k0 + 64 < kend) fetch(k0 + 64);
+      if (w < 8) dw_tiles(0); else dx_tiles(0);
+      __syncthreads();
+    }
+    if (w >= 8) dx_store(k0 - 64);
   }
   // partial dW tile of split s -> slab s of the workspace (TM x TN floats)
   if (w < 8) {
@@ -1190,8 +1207,8 @@ __global__ __launch_bounds__(1024) void sa_layer_bwd_kernel(const WgradXArgs a, 
 #undef SLB_T2
 }
 
-template <int TM, int TN>
-constexpr size_t sa_layer_bwd_lds_bytes() { return sizeof(float) * (2 * 64 * (TM + 4 + TN + 4) + 4 * TN + 5 * TM + 256 + TM * (TN + 4)); }
+template <int TM, int TN, int NBUF>
+constexpr size_t sa_layer_bwd_lds_bytes() { return sizeof(float) * (NBUF * 64 * (TM + 4 + TN + 4) + 4 * TN + 5 * TM + 256 + TM * (TN + 4)); }
 
 namespace {
 struct WgxPlan { int TM, TN, tiles_m, tiles_n, splits, cps; };
@@ -1242,7 +1259,7 @@ void wgx_launch(const WgradXArgs &a, const WgxPlan &p, hipStream_t stream) {
 }
 }  // namespace
 
-bool eda_wgrad_x_fuses_dx(int M, int N) { return (M == 128 || M == 64) && N == 64; }
+bool eda_wgrad_x_fuses_dx(int M, int N) { return ((M == 128 || M == 64) && N == 64) || (M == 128 && N == 128); }
 
 size_t eda_wgrad_x_workspace_bytes(long R, int M, int N) {
   if (R <= 0 || M <= 0 || N <= 0) return 0;
@@ -1292,16 +1309,16 @@ int eda_wgrad_x_launch(const WgradXArgs &a, hipStream_t stream) {
     }
     const dim3 grid((unsigned)(8 * ((p.splits + 7) / 8))), block(1024);
     const int dym = a.dy_pool > 0 ? 1 : a.dy_bn ? 2 : 0;
-#define EDA_SLB(TM_, TN_)                                                                                                   \
+#define EDA_SLB(TM_, TN_, NB_)                                                                                              \
     do {                                                                                                                    \
-      const size_t lds = sa_layer_bwd_lds_bytes<TM_, TN_>();                                                                \
-      void (*kern)(const WgradXArgs, int, int) = dym == 1 ? sa_layer_bwd_kernel<TM_, TN_, 1>                                 \
-                                               : dym == 2 ? sa_layer_bwd_kernel<TM_, TN_, 2> : sa_layer_bwd_kernel<TM_, TN_, 0>; \
+      const size_t lds = sa_layer_bwd_lds_bytes<TM_, TN_, NB_>();                                                           \
+      void (*kern)(const WgradXArgs, int, int) = dym == 1 ? sa_layer_bwd_kernel<TM_, TN_, 1, NB_>                            \
+                                               : dym == 2 ? sa_layer_bwd_kernel<TM_, TN_, 2, NB_> : sa_layer_bwd_kernel<TM_, TN_, 0, NB_>; \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e != hipSuccess) { eda_set_error("wgrad_x: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }           \
       hipLaunchKernelGGL(kern, grid, block, lds, stream, a, p.cps, p.splits);                                               \
     } while (0)
-    if (a.M == 128) EDA_SLB(128, 64); else EDA_SLB(64, 64);
+    if (a.N == 128) EDA_SLB(128, 128, 1); else if (a.M == 128) EDA_SLB(128, 64, 2); else EDA_SLB(64, 64, 2);
 #undef EDA_SLB
     EDA_CHECK_LAUNCH();
     const long MN = (long)a.M * a.N;
