@@ -84,7 +84,12 @@ struct WgradXArgs {
   // same launch -- g_prev = (dz W) where the input's ReLU was open -> dx_out (R x N), its BatchNorm-backward column sums
   // (sum g_prev, sum g_prev * xhat) -> dx_s1 / dx_s2 (fp64 atomics); dx_w = the layer's (M, N) weight
   const float *dx_w; long dx_ldw; float *dx_out; const float *dx_mean, *dx_rstd; double *dx_s1, *dx_s2;
+  float *dx_scatter;
 };
 bool eda_wgrad_x_fuses_dx(int M, int N);
+// xmode X_GATHER with dx_out = scratch rows (R x c_feat), dx_scatter = d(features) (B * n_pts x c_feat, zeroed by the caller),
+// dx_w = the (M, 3 + c_feat) weight and dy_bn: the first layer's weight gradient and input-gradient rows in one launch
+// (sa_gather_layer_bwd_kernel), then their scatter-add (rows_scatter_add_kernel)
+bool eda_wgrad_x_fuses_gather(int M, int c_feat);
 size_t eda_wgrad_x_workspace_bytes(long R, int M, int N);
 int eda_wgrad_x_launch(const WgradXArgs &a, hipStream_t stream);

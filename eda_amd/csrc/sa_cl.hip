@@ -1194,6 +1194,9 @@ static int sa_fused_bwd_impl(const float *dout, const unsigned char *argmax, con
   bool layer_fuse = training != 0;
   { const char *e = getenv("EDA_SA_LAYER_FUSE"); if (e && atoi(e) == 0) layer_fuse = false; }
   const bool need_dx0 = g.gather ? (dfeats_cl && c_feat > 0) : dx != nullptr;
+  // first layer of a gathering stack with 128 feature channels (SA2): weight gradient + scatter of d(features) in one launch
+  const bool gl0 = layer_fuse && g.gather && need_dx0 && nlayers >= 2 && eda_wgrad_x_fuses_gather(channels[1], c_feat) &&
+                   (reinterpret_cast<uintptr_t>(feats_cl) & 15u) == 0;
   bool pending = false;
   // Pooled last layer in training mode: its dz = ka*d + kb*z + kd need not be written and read back -- the two kernels
   // that consume it (weight gradient, input gradient) form it while staging z, when the input gradient is a launch
@@ -1271,6 +1274,9 @@ static int sa_fused_bwd_impl(const float *dout, const unsigned char *argmax, con
       } else if (pending) {
         wa.dy_bn = 1; wa.dyz = z[l]; wa.dy_consts = consts_all + const_floats * (size_t)l;
       }
+      if (l == 0 && gl0 && pending) {
+        wa.dx_w = weight[0]; wa.dx_ldw = 3 + c_feat; wa.dx_out = other; wa.dx_scatter = dfeats_cl;
+      }
       if (fl) {
         const float *st = stats[l - 1];
         double *red = red_all + 2 * (size_t)cmax * (l - 1);
@@ -1290,7 +1296,7 @@ static int sa_fused_bwd_impl(const float *dout, const unsigned char *argmax, con
     }
     // dX = dz W as an NT product with W^T (output columns x cout), transposed into the workspace
     const int wcols = (l == 0 && g.gather) ? c_feat : cin, wc0 = (l == 0 && g.gather) ? 3 : 0;
-    const bool need_dx = !fl && (l > 0 || need_dx0);         // (fl: the input gradient rides in the weight-gradient launch)
+    const bool need_dx = !fl && !(l == 0 && gl0 && pending) && (l > 0 || need_dx0);   // (the input gradient rides in the weight-gradient launch)
     const float *wt_l = wt;
     if (need_dx && weight_t && weight_t[l] && (reinterpret_cast<uintptr_t>(weight_t[l]) & 15u) == 0 && cout % 4 == 0) {
       wt_l = weight_t[l] + (size_t)wc0 * cout;              // rows wc0.. of W^T: the feature columns of a gather layer
@@ -1319,7 +1325,7 @@ static int sa_fused_bwd_impl(const float *dout, const unsigned char *argmax, con
       // dz_{l-1} = A*gy + B*z + D: in place (gy is already masked: the kernel's mask is idempotent), or -- when every
       // consumer of dz_{l-1} forms it while staging -- only the five column constants (and d(gamma), d(beta))
       const bool next_fl = layer_fuse && l - 1 >= 1 && eda_wgrad_x_fuses_dx(cin, channels[l - 1]);
-      pending = layer_fuse && cin % 4 == 0 && (next_fl || (l - 1 == 0 && !need_dx0));
+      pending = layer_fuse && cin % 4 == 0 && (next_fl || (l - 1 == 0 && (!need_dx0 || gl0)));
       if (pending)
         hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3((cin + 255) / 256), dim3(256), 0, stream, st, st + cin, st + 2 * cin,
                            st + 3 * cin, gamma[l - 1], red, red + cin, inv_n, gscale, cin, dgamma[l - 1], dbeta[l - 1],
@@ -1331,7 +1337,7 @@ static int sa_fused_bwd_impl(const float *dout, const unsigned char *argmax, con
       EDA_CHECK_LAUNCH();
       float *t = cur; cur = other; other = t;
     } else if (g.gather) {
-      if (dfeats_cl && c_feat > 0) {
+      if (dfeats_cl && c_feat > 0 && need_dx) {
         a.N = c_feat; a.epi = E_SCATTER;                       // (wt holds the feature columns of the (C1, 3 + c_feat) weight)
         a.idx = idx; a.n_pts = n; a.m = m; a.ns = ns; a.c_feat = c_feat; a.dfeats = dfeats_cl;
         const int rc = eda_gemm_launch(a, W_NT, stream);

@@ -1207,6 +1207,180 @@ __global__ __launch_bounds__(1024) void sa_layer_bwd_kernel(const WgradXArgs a, 
 #undef SLB_T2
 }
 
+// The FIRST layer of an SA stack with 128 gathered feature channels and 128 outputs (SA2: 128 <- 3 + 128), same idea: one pass
+// over dz (formed while staging from the masked gradient and the pre-activation, WgradXArgs::dy_bn) gives
+//   waves 0-7   dW += dz^T [dx dy dz 0 | gathered features]   (wgrad_x_kernel's X_GATHER staging: neighbour indices one chunk
+//               ahead of the feature rows they address; nine 16-column tiles per wave, 132 of the 144 columns are real)
+//   waves 8-15  dz W[:, 3:] -> dense rows (R x 128), stored one phase later; rows_scatter_add_kernel then adds them to
+//               d(features)[point of the row] with one atomic instruction per 64 consecutive channels of a row.  (Scattering
+//               straight from the MFMA tiles -- a lane owns four channels of a row, an instruction 16 rows -- was measured
+//               first: 2.24 ms for SA2, the atomics want contiguous channels.)
+// instead of element-wise pass + weight-gradient kernel + scatter kernel (gemm.hip E_SCATTER), each with its own pass over dz.
+// One LDS image (dz 33 KB, rows 37 KB, feature columns of W 66 KB), point indices of three consecutive chunks in LDS.
+__global__ __launch_bounds__(1024) void sa_gather_layer_bwd_kernel(const WgradXArgs a, int chunks_per_split, int nsplits) {
+  constexpr int THREADS = 1024, TM = 128, CF = 128, TN = 144;
+  constexpr int SA = TM + 4, SB = TN + 4, SW = CF + 4;
+  constexpr int NCT = TN / 16;                     // 9 column tiles of dW per wave of the first kind (row strip = wave)
+  extern __shared__ __attribute__((aligned(16))) float slb_smem[];
+  float *As = slb_smem, *Bs = As + 64 * SA, *Ws = Bs + 64 * SB;
+  float *qtab = Ws + TM * SW;                      // . | . | ka | kb | kd of the layer's BatchNorm backward
+  int *pidx = reinterpret_cast<int *>(qtab + 5 * TM);      // [3][64]: b * n_pts + neighbour index of the rows of chunks k - 1, k, k + 1
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int s = xcd + 8 * j;
+  if (s >= nsplits) return;
+  const long kbeg_l = (long)s * chunks_per_split * 64;
+  long kend_l = kbeg_l + (long)chunks_per_split * 64;
+  if (kend_l > a.R) kend_l = a.R;
+  if (kbeg_l >= kend_l) return;
+  const int kbeg = (int)kbeg_l, kend = (int)kend_l;
+  const int rps = a.m * a.ns, ldw = 3 + CF;
+  for (int e = tid; e < 5 * TM; e += THREADS) qtab[e] = a.dy_consts[e];
+  for (int e = tid; e < TM * CF; e += THREADS) Ws[(e >> 7) * SW + (e & 127)] = a.dx_w[(long)(e >> 7) * ldw + 3 + (e & 127)];
+  for (int e = tid; e < 64 * 4; e += THREADS)      // columns 132..147 of the row image stay zero
+    *reinterpret_cast<float4 *>(&Bs[(e >> 2) * SB + 132 + 4 * (e & 3)]) = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto point_of = [&](int k) {                     // (clamped row: staged against zero dz rows)
+    if (k >= kend) k = kend - 1;
+    return (k / rps) * a.n_pts + a.idx[k];
+  };
+  int pnext = 0;                                   // threads 0..63: point of row tid of the chunk after the one being fetched
+  if (tid < 64) { pidx[tid] = point_of(kbeg + tid); pnext = point_of(kbeg + 64 + tid); }
+  __syncthreads();
+
+  const int acol = (tid & 31) * 4, row0 = tid >> 5;          // rows row0, row0 + 32 of dz and of the feature part
+  float4 ra[2], rz[2], rb[2];
+  float gx[3], gc[3];
+  auto fetch = [&](int k0, int slot) {             // uses pidx[slot] (written before the last barrier)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int k = k0 + row0 + 32 * i;
+      if (k >= kend) k = kend - 1;
+      ra[i] = *reinterpret_cast<const float4 *>(a.dy + (unsigned)(k * (int)a.ld_dy + acol));
+      rz[i] = *reinterpret_cast<const float4 *>(a.dyz + (unsigned)(k * TM + acol));
+      rb[i] = *reinterpret_cast<const float4 *>(a.feats + (unsigned)(pidx[64 * slot + row0 + 32 * i] * CF + acol));
+    }
+    if (tid < 64) {
+      int k = k0 + tid;
+      if (k >= kend) k = kend - 1;
+      const int b = k / rps, cen = b * a.m + (k - b * rps) / a.ns, pt = pidx[64 * slot + tid];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) { gx[u] = a.xyz[(unsigned)(pt * 3 + u)]; gc[u] = a.new_xyz[(unsigned)(cen * 3 + u)]; }
+    }
+  };
+  auto stage = [&](int k0) {
+    const float4 qka = *reinterpret_cast<const float4 *>(&qtab[2 * TM + acol]);
+    const float4 qkb = *reinterpret_cast<const float4 *>(&qtab[3 * TM + acol]);
+    const float4 qkd = *reinterpret_cast<const float4 *>(&qtab[4 * TM + acol]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float4 va = ra[i];
+      va.x = qka.x * va.x + qkb.x * rz[i].x + qkd.x; va.y = qka.y * va.y + qkb.y * rz[i].y + qkd.y;
+      va.z = qka.z * va.z + qkb.z * rz[i].z + qkd.z; va.w = qka.w * va.w + qkb.w * rz[i].w + qkd.w;
+      if (k0 + row0 + 32 * i >= kend) va = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4 *>(&As[(row0 + 32 * i) * SA + acol]) = va;
+      *reinterpret_cast<float4 *>(&Bs[(row0 + 32 * i) * SB + 4 + acol]) = rb[i];
+    }
+    if (tid < 64)
+      *reinterpret_cast<float4 *>(&Bs[tid * SB]) = make_float4((gx[0] - gc[0]) * a.inv_radius, (gx[1] - gc[1]) * a.inv_radius,
+                                                               (gx[2] - gc[2]) * a.inv_radius, 0.f);
+  };
+
+  f32x4 U[NCT];                                    // first kind: 9 accumulators; second kind: U[0..3] = the tiles held for the scatter
+#pragma unroll
+  for (int t = 0; t < NCT; ++t) U[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float *ap = &As[4 * g * SA + 16 * (w & 7) + li];
+  const float *bp = &Bs[4 * g * SB + li];
+  const int ct = w & 7;
+  const float *dp = &As[li * SA + 4 * g];
+  const float *wp = &Ws[4 * g * SW + 16 * ct + li];
+
+  auto dw_tiles = [&]() {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {                       // k step q takes rows 16 (q / 4) + (q % 4) + 4 g
+      const int r = 16 * (q >> 2) + (q & 3);
+      const float av = ap[r * SA];
+      float bv[NCT];
+#pragma unroll
+      for (int t = 0; t < NCT; ++t) bv[t] = bp[r * SB + 16 * t];
+#pragma unroll
+      for (int t = 0; t < NCT; ++t) U[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], U[t], 0, 0, 0);
+    }
+  };
+  auto dx_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) U[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kq = 0; kq < TM / 16; ++kq) {
+      float wv[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) wv[jj] = wp[(16 * kq + jj) * SW];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 dz = *reinterpret_cast<const f32x4 *>(dp + 16 * i * SA + 16 * kq);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) U[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[jj], dz[jj], U[i], 0, 0, 0);
+      }
+    }
+  };
+  auto scatter = [&](int k0, int) {                // chunk k0's tiles: row 16 i + li, channels 16 ct + 4 g .. (dense rows; see the header)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = k0 + 16 * i + li;
+      if (row < kend) *reinterpret_cast<f32x4 *>(a.dx_out + (unsigned)(row * CF + 16 * ct + 4 * g)) = U[i];
+    }
+  };
+
+  // stage | [scatter the previous chunk] | barrier | request the next chunk, multiply | barrier
+  fetch(kbeg, 0);
+  int slot = 0;                                    // pidx slot of the chunk being staged
+  int k0 = kbeg;
+  for (; k0 < kend; k0 += 64) {
+    const int nslot = slot == 2 ? 0 : slot + 1, pslot = slot == 0 ? 2 : slot - 1;
+    stage(k0);
+    if (w >= 8 && k0 > kbeg) scatter(k0 - 64, pslot);
+    if (tid < 64) pidx[64 * nslot + tid] = pnext;
+    __syncthreads();
+    if (k0 + 64 < kend) {
+      if (tid < 64) pnext = point_of(k0 + 128 + tid);
+      fetch(k0 + 64, nslot);
+    }
+    if (w < 8) dw_tiles(); else dx_tiles();
+    __syncthreads();
+    slot = nslot;
+  }
+  if (w >= 8) {
+    scatter(k0 - 64, slot == 0 ? 2 : slot - 1);
+  } else {
+    // partial dW tile of split s -> slab s (128 x 132 floats, kernel column order [dx dy dz 0 | features])
+    float *o = a.ws + (long)s * TM * 132;
+#pragma unroll
+    for (int t = 0; t < NCT; ++t) {
+      const int col = 16 * t + li;
+      if (col < 132) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[(16 * w + 4 * g + r) * 132 + col] = U[t][r];
+      }
+    }
+  }
+}
+// d(features)[(row / rows_per_scene) * n_pts + idx[row]][:] += g[row][:] for dense rows of C = 64 q channels: a wave = 64
+// consecutive channels of one row per atomic instruction.
+__global__ __launch_bounds__(256) void rows_scatter_add_kernel(const float *__restrict__ g, const int *__restrict__ idx, long R,
+                                                               int rps, int n_pts, int C, float *__restrict__ dfeats) {
+  const int lane = threadIdx.x & 63;
+  const int parts = C >> 6;                        // 64-channel parts of a row
+  const long nitems = R * parts;
+  const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  for (long it = wave; it < nitems; it += nwaves) {
+    const long row = it / parts;
+    const int part = (int)(it - row * parts);
+    const long p = (row / rps) * n_pts + idx[row];
+    atomicAdd(dfeats + p * C + 64 * part + lane, g[row * C + 64 * part + lane]);
+  }
+}
+constexpr size_t sa_gather_layer_bwd_lds_bytes() { return sizeof(float) * (64 * 132 + 64 * 148 + 128 * 132 + 5 * 128 + 3 * 64); }
+
 template <int TM, int TN, int NBUF>
 constexpr size_t sa_layer_bwd_lds_bytes() { return sizeof(float) * (NBUF * 64 * (TM + 4 + TN + 4) + 4 * TN + 5 * TM + 256 + TM * (TN + 4)); }
 
@@ -1259,6 +1433,7 @@ void wgx_launch(const WgradXArgs &a, const WgxPlan &p, hipStream_t stream) {
 }
 }  // namespace
 
+bool eda_wgrad_x_fuses_gather(int M, int c_feat) { return M == 128 && c_feat == 128; }
 bool eda_wgrad_x_fuses_dx(int M, int N) { return ((M == 128 || M == 64) && N == 64) || (M == 128 && N == 128); }
 
 size_t eda_wgrad_x_workspace_bytes(long R, int M, int N) {
@@ -1298,6 +1473,31 @@ int eda_wgrad_x_launch(const WgradXArgs &a, hipStream_t stream) {
   if (!a.ws || a.ws_bytes < sizeof(float) * (size_t)p.splits * a.M * a.N) {
     eda_set_error("wgrad_x: workspace too small");
     return EDA_ERR_WORKSPACE;
+  }
+  if (a.dx_out && a.xmode == X_GATHER) {
+    // first layer of an SA stack: weight gradient and the scatter of the input gradient in one launch
+    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    if (!eda_wgrad_x_fuses_gather(a.M, a.c_feat) || !a.dy_bn || a.R * 128 >= 0x7fffffffL || a.ld_dy != a.M || !a.dx_w || !a.dx_scatter || !al16(a.dx_out) ||
+        !al16(a.feats) || !a.idx || !a.xyz || !a.new_xyz || (long)a.n_pts * (a.R / ((long)a.m * a.ns) + 1) * 128 >= 0x7fffffffL ||
+        p.tiles_m * p.tiles_n != 1) {
+      eda_set_error("wgrad_x: bad operands for the fused gather layer");
+      return EDA_ERR_INVALID_ARG;
+    }
+    const dim3 grid((unsigned)(8 * ((p.splits + 7) / 8))), block(1024);
+    const size_t lds = sa_gather_layer_bwd_lds_bytes();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sa_gather_layer_bwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { eda_set_error("wgrad_x: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(sa_gather_layer_bwd_kernel, grid, block, lds, stream, a, p.cps, p.splits);
+    EDA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(rows_scatter_add_kernel, dim3(2048), dim3(256), 0, stream, a.dx_out, a.idx, a.R, a.m * a.ns, a.n_pts,
+                       a.c_feat, a.dx_scatter);
+    EDA_CHECK_LAUNCH();
+    const long MN = (long)a.M * a.N;
+    hipLaunchKernelGGL(wgrad_x_reduce_kernel, dim3((unsigned)((MN + 31) / 32)), dim3(256), 0, stream, a.ws, p.splits,
+                       a.M, a.N, 1, a.dW);
+    EDA_CHECK_LAUNCH();
+    return 0;
   }
   if (a.dx_out) {
     // the layer's input gradient in the same launch (sa_layer_bwd_kernel)

@@ -265,6 +265,9 @@ def test_full_size_gradients_vs_fp64_backward_on_the_same_relu_and_argmax_decisi
     (2, 4000, 300, 64, 3, [64, 64, 128], False),       # one pooling group per 64-row chunk
     (2, 1024, 100, 32, 0, [64, 64, 64, 128], False),   # no features at all, four layers
     (1, 900, 37, 16, 3, [128, 64, 64], False),         # 64 <- 128 is not a fused shape, 64 <- 64 is
+    (2, 2048, 256, 32, 128, [128, 128, 256], True),    # SA2's stack: first layer = weight gradient + scatter of d(features) in one launch
+    (3, 700, 50, 9, 128, [128, 128], True),            # ragged chunks, unpooled-fused last layer, many rows per point
+    (2, 300, 64, 16, 128, [128, 128, 128], False),     # same shapes, d(features) not wanted
 ])
 def test_layer_backward_in_one_launch_matches_the_separate_kernels(B, N, m, ns, C, chans, feats_grad, monkeypatch):
     from eda_amd import pointnet2_utils as PU
