@@ -16,11 +16,13 @@
 // split the first kernel writes dW directly.  Workgroups of the first column tile also sum
 // their dY chunk's columns from LDS: d(bias) costs no extra pass over dY.
 //
-// Three kernels live here: the one-at-a-time split-K form (wgrad_partial_kernel + wgrad_reduce_kernel), the GROUPED form
-// that computes every queued weight gradient of a backward pass in one launch -- on fp32 MFMA (wgrad_grouped_kernel) or,
+// Four kernel families live here: the one-at-a-time split-K form (wgrad_partial_kernel + wgrad_reduce_kernel), the GROUPED
+// form that computes every queued weight gradient of a backward pass in one launch -- on fp32 MFMA (wgrad_grouped_kernel) or,
 // by default since round 4, on the bf16 matrix pipe with exactly split operands and fp32-level accuracy
-// (wgrad_grouped_bf16x3_kernel: see the comment in front of it) --, and the prologue form of the fused SA / FP layers
-// (wgrad_x_kernel).
+// (wgrad_grouped_bf16x3_kernel: see the comment in front of it) --, the prologue form of the fused SA / FP layers
+// (wgrad_x_kernel), and the whole backward of an SA layer in one launch where its dW is a single tile (sa_layer_bwd_kernel:
+// weight gradient + masked input gradient + BatchNorm-backward sums; sa_gather_layer_bwd_kernel + rows_scatter_add_kernel for
+// the first layer of SA2).
 #include "eda_common.h"
 #include "gemm.h"
 #include <stdlib.h>
