@@ -43,6 +43,34 @@ def _clone(batch):
             for k, v in batch.items()}
 
 
+def _rebuild(batch, tensors):
+    """`batch` with its tensors replaced, in _flat() order, by `tensors`."""
+    it = iter(tensors)
+    out = {}
+    for k in sorted(batch):
+        v = batch[k]
+        if isinstance(v, dict):
+            out[k] = {kk: next(it) for kk in sorted(v)}
+        elif torch.is_tensor(v):
+            out[k] = next(it)
+        else:
+            out[k] = v
+    return out
+
+
+def _packed_like(tensors):
+    """One byte buffer holding a contiguous copy-shaped view per tensor (256-byte aligned, any mix of dtypes): returns
+    (buffer, views).  Rotating / handing over ALL of them is then one copy of the buffer instead of one memcpy node per
+    tensor (a hipGraph memcpy node costs ~7 us of queue time around a few-KB copy: 24 of them opened every step)."""
+    offs, total = [], 0
+    for t in tensors:
+        offs.append(total)
+        total += (t.numel() * t.element_size() + 255) // 256 * 256
+    buf = torch.zeros(max(total, 256), dtype=torch.uint8, device=tensors[0].device)
+    views = [buf[o:o + t.numel() * t.element_size()].view(t.dtype).view(t.shape) for o, t in zip(offs, tensors)]
+    return buf, views
+
+
 class PipelinedTrainStep:
     def __init__(self, model, first_batch, loss_fn, backward_fn, update_fn, *, stream=None, all_reduce=None,
                  split_update=False, prefetch="sa1", text_prefetch=True, after_loss=None, sa1_samples=2048,
@@ -68,49 +96,69 @@ class PipelinedTrainStep:
         dev = first_batch["point_clouds"].device
         self.main = stream or torch.cuda.current_stream()
         self.side = torch.cuda.Stream()
-        self.cur, self.nxt = _clone(first_batch), _clone(first_batch)
-        self._cur_flat, self._nxt_flat = _flat(self.cur), _flat(self.nxt)
         mode = dict(capture_error_mode="thread_local")
+
+        # ---- side stream, eager once: creates this stream's FPS workspace outside the capture (its sticky give-up flag
+        # must not be re-zeroed by a captured fill), warms the text encoder's library kernels, and tells the shapes of
+        # everything that is handed from the side stream to the step
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side):
+            xyz = first_batch["point_clouds"][..., 0:3].contiguous()
+            geo_keys, warm = [], []
+            if prefetch_geometry:
+                geo = model.backbone_net.geometry(xyz)
+                geo_keys, warm = list(geo.keys()), list(geo.values())
+            elif prefetch is not None:
+                warm = [pointnet2_utils.furthest_point_sample(xyz, sa1_samples)]
+            text_warm = model.encode_text_frozen(first_batch["tokenized"]["input_ids"], first_batch["tokenized"]["attention_mask"])
+        self.side.synchronize()
+        # nxt / cur: ONE buffer each for the batch tensors, the prefetched indices and the prefetched hidden states -- the
+        # rotation at the head of the point graph is one copy
+        flat0 = _flat(first_batch)
+        order = flat0 + warm + ([text_warm] if text_prefetch else [])
+        self._pack_next, nv = _packed_like(order)
+        self._pack_cur, cv = _packed_like(order)
+        for v, t in zip(nv, order):
+            v.copy_(t)
+        self._pack_cur.copy_(self._pack_next)
+        nb, ni = len(flat0), len(warm)
+        self._nxt_flat, self._cur_flat = nv[:nb], cv[:nb]
+        self.nxt, self.cur = _rebuild(first_batch, self._nxt_flat), _rebuild(first_batch, self._cur_flat)
+        self.inds_next, self.inds_cur = nv[nb:nb + ni], cv[nb:nb + ni]
+        self.text_prefetch = text_prefetch
         # the text encoder reads the NEXT batch's tokens when it is prefetched, else the current batch's
         tok = (self.nxt if text_prefetch else self.cur)["tokenized"]
 
         # ---- side stream: sampling (+ optionally all coordinate-only geometry) and text encoder of the NEXT batch ----
-        self.side.wait_stream(self.main)
-        with torch.cuda.stream(self.side):
-            # eager once: creates this stream's FPS workspace outside the capture (its sticky give-up flag must not be
-            # re-zeroed by a captured fill) and warms the text encoder's library kernels
-            xyz = self.nxt["point_clouds"][..., 0:3].contiguous()
-            if prefetch_geometry:
-                model.backbone_net.geometry(xyz)
-            elif prefetch is not None:
-                pointnet2_utils.furthest_point_sample(xyz, sa1_samples)
-            model.encode_text_frozen(tok["input_ids"], tok["attention_mask"])
-        self.side.synchronize()
         self.g_fps, self.g_text = None, torch.cuda.CUDAGraph()
-        self.inds_next, self.inds_cur = [], []
         if prefetch is not None:
             self.g_fps = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_fps, stream=self.side, **mode):
                 xyz_next = self.nxt["point_clouds"][..., 0:3].contiguous()
                 if prefetch_geometry:
-                    geo_next = model.backbone_net.geometry(xyz_next)
-                    self.inds_next = list(geo_next.values())
+                    outs = list(model.backbone_net.geometry(xyz_next).values())
                 else:
-                    self.inds_next = [pointnet2_utils.furthest_point_sample(xyz_next, sa1_samples)]
+                    outs = [pointnet2_utils.furthest_point_sample(xyz_next, sa1_samples)]
+                for v, t in zip(self.inds_next, outs):     # (side stream: off the critical path)
+                    v.copy_(t)
         with torch.cuda.graph(self.g_text, stream=self.side, **mode):
-            self.text_next = model.encode_text_frozen(tok["input_ids"], tok["attention_mask"])
+            hidden = model.encode_text_frozen(tok["input_ids"], tok["attention_mask"])
+            if text_prefetch:
+                self.text_next = nv[-1]
+                self.text_next.copy_(hidden)
+            else:
+                self.text_next = hidden
         self.side.synchronize()
         if self.g_fps is not None:
             self.g_fps.replay()
         self.g_text.replay()
         torch.cuda.synchronize()
-        self.inds_cur = [t.clone() for t in self.inds_next]
-        self.text_prefetch = text_prefetch
-        self.text_cur = self.text_next.clone() if self.text_prefetch else self.text_next
+        self._pack_cur.copy_(self._pack_next)
+        self.text_cur = cv[-1] if self.text_prefetch else self.text_next
         inputs_h = dict(self.cur)
         inputs_h["text_hidden"] = self.text_cur
         if prefetch_geometry:
-            inputs_h["backbone_geometry"] = dict(zip(geo_next.keys(), self.inds_cur))
+            inputs_h["backbone_geometry"] = dict(zip(geo_keys, self.inds_cur))
         elif prefetch is not None:
             inputs_h["sa1_inds"] = self.inds_cur[0]
         self.inputs = inputs_h
@@ -120,12 +168,9 @@ class PipelinedTrainStep:
         self.g_up = torch.cuda.CUDAGraph() if split_update else None
         pool = torch.cuda.graph_pool_handle()
         with torch.cuda.graph(self.g_pts, pool=pool, stream=self.main, **mode):
-            # rotate: the batch prefetched during the previous step becomes the batch of this step
-            torch._foreach_copy_(self._cur_flat, self._nxt_flat)
-            if self.inds_cur:
-                torch._foreach_copy_(self.inds_cur, self.inds_next)
-            if self.text_prefetch:
-                self.text_cur.copy_(self.text_next)
+            # rotate: the batch prefetched during the previous step (its tensors, sampling indices, hidden states) becomes
+            # the batch of this step -- one copy of the packed buffer
+            self._pack_cur.copy_(self._pack_next)
             attention.advance_dropout_state(dev)
             ep_static = model.forward_point_backbone(inputs_h)
         with torch.cuda.graph(self.g_rest, pool=pool, stream=self.main, **mode):
@@ -153,7 +198,8 @@ class PipelinedTrainStep:
     def _feed(self, batch):
         """Copy `batch` (same layout as the first one) into the nxt buffers, on the side stream."""
         src = _flat(batch)
-        torch._foreach_copy_(self._nxt_flat, src)
+        for v, t in zip(self._nxt_flat, src):
+            v.copy_(t)
         for t in src:                       # the copy runs on the side stream: keep the caller's memory alive until it is done
             t.record_stream(self.side)
 
