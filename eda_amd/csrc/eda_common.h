@@ -20,6 +20,25 @@ extern int g_eda_fma_mode;
     }                                                    \
   } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize for a kernel that needs more than 64 KB of dynamic LDS: set once per (kernel,
+// device) -- the attribute is per device, and setting it before EVERY launch costs an eager (un-captured) caller a host call
+// per launch.  Returns hipSuccess or the error of the runtime call.
+#include <mutex>
+#include <set>
+#include <utility>
+static inline hipError_t eda_set_max_dynamic_lds(const void *kern, size_t bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void *, int>> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({kern, dev})) return hipSuccess;
+  e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) done.insert({kern, dev});
+  return e;
+}
+
 #define EDA_CHECK_LAUNCH()                                              \
   do {                                                                  \
     hipError_t e__ = hipGetLastError();                                 \

@@ -1487,8 +1487,7 @@ int eda_wgrad_x_launch(const WgradXArgs &a, hipStream_t stream) {
     }
     const dim3 grid((unsigned)(8 * ((p.splits + 7) / 8))), block(1024);
     const size_t lds = sa_gather_layer_bwd_lds_bytes();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sa_gather_layer_bwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = eda_set_max_dynamic_lds(reinterpret_cast<const void *>(sa_gather_layer_bwd_kernel), lds);
     if (e != hipSuccess) { eda_set_error("wgrad_x: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
     hipLaunchKernelGGL(sa_gather_layer_bwd_kernel, grid, block, lds, stream, a, p.cps, p.splits);
     EDA_CHECK_LAUNCH();
@@ -1516,7 +1515,7 @@ int eda_wgrad_x_launch(const WgradXArgs &a, hipStream_t stream) {
       const size_t lds = sa_layer_bwd_lds_bytes<TM_, TN_, NB_>();                                                           \
       void (*kern)(const WgradXArgs, int, int) = dym == 1 ? sa_layer_bwd_kernel<TM_, TN_, 1, NB_>                            \
                                                : dym == 2 ? sa_layer_bwd_kernel<TM_, TN_, 2, NB_> : sa_layer_bwd_kernel<TM_, TN_, 0, NB_>; \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipError_t e = eda_set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds); \
       if (e != hipSuccess) { eda_set_error("wgrad_x: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }           \
       hipLaunchKernelGGL(kern, grid, block, lds, stream, a, p.cps, p.splits);                                               \
     } while (0)
