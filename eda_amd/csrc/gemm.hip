@@ -1877,11 +1877,7 @@ int launch_stream_b3(GemmArgs &a, hipStream_t stream) {
   if (!on) return -1;
   if (a.epi == E_MASK && a.xmode == X_BNBWDPOOL) return launch_stream_b3_1<KT, NT, X_BNBWDPOOL, E_MASK, NW>(a, stream);
   if (a.epi == E_MASK && a.xmode == X_PLAIN) return launch_stream_b3_1<KT, NT, X_PLAIN, E_MASK, NW>(a, stream);
-  // (the gather layers only with EDA_GEMM_STREAM_B3=3: 102 -> 86 us at SA2, but tests/test_sa_fused_gpu.py::test_gathered_rows
-  // has one case in which the different rounding of z flips ONE ReLU decision of the next layer -- |bn(z)| = 2.4e-7 -- and the
-  // re-routed gradient row moves 10 % of dW0's entries past that test's element-wise bound; until the test takes the
-  // kernels' own decisions like the full-size one does, the gather layers keep the fp32 pipe)
-  if (a.epi == E_STATS && a.xmode == X_GATHER && on == 3) return launch_stream_b3_1<KT, NT, X_GATHER, E_STATS, NW>(a, stream);
+  if (a.epi == E_STATS && a.xmode == X_GATHER) return launch_stream_b3_1<KT, NT, X_GATHER, E_STATS, NW>(a, stream);
   if (a.epi == E_STATS && a.xmode == X_BNRELU) return launch_stream_b3_1<KT, NT, X_BNRELU, E_STATS, NW>(a, stream);
   if (a.epi == E_STATS && a.xmode == X_PLAIN) return launch_stream_b3_1<KT, NT, X_PLAIN, E_STATS, NW>(a, stream);
   return -1;

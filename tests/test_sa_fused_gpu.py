@@ -33,6 +33,48 @@ def _mlp_ref64(rows, Ws, gammas, betas, running, training, pool, eps=1e-5):
     return x
 
 
+def _kernel_decisions(out, L):
+    """(arg-max rows, pre-activations, per-channel constants) the fused call saved -- to be taken BEFORE the backward pass
+    releases them."""
+    saved = out.grad_fn.saved_tensors
+    return (saved[5], [t.clone() for t in saved[6 + 2 * L:6 + 3 * L]], [t.clone() for t in saved[6 + 3 * L:6 + 4 * L]])
+
+
+def _grads_on_kernel_decisions(out, dec, rows64, leaves64, W64, g64, b64, running, training, pool, chans, w):
+    """fp64 gradients of the MLP with every DECISION taken from the kernels -- the ReLU masks they apply (sign of
+    z * scale + shift on their saved pre-activations and per-channel constants, their own two fp32 operations) and the
+    pooling rows they recorded.  Given the decisions the network is smooth: gradients must agree to rounding (2e-4 of
+    the largest entry), whereas ONE decision on a tie (|bn(z)| ~ 1e-7) that falls the other way in fp64 re-routes a
+    gradient row and moves a rank-1 share of every weight gradient below it."""
+    L = len(W64)
+    argmax, z32, stats = dec
+    x = rows64
+    R = x.shape[0]
+    for l in range(L):
+        z = x @ W64[l].reshape(chans[l + 1], -1).t()
+        if training:
+            mean, var = z.mean(0), z.var(0, unbiased=False)
+        else:
+            mean, var = running[l][0].double(), running[l][1].double()
+        y = (z - mean) / torch.sqrt(var + 1e-5) * g64[l] + b64[l]
+        if l < L - 1 or pool == 1:
+            mask = (z32[l] * stats[l][2] + stats[l][3]) > 0
+            assert float(((y > 0) != mask).float().mean()) <= 1e-3       # only rounding-close pre-activations may differ
+            x = y * mask
+    if pool > 1:
+        rows = (torch.arange(R // pool, device=x.device) * pool)[:, None] + argmax.long()
+        cols = torch.arange(chans[L], device=x.device)[None, :].expand_as(rows)
+        x = y[rows, cols] * (out > 0)
+    return torch.autograd.grad((x * w.double()).sum(), leaves64)
+
+
+def _check_grads(names, got, exp):
+    for n, g_, e_ in zip(names, got, exp):
+        scale = float(e_.abs().max()) + 1e-30
+        err = float((g_.double() - e_).abs().max())
+        assert err <= 2e-4 * scale + 1e-9, (n, err, scale)
+
+
 def _check(name, got, exp, rtol, frac=1e-4, ref32=None):
     """All but a fraction `frac` of the elements within rtol * max|exp|.  Input gradients (dx,
     dfeats) are judged per ROW: one ReLU / arg-max decision that sits on a tie in fp32 re-routes the
@@ -105,18 +147,18 @@ def test_plain_rows(R, chans, training, stream_kernels):
     run_a = [(rm.clone(), rv.clone()) for rm, rv in running]
     out = _run_fused({}, Ws, gammas, betas, run_a, training, 1, x_rows=x)
     w = torch.randn_like(out)
+    L = len(chans) - 1
+    dec = _kernel_decisions(out, L)
     got = torch.autograd.grad((out * w).sum(), leaves)
     l64 = [t.detach().double().requires_grad_(True) for t in leaves]
-    L = len(chans) - 1
-    ref = _mlp_ref64(l64[0], l64[1:1 + L], l64[1 + L:1 + 2 * L], l64[1 + 2 * L:], running, training, 1)
-    exp = torch.autograd.grad((ref * w.double()).sum(), l64)
-    l32 = [t.detach().clone().requires_grad_(True) for t in leaves]
-    r32 = _mlp_ref64(l32[0], l32[1:1 + L], l32[1 + L:1 + 2 * L], l32[1 + 2 * L:], running, training, 1)
-    e32 = torch.autograd.grad((r32 * w).sum(), l32)
-    _check("out", out.double(), ref.detach(), 1e-4)
+    with torch.no_grad():
+        ref = _mlp_ref64(l64[0], l64[1:1 + L], l64[1 + L:1 + 2 * L], l64[1 + 2 * L:], running, training, 1)
+    _check("out", out.double(), ref, 1e-4)
     names = ["dx"] + [f"dW{l}" for l in range(L)] + [f"dgamma{l}" for l in range(L)] + [f"dbeta{l}" for l in range(L)]
-    for n, g_, e_, r_ in zip(names, got, exp, e32):
-        _check(n, g_.double(), e_, 2e-4, frac=2e-4, ref32=r_)
+    # gradients: against fp64 on the kernels' own ReLU decisions (2e-4 of the largest entry, every element)
+    exp = _grads_on_kernel_decisions(out, dec, l64[0], l64, l64[1:1 + L], l64[1 + L:1 + 2 * L], l64[1 + 2 * L:], running, training,
+                                     1, chans, w)
+    _check_grads(names, got, exp)
     if training:
         for l, ((rm, rv), (rm0, rv0)) in enumerate(zip(run_a, running)):
             # torch semantics: running <- 0.9 running + 0.1 batch (unbiased variance)
@@ -162,6 +204,7 @@ def test_gathered_rows(B, N, m, ns, C, chans, training, stream_kernels):
     out = _run_fused(dict(radius=radius, normalize_xyz=True), Ws, gammas, betas, run_a, training, ns,
                      xyz=xyz, new_xyz=new_xyz, feats_cl=feats_cl, idx=idx)
     w = torch.randn_like(out)
+    dec = _kernel_decisions(out, len(chans) - 1)
     got = torch.autograd.grad((out * w).sum(), leaves)
     # fp64 composition of the reference ops: gather, centre, * (1/r), concat [xyz | feats]
     l64 = [t.detach().double().requires_grad_(True) for t in leaves]
@@ -173,17 +216,14 @@ def test_gathered_rows(B, N, m, ns, C, chans, training, stream_kernels):
     rows = gx.double()
     if C:
         rows = torch.cat([rows, f64[bidx, idx.long()]], dim=-1)
-    ref = _mlp_ref64(rows.reshape(B * m * ns, 3 + C), rest[:L], rest[L:2 * L], rest[2 * L:], running, training, ns)
-    exp = torch.autograd.grad((ref * w.double()).sum(), l64)
-    l32 = [t.detach().clone().requires_grad_(True) for t in leaves]
-    rest32 = l32[1:] if C else l32
-    rows32 = gx if not C else torch.cat([gx, l32[0][bidx, idx.long()]], dim=-1)
-    r32 = _mlp_ref64(rows32.reshape(B * m * ns, 3 + C), rest32[:L], rest32[L:2 * L], rest32[2 * L:], running, training, ns)
-    e32 = torch.autograd.grad((r32 * w).sum(), l32)
-    _check("out", out.double(), ref.detach(), 1e-4)
+    with torch.no_grad():
+        ref = _mlp_ref64(rows.reshape(B * m * ns, 3 + C), rest[:L], rest[L:2 * L], rest[2 * L:], running, training, ns)
+    _check("out", out.double(), ref, 1e-4)
     names = (["dfeats"] if C else []) + [f"dW{l}" for l in range(L)] + [f"dgamma{l}" for l in range(L)] + [f"dbeta{l}" for l in range(L)]
-    for n_, g_, e_, r_ in zip(names, got, exp, e32):
-        _check(n_, g_.double(), e_, 2e-4, frac=2e-4, ref32=r_)
+    # gradients: against fp64 on the kernels' own ReLU / arg-max decisions (2e-4 of the largest entry, every element)
+    exp = _grads_on_kernel_decisions(out, dec, rows.reshape(B * m * ns, 3 + C), l64, rest[:L], rest[L:2 * L], rest[2 * L:], running,
+                                     training, ns, chans, w)
+    _check_grads(names, got, exp)
 
 
 # ---- full size, gradients at 2e-4: fp64 backward on the GPU's OWN decisions -----------------------
