@@ -946,8 +946,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void gemm_stream_b3_kernel(const Gem
   constexpr int WSS = KT + 8;                // weight row stride in bf16 ([n][k] per plane)
   constexpr int KH = KT / 64, NJ = NT / 16;
   constexpr bool mask = EPI == E_MASK, stats = EPI == E_STATS || EPI == E_MASK, gather = XMODE == X_GATHER;
-  static_assert(KT % 64 == 0 && NT % 64 == 0 && EPI != E_SCATTER, "shape");
+  static_assert(KT % 64 == 0 && NT % 64 == 0, "shape");
   constexpr int WPL = NT * WSS, SPL = 16 * XS;     // bf16 elements of a weight plane / of a strip plane
+  static_assert(16 * XS * 4 <= 3 * SPL * 2, "the scatter epilogue's 16 x 72 float image must fit the strip planes");
   // LDS (dynamic, gemm_stream_b3_lds_bytes): weight planes h | m | l, then per wave its strip planes h | m | l; the column
   // partials of the epilogue are parked in the wave's strip (3 * 16 * 72 * 2 = 6912 bytes >= 2 * NT floats)
   extern __shared__ __attribute__((aligned(16))) unsigned short b3_smem[];
@@ -1877,6 +1878,7 @@ int launch_stream_b3(GemmArgs &a, hipStream_t stream) {
   if (!on) return -1;
   if (a.epi == E_MASK && a.xmode == X_BNBWDPOOL) return launch_stream_b3_1<KT, NT, X_BNBWDPOOL, E_MASK, NW>(a, stream);
   if (a.epi == E_MASK && a.xmode == X_PLAIN) return launch_stream_b3_1<KT, NT, X_PLAIN, E_MASK, NW>(a, stream);
+  if (a.epi == E_SCATTER && a.xmode == X_PLAIN) return launch_stream_b3_1<KT, NT, X_PLAIN, E_SCATTER, NW>(a, stream);
   if (a.epi == E_STATS && a.xmode == X_GATHER) return launch_stream_b3_1<KT, NT, X_GATHER, E_STATS, NW>(a, stream);
   if (a.epi == E_STATS && a.xmode == X_BNRELU) return launch_stream_b3_1<KT, NT, X_BNRELU, E_STATS, NW>(a, stream);
   if (a.epi == E_STATS && a.xmode == X_PLAIN) return launch_stream_b3_1<KT, NT, X_PLAIN, E_STATS, NW>(a, stream);
