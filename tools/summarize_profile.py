@@ -7,7 +7,7 @@ import sys
 
 NATIVE = [
     ("native: own row GEMMs fwd / dX, tiled (gemm_rows / gemm_dma: linear layers incl. the text encoder's and the LayerNorm-epilogue launches, small SA/FP layers)", r"^gemm_rows_kernel|^gemm_dma_kernel"),
-    ("native: own row GEMMs fwd / dX, streaming (gemm_stream / gemm_gather3: many-row SA layers)", r"^gemm_stream_kernel|^gemm_gather3"),
+    ("native: own row GEMMs fwd / dX, streaming (gemm_stream, fp32 MFMA or bf16 x 3 / gemm_gather3: many-row SA layers)", r"^gemm_stream_kernel|^gemm_stream_b3_kernel|^gemm_gather3"),
     ("native: furthest point sampling", r"^fps_"),
     ("native: fused attention (fwd, dQ, dK/dV)", r"^mha2?_"),
     ("native: BN+ReLU(+pool) fwd/bwd", r"^bn_"),
