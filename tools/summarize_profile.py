@@ -12,7 +12,7 @@ NATIVE = [
     ("native: fused attention (fwd, dQ, dK/dV)", r"^mha2?_"),
     ("native: BN+ReLU(+pool) fwd/bwd", r"^bn_"),
     ("native: residual+dropout+LayerNorm", r"^add_dropout_ln|^ln_reduce"),
-    ("native: weight/bias gradients (grouped wgrad fp32 / bf16 x 3, wgrad_x, colsum, the heads' 3-channel layers) and the SA layers' one-launch backward (sa_layer_bwd: weight + input gradient)", r"^wgrad_|^colsum_|^wcolsum_|^weight_transpose|^tiny_out_|^sa_layer_bwd"),
+    ("native: weight/bias gradients (grouped wgrad fp32 / bf16 x 3, wgrad_x, colsum, the heads' 3-channel layers) and the SA layers' one-launch backward (sa_layer_bwd: weight + input gradient)", r"^wgrad_|^colsum_|^wcolsum_|^weight_transpose|^tiny_out_|^sa_layer_bwd|^sa_gather_layer_bwd|^rows_scatter_add"),
     ("native: ball query (grid build + query)", r"^gq_|^ball_query"),
     ("native: gather/group/3-NN", r"^group_|^gather_|^three_"),
     ("native: zero-fill", r"^zero_kernel"),
