@@ -1,3 +1,7 @@
+"""Run the SA2-shaped fused MLP (forward + backward) of tests/test_sa_fused_gpu.py::test_gathered_rows with EDA_GEMM_STREAM_B3=<mode>
+and, on the second call (mode 2), compare everything the forward saved, the ReLU decisions and every gradient with the first
+call (mode 1): how one decision on a tie turns rounding differences of 4e-6 into a rank-1 change of the weight gradients.
+    python tools/compare_b3_runs.py 1; python tools/compare_b3_runs.py 2"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

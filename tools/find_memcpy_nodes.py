@@ -1,3 +1,5 @@
+"""Which aten::copy_ calls of one eager training step become device-to-device memcpy launches (in a captured step: memcpy
+nodes, ~7 us of queue time each) -- torch.profiler with stacks.    python tools/find_memcpy_nodes.py"""
 import os, sys, collections
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
