@@ -1191,12 +1191,13 @@ static int sa_fused_bwd_impl(const float *dout, const unsigned char *argmax, con
   // One launch per layer (wgrad.hip, sa_layer_bwd_kernel: weight gradient + masked input gradient + its BatchNorm-backward sums
   // from one pass over dz) where the layer's dW is one tile; and a non-pooled layer's dz = ka*g + kb*z + kd is formed by
   // its consumer(s) while staging instead of by bn_relu_bwd_apply_kernel whenever all of them can (`pending`).
-  bool layer_fuse = training != 0;
+  // (the layer launches address rows with 32-bit element offsets: beyond 2^31 / 128 rows per call the separate kernels run)
+  bool layer_fuse = training != 0 && R * 128 < 0x7fffffffL;
   { const char *e = getenv("EDA_SA_LAYER_FUSE"); if (e && atoi(e) == 0) layer_fuse = false; }
   const bool need_dx0 = g.gather ? (dfeats_cl && c_feat > 0) : dx != nullptr;
   // first layer of a gathering stack with 128 feature channels (SA2): weight gradient + scatter of d(features) in one launch
   const bool gl0 = layer_fuse && g.gather && need_dx0 && nlayers >= 2 && eda_wgrad_x_fuses_gather(channels[1], c_feat) &&
-                   (reinterpret_cast<uintptr_t>(feats_cl) & 15u) == 0;
+                   (reinterpret_cast<uintptr_t>(feats_cl) & 15u) == 0 && (long)(b + 1) * n * 128 < 0x7fffffffL;
   bool pending = false;
   // Pooled last layer in training mode: its dz = ka*d + kb*z + kd need not be written and read back -- the two kernels
   // that consume it (weight gradient, input gradient) form it while staging z, when the input gradient is a launch
