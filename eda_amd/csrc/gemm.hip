@@ -1873,9 +1873,8 @@ int launch_stream_b3_1(GemmArgs &a, hipStream_t stream) {
 // EDA_GEMM_STREAM_B3=0 keeps the fp32-MFMA kernel.  Returns -1 when the launch is not one of them.
 template <int KT, int NT, int NW>
 int launch_stream_b3(GemmArgs &a, hipStream_t stream) {
-  static int on = -1;
-  if (on < 0) { const char *e = getenv("EDA_GEMM_STREAM_B3"); on = e ? atoi(e) : 1; }
-  if (!on) return -1;
+  const char *e = getenv("EDA_GEMM_STREAM_B3");          // (read per call: tests switch it inside one process)
+  if (e && atoi(e) == 0) return -1;
   if (a.epi == E_MASK && a.xmode == X_BNBWDPOOL) return launch_stream_b3_1<KT, NT, X_BNBWDPOOL, E_MASK, NW>(a, stream);
   if (a.epi == E_MASK && a.xmode == X_PLAIN) return launch_stream_b3_1<KT, NT, X_PLAIN, E_MASK, NW>(a, stream);
   if (a.epi == E_SCATTER && a.xmode == X_PLAIN) return launch_stream_b3_1<KT, NT, X_PLAIN, E_SCATTER, NW>(a, stream);

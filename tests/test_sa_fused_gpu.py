@@ -340,3 +340,43 @@ def test_layer_backward_in_one_launch_matches_the_separate_kernels(B, N, m, ns, 
     again = run(True)
     for g_, e_ in zip(again[:len(Ws) + (1 if C and feats_grad else 0)], got):
         assert float((g_ - e_).abs().max()) <= 1e-5 * (float(e_.abs().max()) + 1e-30)     # (fp64 atomics: order-dependent sums only)
+
+
+# ---- the streaming products on the bf16 pipe (three exact bf16 terms per operand, six MFMAs per step) against the fp32 pipe ----
+@pytest.mark.parametrize("B,N,m,ns,C,chans", [
+    (2, 2048, 256, 32, 128, [128, 128, 256]),      # SA2's stack: gather, BatchNorm+ReLU prologues, pooled input gradient
+    (2, 1024, 128, 16, 256, [128, 128, 256]),      # SA3 / SA4: 256 gathered channels, scatter epilogue
+    (3, 700, 50, 9, 128, [128, 128]),              # ragged row tiles, no pooled prologue
+])
+def test_streaming_products_bf16x3_match_the_fp32_pipe(B, N, m, ns, C, chans, monkeypatch):
+    """gemm_stream_b3_kernel against gemm_stream_kernel on the same launches (EDA_GEMM_STREAM_B3): pre-activations and the
+    pooled output agree to fp32 rounding (3e-6 of the largest entry: the split v = h + m + l is exact to 2^-24 and only the
+    three products below 2^-32 are dropped; a decision on a tie moves an activation by no more than the tie's distance from
+    zero).  Gradients: the fp64-on-own-decisions checks of the tests above run on whichever kernel is the default."""
+    from eda_amd import pointnet2_utils as PU
+    dev = "cuda"
+    monkeypatch.setenv("EDA_GEMM_STREAM_MINR", "1")
+    rng = np.random.default_rng(N + ns + C)
+    xyz = torch.from_numpy(rng.uniform(-2, 2, (B, N, 3)).astype(np.float32)).to(dev)
+    new_xyz = xyz[:, :m].contiguous()
+    idx = PU.ball_query(0.7, ns, xyz, new_xyz)
+    chans = [3 + C] + chans
+    L = len(chans) - 1
+    Ws, gammas, betas, running = _build(chans, dev, N + C)
+    feats_cl = torch.randn(B, N, C, device=dev)
+    for t in Ws + gammas + betas:                   # (a graph, so that the call saves its pre-activations and constants)
+        t.requires_grad_(True)
+
+    def run(b3):
+        monkeypatch.setenv("EDA_GEMM_STREAM_B3", "1" if b3 else "0")
+        out = _run_fused(dict(radius=0.7, normalize_xyz=True), Ws, gammas, betas, [(a.clone(), b.clone()) for a, b in running],
+                         True, ns, xyz=xyz, new_xyz=new_xyz, feats_cl=feats_cl, idx=idx)
+        _, z, stats = _kernel_decisions(out, L)
+        return out.detach(), z, stats
+
+    o1, z1, s1 = run(True)
+    o0, z0, s0 = run(False)
+    for a, b in zip(z1 + s1 + [o1], z0 + s0 + [o0]):
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 3e-6 * scale, (float((a - b).abs().max()), scale)
+    assert not all(torch.equal(a, b) for a, b in zip(z1, z0)), "the switch did not select two different kernels"
