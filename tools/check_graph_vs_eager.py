@@ -56,15 +56,15 @@ def compare_grads(scenes=2, points=20000, tokens=24, **model_kw):
     return ((grads[0] - grads[1]).abs().max() / grads[0].abs().max()).item(), njobs
 
 
-def compare(steps=4, scenes=8, points=50000, tokens=80, verbose=True, defer_in_graph=True, pipelined=False,
+def compare(steps=4, scenes=8, points=50000, tokens=80, verbose=True, defer_in_graph=True, pipelined=False, seed=0,
             **model_kw):
     """pipelined=True: the replays are issued back to back (no host sync per replay) with ONE host
     synchronisation in the middle -- the pattern of a benchmark / training loop (warm-up, sync, timed
     steps), and the one that went wrong on ROCm 7.2 with the runtime's graph packet capture on."""
     dev = torch.device("cuda", 0)
-    a = make(0, dev, **model_kw)
+    a = make(seed, dev, **model_kw)
     b = copy.deepcopy(a)
-    inputs = bench.make_inputs(0, scenes, dev, points, tokens)
+    inputs = bench.make_inputs(seed, scenes, dev, points, tokens)
     losses = {}
     for name, model, use_graph in (("eager", a, False), ("graph", b, True)):
         flat = FlatParams(model)
