@@ -303,8 +303,8 @@ def main():
                     help="synthetic: the sync-free scalar of SURVEY 8d (the headline metric); hungarian: the "
                          "reference's training loss with the matching solved on the device (eda_amd/losses.py)")
     ap.add_argument("--gemm-tuning", choices=["shipped", "online", "record", "off"], default="online",
-                    help="library-GEMM selection through TunableOp (eda_amd/gemm_tuning.py): shipped = the "
-                         "results in eda_amd/tuned only; online = those + tune unseen shapes during warm-up; "
+                    help="EDA_FAST_ROBERTA=0 comparison line only -- library-GEMM selection through TunableOp "
+                         "(tools/gemm_tuning.py): shipped = the results in tools/tuned only; online = those + tune unseen shapes during warm-up; "
                          "record = tune everything and write gpurun_out/tunableop_<ordinal>.csv; off = library default")
     ap.add_argument("--defer-wgrad", type=int, default=1,
                     help="1: queue the pointwise layers' weight gradients during the backward and compute them "
@@ -434,7 +434,8 @@ def main():
     if fast_roberta:
         args.gemm_tuning = "off"        # no library GEMM is left in the step (eda_amd/roberta_fast.py): nothing to select
     if args.gemm_tuning != "off":
-        from eda_amd import gemm_tuning
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import gemm_tuning
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         tuning_file, shipped_ok = gemm_tuning.enable(
             online=args.gemm_tuning in ("online", "record"),
@@ -630,13 +631,25 @@ def main():
                 pool = torch.cuda.graph_pool_handle()
                 with torch.cuda.graph(g_fb, pool=pool, stream=side, **mode):
                     static_loss = fwd_bwd()
+                g_sb = None
+                if overlap_ar:
+                    # range B's flush is queue state + launches that only exist while CAPTURING (the weight-gradient
+                    # queue is filled by the captured backward): it has to be a graph of its own between the two
+                    # collectives, as PipelinedTrainStep's post_stages are -- run eagerly after g_fb.replay() it would
+                    # flush an empty queue from the second step on and leave range B at the captured zero fill
+                    g_sb = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_sb, pool=pool, stream=side, **mode):
+                        stage_b()
                 with torch.cuda.graph(g_up, pool=pool, stream=side, **mode):
                     update()
 
                 def step():
                     load_batch()
                     g_fb.replay()
-                    all_reduce()
+                    if g_sb is not None:
+                        reduce_a(); g_sb.replay(); reduce_b()
+                    else:
+                        all_reduce()
                     g_up.replay()
                     return static_loss
             log("step captured in HIP graph(s)")

@@ -21,6 +21,9 @@ SIGNATURES = {
     "eda_last_error_string": (ctypes.c_char_p, []),
     "eda_set_fma_mode": (_i, [_i]),
     "eda_get_fma_mode": (_i, []),
+    "eda_reload_env": (_i, []),
+    "eda_set_deterministic": (_i, [_i]),
+    "eda_get_deterministic": (_i, []),
     "eda_fps_workspace_bytes": (_sz, [_i, _i, _i]),
     "eda_furthest_point_sampling_f32": (_i, [_p, _i, _i, _i, _p, _p, _sz, _p]),
     "eda_fps_prefix_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -16,6 +16,7 @@ HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off",        # every fused multiply-add in the kernels is explicit
     "-munsafe-fp-atomics",      # hardware fp32 atomic add for the scatter-add gradients
+    "-fvisibility=hidden",      # exports = the names include/eda_hip.h declares (its visibility pragma), nothing else
     "-Wall", "-Wno-unused-function",
 ]
 
@@ -71,7 +72,8 @@ def _compile_objects(objdir, extra_flags, force, verbose):
 
 def _link(objs, out, verbose):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC",
+           "-Wl,--version-script=" + os.path.join(CSRC, "exports.map")] + objs + ["-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -360,7 +360,7 @@ extern "C" int eda_ball_query_f32(const float *new_xyz, const float *xyz, int b,
   EDA_CHECK_ARG(new_xyz && idx && (xyz || n == 0), "null pointer");
   const float radius2 = radius * radius;          // ball_query_gpu.cu:26, fp32
   const bool use_grid = ws && n >= 4096 && b <= 65535 && radius > 0.f &&
-                        ws_bytes >= eda_ball_query_workspace_bytes(b, n, m) && !getenv("EDA_BQ_SCAN");
+                        ws_bytes >= eda_ball_query_workspace_bytes(b, n, m) && !eda_knob_set(EDA_K_BQ_SCAN);
   if (!use_grid) return launch_scan(new_xyz, xyz, b, n, m, radius2, nsample, idx, stream);
 
   // carve the workspace (all offsets 16-byte aligned)

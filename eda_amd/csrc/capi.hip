@@ -26,6 +26,88 @@ extern "C" int eda_set_fma_mode(int mode) {
 }
 extern "C" int eda_get_fma_mode(void) { return g_eda_fma_mode; }
 
+// ---- the environment knobs (eda_common.h: EdaKnob / EdaEnv) ------------------------------------------------------
+#include <atomic>
+#include <mutex>
+#include <stdlib.h>
+namespace {
+struct KnobRow { const char *name; long dflt; };
+const KnobRow kKnobs[EDA_K_COUNT] = {
+    {"EDA_FPS_CU_RESERVE", 0},      // CUs the cluster sampler leaves free (eda_fps_set_cu_reserve)
+    {"EDA_FPS_BUCKET", -1},         // 0 / 1: cluster / bucket sampler for every call (unset: the policy of eda_fps_set_policy)
+    {"EDA_FPS_BUCKET_NW", 16},      // waves of the bucket sampler (8 | 16)
+    {"EDA_FPS_SMALL_T", 512},       // 1024: 1024-thread single-workgroup sampler for 2049..8192 points
+    {"EDA_FPS_SPEC", 1},            // 0: cluster kernels without the speculative hand-off
+    {"EDA_FPS_T", 512},             // threads per workgroup of the cluster kernels
+    {"EDA_FPS_P", -1},              // points per thread of the cluster kernels (unset: by size)
+    {"EDA_FPS_TEST_GIVEUP", 0},     // test hook: behave like a cluster launch that was not co-resident
+    {"EDA_BQ_SCAN", 0},             // set: ball query by linear scan instead of the uniform grid
+    {"EDA_GEMM_DBG", 0},
+    {"EDA_GEMM_DMA", -1},           // eda_gemm_set_dma
+    {"EDA_GEMM_DMA_MAP", -1},       // 0 / 1: tile -> XCD mapping of the DMA-staged products
+    {"EDA_GEMM_STREAM_GRID", 0},    // workgroups of the streaming kernels (tests: any grid must work)
+    {"EDA_GEMM_STREAM_B3", 1},      // 0: fp32-MFMA streaming kernels instead of bf16 x 3
+    {"EDA_GEMM_STREAM", 1},         // 0: streaming kernels off
+    {"EDA_GEMM_STREAM_MINR", 32768},
+    {"EDA_GEMM_CFG", -1},           // force a tile of gemm_rows_kernel
+    {"EDA_GEMM_LN_BM", 0},
+    {"EDA_GEMM_LN_VAR", 0},
+    {"EDA_GEMM_SPLITK", -1},        // 0: no split contraction; n >= 2: n slices for every eligible launch (unset: by shape)
+    {"EDA_MHA2_PRIO", 1},
+    {"EDA_MHA2_KSPLIT", -1},        // 0: no key-split forward; n >= 2: n key slices for every eligible launch (unset: by shape)
+    {"EDA_BN_SMALL_CQ", 4},
+    {"EDA_SA_LAYER_FUSE", 1},
+    {"EDA_SA_BNBWD_FUSE", 1},
+    {"EDA_SA_BWD_B3", 1},           // 0: fp32-MFMA set-abstraction backward launches instead of bf16 x 3
+    {"EDA_WGRAD_BF16X3", 1},        // eda_wgrad_set_arith
+    {"EDA_WGRAD_WGS", 144},
+    {"EDA_DETERMINISTIC", 0},       // eda_set_deterministic
+};
+EdaEnv g_env;
+std::atomic<int> g_env_ready{0};
+std::atomic<unsigned> g_env_epoch{1};
+std::mutex g_env_mu;
+void env_load(EdaEnv &e) {
+  for (int k = 0; k < EDA_K_COUNT; ++k) {
+    const char *s = getenv(kKnobs[k].name);
+    e.set[k] = s && *s;
+    e.val[k] = e.set[k] ? atol(s) : kKnobs[k].dflt;
+  }
+  e.skip_on = false; e.skip_k = e.skip_n = 0; e.skip_e = -1;
+  if (const char *sk = getenv("EDA_GEMM_STREAM_SKIP"))
+    e.skip_on = sscanf(sk, "%d,%d,%d", &e.skip_k, &e.skip_n, &e.skip_e) >= 2;
+}
+}  // namespace
+int g_eda_deterministic = -1;
+const EdaEnv &eda_env() {
+  if (!g_env_ready.load(std::memory_order_acquire)) {
+    std::lock_guard<std::mutex> lock(g_env_mu);
+    if (!g_env_ready.load(std::memory_order_relaxed)) { env_load(g_env); g_env_ready.store(1, std::memory_order_release); }
+  }
+  return g_env;
+}
+unsigned eda_env_epoch() { return g_env_epoch.load(std::memory_order_relaxed); }
+void eda_fps_env_reset();      // fps.hip
+void eda_gemm_env_reset();     // gemm.hip
+void eda_wgrad_env_reset();    // wgrad.hip
+extern "C" int eda_reload_env(void) {
+  {
+    std::lock_guard<std::mutex> lock(g_env_mu);
+    env_load(g_env);
+    g_env_ready.store(1, std::memory_order_release);
+    g_env_epoch.fetch_add(1, std::memory_order_relaxed);
+  }
+  g_eda_deterministic = -1;
+  eda_fps_env_reset(); eda_gemm_env_reset(); eda_wgrad_env_reset();
+  return 0;
+}
+extern "C" int eda_set_deterministic(int on) {
+  if (on != 0 && on != 1) { eda_set_error("eda_set_deterministic: 0 or 1"); return EDA_ERR_INVALID_ARG; }
+  g_eda_deterministic = on;
+  return 0;
+}
+extern "C" int eda_get_deterministic(void) { return eda_deterministic() ? 1 : 0; }
+
 namespace {
 __global__ __launch_bounds__(256) void zero_kernel(uint4 *p16, size_t n16, unsigned char *tail, size_t ntail) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

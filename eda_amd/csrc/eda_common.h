@@ -12,6 +12,32 @@
 void eda_set_error(const char *fmt, ...);
 extern int g_eda_fma_mode;
 
+// ---- the EDA_* environment knobs ------------------------------------------
+// Every tuning / debugging switch of the library is one row of this table (capi.hip holds names and defaults).  The
+// environment is read ONCE, on first use, into one process-wide EdaEnv; nothing in a launch path calls getenv().
+// eda_reload_env() (C ABI) re-reads it and resets the setter-backed state to "from the environment" -- for tests that
+// flip a knob inside a process.  eda_env_epoch() changes with every reload: code that caches a value DERIVED from a
+// knob compares it.
+enum EdaKnob : int {
+  EDA_K_FPS_CU_RESERVE, EDA_K_FPS_BUCKET, EDA_K_FPS_BUCKET_NW, EDA_K_FPS_SMALL_T, EDA_K_FPS_SPEC, EDA_K_FPS_T, EDA_K_FPS_P,
+  EDA_K_FPS_TEST_GIVEUP, EDA_K_BQ_SCAN, EDA_K_GEMM_DBG, EDA_K_GEMM_DMA, EDA_K_GEMM_DMA_MAP, EDA_K_GEMM_STREAM_GRID,
+  EDA_K_GEMM_STREAM_B3, EDA_K_GEMM_STREAM, EDA_K_GEMM_STREAM_MINR, EDA_K_GEMM_CFG, EDA_K_GEMM_LN_BM, EDA_K_GEMM_LN_VAR,
+  EDA_K_GEMM_SPLITK, EDA_K_MHA2_PRIO, EDA_K_MHA2_KSPLIT, EDA_K_BN_SMALL_CQ, EDA_K_SA_LAYER_FUSE, EDA_K_SA_BNBWD_FUSE,
+  EDA_K_SA_BWD_B3, EDA_K_WGRAD_BF16X3, EDA_K_WGRAD_WGS, EDA_K_DETERMINISTIC, EDA_K_COUNT
+};
+struct EdaEnv {
+  long val[EDA_K_COUNT];          // the variable's integer value, or the table's default when it is unset / empty
+  bool set[EDA_K_COUNT];          // the variable is present and non-empty
+  int skip_k, skip_n, skip_e;     // EDA_GEMM_STREAM_SKIP="K,N,epi" (debugging aid); skip_on = it parsed
+  bool skip_on;
+};
+const EdaEnv &eda_env();
+unsigned eda_env_epoch();
+static inline long eda_knob(EdaKnob k) { return eda_env().val[k]; }
+static inline bool eda_knob_set(EdaKnob k) { return eda_env().set[k]; }
+extern int g_eda_deterministic;   // -1: from EDA_DETERMINISTIC
+static inline bool eda_deterministic() { return (g_eda_deterministic < 0 ? eda_knob(EDA_K_DETERMINISTIC) : g_eda_deterministic) != 0; }
+
 #define EDA_CHECK_ARG(cond, msg)                         \
   do {                                                   \
     if (!(cond)) {                                       \

@@ -37,7 +37,8 @@
 namespace {
 
 constexpr int kRecWords = 8;          // u64 words per mailbox record (5 used, 64-byte record)
-int g_fps_cu_reserve = [] { const char *e = getenv("EDA_FPS_CU_RESERVE"); return e ? atoi(e) : 0; }();
+int g_fps_cu_reserve = INT_MIN;       // INT_MIN: from EDA_FPS_CU_RESERVE (eda_fps_set_cu_reserve overrides)
+int fps_cu_reserve() { return g_fps_cu_reserve == INT_MIN ? (int)eda_knob(EDA_K_FPS_CU_RESERVE) : g_fps_cu_reserve; }
 constexpr int kMaxG = 64;             // workgroups per scene (one poll lane each)
 constexpr size_t kStatusBytes = 256;  // status words in front of the mailboxes
 constexpr unsigned kSpinLimit = 1u << 20;   // ~1 s of polling, then give up (per-call flag set, indices zero-filled)
@@ -46,10 +47,7 @@ constexpr unsigned kSpinLimit = 1u << 20;   // ~1 s of polling, then give up (pe
 // int 3: duration of the last launch (10 ns ticks); ints 4..59: diagnostics; int 60 (kFailInt): give-up flag of the
 // CURRENT call (zeroed per call with ints 4..63, set by the cluster kernels, consumed by the launches behind them).
 constexpr int kFailInt = 60;
-int g_fps_policy = [] {                      // EDA_FPS_AUTO / CLUSTER / BUCKET (include/eda_hip.h); EDA_FPS_BUCKET=0|1 overrides
-  const char *e = getenv("EDA_FPS_BUCKET");
-  return (e && *e) ? (atoi(e) != 0 ? EDA_FPS_BUCKET : EDA_FPS_CLUSTER) : EDA_FPS_AUTO;
-}();
+int g_fps_policy = EDA_FPS_AUTO;             // EDA_FPS_AUTO / CLUSTER / BUCKET (include/eda_hip.h); EDA_FPS_BUCKET=0|1 overrides
 
 // a give-up that nothing can recover becomes sticky
 __global__ void fps_fail_latch_kernel(int *status) {
@@ -725,12 +723,9 @@ int round_up_pow2(int v) {
   return p;
 }
 
-int env_int(const char *name, int dflt) {
-  const char *s = getenv(name);
-  return (s && *s) ? atoi(s) : dflt;
-}
-
 }  // namespace
+
+void eda_fps_env_reset() { g_fps_cu_reserve = INT_MIN; g_fps_policy = EDA_FPS_AUTO; }
 
 // status block + mailboxes of the cluster kernels (zeroed per call), then the sorted points of the bucket sampler
 static size_t fps_mail_bytes(int b) {
@@ -777,7 +772,7 @@ extern "C" int eda_furthest_point_sampling_f32(const float *xyz, int b, int n, i
   //   CLUSTER  cluster kernels only (a give-up becomes the sticky status word)
   //   BUCKET   bucket sampler only (what a data-parallel job next to RCCL's spinning channel kernels should use)
   int policy = g_fps_policy;
-  { const char *e = getenv("EDA_FPS_BUCKET"); if (e && *e) policy = atoi(e) != 0 ? EDA_FPS_BUCKET : EDA_FPS_CLUSTER; }
+  if (eda_knob_set(EDA_K_FPS_BUCKET)) policy = eda_knob(EDA_K_FPS_BUCKET) != 0 ? EDA_FPS_BUCKET : EDA_FPS_CLUSTER;
   const bool bucket_ok = eda_fps_bucket_supports(n);
   if (bucket_ok && policy == EDA_FPS_BUCKET) {
     { const int zrc__ = eda_zero_async(reinterpret_cast<unsigned char *>(ws) + 16, kStatusBytes - 16, stream); if (zrc__) return zrc__; }
@@ -792,15 +787,15 @@ extern "C" int eda_furthest_point_sampling_f32(const float *xyz, int b, int n, i
     T = 512;
     P = round_up_pow2((n + T - 1) / T);
     G = 1;
-    if (n > 2048 && env_int("EDA_FPS_SMALL_T", 512) == 1024) { T = 1024; P = round_up_pow2((n + T - 1) / T); }
+    if (n > 2048 && eda_knob(EDA_K_FPS_SMALL_T) == 1024) { T = 1024; P = round_up_pow2((n + T - 1) / T); }
   } else {
     // measured on MI355X (B=8, N=50 000 -> 2048).  Speculative K=4 kernel: (512,8) 3.1 ms,
     // (512,16) 3.8 ms.  Sequential cluster kernel (EDA_FPS_SPEC=0): (512,16) 4.41 ms,
     // (1024,8) 4.75 ms, (512,8) 4.79 ms, (1024,4) 5.12 ms.
-    const bool want_spec = env_int("EDA_FPS_SPEC", 1) != 0;
+    const bool want_spec = eda_knob(EDA_K_FPS_SPEC) != 0;
     const int p_dflt = (want_spec && ((n + 511) / 512 + 7) / 8 <= kSpecMaxG) ? 8 : 16;
-    T = env_int("EDA_FPS_T", 512);
-    P = env_int("EDA_FPS_P", p_dflt);
+    T = (int)eda_knob(EDA_K_FPS_T);
+    P = eda_knob_set(EDA_K_FPS_P) ? (int)eda_knob(EDA_K_FPS_P) : p_dflt;
     if (T != 512 && T != 1024) T = 1024;
     if (!(P == 1 || P == 2 || P == 4 || P == 8 || (P == 16 && T == 512))) { T = 512; P = 16; }
     const int chunks = (n + T - 1) / T;
@@ -821,7 +816,7 @@ extern "C" int eda_furthest_point_sampling_f32(const float *xyz, int b, int n, i
   // Every workgroup of a launch must be co-resident (they spin on each other): at most one workgroup per CU is
   // assumed, minus a reserve the host sets aside for other resident spin-kernels (RCCL's channel workgroups at N > 1:
   // eda_fps_set_cu_reserve / EDA_FPS_CU_RESERVE) -- larger batches are then sampled in more launches.
-  const int avail_cu = num_cu - g_fps_cu_reserve > 16 ? num_cu - g_fps_cu_reserve : 16;
+  const int avail_cu = num_cu - fps_cu_reserve() > 16 ? num_cu - fps_cu_reserve() : 16;
   int scenes_per_launch = G == 1 ? b : avail_cu / G;
   if (scenes_per_launch < 1) {
     eda_set_error("fps: a cluster of %d workgroups does not fit %d CUs", G, num_cu);
@@ -837,8 +832,8 @@ extern "C" int eda_furthest_point_sampling_f32(const float *xyz, int b, int n, i
   const int mode = g_eda_fma_mode;
   // clusters of the default geometry run the speculative K=4 kernel (EDA_FPS_SPEC=0: one sample
   // per hand-off, the kernel above)
-  const bool use_spec = G > 1 && G <= kSpecMaxG && T == 512 && (P == 16 || P == 8) && env_int("EDA_FPS_SPEC", 1) != 0;
-  const bool fake_giveup = G > 1 && env_int("EDA_FPS_TEST_GIVEUP", 0) != 0;
+  const bool use_spec = G > 1 && G <= kSpecMaxG && T == 512 && (P == 16 || P == 8) && eda_knob(EDA_K_FPS_SPEC) != 0;
+  const bool fake_giveup = G > 1 && eda_knob(EDA_K_FPS_TEST_GIVEUP) != 0;
   if (fake_giveup) {
     hipLaunchKernelGGL(fps_fake_giveup_kernel, dim3(64), dim3(256), 0, stream, status, idx, (long)b * m);
     EDA_CHECK_LAUNCH();

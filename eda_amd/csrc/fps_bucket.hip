@@ -627,7 +627,7 @@ int eda_fps_bucket_launch(const float *xyz, int b, int n, int m, int *idx, int p
   const long stride = 5L * ((n + BGS - 1) / BGS * BGS);
   float *w = reinterpret_cast<float *>(ws);
   // measured (8 x 50 000 -> 2048, MI355X): 16 waves x 16 slots 4.76 ms, 8 waves x 32 slots 5.23 ms (EDA_FPS_BUCKET_NW=8)
-  static const int nw = [] { const char *e = getenv("EDA_FPS_BUCKET_NW"); return e ? atoi(e) : 16; }();
+  const int nw = (int)eda_knob(EDA_K_FPS_BUCKET_NW);
   if (nw == 8)
     return mode == 0 ? launch_bucket<0, 8, 16>(xyz, b, n, m, idx, p_log2, w, stride, status, only_if, stream)
                      : launch_bucket<1, 8, 16>(xyz, b, n, m, idx, p_log2, w, stride, status, only_if, stream);

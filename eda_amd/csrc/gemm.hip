@@ -1706,11 +1706,7 @@ int launch_cfg(GemmArgs &a, int wmode, hipStream_t stream) {
     a.col_tiles = ct;
   }
   long groups = (a.row_blocks + 7) / 8;
-  {
-    static int dbg = -1;
-    if (dbg < 0) { const char *e = getenv("EDA_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
-    a.dbg = dbg;
-  }
+  a.dbg = (int)eda_knob(EDA_K_GEMM_DBG);
   if ((a.epi == E_STATS || a.epi == E_MASK) && !(a.dbg & 2)) {
     // ~2048 persistent workgroups (every CU full at 5-6 waves per SIMD, 1.5 rounds)
     const long cap = 2048 / (8 * a.col_tiles) > 1 ? 2048 / (8 * a.col_tiles) : 1;
@@ -1741,11 +1737,8 @@ int launch_cfg(GemmArgs &a, int wmode, hipStream_t stream) {
 // ---- DMA-staged plain products ---------------------------------------------------------------------------
 // EDA_GEMM_DMA=0 switches the kernel off, =<id> forces configuration <id> of the table below for every eligible
 // launch (experiments); EDA_GEMM_DMA_MAP=0/1 forces the tile -> XCD mapping
-int g_dma_mode_v = -2;
-int g_dma_mode() {
-  if (g_dma_mode_v == -2) { const char *e = getenv("EDA_GEMM_DMA"); g_dma_mode_v = e ? atoi(e) : -1; }
-  return g_dma_mode_v;
-}
+int g_dma_mode_v = -2;                 // -2: from EDA_GEMM_DMA (eda_gemm_set_dma overrides)
+int g_dma_mode() { return g_dma_mode_v == -2 ? (int)eda_knob(EDA_K_GEMM_DMA) : g_dma_mode_v; }
 
 bool dma_takes(const GemmArgs &a, int wmode) {
   if (g_dma_mode() == 0) return false;
@@ -1767,8 +1760,7 @@ template <int BM, int BN, int NWM, int NWN, int NST>
 int launch_dma1(GemmArgs &a, int wmode, hipStream_t stream) {
   a.row_blocks = (a.R + BM - 1) / BM;
   a.col_tiles = (a.N + BN - 1) / BN;
-  static int force_map = -2;
-  if (force_map == -2) { const char *e = getenv("EDA_GEMM_DMA_MAP"); force_map = e ? atoi(e) : -1; }
+  const int force_map = (int)eda_knob(EDA_K_GEMM_DMA_MAP);
   {
     // bytes an XCD pulls through its L2 under either mapping
     const double xb = 4.0 * a.R * a.K, wb = 4.0 * a.N * a.K;
@@ -1819,7 +1811,7 @@ int stream_grid(KernelT kern, int threads, long ntiles, int nw) {
     per_cu = slot;
   }
   long wgs = (long)per_cu * 256;
-  if (const char *g = getenv("EDA_GEMM_STREAM_GRID")) { const long v = atol(g); if (v > 0) wgs = v; }   // (tests: any grid must work)
+  if (eda_knob(EDA_K_GEMM_STREAM_GRID) > 0) wgs = eda_knob(EDA_K_GEMM_STREAM_GRID);   // (tests: any grid must work)
   const long need = (ntiles + nw - 1) / nw;
   if (wgs > need) wgs = need;
   return (int)(wgs < 1 ? 1 : wgs);
@@ -1853,7 +1845,7 @@ int launch_stream_b3_1(GemmArgs &a, hipStream_t stream) {
   const long ntiles = (a.R + 15) / 16;
   a.col_tiles = a.N / NT;
   long wgs = 256;
-  if (const char *g = getenv("EDA_GEMM_STREAM_GRID")) { const long v = atol(g); if (v > 0) wgs = v; }
+  if (eda_knob(EDA_K_GEMM_STREAM_GRID) > 0) wgs = eda_knob(EDA_K_GEMM_STREAM_GRID);
   const long need = (ntiles + NW - 1) / NW;
   if (wgs > need) wgs = need;
   int slots = (int)(wgs < 1 ? 1 : wgs) / a.col_tiles;
@@ -1873,8 +1865,7 @@ int launch_stream_b3_1(GemmArgs &a, hipStream_t stream) {
 // EDA_GEMM_STREAM_B3=0 keeps the fp32-MFMA kernel.  Returns -1 when the launch is not one of them.
 template <int KT, int NT, int NW>
 int launch_stream_b3(GemmArgs &a, hipStream_t stream) {
-  const char *e = getenv("EDA_GEMM_STREAM_B3");          // (read per call: tests switch it inside one process)
-  if (e && atoi(e) == 0) return -1;
+  if (eda_knob(EDA_K_GEMM_STREAM_B3) == 0) return -1;    // (tests switch it inside one process: eda_reload_env)
   if (a.epi == E_MASK && a.xmode == X_BNBWDPOOL) return launch_stream_b3_1<KT, NT, X_BNBWDPOOL, E_MASK, NW>(a, stream);
   if (a.epi == E_MASK && a.xmode == X_PLAIN) return launch_stream_b3_1<KT, NT, X_PLAIN, E_MASK, NW>(a, stream);
   if (a.epi == E_SCATTER && a.xmode == X_PLAIN) return launch_stream_b3_1<KT, NT, X_PLAIN, E_SCATTER, NW>(a, stream);
@@ -1904,10 +1895,8 @@ int launch_stream(GemmArgs &a, hipStream_t stream) {
 // Returns -1 if the launch is not theirs.
 int try_stream(GemmArgs &a, int wmode, hipStream_t stream, bool dry = false) {
   if (wmode != W_NT || a.ngroups > 1 || a.epi == E_PLAIN) return -1;
-  const char *e = getenv("EDA_GEMM_STREAM");
-  if (e && atoi(e) == 0) return -1;
-  long minr = 32768;
-  if (const char *m = getenv("EDA_GEMM_STREAM_MINR")) minr = atol(m);
+  if (eda_knob(EDA_K_GEMM_STREAM) == 0) return -1;
+  const long minr = eda_knob(EDA_K_GEMM_STREAM_MINR);
   if (a.R < minr || a.R >= 0x7fffffffL) return -1;
   auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
   if (a.bias || a.relu) return -1;
@@ -1937,9 +1926,9 @@ int try_stream(GemmArgs &a, int wmode, hipStream_t stream, bool dry = false) {
   }
   const int N = a.N;
   if (N % 64 != 0) return -1;
-  if (const char *sk = getenv("EDA_GEMM_STREAM_SKIP")) {       // debugging aid: "K,N,epi" leaves one shape to the tiled kernel
-    int sK = 0, sN = 0, sE = -1;
-    if (sscanf(sk, "%d,%d,%d", &sK, &sN, &sE) >= 2 && (sK == 0 || sK == K) && (sN == 0 || sN == N) && (sE < 0 || sE == a.epi)) return -1;
+  if (eda_env().skip_on) {       // EDA_GEMM_STREAM_SKIP, debugging aid: "K,N,epi" leaves one shape to the tiled kernel
+    const EdaEnv &ev = eda_env();
+    if ((ev.skip_k == 0 || ev.skip_k == K) && (ev.skip_n == 0 || ev.skip_n == N) && (ev.skip_e < 0 || ev.skip_e == a.epi)) return -1;
   }
   if (dry) return ((K == 64 || K == 128) && (N == 64 || N % 128 == 0)) || K == 256 ? 0 : -1;
   if (K == 64 && N == 64) return launch_stream<64, 64, 8, 4>(a, stream);
@@ -1961,11 +1950,7 @@ bool stream_takes(const GemmArgs &a, int wmode) {
   return try_stream(t, wmode, nullptr, true) == 0;
 }
 
-int g_force_cfg() {
-  static int v = -2;
-  if (v == -2) { const char *e = getenv("EDA_GEMM_CFG"); v = e ? atoi(e) : -1; }
-  return v;
-}
+int g_force_cfg() { return (int)eda_knob(EDA_K_GEMM_CFG); }
 
 }  // namespace
 
@@ -2074,8 +2059,7 @@ extern "C" int eda_linear_add_dropout_ln_fwd_f32(const float *x, long ldx, long 
   a.ln_z = z; a.ln_out = out; a.ln_out_pos = out_pos; a.ln_mean = mean; a.ln_rstd = rstd;
   a.col_tiles = 1; a.row_slots = 0;
   // 16-row blocks (6 waves) below 4096 rows, 32-row blocks (12 waves) from there (EDA_GEMM_LN_BM forces one)
-  static int force_bm = -2;
-  if (force_bm == -2) { const char *e = getenv("EDA_GEMM_LN_BM"); force_bm = e ? atoi(e) : 0; }
+  const int force_bm = (int)eda_knob(EDA_K_GEMM_LN_BM);
   const int bm = force_bm == 16 || force_bm == 32 ? force_bm : (R >= 4096 ? 32 : 16);
   hipStream_t stream = (hipStream_t)stream_;
   if (bm == 32) {
@@ -2086,7 +2070,7 @@ extern "C" int eda_linear_add_dropout_ln_fwd_f32(const float *x, long ldx, long 
     a.row_blocks = (R + 15) / 16;
     const long blocks = (a.row_blocks + 7) / 8 * 8;
     // experiment switch (tools/bench_linear_ln.py): ring depth x waves of the 16-row variant
-    static const int var = [] { const char *e = getenv("EDA_GEMM_LN_VAR"); return e ? atoi(e) : 0; }();
+    const int var = (int)eda_knob(EDA_K_GEMM_LN_VAR);
     if (var == 63) hipLaunchKernelGGL((gemm_dma_kernel<16, 288, 1, 6, W_NT, 3, true>), dim3((unsigned)blocks), dim3(384), 0, stream, a);
     else if (var == 64) hipLaunchKernelGGL((gemm_dma_kernel<16, 288, 1, 6, W_NT, 4, true>), dim3((unsigned)blocks), dim3(384), 0, stream, a);
     else if (var == 92) hipLaunchKernelGGL((gemm_dma_kernel<16, 288, 1, 9, W_NT, 2, true>), dim3((unsigned)blocks), dim3(576), 0, stream, a);
@@ -2108,6 +2092,8 @@ extern "C" int eda_gemm_profile_read(unsigned long long *out8) {
   return hipMemcpyToSymbol(HIP_SYMBOL(gemm_prof), zero, sizeof(zero)) != hipSuccess;
 }
 #endif
+
+void eda_gemm_env_reset() { g_dma_mode_v = -2; }
 
 extern "C" int eda_gemm_set_dma(int mode) {
   EDA_CHECK_ARG(mode >= -1 && mode <= 10, "mode: -1 (own selection), 0 (off), 1..10 (configuration for every eligible launch)");

@@ -1128,11 +1128,6 @@ int launch_bwd(Mha2Args &a, hipStream_t stream) {
   return 0;
 }
 
-int env_int(const char *name, int dflt) {
-  const char *s = getenv(name);
-  return s ? atoi(s) : dflt;
-}
-
 }  // namespace
 
 // Shape -> configuration.  B*H = 64 in EDA; the chip has 256 CUs.
@@ -1187,8 +1182,7 @@ size_t eda_mha2_bwd_workspace_bytes(int B, int H, int Lq, int Lk) {
 
 int eda_mha2_bwd_launch(Mha2Args &a, void *ws, size_t ws_bytes, hipStream_t stream) {
   if (a.B == 0) return 0;
-  static const int prio = env_int("EDA_MHA2_PRIO", 1);
-  a.prio_mode = prio;
+  a.prio_mode = (int)eda_knob(EDA_K_MHA2_PRIO);
   const BwdPlan p = bwd_plan(a.B, a.H, a.Lq, a.Lk);
   a.n_kb = p.n_kb; a.n_qs = p.n_qs; a.q_per_wg = p.q_per_wg;
   const size_t need = sizeof(float) * bwd_workspace_floats(p, a.B, a.H, a.Lq, a.Lk);

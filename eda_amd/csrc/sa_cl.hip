@@ -712,11 +712,7 @@ __device__ __forceinline__ void bn_relu_small_bwd_body(
 
 // Column quads per workgroup of the single-launch kernels: 4 (64-byte row segments per 4 threads)
 // measured ~8 % faster than 1 at 2048 x 288 (EDA_BN_SMALL_CQ=1/2/4 to compare).
-int small_cq() {
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("EDA_BN_SMALL_CQ"); v = e ? atoi(e) : 4; }
-  return v;
-}
+int small_cq() { return (int)eda_knob(EDA_K_BN_SMALL_CQ); }
 
 constexpr long SMALL_ROWS = 4096;    // below this the single-launch kernels win (at 8192 rows the strided sweep loses)
 
@@ -1193,7 +1189,7 @@ static int sa_fused_bwd_impl(const float *dout, const unsigned char *argmax, con
   // its consumer(s) while staging instead of by bn_relu_bwd_apply_kernel whenever all of them can (`pending`).
   // (the layer launches address rows with 32-bit element offsets: beyond 2^31 / 128 rows per call the separate kernels run)
   bool layer_fuse = training != 0 && R * 128 < 0x7fffffffL;
-  { const char *e = getenv("EDA_SA_LAYER_FUSE"); if (e && atoi(e) == 0) layer_fuse = false; }
+  if (eda_knob(EDA_K_SA_LAYER_FUSE) == 0) layer_fuse = false;
   const bool need_dx0 = g.gather ? (dfeats_cl && c_feat > 0) : dx != nullptr;
   // first layer of a gathering stack with 128 feature channels (SA2): weight gradient + scatter of d(features) in one launch
   const bool gl0 = layer_fuse && g.gather && need_dx0 && nlayers >= 2 && eda_wgrad_x_fuses_gather(channels[1], c_feat) &&
@@ -1204,14 +1200,13 @@ static int sa_fused_bwd_impl(const float *dout, const unsigned char *argmax, con
   // of the streaming kernels (gemm.hip X_BNBWDPOOL); otherwise bn_relu_bwd_apply_kernel<true> materialises it.
   bool fuse_pool = false;
   if (training && pool > 1 && pool % 16 == 0 && nlayers >= 2) {
-    const char *e = getenv("EDA_SA_BNBWD_FUSE");
     const int l = nlayers - 1, cin = channels[l], cout = channels[l + 1];
     GemmArgs t;
     memset(&t, 0, sizeof(t));
     t.xmode = X_BNBWDPOOL; t.epi = E_MASK; t.x = z[l]; t.ldx = cout; t.R = R; t.K = cout;
     t.w = wt; t.ldw = cout; t.N = cin; t.y = scratch_b; t.ldy = cin; t.zm = z[l - 1]; t.ldzm = cin;
     t.bb_argmax = argmax; t.bb_dout = dout; t.bb_consts = pool_consts; t.bb_pool = pool;
-    fuse_pool = !(e && atoi(e) == 0) && cout % 64 == 0 && eda_gemm_stream_takes(t, W_NT);
+    fuse_pool = eda_knob(EDA_K_SA_BNBWD_FUSE) != 0 && cout % 64 == 0 && eda_gemm_stream_takes(t, W_NT);
   }
 
   // ---- last layer: BatchNorm+ReLU(+pool) backward from d(out) -> dz in scratch_a

@@ -539,11 +539,9 @@ __global__ __launch_bounds__(WB_THREADS, 2) void wgrad_grouped_bf16x3_kernel(
 
 // arithmetic of eda_wgrad_grouped_f32: 0 = fp32 MFMA (wgrad_grouped_kernel), 1 = bf16 x 3 (wgrad_grouped_bf16x3_kernel);
 // default from EDA_WGRAD_BF16X3
-static int g_wgrad_arith = -1;
-static int wgrad_arith() {
-  if (g_wgrad_arith < 0) { const char *e = getenv("EDA_WGRAD_BF16X3"); g_wgrad_arith = e ? (atoi(e) != 0) : 1; }
-  return g_wgrad_arith;
-}
+static int g_wgrad_arith = -1;          // -1: from EDA_WGRAD_BF16X3 (eda_wgrad_set_arith overrides)
+static int wgrad_arith() { return g_wgrad_arith < 0 ? (eda_knob(EDA_K_WGRAD_BF16X3) != 0) : g_wgrad_arith; }
+void eda_wgrad_env_reset() { g_wgrad_arith = -1; }
 extern "C" int eda_wgrad_set_arith(int mode) {
   if (mode < -1 || mode > 1) { eda_set_error("eda_wgrad_set_arith: mode must be -1 (default), 0 (fp32 MFMA) or 1 (bf16 x 3)"); return EDA_ERR_INVALID_ARG; }
   g_wgrad_arith = mode;
@@ -571,12 +569,8 @@ WgPlan wg_plan(long K, int M, int N) {
   p.tiles_m = (M + WG_T - 1) / WG_T;
   p.tiles_n = (N + WG_T - 1) / WG_T;
   const long nchunks = (K + WG_KC - 1) / WG_KC;
-  static int target = -1;
-  if (target < 0) {
-    const char *e = getenv("EDA_WGRAD_WGS");
-    target = e ? atoi(e) : 144;     // measured best for the 288x288 outputs (tools/bench_dw.py)
-    if (target < 1) target = 1;
-  }
+  long target = eda_knob(EDA_K_WGRAD_WGS);     // 144: measured best for the 288x288 outputs (tools/bench_dw.py)
+  if (target < 1) target = 1;
   long want = (target + p.tiles_m * p.tiles_n - 1) / (p.tiles_m * p.tiles_n);   // splits for ~target workgroups
   if (want > nchunks) want = nchunks;
   if (want < 1) want = 1;

@@ -84,6 +84,10 @@ class FlatParams:
         total = sum((p.numel() + 3) // 4 * 4 for p in self.params)
         self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        # this class reads gradients from `.grad` after the backward (collect_grads / the deferred queue) and reduces the
+        # flat buffer itself: the backward forms that assign `.grad` without autograd delivery may run
+        from . import posembed_batched
+        posembed_batched.enable(True)
         self._grad_views = []
         self.layout = []                   # (parameter name, group key, offset in the flat buffers, numel)
         off = 0

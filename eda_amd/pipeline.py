@@ -201,14 +201,18 @@ class PipelinedTrainStep:
         for v, t in zip(self._nxt_flat, src):
             v.copy_(t)
         for t in src:                       # the copy runs on the side stream: keep the caller's memory alive until it is done
-            t.record_stream(self.side)
+            if t.is_cuda:                   # (host / pinned sources have no stream bookkeeping: record_stream raises)
+                t.record_stream(self.side)
 
     def step(self, next_batch=None):
         """Train on the batch fed by the previous call (the first batch initially); start the sampling / text encoding
         of `next_batch` underneath.  Returns the (static) loss tensor of this step."""
-        if torch.cuda.current_stream() != self.main:
+        caller = torch.cuda.current_stream()
+        if caller != self.main:
             # the graphs were captured on self.main and the events order against it: replay there whatever the caller's
-            # current stream is (ADVICE r03)
+            # current stream is (ADVICE r03) -- AFTER the work the caller has queued on its own stream, which is what
+            # produced `next_batch` (ADVICE r04: the side stream's copies read it, and side only ever waits for main)
+            self.main.wait_stream(caller)
             with torch.cuda.stream(self.main):
                 return self.step(next_batch)
         cur = self.main

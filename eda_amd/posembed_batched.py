@@ -9,8 +9,15 @@ kept); a stub node hands the output to the graph, its backward only stores the i
 end of the backward pass (`Engine.queue_callback`), which runs every stage for all layers at once: grouped input gradient
 (eda_linear_grouped_dgrad_f32), the BatchNorm backward of six matrices in one launch (eda_bn_relu_grouped_bwd_multi_f32), the
 6-column weight gradients as one batched product; the 288-wide weight / bias gradients go to the deferred queue.  The
-parameters' `.grad` is assigned by the callback exactly where autograd would have put it.  EDA_BATCHED_POSEMBED=0 keeps the
-per-layer autograd nodes.
+parameters' `.grad` is assigned by the callback exactly where autograd would have put it.
+
+OPT-IN.  Because the callback writes `.grad` itself, autograd never DELIVERS these 6 x 6 gradients: grad-accumulator hooks (the
+DDP reducer's), tensor hooks and `torch.autograd.grad` do not see them.  The batched form is therefore off unless the owner of
+the gradients says it reads `.grad` after the backward and nothing else -- `eda_amd.parallel.FlatParams` does (it gathers
+`.grad` into its flat buffer and all-reduces that), and calls `enable(True)`; a host that wraps the model in
+`torch.nn.parallel.DistributedDataParallel` leaves it off and gets the per-layer autograd nodes.
+A parameter with a registered tensor hook, or a frozen one among the six, also selects the per-layer nodes.
+EDA_BATCHED_POSEMBED=0 switches it off regardless.
 """
 import os
 
@@ -20,6 +27,19 @@ from torch.autograd import Function, Variable
 from . import gemm, grouped
 from .grouped import _weight_grads
 from .heads_batched import _bn_bwd_multi, _dgrad_groups
+
+
+_ENABLED = False
+
+
+def enable(on=True):
+    """Declare that parameter gradients are consumed from `.grad` after the backward (no autograd-delivery hooks)."""
+    global _ENABLED
+    _ENABLED = bool(on)
+
+
+def enabled():
+    return _ENABLED
 
 
 class _Rec:
@@ -58,14 +78,17 @@ class PosEmbedBatch:
     def usable(mod, xyz):
         from . import _lib, sync_bn
         from .nn_utils import rows_ok
-        if os.environ.get("EDA_BATCHED_POSEMBED", "1") == "0" or mod is None:
+        if not _ENABLED or os.environ.get("EDA_BATCHED_POSEMBED", "1") == "0" or mod is None:
             return False
         head = mod.position_embedding_head
         bn = head[1]
+        six = [head[0].weight, head[0].bias, bn.weight, bn.bias, head[3].weight, head[3].bias]
+        if any(p is None or not p.requires_grad or getattr(p, "_backward_hooks", None) for p in six):
+            return False
         R = xyz.shape[0] * xyz.shape[1]
         return (xyz.is_cuda and torch.is_grad_enabled() and bn.training and bn.track_running_stats and not sync_bn.enabled()
                 and rows_ok(xyz, head[0].out_channels) and head[0].out_channels % 16 == 0
-                and R <= _lib.lib().eda_bn_relu_dropout_max_rows() and head[3].weight.requires_grad)
+                and R <= _lib.lib().eda_bn_relu_dropout_max_rows())
 
     def add(self, mod, xyz):
         from .nn_utils import bump_batches_tracked

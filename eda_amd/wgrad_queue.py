@@ -33,19 +33,29 @@ class WgradQueue:
         self.locate = locate
         self._targets = {}       # dW data_ptr -> [dW, db, M, N, [(dy2, x2), ...]]
         self._ln = {}            # dgamma data_ptr -> (partial ws, rows, C, dgamma, dbeta, dbias or None)
-        self._ring = []          # descriptor staging: [pinned host words, device words, copy-done event]
+        self._ring = []          # descriptor staging of EAGER flushes: [pinned host words, device words, copy-done event]
         self._ring_pos = 0
+        self._capture_pool = []  # slots a CAPTURED flush takes for good (its graph replays the copy from them)
+        self._captured = []
 
-    _RING = 6
+    _RING = 6                    # eager slots (never shrinks)
+    _CAPTURE_SLOTS = 16          # captured stagings per reserve(): 4 per overlapped step capture (LN + targets, two ranges)
     _WORDS = 1 << 17             # 1 MiB of descriptors per slot (bench step: ~15 k words)
 
-    def reserve(self, device):
+    def _new_slot(self, device):
+        return [torch.empty((self._WORDS,), dtype=torch.int64, pin_memory=True),
+                torch.empty((self._WORDS,), dtype=torch.int64, device=device), None]
+
+    def reserve(self, device, captures=None):
         """Allocate the descriptor staging buffers.  Must happen outside stream capture (pinned
-        allocation is not capturable); FlatParams does it at construction."""
-        if not self._ring:
-            for _ in range(self._RING):
-                self._ring.append([torch.empty((self._WORDS,), dtype=torch.int64, pin_memory=True),
-                                   torch.empty((self._WORDS,), dtype=torch.int64, device=device), None])
+        allocation is not capturable); FlatParams does it at construction.  `captures`: slots to hold for
+        captured flushes (each captured flush keeps one for the lifetime of its graph); call again before
+        re-capturing many times -- the pool is topped up, never shrunk."""
+        while len(self._ring) < self._RING:
+            self._ring.append(self._new_slot(device))
+        want = self._CAPTURE_SLOTS if captures is None else int(captures)
+        while len(self._capture_pool) < want:
+            self._capture_pool.append(self._new_slot(device))
 
     # ------------------------------------------------------------------ submit
     @staticmethod
@@ -220,17 +230,19 @@ class WgradQueue:
             self.reserve(dev)
         if words.size > self._WORDS:
             raise RuntimeError(f"wgrad queue: {words.size} descriptor words exceed the staging buffer")
-        # A ring of pinned staging slots: a slot is rewritten only after the copy that last read it
-        # has completed.  A captured graph keeps replaying the copy from the slot it was captured
-        # with, so that slot leaves the ring for good.
-        slot = self._ring[self._ring_pos]
+        # Eager flushes rotate over a ring of pinned staging slots: a slot is rewritten only after the copy that last
+        # read it has completed.  A captured graph keeps replaying the copy from the slot it was captured with, so a
+        # captured flush takes its slot from a separate pool, for good (taking it from the eager ring left
+        # that ring empty after two overlapped captures).
         if capturing:
-            self._ring.pop(self._ring_pos)
-            if not self._ring:
-                self._ring_pos = 0
-            else:
-                self._ring_pos %= len(self._ring)
+            if not self._capture_pool:
+                raise RuntimeError(
+                    "wgrad queue: staging slots for captured flushes exhausted (%d graphs hold one each); call "
+                    "WgradQueue.reserve(device, captures=N) outside stream capture before capturing again"
+                    % len(self._captured))
+            slot = self._capture_pool.pop()
         else:
+            slot = self._ring[self._ring_pos]
             self._ring_pos = (self._ring_pos + 1) % len(self._ring)
             if slot[2] is not None:
                 slot[2].synchronize()
@@ -238,7 +250,7 @@ class WgradQueue:
         host.numpy()[:words.size] = words
         desc[:words.size].copy_(host[:words.size], non_blocking=True)
         if capturing:
-            self._captured = getattr(self, "_captured", []) + [slot]      # keep alive for the replays
+            self._captured.append(slot)                                   # keep alive for the replays
         else:
             slot[2] = torch.cuda.Event()
             slot[2].record()

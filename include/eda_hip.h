@@ -21,7 +21,21 @@
  *  - outputs are written completely by the kernels (the reference relies on
  *    torch::zeros + partial writes; results are identical).  The *_grad entry
  *    points zero their output themselves before accumulating.
- *  - re-entrant; the only process-global state is the arithmetic mode below.
+ *  - re-entrant.  PROCESS-WIDE state (one process drives one GPU, as the
+ *    reference's one-process-per-GPU launcher does, train_dist_mod.py; the
+ *    values are not per device and not per thread):
+ *      eda_set_fma_mode          arithmetic form of the squared distances
+ *      eda_fps_set_cu_reserve    CUs the cluster sampler leaves to other streams
+ *      eda_fps_set_policy        cluster / bucket / auto sampler
+ *      eda_gemm_set_dma          kernel selection of the plain row products
+ *      eda_wgrad_set_arith       fp32 MFMA or bf16 x 3 weight gradients
+ *      eda_set_bn_sync           SyncBatchNorm hook + world size
+ *      eda_set_deterministic     ordered reductions instead of fp32 atomics
+ *    plus the EDA_* environment knobs, read ONCE into one table on first use
+ *    (eda_reload_env() re-reads them; tests only).  Nothing else persists
+ *    between calls except per-(kernel, device) launch attributes.
+ *  - exported symbols are exactly the names declared here (the library is
+ *    built with -fvisibility=hidden; tests/test_abi.py compares nm -D).
  */
 #ifndef EDA_HIP_H
 #define EDA_HIP_H
@@ -32,6 +46,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)
 
 #define EDA_HIP_ABI_VERSION 1
 
@@ -47,6 +62,18 @@ const char *eda_last_error_string(void);
  * [t=dy*dy; t=fma(dx,dx,t); t=fma(dz,dz,t)] (default), 1 = no contraction. */
 int eda_set_fma_mode(int mode);
 int eda_get_fma_mode(void);
+
+/* Re-read every EDA_* environment knob of the library (they are read once, on first use, into one
+ * process-wide table; a test that flips a knob inside a process calls this afterwards).  Returns 0. */
+int eda_reload_env(void);
+
+/* 1: every floating-point reduction of the backward ops runs in a fixed order (sorted-segment / per-owner
+ * sums instead of fp32 atomics: group_points_grad, gather_points_grad, three_interpolate_grad, the fused
+ * set-abstraction backward's scatter), so two runs of the same step are bit-identical -- the counterpart of
+ * the reference's cudnn.deterministic = True (train_dist_mod.py:342-344).  0 (default): atomics.
+ * Process-wide; default from EDA_DETERMINISTIC.  Returns 0, or EDA_ERR_INVALID_ARG. */
+int eda_set_deterministic(int on);
+int eda_get_deterministic(void);
 
 /* ---- furthest point sampling ------------------------------------------
  * replaces furthest_point_sampling()            src/sampling.cpp:70-91
@@ -548,6 +575,7 @@ int eda_gemm_set_dma(int mode);
 typedef int (*eda_bn_sync_fn)(void *user, double *buf, long n, void *stream);
 int eda_set_bn_sync(eda_bn_sync_fn fn, void *user, int world);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -13,13 +13,6 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    if os.environ.get("EDA_TUNED_GEMMS") == "1":
-        # tests/test_tuned_gemms_gpu.py re-runs the model parity tests in a child process with the
-        # TunableOp-selected library GEMMs that bench.py uses (eda_amd/gemm_tuning.py)
-        import torch
-        if torch.cuda.is_available():
-            from eda_amd import gemm_tuning
-            gemm_tuning.enable(online=False)
 
 
 def pytest_collection_modifyitems(config, items):
@@ -46,6 +39,35 @@ def _poisoned_allocator():
         torch.cuda.synchronize()
         del junk
     yield
+
+
+def _reload_knobs():
+    """The library reads its EDA_* knobs once into one table (csrc/capi.hip); re-read them if it is loaded."""
+    from eda_amd import _lib
+    if _lib._lib is not None:
+        _lib._lib.eda_reload_env()
+
+
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    """pytest's monkeypatch, with setenv / delenv of an EDA_* knob followed by eda_reload_env() (and once more after
+    the environment is restored), so a test can flip a library knob inside the process."""
+    setenv, delenv = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv_reload(name, value, *a, **k):
+        setenv(name, value, *a, **k)
+        if name.startswith("EDA_"):
+            _reload_knobs()
+
+    def delenv_reload(name, *a, **k):
+        delenv(name, *a, **k)
+        if name.startswith("EDA_"):
+            _reload_knobs()
+
+    monkeypatch.setenv, monkeypatch.delenv = setenv_reload, delenv_reload
+    yield monkeypatch
+    monkeypatch.undo()
+    _reload_knobs()
 
 
 @pytest.fixture(scope="session")

@@ -31,6 +31,12 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     # ctypes table covers the header one to one
     assert sorted(_lib.SIGNATURES) == _declared()
+    # ... and the dynamic symbol table IS the header: the library is built with -fvisibility=hidden and linked with
+    # csrc/exports.map, so no kernel handle / internal C++ helper leaks
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == _declared(), sorted(set(exported) ^ set(_declared()))
     lib = _lib.lib()
     assert lib.eda_version() == 1
     assert lib.eda_get_fma_mode() == 0

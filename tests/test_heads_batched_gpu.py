@@ -77,3 +77,46 @@ def test_batched_posembed_backward_equals_per_layer_nodes(defer):
     assert torch.isfinite(g_b).all()
     assert (g_b - g_p).abs().max().item() <= 2e-5 * scale
     assert abs((g_b != 0).float().mean().item() - (g_p != 0).float().mean().item()) < 1e-3
+
+
+def test_batched_posembed_is_opt_in_and_autograd_delivers_without_it():
+    """the batched form assigns `.grad` from an end-of-backward callback, so hooks keyed on autograd delivery
+    (DDP's reducer) would never see these gradients.  Without FlatParams (or with a tensor hook on one of the six
+    parameters) the per-layer autograd nodes run and every hook fires."""
+    from eda_amd import posembed_batched, synthetic
+    from eda_amd.bdetr import BeaUTyDETR
+    from eda_amd.parallel import FlatParams
+    was = posembed_batched.enabled()
+    try:
+        posembed_batched.enable(False)
+        torch.manual_seed(0)
+        dev = torch.device("cuda", 0)
+        model = BeaUTyDETR(num_queries=64, num_decoder_layers=2).to(dev).train()
+        head = model.decoder[0].self_posembed.position_embedding_head
+        six = [head[0].weight, head[0].bias, head[1].weight, head[1].bias, head[3].weight, head[3].bias]
+        seen = []
+        handles = [p.register_hook(lambda g, i=i: seen.append(i)) for i, p in enumerate(six)]
+        pc = synthetic.batch([0, 1], 6000)
+        ids, am = synthetic.utterance_tokens(0, 2, max_len=12)
+        boxes, bmask, cls = synthetic.detected_boxes(0, 2)
+        inputs = {"point_clouds": torch.from_numpy(pc).to(dev),
+                  "tokenized": {"input_ids": torch.from_numpy(ids).to(dev), "attention_mask": torch.from_numpy(am).to(dev)},
+                  "det_boxes": torch.from_numpy(boxes).to(dev), "det_bbox_label_mask": torch.from_numpy(bmask).to(dev),
+                  "det_class_ids": torch.from_numpy(cls).to(dev)}
+        ep = model(inputs)
+        (ep["last_center"].pow(2).sum() + ep["last_sem_cls_scores"].pow(2).mean()).backward()
+        assert sorted(set(seen)) == list(range(6)), seen
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in six)
+        for h in handles:
+            h.remove()
+        # the owner that reads `.grad` itself switches the batched form on ...
+        FlatParams(model)
+        assert posembed_batched.enabled()
+        probe = torch.zeros(2, 64, 6, device=dev)
+        assert posembed_batched.PosEmbedBatch.usable(model.decoder[0].self_posembed, probe)
+        # ... and a hooked parameter still selects the autograd nodes
+        h = six[0].register_hook(lambda g: None)
+        assert not posembed_batched.PosEmbedBatch.usable(model.decoder[0].self_posembed, probe)
+        h.remove()
+    finally:
+        posembed_batched.enable(was)

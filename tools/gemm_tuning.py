@@ -1,15 +1,12 @@
-"""Library-GEMM selection for the path's fp32 GEMMs (PyTorch TunableOp).
+"""TunableOp selection for the LIBRARY GEMMs of the comparison line `EDA_FAST_ROBERTA=0 python bench.py` (the stock
+Hugging Face RoBERTa forward on hipBLASLt).  Not part of the product: every pointwise layer of the model and of the
+frozen text encoder runs in the library's own kernels (csrc/gemm.hip); this only makes the stock baseline as fast as
+the vendor library can be, so that "own text encoder vs stock" is a fair comparison.
 
-The forward / input-gradient GEMMs of the pointwise layers stay library calls (hipBLASLt /
-rocBLAS through torch).  For these small, oddly shaped fp32 problems (2048..8192 x 288 x 288,
-1 048 576 x 64 x 64, ...) the libraries' default heuristics are often not the fastest solution
-they contain: letting TunableOp time the candidates per shape is worth ~2 ms of a 32 ms step
-on MI355X.  `enable()` switches TunableOp on, loads the results shipped in
-``eda_amd/tuned/tunableop_gfx950.csv`` (recorded with `python bench.py --gemm-tuning record` on
-gfx950, ROCm 7.2 / torch 2.10; TunableOp rejects the file when its library-version validators
-differ) and, with ``online=True``, tunes any shape that is not in the file the first time it is
-seen -- which must happen before a HIP-graph capture (bench.py's eager warm-up steps do that).
-Newly tuned results go to `scratch` (TunableOp writes them itself), never into the package.
+`enable()` switches TunableOp on, loads the results recorded on gfx950 / ROCm 7.2 / torch 2.10 in
+``tools/tuned/tunableop_gfx950.csv`` (TunableOp rejects the file when its library-version validators differ) and, with
+``online=True``, tunes any shape that is not in the file the first time it is seen -- which must happen before a
+HIP-graph capture (bench.py's eager warm-up steps do that).  Newly tuned results go to `scratch`.
 """
 import os
 import tempfile
