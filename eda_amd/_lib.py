@@ -66,6 +66,9 @@ SIGNATURES = {
     "eda_mha_fwd_hd64_f32": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _l, _p, _i, _i, _i, _i, _f, _p, _p]),
     "eda_mha_fwd": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _l, _p, _i, _i, _i, _i, _i, _f, _f,
                         _p, _u, _p, _p, _i, _p]),
+    "eda_mha_fwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "eda_mha_fwd_ws": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _l, _p, _i, _i, _i, _i, _i, _f, _f,
+                           _p, _u, _p, _p, _i, _p, _sz, _p]),
     "eda_mha_qproj_supported": (_i, [_i, _i, _i]),
     "eda_mha_qproj_fwd": (_i, [_p, _l, _l, _p, _l, _p, _p, _p, _l, _l, _l, _l, _p, _i, _i, _i, _i, _i, _f, _f, _p, _u,
                               _p, _l, _l, _p, _p, _i, _p]),

@@ -92,6 +92,38 @@ def _rows(t):
     return t
 
 
+_fwd_ws_cache = {}
+
+
+def _fwd_workspace(dev, B, H, Lq, Lk):
+    """Scratch of the key-split forward (eda_mha_fwd_ws: short query sets against the 1024 point keys): per-split
+    (O, m, l) partials behind a block of ticket words that must be ZERO before the first call and that every call leaves
+    zero again -- so one persistent buffer per (device, stream, size) serves every site that runs on that stream."""
+    n = int(_lib.lib().eda_mha_fwd_workspace_bytes(B, H, Lq, Lk))
+    if n == 0:
+        return None
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, n)
+    ws = _fwd_ws_cache.get(key)
+    if ws is None:
+        ws = _fwd_ws_cache[key] = torch.zeros((n + 3) // 4, dtype=torch.int32, device=dev)
+    return ws
+
+
+def _mha_fwd_call(q, k, v, m8, B, num_heads, Lq, Lk, hd, p_drop, salt, out, lse):
+    dev = q.device
+    seed = dropout_state(dev) if p_drop > 0 else None
+    with torch.cuda.device(dev), _timed('mha_fwd', (B, num_heads, Lq, Lk)):
+        ws = _fwd_workspace(dev, B, num_heads, Lq, Lk) if _compute_dtype == 0 else None
+        rc = _lib.lib().eda_mha_fwd_ws(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
+            k.stride(1), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else None,
+            B, num_heads, Lq, Lk, hd, hd ** -0.5, float(p_drop),
+            seed.data_ptr() if seed is not None else None, int(salt), out.data_ptr(),
+            lse.data_ptr(), _compute_dtype, ws.data_ptr() if ws is not None else None,
+            ws.numel() * 4 if ws is not None else 0, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "eda_mha_fwd_ws")
+
+
 class _FusedMHA(Function):
     @staticmethod
     def forward(ctx, q, k, v, mask, num_heads, p_drop, salt):
@@ -106,15 +138,7 @@ class _FusedMHA(Function):
         m8 = None
         if mask is not None:
             m8 = mask.contiguous().view(torch.uint8)
-        seed = dropout_state(q.device) if p_drop > 0 else None
-        with torch.cuda.device(q.device), _timed('mha_fwd', (B, num_heads, Lq, Lk)):
-            rc = _lib.lib().eda_mha_fwd(
-                q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
-                k.stride(1), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else None,
-                B, num_heads, Lq, Lk, hd, hd ** -0.5, float(p_drop),
-                seed.data_ptr() if seed is not None else None, int(salt), out.data_ptr(),
-                lse.data_ptr(), _compute_dtype, torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "eda_mha_fwd")
+        _mha_fwd_call(q, k, v, m8, B, num_heads, Lq, Lk, hd, p_drop, salt, out, lse)
         ctx.dtype_code = _compute_dtype
         ctx.save_for_backward(q, k, v, out, lse)
         ctx.mask8 = m8
@@ -229,15 +253,7 @@ class _ProjectedMHA(Function):
             hd = d // num_heads
             out = torch.empty((B, Lq, d), dtype=torch.float32, device=dev)
             lse = torch.empty((B, num_heads, Lq), dtype=torch.float32, device=dev)
-            seed = dropout_state(dev) if p_drop > 0 else None
-            with torch.cuda.device(dev), _timed('mha_fwd', (B, num_heads, Lq, Lk)):
-                rc = _lib.lib().eda_mha_fwd(
-                    q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
-                    k.stride(1), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else None,
-                    B, num_heads, Lq, Lk, hd, hd ** -0.5, float(p_drop),
-                    seed.data_ptr() if seed is not None else None, int(salt), out.data_ptr(),
-                    lse.data_ptr(), _compute_dtype, torch.cuda.current_stream().cuda_stream)
-            _lib.check(rc, "eda_mha_fwd")
+            _mha_fwd_call(q, k, v, m8, B, num_heads, Lq, Lk, hd, p_drop, salt, out, lse)
         ctx.dtype_code = _compute_dtype
         ctx.save_for_backward(W, out, lse, b, *x2s, *Ps)
         ctx.mask8 = m8
@@ -411,15 +427,7 @@ class _ProjectedMHAPreKV(Function):
             q = gemm.linear_fwd(x2, W[:d], b[:d]).view(B, Lq, d)
             out = torch.empty((B, Lq, d), dtype=torch.float32, device=dev)
             lse = torch.empty((B, num_heads, Lq), dtype=torch.float32, device=dev)
-            seed = dropout_state(dev) if p_drop > 0 else None
-            with torch.cuda.device(dev), _timed('mha_fwd', (B, num_heads, Lq, Lk)):
-                rc = _lib.lib().eda_mha_fwd(
-                    q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
-                    k.stride(1), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else None,
-                    B, num_heads, Lq, Lk, hd, hd ** -0.5, float(p_drop),
-                    seed.data_ptr() if seed is not None else None, int(salt), out.data_ptr(),
-                    lse.data_ptr(), _compute_dtype, torch.cuda.current_stream().cuda_stream)
-            _lib.check(rc, "eda_mha_fwd")
+            _mha_fwd_call(q, k, v, m8, B, num_heads, Lq, Lk, hd, p_drop, salt, out, lse)
         ctx.dtype_code = _compute_dtype
         ctx.save_for_backward(W, b, x2, q, kv, out, lse)
         ctx.mask8 = m8

@@ -29,10 +29,17 @@ struct Mha2Args {
   const float *wq; long ldwq;                 // (H*36, H*36) weight, row-major (row = output column)
   const float *bq;                            // (H*36) bias or null
   float *q_out; long qo_sb, qo_sl;
+  // key-split forward (flash-decoding form, eda_mha_fwd_ws): n_ksplit workgroups per (scene, head, query block), each
+  // over keys_per_split keys (a multiple of the chunk); their (O, m, l) partials meet in `fwd_part` and the LAST arriver
+  // of a block (ticket in `fwd_tickets`, left at zero again) merges them in split order and writes out / lse
+  int n_ksplit, keys_per_split;
+  float *fwd_part;           // [block][split][NQ][64 lanes][16 floats]
+  unsigned *fwd_tickets;     // [block], zero before the first call
 };
 
 // 0 = launched, EDA_ERR_* otherwise.  Both enqueue on `stream` only, allocate nothing, never synchronise.
-int eda_mha2_fwd_launch(Mha2Args &a, hipStream_t stream);
+int eda_mha2_fwd_launch(Mha2Args &a, void *ws, size_t ws_bytes, hipStream_t stream);
+size_t eda_mha2_fwd_workspace_bytes(int B, int H, int Lq, int Lk);
 int eda_mha2_qproj_fwd_launch(Mha2Args &a, hipStream_t stream);      // Lk <= 192
 int eda_mha2_bwd_launch(Mha2Args &a, void *ws, size_t ws_bytes, hipStream_t stream);
 size_t eda_mha2_bwd_workspace_bytes(int B, int H, int Lq, int Lk);

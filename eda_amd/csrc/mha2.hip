@@ -309,7 +309,13 @@ __device__ __forceinline__ void fwd_tile(const float *__restrict__ Kt, const flo
 }
 
 // NQ query sub-tiles x KS key shares = NW waves; CHK keys per LDS chunk, NBUF chunk buffers.
-template <int NQ, int KS, int CHK, int NBUF, bool DROP, class AR>
+// SPLIT: the keys of a (scene, head, query block) are divided over a.n_ksplit WORKGROUPS as well (short query sets
+// against 1024 point keys: 64 x ceil(Lq / 64) workgroups each staging a head's whole 295 KB of K | V leave half the
+// chip idle behind a 12 us staging pass).  A workgroup's merged (O, m, l) goes to a.fwd_part with plain stores, is
+// published with ONE agent-scope release and a ticket (cdna_hip_programming.md, in-launch split-K recipe); the
+// workgroup that draws the last ticket acquires, merges ALL splits in split order (bit-reproducible whoever is last)
+// and writes the output.
+template <int NQ, int KS, int CHK, int NBUF, bool DROP, class AR, bool SPLIT = false>
 __global__ __launch_bounds__(NQ * KS * 64) void mha2_fwd_kernel(const Mha2Args a) {
   constexpr int NW = NQ * KS, NT = NW * 64;
   constexpr int TILES = CHK / 64;
@@ -324,7 +330,9 @@ __global__ __launch_bounds__(NQ * KS * 64) void mha2_fwd_kernel(const Mha2Args a
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, c = lane & 15;
   const int BH = a.B * a.H;
-  const int bh = (int)(blockIdx.x % (unsigned)BH), qb = (int)(blockIdx.x / (unsigned)BH);
+  const int bh = (int)(blockIdx.x % (unsigned)BH);
+  int qb = (int)(blockIdx.x / (unsigned)BH), sp = 0;
+  if (SPLIT) { sp = qb / a.n_qs; qb -= sp * a.n_qs; }
   const int b = bh / a.H, h = bh - b * a.H;
   const int qs = wave / KS, ks = wave - qs * KS;
   const int qi = qb * (16 * NQ) + 16 * qs + c;
@@ -386,10 +394,12 @@ __global__ __launch_bounds__(NQ * KS * 64) void mha2_fwd_kernel(const Mha2Args a
     }
   };
 
-  const int nchunks = (a.Lk + CHK - 1) / CHK;
-  if (nchunks > 0) stage(Ks0, Vs0, dead_s[0], 0);
+  // this workgroup's chunks: all of them, or those of its key split (keys_per_split is a multiple of CHK)
+  const int c_lo = SPLIT ? sp * (a.keys_per_split / CHK) : 0;
+  const int nchunks = SPLIT ? min((a.Lk + CHK - 1) / CHK, c_lo + a.keys_per_split / CHK) : (a.Lk + CHK - 1) / CHK;
+  if (nchunks > c_lo) stage(Ks0, Vs0, dead_s[0], c_lo * CHK);
   __syncthreads();
-  for (int ci = 0; ci < nchunks; ci += NBUF) {
+  for (int ci = c_lo; ci < nchunks; ci += NBUF) {
     // even chunk in buffer 0 (the next one is fetched into buffer 1 meanwhile), odd chunk in buffer 1
     if (NBUF == 2 && ci + 1 < nchunks) stage(Ks1, Vs1, dead_s[1], (ci + 1) * CHK);
     compute(Ks0, Vs0, dead_s[0], ci * CHK);
@@ -441,6 +451,52 @@ __global__ __launch_bounds__(NQ * KS * 64) void mha2_fwd_kernel(const Mha2Args a
     }
   }
   if (KS == 1 || ks == 0) o[2] = grp_sum4(o[2]);
+  if constexpr (SPLIT) {
+    // ---- cross-workgroup merge of the key splits.  Hand-off (cdna_hip_programming.md G16, form R1 / "publish-large"):
+    // WRITE-THROUGH (sc1) partial stores, every storing wave drains them, one lane takes the block's ticket; the last
+    // arriver reads all partials with sc1 loads (served past its L1).  No release / acquire fence anywhere: a release
+    // is a write-back of the XCD's whole L2 (measured here with fences: 80 x 1024 in 4 splits 34 us, no faster than the
+    // unsplit 34; 256 x 1024 in 2 splits 62 us against 38).
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int blk = bh * a.n_qs + qb;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        a.fwd_part + (long)blk * a.n_ksplit * NQ * (64 * 16), 0, a.n_ksplit * NQ * 64 * 16 * 4, 0x00020000);
+    const int my_off = ((sp * NQ + qs) * 64 + lane) * 64;           // bytes
+    if (ks == 0 && wave_live) {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[0]), rs, my_off, 0, 16);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[1]), rs, my_off + 16, 0, 16);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[2]), rs, my_off + 32, 0, 16);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{m, lsum, 0.f, 0.f}), rs, my_off + 48, 0, 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every storing wave drains its stores
+    __syncthreads();                                               // (K/V and the merge scratch are dead now)
+    unsigned *flag = dead_s[0];
+    if (tid == 0) {
+      const unsigned t = __hip_atomic_fetch_add(a.fwd_tickets + blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool last = t == (unsigned)a.n_ksplit - 1u;
+      if (last) __hip_atomic_store(a.fwd_tickets + blk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed
+      flag[0] = last ? 1u : 0u;
+    }
+    __syncthreads();
+    if (flag[0] == 0u || ks != 0 || !wave_live) return;
+    m = -INFINITY; lsum = 0.f;
+    o[0] = o[1] = o[2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int z = 0; z < a.n_ksplit; ++z) {                          // split order: the result does not depend on who is last
+      const int off = ((z * NQ + qs) * 64 + lane) * 64;
+      const f32x4 p0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
+      const f32x4 p1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 16));
+      const f32x4 p2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 32, 0, 16));
+      const f32x4 ml = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 48, 0, 16));
+      const float mo = ml[0], lo = ml[1];
+      const float mn = fmaxf(m, mo);
+      const float ms = (mn == -INFINITY) ? 0.f : mn;
+      const float fa = __builtin_amdgcn_exp2f(m - ms), fb = __builtin_amdgcn_exp2f(mo - ms);
+      o[0] = o[0] * fa + p0 * fb; o[1] = o[1] * fa + p1 * fb; o[2] = o[2] * fa + p2 * fb;
+      lsum = lsum * fa + lo * fb;
+      m = mn;
+    }
+  }
   if (qvalid && (KS == 1 || ks == 0)) {
     const float inv = dc.inv_keep / lsum;          // all keys masked -> NaN, like the reference
     float *orow = a.o + (long)b * a.o_sb + (long)qi * a.o_sl + h * HD;
@@ -1060,16 +1116,16 @@ __global__ __launch_bounds__(256) void mha2_part_reduce_kernel(const float *__re
   *reinterpret_cast<float4 *>(o) = t;
 }
 
-template <int NQ, int KS, int CHK, int NBUF>
+template <int NQ, int KS, int CHK, int NBUF, bool SPLIT = false>
 int launch_fwd(Mha2Args &a, hipStream_t stream) {
   a.n_qs = (a.Lq + 16 * NQ - 1) / (16 * NQ);
-  const unsigned grid = (unsigned)(a.B * a.H * a.n_qs);
+  const unsigned grid = (unsigned)(a.B * a.H * a.n_qs * (SPLIT ? a.n_ksplit : 1));
   const dim3 g(grid), b(NQ * KS * 64);
   const bool drop = a.p_drop > 0.f;
-#define EDA_FWD(AR)                                                                                        \
-  do {                                                                                                     \
-    if (drop) hipLaunchKernelGGL((mha2_fwd_kernel<NQ, KS, CHK, NBUF, true, AR>), g, b, 0, stream, a);      \
-    else hipLaunchKernelGGL((mha2_fwd_kernel<NQ, KS, CHK, NBUF, false, AR>), g, b, 0, stream, a);          \
+#define EDA_FWD(AR)                                                                                               \
+  do {                                                                                                            \
+    if (drop) hipLaunchKernelGGL((mha2_fwd_kernel<NQ, KS, CHK, NBUF, true, AR, SPLIT>), g, b, 0, stream, a);      \
+    else hipLaunchKernelGGL((mha2_fwd_kernel<NQ, KS, CHK, NBUF, false, AR, SPLIT>), g, b, 0, stream, a);          \
   } while (0)
   if (a.dtype == EDA_DTYPE_BF16) EDA_FWD(ArBf16);
   else if (a.dtype == EDA_DTYPE_F16) EDA_FWD(ArFp16);
@@ -1077,6 +1133,31 @@ int launch_fwd(Mha2Args &a, hipStream_t stream) {
 #undef EDA_FWD
   EDA_CHECK_LAUNCH();
   return 0;
+}
+
+// Key-split plan of a forward shape (ns <= 1: none).  Short query sets against >= 512 keys -- the text -> point cross
+// attention, 80 / 130 queries x 1024 keys: 128 / 192 workgroups, each staging a head's whole 295 KB of K | V -- are
+// divided over key splits of whole 256-key chunks until every CU holds a workgroup.  Measured (rocprofv3, B = 8,
+// profiles/r05_mha_ksplit.txt): 80 x 1024 unsplit 34.7 us, 2 splits 24.7, 4 splits 30.7 (4 splits with release / acquire
+// fences instead of write-through stores: 34); one 80-query block of five sub-tiles instead of two 64-query blocks:
+// 31.3 / 25.5 us in 2 / 4 splits -- no better, not kept.  256 queries x 1024 keys stays unsplit: 256 workgroups already
+// fill the chip and a second round of workgroups costs more than the shorter staging returns (37.9 us unsplit, 49.9 /
+// 65.9 in 2 / 4 splits).
+// EDA_MHA2_KSPLIT=0 switches it off, =n forces n splits wherever the shape allows one (<= 256 queries, >= 512 keys).
+constexpr int FWD_SPLIT_CHK = 256, FWD_SPLIT_NQ = 4;
+struct FwdSplit { int ns, nq; };
+FwdSplit fwd_ksplit(int B, int H, int Lq, int Lk) {
+  FwdSplit p = {1, FWD_SPLIT_NQ};
+  const long env = eda_knob(EDA_K_MHA2_KSPLIT);
+  if (env == 0 || Lk < 2 * FWD_SPLIT_CHK || Lq > 256) return p;
+  const int chunks = (Lk + FWD_SPLIT_CHK - 1) / FWD_SPLIT_CHK;
+  const long blocks = (long)B * H * ((Lq + 16 * p.nq - 1) / (16 * p.nq));
+  long want = env > 0 ? env : (blocks >= 224 ? 1 : (256 + blocks - 1) / blocks);
+  if (want > chunks) want = chunks;
+  if (want < 2) return p;
+  const int cps = (int)((chunks + want - 1) / want);          // chunks per split
+  p.ns = (chunks + cps - 1) / cps;
+  return p;
 }
 
 // Backward decomposition of a shape: which kernel variant, how many key blocks / query splits.
@@ -1130,10 +1211,36 @@ int launch_bwd(Mha2Args &a, hipStream_t stream) {
 
 }  // namespace
 
+size_t eda_mha2_fwd_workspace_bytes(int B, int H, int Lq, int Lk) {
+  if (B <= 0 || Lq <= 0 || Lk <= 0) return 0;
+  const FwdSplit sp = fwd_ksplit(B, H, Lq, Lk);
+  if (sp.ns <= 1) return 0;
+  const size_t blocks = (size_t)B * H * ((Lq + 16 * sp.nq - 1) / (16 * sp.nq));
+  const size_t tick = (blocks * sizeof(unsigned) + 255) / 256 * 256;
+  return tick + blocks * sp.ns * sp.nq * 64 * 16 * sizeof(float);
+}
+
 // Shape -> configuration.  B*H = 64 in EDA; the chip has 256 CUs.
-int eda_mha2_fwd_launch(Mha2Args &a, hipStream_t stream) {
+int eda_mha2_fwd_launch(Mha2Args &a, void *ws, size_t ws_bytes, hipStream_t stream) {
   if (a.B == 0 || a.Lq == 0) return 0;
   const int BH = a.B * a.H;
+  {
+    const FwdSplit sp = ws ? fwd_ksplit(a.B, a.H, a.Lq, a.Lk) : FwdSplit{1, 4};
+    if (sp.ns > 1) {
+      const size_t need = eda_mha2_fwd_workspace_bytes(a.B, a.H, a.Lq, a.Lk);
+      EDA_CHECK_ARG(ws_bytes >= need && (reinterpret_cast<uintptr_t>(ws) & 15u) == 0,
+                    "workspace of eda_mha_fwd_workspace_bytes() required (16-byte aligned, its ticket words zero)");
+      const size_t blocks = (size_t)BH * ((a.Lq + 16 * sp.nq - 1) / (16 * sp.nq));
+      const size_t tick = (blocks * sizeof(unsigned) + 255) / 256 * 256;
+      a.fwd_tickets = reinterpret_cast<unsigned *>(ws);
+      a.fwd_part = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(ws) + tick);
+      a.n_ksplit = sp.ns;
+      const int chunks = (a.Lk + FWD_SPLIT_CHK - 1) / FWD_SPLIT_CHK;
+      a.keys_per_split = (chunks + sp.ns - 1) / sp.ns * FWD_SPLIT_CHK;
+      const bool one = a.keys_per_split == FWD_SPLIT_CHK;
+      return one ? launch_fwd<4, 4, FWD_SPLIT_CHK, 1, true>(a, stream) : launch_fwd<4, 4, FWD_SPLIT_CHK, 2, true>(a, stream);
+    }
+  }
   const bool short_q = (long)BH * ((a.Lq + 255) / 256) < 192;        // 16-query waves alone would leave CUs idle
   if (a.Lk <= 144) {
     if (short_q) return launch_fwd<4, 2, 192, 1>(a, stream);
@@ -1239,10 +1346,20 @@ int fill_rows(float *o, long sb, long sl, int B, int L, int D, float value, hipS
 
 }  // namespace
 
+extern "C" size_t eda_mha_fwd_workspace_bytes(int B, int H, int Lq, int Lk) { return eda_mha2_fwd_workspace_bytes(B, H, Lq, Lk); }
+
 extern "C" int eda_mha_fwd(const float *q, const float *k, const float *v, long q_sb, long q_sl, long k_sb, long k_sl,
                            long v_sb, long v_sl, const unsigned char *key_padding_mask, int B, int H, int Lq, int Lk,
                            int head_dim, float scale, float p_drop, const unsigned long long *seed_ptr, unsigned salt,
                            float *out, float *lse, int dtype, void *stream_) {
+  return eda_mha_fwd_ws(q, k, v, q_sb, q_sl, k_sb, k_sl, v_sb, v_sl, key_padding_mask, B, H, Lq, Lk, head_dim, scale, p_drop,
+                        seed_ptr, salt, out, lse, dtype, nullptr, 0, stream_);
+}
+
+extern "C" int eda_mha_fwd_ws(const float *q, const float *k, const float *v, long q_sb, long q_sl, long k_sb, long k_sl,
+                              long v_sb, long v_sl, const unsigned char *key_padding_mask, int B, int H, int Lq, int Lk,
+                              int head_dim, float scale, float p_drop, const unsigned long long *seed_ptr, unsigned salt,
+                              float *out, float *lse, int dtype, void *ws, size_t ws_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EDA_CHECK_ARG(dtype == EDA_DTYPE_F32 || dtype == EDA_DTYPE_BF16 || dtype == EDA_DTYPE_F16,
                 "dtype must be EDA_DTYPE_F32 / BF16 / F16");
@@ -1264,7 +1381,7 @@ extern "C" int eda_mha_fwd(const float *q, const float *k, const float *v, long 
   m.v_sb = v_sb; m.v_sl = v_sl; m.o = out; m.o_sb = (long)Lq * H * HD; m.o_sl = (long)H * HD;
   m.lse = lse; m.mask = key_padding_mask; m.B = B; m.H = H; m.Lq = Lq; m.Lk = Lk; m.scale = scale;
   m.p_drop = p_drop; m.seed_ptr = seed_ptr; m.salt = salt; m.dtype = dtype;
-  return eda_mha2_fwd_launch(m, stream);
+  return eda_mha2_fwd_launch(m, ws, ws_bytes, stream);
 }
 
 extern "C" int eda_mha_qproj_supported(int H, int head_dim, int Lk) { return H * head_dim == QP_D && head_dim == HD && Lk >= 1 && Lk <= 192; }

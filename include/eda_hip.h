@@ -220,6 +220,19 @@ int eda_mha_bwd(const float *q, const float *k, const float *v, long q_sb, long 
                 float *delta_ws, float *dq, float *dk, float *dv, long dq_sb, long dq_sl, long dk_sb,
                 long dk_sl, long dv_sb, long dv_sl, void *ws, size_t ws_bytes, int dtype, void *stream);
 
+/* eda_mha_fwd with scratch for the KEY-SPLIT forward (F32 contractions): for at most 256 queries against >= 512 keys
+ * (the text -> point and query -> point cross-attention, models/encoder_decoder_layers.py:87-93, 393-399) the keys of a
+ * (scene, head, query block) are divided over several workgroups, whose (O, max, sum) partials meet in `ws`; the last
+ * workgroup of a block to arrive merges them in split order (the result does not depend on which one that is) and
+ * writes out / lse.  eda_mha_fwd_workspace_bytes() = 0: the shape is not split, ws may be NULL.  The first
+ * ceil(4 * blocks / 256) * 256 bytes of ws are ticket words: ZERO before the first call, left zero by every call (one
+ * workspace may serve every call of one stream; calls on different streams need their own).  ws == NULL = eda_mha_fwd. */
+size_t eda_mha_fwd_workspace_bytes(int B, int H, int Lq, int Lk);
+int eda_mha_fwd_ws(const float *q, const float *k, const float *v, long q_sb, long q_sl, long k_sb, long k_sl,
+                   long v_sb, long v_sl, const unsigned char *key_padding_mask, int B, int H, int Lq, int Lk,
+                   int head_dim, float scale, float p_drop, const unsigned long long *seed_ptr, unsigned salt,
+                   float *out, float *lse, int dtype, void *ws, size_t ws_bytes, void *stream);
+
 /* The q-projection fused in front of the forward (csrc/mha2.hip, mha2_qproj_fwd_kernel): one launch computes
  * q = x Wq^T + bq for a site whose key set is short (1 <= Lk <= 192: the text tokens / detected boxes of
  * models/encoder_decoder_layers.py:99-117, 375-391 -> nn.MultiheadAttention's in-projection of the query followed by

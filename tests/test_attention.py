@@ -59,6 +59,9 @@ SHAPES = [  # (B, Lq, Lk, masked)
     (2, 90, 24, False), (2, 24, 90, True), (2, 110, 175, True),
     # SR3D-shaped long utterances (BASELINE.json configs[4]: 130 tokens)
     (2, 130, 130, True), (2, 130, 1024, False), (2, 1024, 130, True), (2, 256, 130, True),
+    # key-split forward (csrc/mha2.hip SPLIT: <= 256 queries against >= 512 keys): the bench shapes with masks, a ragged
+    # key count (3 chunks, the last one partial), the full batch (2 splits per block instead of 4)
+    (2, 256, 1024, True), (1, 200, 700, True), (8, 80, 1024, True), (8, 256, 1024, False),
 ]
 
 
@@ -94,6 +97,37 @@ def test_fused_forward_backward_vs_restatement(B, Lq, Lk, masked):
         tol = 1e-4 * e.abs() + 2e-6 * e.abs().max() + 2e-7 * natural[name] + 1e-30
         worst = (err / tol).max().item()
         assert worst <= 1.0, (name, worst, err.max().item(), e.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Lq,Lk", [(2, 80, 1024), (8, 256, 1024), (1, 200, 700), (3, 64, 513)])
+def test_key_split_forward_is_reproducible_and_matches_the_unsplit_kernel(B, Lq, Lk, monkeypatch):
+    """The last workgroup of a block to arrive merges the splits in split order: two calls give the same bits (and the
+    ticket words are back at zero for the second one); against the one-workgroup-per-block kernel (EDA_MHA2_KSPLIT=0)
+    the result differs by the re-association of the online softmax only; forcing other split counts works too."""
+    from eda_amd import _lib, attention
+    torch.manual_seed(Lq + Lk)
+    dev = "cuda"
+    q, k, v = (torch.randn(B, L, 288, device=dev) for L in (Lq, Lk, Lk))
+    mask = _mask(B, Lk, 5, min_valid=Lk // 3).to(dev)
+    # (the library's own plan splits while a (scene, head, query block) grid leaves CUs idle: not at B = 8 x 256 queries)
+    assert (_lib.lib().eda_mha_fwd_workspace_bytes(B, 8, Lq, Lk) > 0) == (B * 8 * ((Lq + 63) // 64) < 224)
+    a = attention.attention_core(q, k, v, mask, 8, 0.1, 7)
+    b = attention.attention_core(q, k, v, mask, 8, 0.1, 7)
+    assert torch.equal(a, b)
+    outs = {}
+    for ks in ("0", "2", "3"):
+        monkeypatch.setenv("EDA_MHA2_KSPLIT", ks)
+        assert (_lib.lib().eda_mha_fwd_workspace_bytes(B, 8, Lq, Lk) > 0) == (ks != "0")
+        outs[ks] = attention.attention_core(q, k, v, mask, 8, 0.1, 7)
+    monkeypatch.delenv("EDA_MHA2_KSPLIT")
+    scale = outs["0"].abs().max().item()
+    for ks in ("2", "3"):
+        assert (outs[ks] - outs["0"]).abs().max().item() <= 2e-6 * scale, ks
+    assert (a - outs["0"]).abs().max().item() <= 2e-6 * scale
+    torch.cuda.synchronize()
+    for ws in attention._fwd_ws_cache.values():          # every ticket word re-armed
+        assert int(ws[:64].abs().sum().item()) == 0
 
 
 @pytest.mark.gpu

@@ -12,7 +12,8 @@ attention.set_compute_dtype(os.environ.get("ATTN_DTYPE", "f32"))      # f32 | bf
 
 SHAPES = [(1024, 1024, "enc self-vis"), (80, 80, "enc self-lang"), (80, 1024, "enc cross_lv"),
           (1024, 80, "enc cross_vl"), (1024, 132, "enc cross_d"), (256, 256, "dec self"),
-          (256, 80, "dec cross_l"), (256, 132, "dec cross_d"), (256, 1024, "dec cross_v")]
+          (256, 80, "dec cross_l"), (256, 132, "dec cross_d"), (256, 1024, "dec cross_v"),
+          (130, 1024, "enc cross_lv, 130 tokens"), (1024, 130, "enc cross_vl, 130 tokens")]
 
 
 def main():
