@@ -86,6 +86,9 @@ SIGNATURES = {
     "eda_device_copy_f32": (_i, [_p, _p, _sz, _p]),
     "eda_transpose_batch_f32": (_i, [_p, _i, ctypes.c_longlong, _p]),
     "eda_linear_ex_f32": (_i, [_p, _l, _l, _i, _p, _l, _i, _p, _i, _f, _p, _u, _p, _l, _f, _p, _l, _p]),
+    "eda_linear_splitk_workspace_bytes": (_sz, [_l, _i, _i]),
+    "eda_linear_ex_ws_f32": (_i, [_p, _l, _l, _i, _p, _l, _i, _p, _i, _f, _p, _u, _p, _l, _f, _p, _l, _p, _sz, _p]),
+    "eda_linear_dgrad_ws_f32": (_i, [_p, _l, _l, _i, _p, _l, _i, _p, _l, _p, _sz, _p]),
     "eda_l2norm_rows_fwd_f32": (_i, [_p, _l, _i, _f, _p, _p, _p]),
     "eda_l2norm_rows_bwd_f32": (_i, [_p, _p, _p, _l, _i, _f, _p, _p]),
     "eda_linear_fwd_f32": (_i, [_p, _l, _l, _i, _p, _l, _i, _p, _i, _p, _l, _p]),

@@ -53,6 +53,12 @@ struct GemmArgs {
   float *ln_z, *ln_out, *ln_out_pos, *ln_mean, *ln_rstd;
   int defer_finalize;   // E_STATS: the last workgroup only re-arms the ticket; the column sums stay in `sum` / `sumsq`
                         // for a cross-rank all-reduce, a separate kernel finalises (sa_cl.hip, eda_set_bn_sync)
+  // gemm_dma_kernel<..., SK = true>: the contraction of a tile is divided over sk_slices WORKGROUPS (few tiles against a
+  // long contraction: the text encoder's 640 x 3072 -> 768, the 3456-deep input gradients of the hoisted K | V
+  // projections); fp32 partial tiles meet in sk_part, the last arriver of a tile (sk_tickets, left at zero) adds them in
+  // slice order and runs the epilogue
+  float *sk_part; unsigned *sk_tickets; int sk_slices, sk_cps; long sk_per;
+  void *sk_ws; size_t sk_ws_bytes;          // (host side: the caller's scratch for it, eda_linear_splitk_workspace_bytes)
   int dbg;   // EDA_GEMM_DBG timing experiments (results are then wrong): 1 skip park, 2 no grid cap, 4 skip atomics, 8 skip z loads
 };
 

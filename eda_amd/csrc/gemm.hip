@@ -1365,8 +1365,14 @@ __device__ unsigned long long gemm_prof[64 * 8];
 // LN: the tile spans all N = BN columns of its rows and the epilogue is the residual + Dropout + LayerNorm of the
 // post-norm blocks (csrc/ln.hip's forward kernel folded in: the product itself is never written, only z = the
 // pre-norm sum, which the LayerNorm backward needs) -- see eda_linear_add_dropout_ln_fwd_f32.
-template <int BM, int BN, int NWM, int NWN, int WMODE, int NST, bool LN = false>
+// SK (split contraction): block id = (slice, tile) -- the tile's chunks [slice * sk_cps, (slice + 1) * sk_cps) only; the
+// partial accumulators are published as write-through (sc1) 16-byte stores, every wave drains them, one lane takes the
+// tile's ticket, and the last workgroup to arrive re-reads ALL slices with sc1 loads and adds them IN SLICE ORDER (so the
+// result does not depend on who arrives last: bit-reproducible), then runs the plain epilogue.  No fences
+// (cdna_hip_programming.md G16 form R1; MI355X_MICROARCH.md rows publish-large / splitk-seam).
+template <int BM, int BN, int NWM, int NWN, int WMODE, int NST, bool LN = false, bool SK = false>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_dma_kernel(const GemmArgs a) {
+  static_assert(!(LN && SK), "the LayerNorm epilogue is not built for a split contraction");
   constexpr int KC = 32, NW = NWM * NWN;
   constexpr int WR = BM / NWM / 16, WC = BN / NWN / 16;
   static_assert(WR * 16 * NWM == BM && WC * 16 * NWN == BN, "wave tiles must be multiples of 16");
@@ -1377,7 +1383,9 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_dma_kernel(const GemmArgs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_m = wave / NWN, wave_n = wave % NWN;
   const int xcd = blockIdx.x & 7;
-  const long q = blockIdx.x >> 3;
+  long q = blockIdx.x >> 3;
+  int slice = 0;
+  if (SK) { slice = (int)(q / a.sk_per); q -= slice * a.sk_per; }      // (all slices of a tile on one XCD)
   // tile -> XCD (block b runs on XCD b % 8, each XCD has its own L2).  row_slots == 0: an XCD owns row blocks (all column
   // tiles of a row block back to back: the row tile is fetched once, every XCD reads the whole weight) -- many rows, small
   // weight.  row_slots == 1: an XCD owns column tiles (its slice of the weight stays in its L2, every XCD reads all rows)
@@ -1516,7 +1524,9 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_dma_kernel(const GemmArgs
   // in order, so "at most the pieces of the NST - 2 youngest chunks still in flight") and releases the stage of chunk
   // ci to the DMA of chunk ci + NST.  A plain s_barrier: __syncthreads() is also a fence, for which the compiler
   // drains vmcnt to 0 -- i.e. waits for the prefetch it was meant to overlap.
-  const int nchunks = K / KC;
+  const int c_lo = SK ? slice * a.sk_cps : 0;
+  const int nchunks = SK ? max(0, min(K / KC, c_lo + a.sk_cps) - c_lo) : K / KC;
+  const int kbase = c_lo * KC;
   constexpr int AHEAD = NST - 1;
   constexpr int KEEP_HI = (NST - 2) * NPW, KEEP_LO = (NST - 2) * (NPW - 1);
   auto wait_keep = [&]() {
@@ -1526,14 +1536,14 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_dma_kernel(const GemmArgs
   constexpr int WAIT_ALL = (7 << 4) | (15 << 8);
 #pragma unroll
   for (int p = 0; p < AHEAD; ++p)
-    if (p < nchunks) issue(p * KC, p);
+    if (p < nchunks) issue(kbase + p * KC, p);
   if (NST > 2 && nchunks >= AHEAD) wait_keep(); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
   __builtin_amdgcn_s_barrier();
   GSTAMP(0);
   int st_cur = 0, st_nxt = AHEAD % NST;
   for (int ci = 0; ci < nchunks; ++ci) {
     const bool more = ci + AHEAD < nchunks;
-    if (more) issue((ci + AHEAD) * KC, st_nxt);
+    if (more) issue(kbase + (ci + AHEAD) * KC, st_nxt);
     GSTAMP(1);
     multiply(smem + st_cur * STAGE);
     GSTAMP(2);
@@ -1543,6 +1553,46 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_dma_kernel(const GemmArgs
     GSTAMP(4);
     st_cur = st_cur + 1 == NST ? 0 : st_cur + 1;
     st_nxt = st_nxt + 1 == NST ? 0 : st_nxt + 1;
+  }
+
+  if constexpr (SK) {
+    // ---- the slices of this tile meet
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const long tile = rb * a.col_tiles + ct;
+    constexpr int WAVE_B = WC * WR * 64 * 16;                        // bytes of one wave's partial
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        a.sk_part + tile * a.sk_slices * (long)(BM * BN), 0, a.sk_slices * BM * BN * 4, 0x00020000);
+    const int woff = wave * WAVE_B + lane * 16;
+#pragma unroll
+    for (int j = 0; j < WC; ++j)
+#pragma unroll
+      for (int i = 0; i < WR; ++i)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[j][i]), rs,
+                                               slice * (BM * BN * 4) + woff + (j * WR + i) * 1024, 0, 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every wave drains its write-through stores
+    __syncthreads();
+    unsigned *flag = reinterpret_cast<unsigned *>(smem);              // (the stages are free after the last barrier)
+    if (tid == 0) {
+      const unsigned t = __hip_atomic_fetch_add(a.sk_tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool last = t == (unsigned)a.sk_slices - 1u;
+      if (last) __hip_atomic_store(a.sk_tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // re-armed
+      flag[0] = last ? 1u : 0u;
+    }
+    __syncthreads();
+    if (flag[0] == 0u) return;
+#pragma unroll
+    for (int j = 0; j < WC; ++j)
+#pragma unroll
+      for (int i = 0; i < WR; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int z = 0; z < a.sk_slices; ++z) {
+#pragma unroll
+      for (int j = 0; j < WC; ++j)
+#pragma unroll
+        for (int i = 0; i < WR; ++i)
+          acc[j][i] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                           rs, z * (BM * BN * 4) + woff + (j * WR + i) * 1024, 0, 16));
+    }
   }
 
   // ---- epilogue (the plain one of gemm_rows_kernel: bias, ReLU / GELU, Dropout, gate) ------------------
@@ -1740,20 +1790,76 @@ int launch_cfg(GemmArgs &a, int wmode, hipStream_t stream) {
 int g_dma_mode_v = -2;                 // -2: from EDA_GEMM_DMA (eda_gemm_set_dma overrides)
 int g_dma_mode() { return g_dma_mode_v == -2 ? (int)eda_knob(EDA_K_GEMM_DMA) : g_dma_mode_v; }
 
-bool dma_takes(const GemmArgs &a, int wmode) {
-  if (g_dma_mode() == 0) return false;
+bool dma_eligible(const GemmArgs &a) {
   if (a.epi != E_PLAIN || a.xmode != X_PLAIN || a.ngroups > 1) return false;
   auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
   if (a.K % 32 != 0 || a.N % 4 != 0 || a.N < 4) return false;
   if (a.ldx % 4 != 0 || a.ldw % 4 != 0 || a.ldy % 4 != 0 || !al16(a.x) || !al16(a.w) || !al16(a.y)) return false;
   if (a.bias && !al16(a.bias)) return false;
   if (a.gate && (a.ldgate % 4 != 0 || !al16(a.gate))) return false;
+  return true;
+}
+
+bool dma_takes(const GemmArgs &a, int wmode) {
+  if (g_dma_mode() == 0) return false;
+  if (!dma_eligible(a)) return false;
   if (g_dma_mode() > 0) return true;
   // where it wins inside the step (bench.py's HIP-event table, r03c): >= 400 tiles of 32 x 96 (the 8192-row layers, the
   // text encoder's 2304- / 3072-wide ones) or a long contraction; the 2048- and 640-row launches of 64-192 tiles stay
   // with the 32 x 32 tiles of gemm_rows_kernel (more, smaller workgroups)
   const long tiles = ((a.R + 31) / 32) * ((a.N + 95) / 96);
   return tiles >= 400 || (a.K >= 2048 && tiles >= 128);
+}
+
+// Split contraction (gemm_dma_kernel SK): few tiles, long contraction.  Slices so that ~2 workgroups land on every CU,
+// each with at least 6 chunks of 32; EDA_GEMM_SPLITK=0 off, =n forces n slices wherever a launch is eligible at all
+// (workspace given, <= 1024 tiles, DMA-staged plain product).
+struct SkCfg { int bm, bn; };
+SkCfg sk_cfg() { return {32, 96}; }     // (64 x 96 and 64 x 192 tiles, 3-stage rings: all slower, profiles/r05_gemm_splitk.txt)
+int splitk_slices(long R, int K, int N) {
+  const long env = eda_knob(EDA_K_GEMM_SPLITK);
+  if (env == 0 || K % 32 != 0) return 1;
+  const SkCfg c = sk_cfg();
+  const long tiles = ((R + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
+  const int nchunks = K / 32;
+  if (tiles > 1024 || nchunks < 2) return 1;
+  long s = env > 0 ? env : (tiles >= 224 ? 1 : (512 + tiles / 2) / tiles);
+  if (env <= 0 && s > nchunks / 6) s = nchunks / 6;
+  if (s > nchunks) s = nchunks;
+  if (s > 16) s = 16;
+  if (s < 2) return 1;
+  const int cps = (int)((nchunks + s - 1) / s);
+  return (nchunks + cps - 1) / cps;
+}
+constexpr size_t SK_TICKET_BYTES = 4096;          // 1024 tiles
+size_t splitk_bytes(long R, int N, int slices) {
+  const SkCfg c = sk_cfg();
+  const long tiles = ((R + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
+  return SK_TICKET_BYTES + (size_t)tiles * slices * c.bm * c.bn * sizeof(float);
+}
+
+template <int BM, int BN, int NWM, int NWN, int NST>
+int launch_dma1_sk(GemmArgs &a, int wmode, int slices, void *ws, hipStream_t stream) {
+  a.row_blocks = (a.R + BM - 1) / BM;
+  a.col_tiles = (a.N + BN - 1) / BN;
+  {
+    const double xb = 4.0 * a.R * a.K, wb = 4.0 * a.N * a.K;
+    const int force_map = (int)eda_knob(EDA_K_GEMM_DMA_MAP);
+    a.row_slots = force_map >= 0 ? force_map : (xb + wb / 8 < xb / 8 + wb ? 1 : 0);
+  }
+  const long blocks = a.row_slots == 0 ? (a.row_blocks + 7) / 8 * 8 * a.col_tiles
+                                       : (long)((a.col_tiles + 7) / 8) * 8 * a.row_blocks;
+  a.sk_tickets = reinterpret_cast<unsigned *>(ws);
+  a.sk_part = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(ws) + SK_TICKET_BYTES);
+  a.sk_slices = slices;
+  a.sk_cps = (a.K / 32 + slices - 1) / slices;
+  a.sk_per = blocks / 8;
+  const dim3 grid((unsigned)(blocks * slices)), block(64 * NWM * NWN);
+  if (wmode == W_NN) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, NWM, NWN, W_NN, NST, false, true>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, NWM, NWN, W_NT, NST, false, true>), grid, block, 0, stream, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { eda_set_error("gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
 }
 
 template <int BM, int BN, int NWM, int NWN, int NST>
@@ -1979,6 +2085,11 @@ int eda_gemm_launch(GemmArgs &a, int wmode, hipStream_t stream) {
     if (rc >= 0) return rc;
   }
   if (!gemm_vec_ok(a, wmode)) return launch_cfg<1, 4, false>(a, wmode, stream);
+  if (a.sk_ws && g_dma_mode() != 0 && dma_eligible(a)) {
+    const int slices = splitk_slices(a.R, a.K, a.N);
+    if (slices > 1 && a.sk_ws_bytes >= splitk_bytes(a.R, a.N, slices) && (reinterpret_cast<uintptr_t>(a.sk_ws) & 15u) == 0)
+      return launch_dma1_sk<32, 96, 2, 2, 2>(a, wmode, slices, a.sk_ws, stream);
+  }
   if (dma_takes(a, wmode)) return launch_dma(a, wmode, stream);
   // measured on MI355X (tools/bench_gemm.py, profiles/r02a_gemm_tiles.txt): the 64x64 tile at 5-6
   // waves per SIMD beats the 128-row tiles at 2-4 on every shape of the path; 64x128 is a few
@@ -2121,6 +2232,14 @@ extern "C" int eda_linear_ex_f32(const float *x, long ldx, long R, int K, const 
                                  const float *bias, int relu, float drop_p, const unsigned long long *drop_seed,
                                  unsigned drop_salt, const float *gate, long ldgate, float gate_scale, float *y,
                                  long ldy, void *stream_) {
+  return eda_linear_ex_ws_f32(x, ldx, R, K, w, ldw, N, bias, relu, drop_p, drop_seed, drop_salt, gate, ldgate, gate_scale, y, ldy,
+                              nullptr, 0, stream_);
+}
+
+extern "C" int eda_linear_ex_ws_f32(const float *x, long ldx, long R, int K, const float *w, long ldw, int N,
+                                    const float *bias, int relu, float drop_p, const unsigned long long *drop_seed,
+                                    unsigned drop_salt, const float *gate, long ldgate, float gate_scale, float *y,
+                                    long ldy, void *ws, size_t ws_bytes, void *stream_) {
   EDA_CHECK_ARG(R >= 0 && K > 0 && N > 0 && ldx >= K && ldw >= K && ldy >= N, "bad dimension");
   EDA_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || drop_seed), "dropout needs 0 <= p < 1 and a seed");
   EDA_CHECK_ARG(!gate || ldgate >= N, "bad gate stride");
@@ -2135,11 +2254,17 @@ extern "C" int eda_linear_ex_f32(const float *x, long ldx, long R, int K, const 
   a.drop_p = drop_p; a.drop_seed = drop_seed; a.drop_salt = drop_salt;
   a.gate = gate; a.ldgate = ldgate; a.gate_scale = gate_scale;
   a.y = y; a.ldy = ldy;
+  a.sk_ws = ws; a.sk_ws_bytes = ws_bytes;
   return eda_gemm_launch(a, W_NT, (hipStream_t)stream_);
 }
 
 extern "C" int eda_linear_dgrad_f32(const float *dy, long lddy, long R, int N, const float *w, long ldw, int K,
                                     float *dx, long lddx, void *stream_) {
+  return eda_linear_dgrad_ws_f32(dy, lddy, R, N, w, ldw, K, dx, lddx, nullptr, 0, stream_);
+}
+
+extern "C" int eda_linear_dgrad_ws_f32(const float *dy, long lddy, long R, int N, const float *w, long ldw, int K,
+                                       float *dx, long lddx, void *ws, size_t ws_bytes, void *stream_) {
   EDA_CHECK_ARG(R >= 0 && K > 0 && N > 0 && lddy >= N && ldw >= K && lddx >= K, "bad dimension");
   if (R == 0) return 0;
   EDA_CHECK_ARG(dy && w && dx, "null pointer");
@@ -2149,7 +2274,15 @@ extern "C" int eda_linear_dgrad_f32(const float *dy, long lddy, long R, int N, c
   a.x = dy; a.ldx = lddy; a.R = R; a.K = N;      // contraction over the layer's output channels
   a.w = w; a.ldw = ldw; a.N = K;                 // W (N, K) read as (contraction, output column)
   a.y = dx; a.ldy = lddx;
+  a.sk_ws = ws; a.sk_ws_bytes = ws_bytes;
   return eda_gemm_launch(a, W_NN, (hipStream_t)stream_);
+}
+
+// contraction = K for the forward form (x (R, K), y (R, N)); for the input-gradient form pass (R, N_layer, K_layer)
+extern "C" size_t eda_linear_splitk_workspace_bytes(long R, int K, int N) {
+  if (R <= 0 || K <= 0 || N <= 0) return 0;
+  const int s = splitk_slices(R, K, N);
+  return s > 1 ? splitk_bytes(R, N, s) : 0;
 }
 
 

@@ -19,6 +19,24 @@ def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else t.shape[1]
 
 
+_SK_BYTES = 16 << 20
+_sk_ws_cache = {}
+
+
+def splitk_workspace(dev, R, K, N):
+    """Scratch of the split-contraction launches (include/eda_hip.h: eda_linear_ex_ws_f32) for a product with R rows,
+    contraction K, N columns, or None when the library does not split that shape: one persistent 16 MiB buffer per
+    (device, stream) -- its leading ticket words start at zero and every call leaves them zero."""
+    n = int(_lib.lib().eda_linear_splitk_workspace_bytes(R, K, N))
+    if n == 0 or n > _SK_BYTES:
+        return None
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _sk_ws_cache.get(key)
+    if ws is None:
+        ws = _sk_ws_cache[key] = torch.zeros(_SK_BYTES // 4, dtype=torch.int32, device=dev)
+    return ws
+
+
 def linear_fwd(x2, w, bias=None, relu=False, out=None):
     """y = x2 @ w.T (+ bias) (ReLU) for fp32 GPU matrices."""
     x2, w = _rows2d(x2), _rows2d(w)
@@ -30,9 +48,16 @@ def linear_fwd(x2, w, bias=None, relu=False, out=None):
     if R == 0:
         return out
     with torch.cuda.device(x2.device), _timed("gemm_fwd", (R, K, N)):
-        rc = _lib.lib().eda_linear_fwd_f32(x2.data_ptr(), _ld(x2), R, K, w.data_ptr(), _ld(w), N,
-                                           bias.data_ptr() if bias is not None else None, int(bool(relu)),
-                                           out.data_ptr(), _ld(out), torch.cuda.current_stream().cuda_stream)
+        ws = splitk_workspace(x2.device, R, K, N)
+        if ws is not None:
+            rc = _lib.lib().eda_linear_ex_ws_f32(x2.data_ptr(), _ld(x2), R, K, w.data_ptr(), _ld(w), N,
+                                                 bias.data_ptr() if bias is not None else None, int(relu), 0.0, None, 0,
+                                                 None, 0, 1.0, out.data_ptr(), _ld(out), ws.data_ptr(), ws.numel() * 4,
+                                                 torch.cuda.current_stream().cuda_stream)
+        else:
+            rc = _lib.lib().eda_linear_fwd_f32(x2.data_ptr(), _ld(x2), R, K, w.data_ptr(), _ld(w), N,
+                                               bias.data_ptr() if bias is not None else None, int(relu),
+                                               out.data_ptr(), _ld(out), torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "eda_linear_fwd_f32")
     return out
 
@@ -55,13 +80,15 @@ def linear_ex(x2, w, bias=None, relu=False, drop=None, gate=None, out=None):
         g = _rows2d(g)
         assert g.shape == (R, N)
     with torch.cuda.device(x2.device), _timed("gemm_fwd", (R, K, N)):
-        rc = _lib.lib().eda_linear_ex_f32(x2.data_ptr(), _ld(x2), R, K, w.data_ptr(), _ld(w), N,
-                                          bias.data_ptr() if bias is not None else None, int(bool(relu)),
-                                          float(p), seed.data_ptr() if (seed is not None and p > 0) else None,
-                                          int(salt) & 0xFFFFFFFF, g.data_ptr() if g is not None else None,
-                                          _ld(g) if g is not None else 0, float(gscale),
-                                          out.data_ptr(), _ld(out), torch.cuda.current_stream().cuda_stream)
-    _lib.check(rc, "eda_linear_ex_f32")
+        ws = splitk_workspace(x2.device, R, K, N)
+        rc = _lib.lib().eda_linear_ex_ws_f32(x2.data_ptr(), _ld(x2), R, K, w.data_ptr(), _ld(w), N,
+                                             bias.data_ptr() if bias is not None else None, int(relu),
+                                             float(p), seed.data_ptr() if (seed is not None and p > 0) else None,
+                                             int(salt) & 0xFFFFFFFF, g.data_ptr() if g is not None else None,
+                                             _ld(g) if g is not None else 0, float(gscale),
+                                             out.data_ptr(), _ld(out), ws.data_ptr() if ws is not None else None,
+                                             ws.numel() * 4 if ws is not None else 0, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "eda_linear_ex_ws_f32")
     return out
 
 
@@ -93,7 +120,10 @@ def linear_dgrad(dy2, w, out=None):
     if R == 0:
         return out
     with torch.cuda.device(dy2.device), _timed("gemm_dgrad", (R, N, K)):
-        rc = _lib.lib().eda_linear_dgrad_f32(dy2.data_ptr(), _ld(dy2), R, N, w.data_ptr(), _ld(w), K,
-                                             out.data_ptr(), _ld(out), torch.cuda.current_stream().cuda_stream)
-    _lib.check(rc, "eda_linear_dgrad_f32")
+        ws = splitk_workspace(dy2.device, R, N, K)
+        rc = _lib.lib().eda_linear_dgrad_ws_f32(dy2.data_ptr(), _ld(dy2), R, N, w.data_ptr(), _ld(w), K,
+                                                out.data_ptr(), _ld(out), ws.data_ptr() if ws is not None else None,
+                                                ws.numel() * 4 if ws is not None else 0,
+                                                torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "eda_linear_dgrad_ws_f32")
     return out

@@ -114,16 +114,8 @@ class FrozenRobertaFast:
 
 
 def _gelu_linear(x2, w, bias):
-    """gelu(x2 @ w.T + bias), erf form, in the GEMM's epilogue (eda_linear_fwd_f32 with activation code 2)."""
-    x2, w = gemm._rows2d(x2), gemm._rows2d(w)
-    R, K = x2.shape
-    N = w.shape[0]
-    out = torch.empty((R, N), dtype=torch.float32, device=x2.device)
-    with torch.cuda.device(x2.device), _timed("gemm_fwd", (R, K, N)):
-        rc = _lib.lib().eda_linear_fwd_f32(x2.data_ptr(), gemm._ld(x2), R, K, w.data_ptr(), gemm._ld(w), N, bias.data_ptr(), 2,
-                                           out.data_ptr(), gemm._ld(out), torch.cuda.current_stream().cuda_stream)
-    _lib.check(rc, "eda_linear_fwd_f32")
-    return out
+    """gelu(x2 @ w.T + bias), erf form, in the GEMM's epilogue (activation code 2 of the row products)."""
+    return gemm.linear_fwd(x2, w, bias, relu=2)
 
 
 def encode(hf_model, input_ids, attention_mask):

@@ -572,6 +572,20 @@ int eda_fps_set_cu_reserve(int cus);
 #define EDA_FPS_BUCKET  2
 int eda_fps_set_policy(int policy);
 
+/* The plain row products with scratch for a SPLIT CONTRACTION: launches of few 32 x 96 output tiles against a long
+ * contraction (the frozen text encoder's 640 x 3072 -> 768, models/bdetr.py:170-175; the 3456-deep input gradients of the
+ * hoisted K | V projections, models/encoder_decoder_layers.py:366-401) divide each tile's contraction over several
+ * workgroups; the fp32 partial tiles meet in `ws`, the last workgroup of a tile to arrive adds them in slice order
+ * (bit-reproducible) and applies the epilogue.  eda_linear_splitk_workspace_bytes(R, contraction, columns) = 0: that shape
+ * is not split, ws may be NULL (= eda_linear_ex_f32 / eda_linear_dgrad_f32).  The first 4096 bytes of ws are ticket
+ * words: ZERO before the first call, left zero by every call; one workspace may serve every call of one stream. */
+size_t eda_linear_splitk_workspace_bytes(long R, int K, int N);
+int eda_linear_ex_ws_f32(const float *x, long ldx, long R, int K, const float *w, long ldw, int N, const float *bias, int relu,
+                         float drop_p, const unsigned long long *drop_seed, unsigned drop_salt, const float *gate, long ldgate,
+                         float gate_scale, float *y, long ldy, void *ws, size_t ws_bytes, void *stream);
+int eda_linear_dgrad_ws_f32(const float *dy, long lddy, long R, int N, const float *w, long ldw, int K, float *dx, long lddx,
+                            void *ws, size_t ws_bytes, void *stream);
+
 /* Kernel selection of the plain row products (eda_linear_fwd_f32 / _ex_f32 / _dgrad_f32): -1 the library's own choice
  * (the DMA-staged kernel of csrc/gemm.hip for launches of >= 400 tiles of 32 x 96, else the register-staged one), 0 the
  * DMA-staged kernel off, 1..4 one of its configurations for every eligible launch (tests, experiments).  Process-wide;

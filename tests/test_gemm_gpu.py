@@ -62,11 +62,12 @@ DMA_SHAPES = [(8192, 288, 576), (640, 768, 2304), (640, 3072, 768), (2048, 288, 
 
 
 @pytest.mark.parametrize("R,K,N", DMA_SHAPES)
-def test_dma_staged_kernel_equals_register_staged_kernel(R, K, N):
+def test_dma_staged_kernel_equals_register_staged_kernel(R, K, N, monkeypatch):
     """gemm_dma_kernel (global_load_lds staging, every configuration, both tile -> XCD maps come up through the shapes)
     forms the same products in the same order as gemm_rows_kernel: forward (bias, ReLU / dropout / gate epilogues) and
-    dX agree bit for bit."""
+    dX agree bit for bit.  (Unsplit contraction: the split form adds slice partials, another association.)"""
     from eda_amd import _lib, gemm
+    monkeypatch.setenv("EDA_GEMM_SPLITK", "0")
     L = _lib.lib()
     g = torch.Generator(device="cuda").manual_seed(R + K + N)
     x = torch.randn(R, K, device="cuda", generator=g); w = torch.randn(N, K, device="cuda", generator=g)
@@ -214,3 +215,61 @@ def test_transpose_batch_c_entry_handles_ragged_matrices():
     _lib.check(rc, "eda_transpose_batch_f32")
     for s_, d_ in zip(srcs, dsts):
         assert torch.equal(d_, s_.t())
+
+
+SPLITK_SHAPES = [(640, 3072, 768), (640, 3456, 288), (1056, 3456, 288), (640, 768, 768), (130, 2304, 100), (33, 1024, 96)]
+
+
+@pytest.mark.parametrize("R,K,N", SPLITK_SHAPES)
+def test_split_contraction_is_reproducible_and_matches_fp64(R, K, N, monkeypatch):
+    """Split contraction of the DMA-staged products (csrc/gemm.hip SK): few 32 x 96 tiles against a long contraction.
+    Forward form with bias + GELU / gate epilogues and the input-gradient form; two calls give the same bits (the slices
+    are added in slice order whoever arrives last, the ticket words are re-armed); forced slice counts agree to fp32."""
+    from eda_amd import _lib, gemm
+    g = torch.Generator(device="cuda").manual_seed(R + K + N)
+    x = torch.randn(R, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g)
+    b = torch.randn(N, device="cuda", generator=g)
+    dy = torch.randn(R, N, device="cuda", generator=g)
+    outs = {}
+    for sk in (None, "0", "2", "5"):
+        if sk is None:
+            monkeypatch.delenv("EDA_GEMM_SPLITK", raising=False)
+        else:
+            monkeypatch.setenv("EDA_GEMM_SPLITK", sk)
+        nbytes = _lib.lib().eda_linear_splitk_workspace_bytes(R, K, N)
+        assert (nbytes > 0) == (sk != "0") or sk is None
+        y1 = gemm.linear_fwd(x, w, b, relu=2)
+        y2 = gemm.linear_fwd(x, w, b, relu=2)
+        assert torch.equal(y1, y2)
+        gate = torch.randn(R, N, device="cuda", generator=g)
+        y3 = gemm.linear_ex(x, w, None, gate=(gate, 0.5))
+        dx = gemm.linear_dgrad(dy, w)                      # contraction over N: split only where N is long
+        outs[sk] = (y1, y3, dx)
+        z = x.double() @ w.double().t()
+        ref = torch.nn.functional.gelu(z + b.double())
+        err = (y1.double() - ref).abs()
+        assert bool((err <= _tol(x, w, K) + 2e-6 * ref.abs() + 1e-6).all()), (sk, float(err.max()))
+        ref3 = torch.where(gate > 0, z * 0.5, torch.zeros_like(z))
+        assert bool(((y3.double() - ref3).abs() <= _tol(x, w, K) + 1e-6 * ref3.abs()).all()), sk
+        refd = dy.double() @ w.double()
+        told = 2e-6 * (N ** 0.5) * (dy.abs().double() @ w.abs().double()) + 1e-30
+        assert bool(((dx.double() - refd).abs() <= told + 1e-6 * refd.abs()).all()), sk
+    torch.cuda.synchronize()
+    for ws in gemm._sk_ws_cache.values():
+        assert int(ws[:1024].abs().sum().item()) == 0
+
+
+def test_split_contraction_input_gradient_form():
+    """dX = dY W with a long contraction over the layer's outputs (the hoisted K | V projections: 3456 outputs)."""
+    from eda_amd import _lib, gemm
+    R, N, K = 640, 3456, 288
+    assert _lib.lib().eda_linear_splitk_workspace_bytes(R, N, K) > 0
+    g = torch.Generator(device="cuda").manual_seed(5)
+    dy = torch.randn(R, N, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g)
+    dx = gemm.linear_dgrad(dy, w)
+    assert torch.equal(dx, gemm.linear_dgrad(dy, w))
+    ref = dy.double() @ w.double()
+    tol = 2e-6 * (N ** 0.5) * (dy.abs().double() @ w.abs().double()) + 1e-30
+    assert bool(((dx.double() - ref).abs() <= tol + 1e-6 * ref.abs()).all())
