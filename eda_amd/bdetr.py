@@ -140,8 +140,8 @@ class BeaUTyDETR(nn.Module):
         """last_hidden_state of the frozen RoBERTa (bdetr.py:78-80, 210-216 of the reference): no gradient.  On the GPU
         the forward runs on the repo's own kernels (eda_amd/roberta_fast.py: packed q|k|v GEMM, head_dim-64 attention,
         fused residual LayerNorm, GELU epilogue); EDA_FAST_ROBERTA=0 keeps the stock Hugging Face forward."""
-        from . import roberta_fast
-        with torch.no_grad():
+        from . import ext, roberta_fast
+        with torch.no_grad(), ext.tagged("side"):      # (bench.py: under the pipelined schedule this runs on the second stream)
             if os.environ.get("EDA_FAST_ROBERTA", "1") != "0" and roberta_fast.supported(self.text_encoder, input_ids):
                 return roberta_fast.encode(self.text_encoder, input_ids, attention_mask)
             return self.text_encoder(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state

@@ -31,16 +31,39 @@ def _stream():
 op_timer = None
 
 
+op_tag = "main"       # which stream of the step schedule the launches being issued belong to (see `tagged`)
+
+
+class tagged:
+    """with tagged("side"): native launches issued inside are recorded by an active OpTimer as work of the step's SECOND
+    stream (the frozen text encoder, the next batch's coordinate geometry): bench.py prices its `roofline` object on the
+    critical path, i.e. on "main" launches only."""
+
+    def __init__(self, tag):
+        self.tag, self.prev = tag, None
+
+    def __enter__(self):
+        global op_tag
+        self.prev, op_tag = op_tag, self.tag
+
+    def __exit__(self, *a):
+        global op_tag
+        op_tag = self.prev
+        return False
+
+
 class OpTimer:
     """Collects (start, end) HIP event pairs per native entry point."""
 
     def __init__(self):
         self.events = {}
+        self.tags = {}
 
     def record(self, name):
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
         self.events.setdefault(name, []).append((s, e))
+        self.tags.setdefault(name, op_tag)
         return s, e
 
     def summary(self):
