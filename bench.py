@@ -309,6 +309,9 @@ def main():
     ap.add_argument("--defer-wgrad", type=int, default=1,
                     help="1: queue the pointwise layers' weight gradients during the backward and compute them "
                          "in one grouped kernel (eda_amd/wgrad_queue.py); 0: compute each where autograd reaches it")
+    ap.add_argument("--deterministic", type=int, default=0,
+                    help="1: ordered per-owner sums instead of fp32 atomics in every gradient scatter "
+                         "(eda_amd/deterministic.py; the reference's cudnn.deterministic, train_dist_mod.py:342-344)")
     ap.add_argument("--overlap", action="store_true",
                     help="run the text encoder on a side stream underneath the point backbone (measured slower)")
     ap.add_argument("--text-stream", type=int, default=1,
@@ -429,6 +432,9 @@ def main():
     from eda_amd.parallel import FlatParams, reference_lr_groups
     if args.blas != "default":
         torch.backends.cuda.preferred_blas_library("cublas" if args.blas == "rocblas" else "cublaslt")
+    if args.deterministic:
+        from eda_amd import deterministic
+        deterministic.enable(True)
     tuning_file, shipped_ok = None, False
     fast_roberta = os.environ.get("EDA_FAST_ROBERTA", "1") != "0"
     if fast_roberta:
@@ -1016,6 +1022,7 @@ def main():
                                         "current step (once per step; --fps-prefetch 0 puts it back on the critical path)")
                        if (args.graph and args.text_stream and not args.overlap and args.fps_prefetch) else "inside the step",
                        "attention_dtype": args.attn_dtype,
+                       "deterministic": bool(args.deterministic),
                        "own_gemms": "every pointwise layer of the model AND of the frozen text encoder (csrc/gemm.hip)" if fast_roberta
                        else "every pointwise layer of the model (csrc/gemm.hip); hipBLASLt only inside RoBERTa",
                        "roberta_gemm_selection": ("TunableOp (%s; shipped results %s)" % (

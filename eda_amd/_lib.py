@@ -24,6 +24,7 @@ SIGNATURES = {
     "eda_reload_env": (_i, []),
     "eda_set_deterministic": (_i, [_i]),
     "eda_get_deterministic": (_i, []),
+    "eda_index_add_rows_ordered_f32": (_i, [_p, _p, _l, _i, _i, _p, _p]),
     "eda_fps_workspace_bytes": (_sz, [_i, _i, _i]),
     "eda_furthest_point_sampling_f32": (_i, [_p, _i, _i, _i, _p, _p, _sz, _p]),
     "eda_fps_prefix_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -148,6 +148,18 @@ __device__ __forceinline__ int eda_lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
+// ---- ordered scatter-add (scatter_det.hip; the eda_deterministic() form of every gradient scatter) --------------------
+// out[b*out_sb + p*out_sp + c*out_sc] = sum over r in [0, R) with idx[b*idx_sb + r] == p, ascending r, of
+//   (wgt ? wgt[b*idx_sb + r] : 1) * src[b*src_sb + (r / rdiv)*src_sr + c*src_sc]        for p < P, c < C
+// (every point of `out` is written: zero where nothing refers to it)
+struct EdaDetScatter {
+  const int *idx; const float *wgt; long idx_sb; int R, rdiv;
+  const float *src; long src_sb, src_sr, src_sc;
+  float *out; long out_sb, out_sp, out_sc;
+  int B, P, C;
+};
+int eda_det_scatter_launch(const EdaDetScatter &a, hipStream_t stream);
+
 // Zero-fill on the stream with a kernel (not hipMemsetAsync): memset NODES of a captured
 // HIP graph were observed to race with the kernel nodes that consume the zeroed buffer
 // on ROCm 7.2 (ball-query cell table corrupted under graph replay), kernel nodes are not.

@@ -165,6 +165,12 @@ extern "C" int eda_group_points_grad_f32(const float *grad_out, const int *idx, 
   const long long J = (long long)npoints * nsample;
   if (b == 0 || c == 0 || n == 0) return 0;
   EDA_CHECK_ARG(grad_points, "null pointer");
+  if (eda_deterministic() && J > 0 && J < (1ll << 31) && b <= 65535) {     // ordered per-point sums instead of atomics
+    EDA_CHECK_ARG(grad_out && idx, "null pointer");
+    EdaDetScatter d = {idx, nullptr, (long)J, (int)J, 1, grad_out, (long)c * J, 1, (long)J,
+                       grad_points, (long)c * n, 1, (long)n, b, n, c};
+    return eda_det_scatter_launch(d, stream);
+  }
   { const int zrc__ = eda_zero_async(grad_points, sizeof(float) * (size_t)b * c * n, stream); if (zrc__) return zrc__; }
   if (J == 0) return 0;
   EDA_CHECK_ARG(grad_out && idx, "null pointer");
@@ -201,6 +207,12 @@ extern "C" int eda_gather_points_grad_f32(const float *grad_out, const int *idx,
   EDA_CHECK_ARG(b >= 0 && c >= 0 && n >= 0 && m >= 0, "negative dimension");
   if (b == 0 || c == 0 || n == 0) return 0;
   EDA_CHECK_ARG(grad_points, "null pointer");
+  if (eda_deterministic() && m > 0 && b <= 65535) {
+    EDA_CHECK_ARG(grad_out && idx, "null pointer");
+    EdaDetScatter d = {idx, nullptr, (long)m, m, 1, grad_out, (long)c * m, 1, (long)m,
+                       grad_points, (long)c * n, 1, (long)n, b, n, c};
+    return eda_det_scatter_launch(d, stream);
+  }
   { const int zrc__ = eda_zero_async(grad_points, sizeof(float) * (size_t)b * c * n, stream); if (zrc__) return zrc__; }
   if (m == 0) return 0;
   EDA_CHECK_ARG(grad_out && idx, "null pointer");

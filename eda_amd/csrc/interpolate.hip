@@ -193,6 +193,12 @@ extern "C" int eda_three_interpolate_grad_f32(const float *grad_out, const int *
   if (b == 0 || c == 0 || m == 0) return 0;
   EDA_CHECK_ARG(grad_points, "null pointer");
   EDA_CHECK_ARG(b <= 65535 && (c + 7) / 8 <= 65535, "shape too large");
+  if (eda_deterministic() && n > 0 && 3L * n < 0x7fffffffL) {       // ordered per-point sums: entry r = (unknown r / 3, neighbour r % 3)
+    EDA_CHECK_ARG(grad_out && idx && weight, "null pointer");
+    EdaDetScatter d = {idx, weight, 3L * n, 3 * n, 3, grad_out, (long)c * n, 1, (long)n,
+                       grad_points, (long)c * m, 1, (long)m, b, m, c};
+    return eda_det_scatter_launch(d, stream);
+  }
   if (n > 0 && m <= TIG_MAXM) {
     EDA_CHECK_ARG(grad_out && idx && weight, "null pointer");
     hipLaunchKernelGGL(three_interpolate_grad_lds_kernel, dim3((unsigned)((c + 7) / 8), (unsigned)b), dim3(256), 0,

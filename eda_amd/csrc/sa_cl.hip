@@ -748,6 +748,13 @@ extern "C" int eda_group_concat_cl_grad_f32(const float *dx, const int *idx, int
   EDA_CHECK_ARG(b >= 0 && n >= 0 && m >= 0 && ns >= 0 && c >= 0, "negative dimension");
   if (b == 0 || n == 0 || c == 0) return 0;
   EDA_CHECK_ARG(dfeats_cl, "null pointer");
+  if (eda_deterministic() && m > 0 && ns > 0 && (long)m * ns < 0x7fffffffL && b <= 65535) {
+    EDA_CHECK_ARG(dx && idx, "bad arguments");
+    const long rows = (long)m * ns;
+    EdaDetScatter d = {idx, nullptr, rows, (int)rows, 1, dx + 3, rows * (3 + c), (long)(3 + c), 1,
+                       dfeats_cl, (long)n * c, (long)c, 1, b, n, c};
+    return eda_det_scatter_launch(d, stream);
+  }
   { const int zrc__ = eda_zero_async(dfeats_cl, sizeof(float) * (size_t)b * n * c, stream); if (zrc__) return zrc__; }
   if (m == 0 || ns == 0) return 0;
   EDA_CHECK_ARG(dx && idx && b <= 65535, "bad arguments");
@@ -1333,7 +1340,17 @@ static int sa_fused_bwd_impl(const float *dout, const unsigned char *argmax, con
       EDA_CHECK_LAUNCH();
       float *t = cur; cur = other; other = t;
     } else if (g.gather) {
-      if (dfeats_cl && c_feat > 0 && need_dx) {
+      if (dfeats_cl && c_feat > 0 && need_dx && eda_deterministic() && (long)m * ns < 0x7fffffffL) {
+        // ordered form: the input-gradient rows densely into the free scratch, then per-point sums in row order
+        a.N = c_feat; a.epi = E_PLAIN; a.y = other; a.ldy = c_feat;
+        const int rc = eda_gemm_launch(a, W_NT, stream);
+        if (rc) return rc;
+        const long rows = (long)m * ns;
+        EdaDetScatter d = {idx, nullptr, rows, (int)rows, 1, other, rows * c_feat, (long)c_feat, 1,
+                           dfeats_cl, (long)n * c_feat, (long)c_feat, 1, b, n, c_feat};
+        const int rc2 = eda_det_scatter_launch(d, stream);
+        if (rc2) return rc2;
+      } else if (dfeats_cl && c_feat > 0 && need_dx) {
         a.N = c_feat; a.epi = E_SCATTER;                       // (wt holds the feature columns of the (C1, 3 + c_feat) weight)
         a.idx = idx; a.n_pts = n; a.m = m; a.ns = ns; a.c_feat = c_feat; a.dfeats = dfeats_cl;
         const int rc = eda_gemm_launch(a, W_NT, stream);

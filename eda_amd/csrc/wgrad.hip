@@ -1485,9 +1485,17 @@ int eda_wgrad_x_launch(const WgradXArgs &a, hipStream_t stream) {
     if (e != hipSuccess) { eda_set_error("wgrad_x: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
     hipLaunchKernelGGL(sa_gather_layer_bwd_kernel, grid, block, lds, stream, a, p.cps, p.splits);
     EDA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(rows_scatter_add_kernel, dim3(2048), dim3(256), 0, stream, a.dx_out, a.idx, a.R, a.m * a.ns, a.n_pts,
-                       a.c_feat, a.dx_scatter);
-    EDA_CHECK_LAUNCH();
+    if (eda_deterministic()) {                    // ordered per-point sums instead of fp32 atomics (scatter_det.hip)
+      const long rows = (long)a.m * a.ns;
+      EdaDetScatter d = {a.idx, nullptr, rows, (int)rows, 1, a.dx_out, rows * a.c_feat, (long)a.c_feat, 1,
+                         a.dx_scatter, (long)a.n_pts * a.c_feat, (long)a.c_feat, 1, (int)(a.R / rows), a.n_pts, a.c_feat};
+      const int rc = eda_det_scatter_launch(d, stream);
+      if (rc) return rc;
+    } else {
+      hipLaunchKernelGGL(rows_scatter_add_kernel, dim3(2048), dim3(256), 0, stream, a.dx_out, a.idx, a.R, a.m * a.ns, a.n_pts,
+                         a.c_feat, a.dx_scatter);
+      EDA_CHECK_LAUNCH();
+    }
     const long MN = (long)a.M * a.N;
     hipLaunchKernelGGL(wgrad_x_reduce_kernel, dim3((unsigned)((MN + 31) / 32)), dim3(256), 0, stream, a.ws, p.splits,
                        a.M, a.N, 1, a.dW);

@@ -386,6 +386,17 @@ class _EmbeddingRows(Function):
     @staticmethod
     def backward(ctx, g):
         (ids,) = ctx.saved_tensors
+        from . import _lib, deterministic
+        if deterministic.enabled() and g.dtype == torch.float32:
+            # ordered per-row sums (csrc/scatter_det.hip) instead of index_add_'s fp32 atomics
+            g2 = g.reshape(-1, g.shape[-1]).contiguous()
+            dW = torch.empty(ctx.wshape, dtype=g.dtype, device=g.device)
+            i32 = ids.reshape(-1).to(torch.int32)
+            with torch.cuda.device(g.device):
+                rc = _lib.lib().eda_index_add_rows_ordered_f32(g2.data_ptr(), i32.data_ptr(), g2.shape[0], g2.shape[1],
+                                                               ctx.wshape[0], dW.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "eda_index_add_rows_ordered_f32")
+            return dW, None
         dW = torch.full(ctx.wshape, 0.0, dtype=g.dtype, device=g.device)        # (a fill kernel, not a memset node)
         dW.index_add_(0, ids.reshape(-1), g.reshape(-1, g.shape[-1]))
         return dW, None

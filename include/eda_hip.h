@@ -74,6 +74,10 @@ int eda_reload_env(void);
  * Process-wide; default from EDA_DETERMINISTIC.  Returns 0, or EDA_ERR_INVALID_ARG. */
 int eda_set_deterministic(int on);
 int eda_get_deterministic(void);
+/* out (P, C) = for every row p the sum, in ascending r, of the rows src[r] (R, C) with idx[r] == p (zero where none):
+ * the ordered form of an index_add_ / embedding weight gradient (models/bdetr.py:150-156 keeps the class-embedding table
+ * trainable); the same per-owner kernel serves every gradient scatter of the library in the deterministic mode. */
+int eda_index_add_rows_ordered_f32(const float *src, const int *idx, long R, int C, int P, float *out, void *stream);
 
 /* ---- furthest point sampling ------------------------------------------
  * replaces furthest_point_sampling()            src/sampling.cpp:70-91

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--points", type=int, default=6000)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--overlap", type=int, default=0)
+    ap.add_argument("--deterministic", type=int, default=0)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
 
@@ -40,6 +41,9 @@ def main():
     from eda_amd.bdetr import BeaUTyDETR
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
+    if a.deterministic:
+        from eda_amd import deterministic
+        deterministic.enable(True)
     if a.world > 1:
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{a.port}", rank=a.rank, world_size=a.world)
         sync_bn.enable()

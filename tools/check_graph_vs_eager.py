@@ -57,7 +57,7 @@ def compare_grads(scenes=2, points=20000, tokens=24, **model_kw):
 
 
 def compare(steps=4, scenes=8, points=50000, tokens=80, verbose=True, defer_in_graph=True, pipelined=False, seed=0,
-            **model_kw):
+            defer_in_eager=False, **model_kw):
     """pipelined=True: the replays are issued back to back (no host sync per replay) with ONE host
     synchronisation in the middle -- the pattern of a benchmark / training loop (warm-up, sync, timed
     steps), and the one that went wrong on ROCm 7.2 with the runtime's graph packet capture on."""
@@ -73,7 +73,7 @@ def compare(steps=4, scenes=8, points=50000, tokens=80, verbose=True, defer_in_g
 
         def step():
             loss = bench.synthetic_loss(model(inputs))
-            if use_graph and defer_in_graph:       # the bench configuration: graph + deferred weight gradients
+            if (use_graph and defer_in_graph) or (not use_graph and defer_in_eager):   # the bench configuration: deferred weight gradients
                 with flat.deferred_wgrad():
                     loss.backward()
             else:
@@ -118,6 +118,7 @@ def compare(steps=4, scenes=8, points=50000, tokens=80, verbose=True, defer_in_g
     pb = torch.cat([p.detach().reshape(-1) for p in b.parameters() if p.requires_grad])
     rel = ((pa - pb).abs().max() / pa.abs().max()).item()
     bad = max(abs(x - y) / max(abs(x), 1e-9) for x, y in zip(losses["eager"], losses["graph"]))
+    losses["param_bits_equal"] = bool(torch.equal(pa, pb))
     if verbose:
         print("max |param diff| / max |param| after %d steps: %.3e" % (steps, rel))
         print("max relative loss difference: %.3e" % bad)
