@@ -342,11 +342,12 @@ def main():
                     help="arithmetic of the attention QK^T / PV contractions: f32 = the headline / parity path; bf16 / "
                          "f16 = 16-bit MFMA with fp32 accumulation (csrc/mha2.hip with packed 16-bit quads, BASELINE.json configs[2] / [4]) -- "
                          "a SEPARATE bench line, never the headline")
-    ap.add_argument("--sync-bn", action="store_true",
-                    help="N > 1: global-batch BatchNorm statistics like the reference's SyncBatchNorm "
-                         "(eda_amd/sync_bn.py: one packed statistics all-reduce per BN layer and direction; the fused SA / FP "
-                         "calls stay fused and exchange their sums through eda_set_bn_sync, the single-launch small-row BN "
-                         "kernels are replaced by torch ops).  Default: per-GPU statistics (DESIGN.md §5)")
+    ap.add_argument("--sync-bn", nargs="?", const="native", default=None, choices=["native", "collective"],
+                    help="N > 1: global-batch BatchNorm statistics like the reference's SyncBatchNorm (main_utils.py:336-338). "
+                         "native (default when the flag is given): the BatchNorm kernels exchange their sums through "
+                         "peer-mapped memory themselves (csrc/peer.h) -- no collective, every site stays fused, the step is "
+                         "captured; collective: one packed all-reduce per BN layer and direction (eager launches, small-row "
+                         "sites on torch ops).  Without the flag: per-GPU statistics (DESIGN.md §5)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="N > 1: nccl (= RCCL over xGMI, the measured configuration) or gloo on device tensors (debugging)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -412,7 +413,7 @@ def main():
             _par.sampler_without_co_residency()
 
     from eda_amd import ext
-    if args.sync_bn and dist_on and args.graph:
+    if args.sync_bn == "collective" and dist_on and args.graph:
         # SyncBN puts collectives INSIDE the step; a captured collective's events are queried by RCCL's watchdog thread on this
         # torch / ROCm ("operation not permitted on an event last recorded in a capturing stream": the process aborts), so this
         # configuration runs with eager launches.  The default N > 1 step (per-GPU statistics) keeps its graphs: its one
@@ -422,11 +423,11 @@ def main():
         args.graph = 0
     if args.sync_bn and dist_on:
         from eda_amd import sync_bn
-        if dist.get_backend() == "gloo" and args.graph:
+        if args.sync_bn == "collective" and dist.get_backend() == "gloo" and args.graph:
             log_early = lambda m: print("[bench] " + m, file=sys.stderr, flush=True)
-            log_early("gloo collectives cannot be captured in a HIP graph: --sync-bn with gloo runs eager (--graph 0)")
+            log_early("gloo collectives cannot be captured in a HIP graph: --sync-bn collective with gloo runs eager (--graph 0)")
             args.graph = 0
-        sync_bn.enable(single_rank_too=(world == 1))        # fused SA / FP calls keep their fusion (library hook); no host synchronisation anywhere, so the
+        sync_bn.enable(single_rank_too=(world == 1), native=(args.sync_bn == "native"))        # fused SA / FP calls keep their fusion (library hook); no host synchronisation anywhere, so the
         # step is captured like the default one (a capture failure falls back to eager launches below)
     from eda_amd.bdetr import BeaUTyDETR
     from eda_amd.parallel import FlatParams, reference_lr_groups
@@ -1004,7 +1005,8 @@ def main():
                                               "two ranges of the flat fp32 buffer, the first in flight underneath the second "
                                               "range's grouped weight-gradient kernel" if overlap_ar else
                                               "one all-reduce of the flat fp32 buffer after the backward"),
-                       "batchnorm": "global-batch statistics (sync_bn)" if (args.sync_bn and world > 1) else "per-GPU statistics",
+                       "batchnorm": ("global-batch statistics (sync_bn, %s%s)" % (args.sync_bn, "; one rank: the N > 1 code path" if world == 1 else ""))
+                       if (args.sync_bn and dist_on) else "per-GPU statistics",
                        "launch": ("eager" if not args.graph else
                                   ("three hipGraphs on two streams (frozen text encoder underneath the point backbone | "
                                    "rest of the step)" + ("" if world == 1 and not args.split_graphs else

@@ -60,6 +60,15 @@ SIGNATURES = {
                             _p, _u, _p, _p, _p, _l, _l, _p, _p, _p, _p, _l, _l, _l, _l, _l, _l, _p, _sz, _p]),
     "eda_mha_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "eda_set_bn_sync": (_i, [_p, _p, _i]),
+    "eda_peer_slab_bytes": (_sz, []),
+    "eda_peer_create": (_i, [_p]),
+    "eda_peer_connect": (_i, [_i, _i, _p]),
+    "eda_peer_disconnect": (_i, []),
+    "eda_peer_connected": (_i, []),
+    "eda_peer_timeouts": (_l, []),
+    "eda_peer_allreduce_f64": (_i, [_p, _l, _p]),
+    "eda_peer_bn_hook": (_i, [_p, _p, _l, _p]),
+    "eda_set_bn_sync_native": (_i, [_i]),
     "eda_fps_set_cu_reserve": (_i, [_i]),
     "eda_fps_set_policy": (_i, [_i]),
     "eda_add_n_f32": (_i, [_p, _i, _sz, _p, _p]),

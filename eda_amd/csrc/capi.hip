@@ -62,6 +62,7 @@ const KnobRow kKnobs[EDA_K_COUNT] = {
     {"EDA_WGRAD_BF16X3", 1},        // eda_wgrad_set_arith
     {"EDA_WGRAD_WGS", 144},
     {"EDA_DETERMINISTIC", 0},       // eda_set_deterministic
+    {"EDA_PEER_SPIN_LOG2", 24},     // log2 of the polls an in-kernel statistics exchange waits for a peer (csrc/peer.h)
 };
 EdaEnv g_env;
 std::atomic<int> g_env_ready{0};

@@ -24,6 +24,7 @@
 // Results equal the reference's to fp32 rounding (tested against goldens generated
 // by the reference's own modules, tests/golden/model_sa_*).
 #include "eda_common.h"
+#include "peer.h"
 #include "gemm.h"
 #include <string.h>
 
@@ -85,11 +86,28 @@ __global__ __launch_bounds__(CL_THREADS) void group_concat_cl_grad_kernel(
 // Column sums of Z (R, C): every block owns a slab of rows, sums it in fp32
 // (<= a few hundred terms per partial), then merges into fp64 accumulators.
 // Thread t handles column (t % C4)*4.. +3 of rows (t / C4) + k * rows_per_pass.
+// Global-batch statistics inside the kernels (SyncBatchNorm, main_utils.py:336-338, without a collective): world > 0 = the
+// per-channel sums are exchanged with the other ranks through peer memory (csrc/peer.h) where they are formed; the row
+// count of the statistics is then R * world.
+struct BnSync { EdaPeer P; int world; };
+eda_bn_sync_fn g_sync_fn = nullptr;
+void *g_sync_user = nullptr;
+int g_sync_world = 1;
+bool g_sync_native = false;      // the hook is eda_peer_bn_hook and the single-launch kernels exchange their sums themselves
+bool bn_sync_on() { return g_sync_fn != nullptr; }   // (world == 1 with a hook: the split kernels alone -- tests)
+BnSync bn_sync_native_arg() {
+  BnSync S;
+  memset(&S, 0, sizeof(S));
+  const EdaPeer *P = eda_peer_active();
+  if (g_sync_native && P) { S.P = *P; S.world = g_sync_world; }
+  return S;
+}
 struct BnFinalize {          // what the last block of bn_stats_kernel needs to finish the statistics
   const float *gamma, *beta;
   float eps, momentum;
   float *running_mean, *running_var, *mean_out, *rstd_out, *scale, *shift;
   unsigned *ticket;
+  BnSync sync;
 };
 
 template <int VEC>
@@ -167,13 +185,16 @@ __global__ __launch_bounds__(CL_THREADS) void bn_stats_kernel(const float *__res
     is_last = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
   __syncthreads();
   if (!is_last) return;
+  const unsigned long long pseq = fin.sync.world > 0 ? eda_peer_seq(fin.sync.P) : 0ull;
+  const double Rt = fin.sync.world > 0 ? (double)R * fin.sync.world : (double)R;
   for (int c = threadIdx.x; c < C; c += CL_THREADS) {
-    const double su = __hip_atomic_load(sum + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const double sq = __hip_atomic_load(sumsq + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double su = __hip_atomic_load(sum + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double sq = __hip_atomic_load(sumsq + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(sum + c, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(sumsq + c, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const double mean = su / (double)R;
-    double var = sq / (double)R - mean * mean;
+    if (fin.sync.world > 0) eda_peer_exchange2(fin.sync.P, pseq, c, su, sq);
+    const double mean = su / Rt;
+    double var = sq / Rt - mean * mean;
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)fin.eps));
     const float meanf = (float)mean;
@@ -183,10 +204,14 @@ __global__ __launch_bounds__(CL_THREADS) void bn_stats_kernel(const float *__res
     fin.scale[c] = sc;
     fin.shift[c] = fin.beta[c] - meanf * sc;
     if (fin.running_mean) {
-      const double unbiased = R > 1 ? var * (double)R / (double)(R - 1) : var;
+      const double unbiased = Rt > 1.0 ? var * Rt / (Rt - 1.0) : var;
       fin.running_mean[c] = (1.f - fin.momentum) * fin.running_mean[c] + fin.momentum * meanf;
       fin.running_var[c] = (1.f - fin.momentum) * fin.running_var[c] + fin.momentum * (float)unbiased;
     }
+  }
+  if (fin.sync.world > 0) {                  // (only this block exchanges: a one-workgroup launch for the peer protocol)
+    __syncthreads();
+    if (threadIdx.x == 0) eda_peer_done(fin.sync.P, 1u);
   }
   if (threadIdx.x == 0) __hip_atomic_store(fin.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -517,10 +542,11 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_fwd_kernel(
     const float *__restrict__ z, int R, int C, const BnGrp G, float eps, float momentum, int training,
     float *__restrict__ mean_out,
     float *__restrict__ rstd_out, float *__restrict__ scale_out, float *__restrict__ shift_out,
-    float *__restrict__ out, float p_drop, const unsigned long long *seed_ptr) {
+    float *__restrict__ out, float p_drop, const unsigned long long *seed_ptr, const BnSync S) {
   constexpr int RL = SM_THREADS / CQ;              // row lanes
   __shared__ float red[8][CQ][SM_WAVES];
   __shared__ float sc_l[4 * CQ], sh_l[4 * CQ];
+  const unsigned long long pseq = (S.world > 0 && training) ? eda_peer_seq(S.P) : 0ull;
   const int grp = (blockIdx.x * 4 * CQ) / G.cpg, gc0 = grp * G.cpg;     // (a block's channels lie in one group)
   const float *gamma = G.gamma[grp] - gc0, *beta = G.beta[grp] - gc0;
   float *running_mean = G.running_mean[grp] ? G.running_mean[grp] - gc0 : nullptr;
@@ -550,8 +576,10 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_fwd_kernel(
       const int c = blockIdx.x * 4 * CQ + threadIdx.x;
       double a = 0.0, b = 0.0;
       for (int w = 0; w < SM_WAVES; ++w) { a += (double)red[v][jq][w]; b += (double)red[4 + v][jq][w]; }
-      const double mean = a / (double)R;
-      double var = b / (double)R - mean * mean;
+      double Rt = (double)R;
+      if (S.world > 0) { eda_peer_exchange2(S.P, pseq, c, a, b); Rt *= S.world; }     // global-batch sums (csrc/peer.h)
+      const double mean = a / Rt;
+      double var = b / Rt - mean * mean;
       if (var < 0.0) var = 0.0;
       const float rstd = (float)(1.0 / sqrt(var + (double)eps));
       const float meanf = (float)mean;
@@ -559,7 +587,7 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_fwd_kernel(
       mean_out[c] = meanf; rstd_out[c] = rstd; scale_out[c] = sc; shift_out[c] = sh;
       sc_l[threadIdx.x] = sc; sh_l[threadIdx.x] = sh;
       if (running_mean) {
-        const double unbiased = R > 1 ? var * (double)R / (double)(R - 1) : var;
+        const double unbiased = Rt > 1.0 ? var * Rt / (Rt - 1.0) : var;
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
       }
@@ -572,6 +600,7 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_fwd_kernel(
     sc_l[threadIdx.x] = sc; sh_l[threadIdx.x] = sh;
   }
   __syncthreads();
+  if (S.world > 0 && training && threadIdx.x == 0) eda_peer_done(S.P, gridDim.x * gridDim.y);
   const float sc0 = sc_l[4 * cq], sc1 = sc_l[4 * cq + 1], sc2 = sc_l[4 * cq + 2], sc3 = sc_l[4 * cq + 3];
   const float sh0 = sh_l[4 * cq], sh1 = sh_l[4 * cq + 1], sh2 = sh_l[4 * cq + 2], sh3 = sh_l[4 * cq + 3];
 #pragma unroll 4
@@ -594,7 +623,7 @@ __device__ __forceinline__ void bn_relu_small_bwd_body(
     const BnGrp &G, const float *__restrict__ mean, const float *__restrict__ rstd,
     const float *__restrict__ scale, const float *__restrict__ shift, int train,
     float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dz, float p_drop,
-    const unsigned long long *seed_ptr);
+    const unsigned long long *seed_ptr, const BnSync &S, int gbase);
 
 template <int CQ>
 __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_bwd_kernel(
@@ -602,8 +631,8 @@ __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_bwd_kernel(
     const BnGrp G, const float *__restrict__ mean, const float *__restrict__ rstd,
     const float *__restrict__ scale, const float *__restrict__ shift, int train,
     double *__restrict__ s1_out, double *__restrict__ s2_out, float *__restrict__ dgamma,
-    float *__restrict__ dbeta, float *__restrict__ dz, float p_drop, const unsigned long long *seed_ptr) {
-  bn_relu_small_bwd_body<CQ>(da, z, R, C, G, mean, rstd, scale, shift, train, dgamma, dbeta, dz, p_drop, seed_ptr);
+    float *__restrict__ dbeta, float *__restrict__ dz, float p_drop, const unsigned long long *seed_ptr, const BnSync S) {
+  bn_relu_small_bwd_body<CQ>(da, z, R, C, G, mean, rstd, scale, shift, train, dgamma, dbeta, dz, p_drop, seed_ptr, S, 0);
 }
 
 // The same backward for up to BN_MAXMAT packed matrices of one shape in ONE launch (blockIdx.y = matrix): the seven
@@ -617,11 +646,11 @@ struct BnMulti {
 };
 template <int CQ>
 __global__ __launch_bounds__(SM_THREADS) void bn_relu_small_bwd_multi_kernel(const BnMulti M, int R, int C, int train, float p_drop,
-                                                                             const unsigned long long *seed_ptr) {
+                                                                             const unsigned long long *seed_ptr, const BnSync S) {
   const int m = blockIdx.y;
   const float *st = M.stats[m];
   bn_relu_small_bwd_body<CQ>(M.da[m], M.z[m], R, C, M.grp[m], st, st + C, st + 2 * C, st + 3 * C, train, M.dgb[m], M.dgb[m] + C,
-                             M.dz[m], p_drop, seed_ptr);
+                             M.dz[m], p_drop, seed_ptr, S, m * C);
 }
 
 template <int CQ>
@@ -630,10 +659,12 @@ __device__ __forceinline__ void bn_relu_small_bwd_body(
     const BnGrp &G, const float *__restrict__ mean, const float *__restrict__ rstd,
     const float *__restrict__ scale, const float *__restrict__ shift, int train,
     float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dz, float p_drop,
-    const unsigned long long *seed_ptr) {
+    const unsigned long long *seed_ptr, const BnSync &S, int gbase) {
   constexpr int RL = SM_THREADS / CQ;              // row lanes (see the forward kernel)
   __shared__ float red[8][CQ][SM_WAVES];
   __shared__ float ka_l[4 * CQ], kb_l[4 * CQ], kd_l[4 * CQ];
+  const bool psync = S.world > 0 && train;
+  const unsigned long long pseq = psync ? eda_peer_seq(S.P) : 0ull;
   const int grp = (blockIdx.x * 4 * CQ) / G.cpg;
   const float *gamma = G.gamma[grp] - grp * G.cpg;
   const BnDrop dr = bn_drop(p_drop, seed_ptr, G.salt[grp]);
@@ -675,7 +706,11 @@ __device__ __forceinline__ void bn_relu_small_bwd_body(
     double t1 = 0.0, t2 = 0.0;
     for (int w = 0; w < SM_WAVES; ++w) { t1 += (double)red[v][jq][w]; t2 += (double)red[4 + v][jq][w]; }
     dbeta[c] = (float)t1; dgamma[c] = (float)t2;   // (the shared workspace stays untouched: it must remain zero)
-    const float invR = 1.f / (float)R;
+    float invR = 1.f / (float)R;
+    if (psync) {     // the mean terms of dz use the GLOBAL sums; d(gamma), d(beta) stay local (the gradient all-reduce adds them)
+      eda_peer_exchange2(S.P, pseq, gbase + c, t1, t2);
+      invR = 1.f / ((float)R * (float)S.world);
+    }
     const float gr = gamma[c] * rstd[c];
     ka_l[threadIdx.x] = gr;
     if (train) {
@@ -687,6 +722,7 @@ __device__ __forceinline__ void bn_relu_small_bwd_body(
     }
   }
   __syncthreads();
+  if (psync && threadIdx.x == 0) eda_peer_done(S.P, gridDim.x * gridDim.y);
   float ka[4], kb[4], kd[4];
 #pragma unroll
   for (int v = 0; v < 4; ++v) { ka[v] = ka_l[4 * cq + v]; kb[v] = kb_l[4 * cq + v]; kd[v] = kd_l[4 * cq + v]; }
@@ -798,15 +834,15 @@ extern "C" int eda_bn_relu_fwd_f32(const float *z, long R, int C, const float *g
     if (cq_env == 4 && C % 16 == 0)
       hipLaunchKernelGGL(bn_relu_small_fwd_kernel<4>, dim3(C / 16), dim3(SM_THREADS), 0, stream, z, (int)R, C,
                          G, eps, momentum, training, mean, rstd, scale,
-                         shift, out, p_drop, seed_ptr);
+                         shift, out, p_drop, seed_ptr, bn_sync_native_arg());
     else if (cq_env == 2 && C % 8 == 0)
       hipLaunchKernelGGL(bn_relu_small_fwd_kernel<2>, dim3(C / 8), dim3(SM_THREADS), 0, stream, z, (int)R, C,
                          G, eps, momentum, training, mean, rstd, scale,
-                         shift, out, p_drop, seed_ptr);
+                         shift, out, p_drop, seed_ptr, bn_sync_native_arg());
     else
       hipLaunchKernelGGL(bn_relu_small_fwd_kernel<1>, dim3(C / 4), dim3(SM_THREADS), 0, stream, z, (int)R, C,
                          G, eps, momentum, training, mean, rstd, scale,
-                         shift, out, p_drop, seed_ptr);
+                         shift, out, p_drop, seed_ptr, bn_sync_native_arg());
     EDA_CHECK_LAUNCH();
     return 0;
   }
@@ -819,7 +855,7 @@ extern "C" int eda_bn_relu_fwd_f32(const float *z, long R, int C, const float *g
     if (rpb < 64) rpb = 64;
     nblocks = (int)((R + rpb - 1) / rpb);
     BnFinalize fin = {gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift,
-                      reinterpret_cast<unsigned *>(ws + 2 * C)};
+                      reinterpret_cast<unsigned *>(ws + 2 * C), bn_sync_native_arg()};
     hipLaunchKernelGGL(bn_stats_kernel<4>, dim3(nblocks), dim3(CL_THREADS), 0, stream, z, R, C, rpb, ws,
                        ws + C, fin);
   } else {
@@ -870,15 +906,15 @@ extern "C" int eda_bn_relu_bwd_f32(const float *dout, const unsigned char *argma
     if (cq_env == 4 && C % 16 == 0)
       hipLaunchKernelGGL(bn_relu_small_bwd_kernel<4>, dim3(C / 16), dim3(SM_THREADS), 0, stream, dout, z, (int)R,
                          C, G, mean, rstd, scale, shift, training, ws, ws + C, dgamma, dbeta, dz, p_drop,
-                         seed_ptr);
+                         seed_ptr, bn_sync_native_arg());
     else if (cq_env == 2 && C % 8 == 0)
       hipLaunchKernelGGL(bn_relu_small_bwd_kernel<2>, dim3(C / 8), dim3(SM_THREADS), 0, stream, dout, z, (int)R,
                          C, G, mean, rstd, scale, shift, training, ws, ws + C, dgamma, dbeta, dz, p_drop,
-                         seed_ptr);
+                         seed_ptr, bn_sync_native_arg());
     else
       hipLaunchKernelGGL(bn_relu_small_bwd_kernel<1>, dim3(C / 4), dim3(SM_THREADS), 0, stream, dout, z, (int)R,
                          C, G, mean, rstd, scale, shift, training, ws, ws + C, dgamma, dbeta, dz, p_drop,
-                         seed_ptr);
+                         seed_ptr, bn_sync_native_arg());
     EDA_CHECK_LAUNCH();
     return 0;
   }
@@ -897,15 +933,21 @@ extern "C" int eda_bn_relu_bwd_f32(const float *dout, const unsigned char *argma
     hipLaunchKernelGGL(bn_relu_bwd_stats_vec_kernel, dim3(nblocks), dim3(CL_THREADS), 0, stream, dout, z,
                        R, C, rpb, mean, rstd, scale, shift, ws, ws + C);
   EDA_CHECK_LAUNCH();
+  float inv_n = 1.f / (float)R, gscale = 1.f;
+  if (training && g_sync_native && eda_peer_active()) {     // global-batch sums; d(gamma), d(beta) = global / world
+    const int rc = eda_peer_bn_hook(nullptr, ws, 2L * C, stream_);
+    if (rc) return rc;
+    inv_n = 1.f / ((float)R * g_sync_world); gscale = 1.f / g_sync_world;
+  }
   const int apply_grid = grid_for(R * (C / 4));
   if (pool > 1)
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<true>, dim3(apply_grid), dim3(CL_THREADS), 0, stream,
                        dout, argmax, z, R, C, pool, mean, rstd, scale, shift, gamma, ws, ws + C, training,
-                       dgamma, dbeta, dz, 1.f / (float)R, 1.f);
+                       dgamma, dbeta, dz, inv_n, gscale);
   else
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<false>, dim3(apply_grid), dim3(CL_THREADS), 0, stream,
                        dout, argmax, z, R, C, pool, mean, rstd, scale, shift, gamma, ws, ws + C, training,
-                       dgamma, dbeta, dz, 1.f / (float)R, 1.f);
+                       dgamma, dbeta, dz, inv_n, gscale);
   EDA_CHECK_LAUNCH();
   return 0;
 }
@@ -1018,10 +1060,6 @@ __global__ void bn_bwd_consts_kernel(const float *__restrict__ mean, const float
 // holds the same number of rows: scenes x positions are fixed per GPU).  d(gamma), d(beta) are the global sums / world,
 // i.e. what the gradient all-reduce's mean makes of the ranks' local sums.
 namespace {
-eda_bn_sync_fn g_sync_fn = nullptr;
-void *g_sync_user = nullptr;
-int g_sync_world = 1;
-bool bn_sync_on() { return g_sync_fn != nullptr; }   // (world == 1 with a hook: the split kernels alone -- tests)
 
 __global__ void bn_sync_finalize_kernel(double *__restrict__ sum, double *__restrict__ sumsq, double count, int C,
                                         const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
@@ -1052,6 +1090,17 @@ __global__ void bn_sync_finalize_kernel(double *__restrict__ sum, double *__rest
 extern "C" int eda_set_bn_sync(eda_bn_sync_fn fn, void *user, int world) {
   EDA_CHECK_ARG(world >= 1, "world size must be >= 1");
   g_sync_fn = fn; g_sync_user = user; g_sync_world = fn ? world : 1;
+  g_sync_native = false;
+  return 0;
+}
+
+extern "C" int eda_peer_bn_hook(void *user, double *buf, long n, void *stream);     // peer.hip
+extern "C" int eda_set_bn_sync_native(int world) {
+  EDA_CHECK_ARG(world >= 0 && world <= PEER_MAXW, "0 (off) .. 8 ranks");
+  if (world == 0) { g_sync_fn = nullptr; g_sync_user = nullptr; g_sync_world = 1; g_sync_native = false; return 0; }
+  const EdaPeer *P = eda_peer_active();
+  EDA_CHECK_ARG(P && P->world == world, "eda_peer_connect() with the same world size first");
+  g_sync_fn = eda_peer_bn_hook; g_sync_user = nullptr; g_sync_world = world; g_sync_native = true;
   return 0;
 }
 
@@ -1421,7 +1470,7 @@ extern "C" int eda_bn_relu_grouped_fwd_f32(const float *z, long R, int ngroups, 
   }
   const int C = ngroups * cpg;
   hipLaunchKernelGGL(bn_relu_small_fwd_kernel<4>, dim3(C / 16), dim3(SM_THREADS), 0, stream, z, (int)R, C, G, eps,
-                     momentum, training, mean, rstd, scale, shift, out, p_drop, seed_ptr);
+                     momentum, training, mean, rstd, scale, shift, out, p_drop, seed_ptr, bn_sync_native_arg());
   EDA_CHECK_LAUNCH();
   return 0;
 }
@@ -1447,7 +1496,7 @@ extern "C" int eda_bn_relu_grouped_bwd_f32(const float *dout, const float *z, lo
   G.cpg = cpg;
   for (int g = 0; g < ngroups; ++g) { EDA_CHECK_ARG(gamma[g], "null pointer"); G.gamma[g] = gamma[g]; G.salt[g] = salts ? salts[g] : 0u; }
   hipLaunchKernelGGL(bn_relu_small_bwd_kernel<4>, dim3(C / 16), dim3(SM_THREADS), 0, stream, dout, z, (int)R, C, G, mean,
-                     rstd, scale, shift, training, nullptr, nullptr, dgamma, dbeta, dz, p_drop, seed_ptr);
+                     rstd, scale, shift, training, nullptr, nullptr, dgamma, dbeta, dz, p_drop, seed_ptr, bn_sync_native_arg());
   EDA_CHECK_LAUNCH();
   return 0;
 }
@@ -1476,7 +1525,7 @@ extern "C" int eda_bn_relu_grouped_bwd_multi_f32(int nmat, const float *const *d
     }
   }
   hipLaunchKernelGGL(bn_relu_small_bwd_multi_kernel<4>, dim3(C / 16, nmat), dim3(SM_THREADS), 0, stream, M, (int)R, C, training,
-                     p_drop, seed_ptr);
+                     p_drop, seed_ptr, bn_sync_native_arg());
   EDA_CHECK_LAUNCH();
   return 0;
 }

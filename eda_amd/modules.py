@@ -132,7 +132,7 @@ class ClsAgnosticPredictHead(nn.Module):
         from . import _lib, sync_bn
         nets = [getattr(self, n).net for n in self.sibling_stacks()]
         bn0 = nets[0][1]
-        return (_GROUPED_HEADS and not sync_bn.enabled() and rows.is_cuda and rows.shape[0] <= _lib.lib().eda_bn_relu_dropout_max_rows()
+        return (_GROUPED_HEADS and not sync_bn.diverts() and rows.is_cuda and rows.shape[0] <= _lib.lib().eda_bn_relu_dropout_max_rows()
                 and self.seed_feat_dim % 16 == 0 and 2 <= len(nets) <= 4
                 and all(n[1].training == bn0.training and n[5].training == bn0.training for n in nets)
                 # the grouped launches take eps / momentum / running-statistics mode / dropout state from sibling 0

@@ -305,7 +305,7 @@ def bn_relu_rows(bn, z, dropout=None):
     counter-based mask (deviations) instead of torch's Philox stream."""
     global _bn_drop_rows
     from . import sa_ops, sync_bn
-    if sync_bn.enabled():
+    if sync_bn.diverts():
         out = sync_bn.bn_relu(bn, z)
         if bn.training and bn.track_running_stats:
             bump_batches_tracked(bn)

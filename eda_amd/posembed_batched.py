@@ -86,7 +86,7 @@ class PosEmbedBatch:
         if any(p is None or not p.requires_grad or getattr(p, "_backward_hooks", None) for p in six):
             return False
         R = xyz.shape[0] * xyz.shape[1]
-        return (xyz.is_cuda and torch.is_grad_enabled() and bn.training and bn.track_running_stats and not sync_bn.enabled()
+        return (xyz.is_cuda and torch.is_grad_enabled() and bn.training and bn.track_running_stats and not sync_bn.diverts()
                 and rows_ok(xyz, head[0].out_channels) and head[0].out_channels % 16 == 0
                 and R <= _lib.lib().eda_bn_relu_dropout_max_rows())
 

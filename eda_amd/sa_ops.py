@@ -344,7 +344,7 @@ def shared_mlp_rows(mlp, rows, pool):
     from . import sync_bn
     from .nn_utils import linear_rows
     for i, layer in enumerate(layers):
-        if sync_bn.enabled():
+        if sync_bn.diverts():
             z = linear_rows(x, layer.conv.weight.reshape(layer.conv.weight.shape[0], -1), None)
             bn = layer.bn.bn
             x = sync_bn.bn_relu(bn, z, pool if i == len(layers) - 1 else 1)

@@ -23,6 +23,14 @@ Two implementations:
 * the single-launch small-row kernels of the heads / positional embeddings cannot stop in the middle for a collective:
   those sites run the device-agnostic torch ops below (also what runs under gloo on CPU in
   tests/test_parallel_cpu.py), one packed collective per BatchNorm and direction, no host synchronisation either.
+
+Round 5, `enable(native=True)`: NO collective at all.  Every rank's process maps a slab of every other rank's device memory
+(csrc/peer.hip; the 64-byte IPC handles travel once through `dist.all_gather_object`), and the kernels that hold a
+channel's local sums exchange them there themselves (csrc/peer.h) -- inside the single-launch heads / positional-embedding
+kernels, in the last block of the statistics kernel, and as a one-launch vector exchange behind the fused calls' hook.
+Every BatchNorm site stays on its fused kernel, nothing runs on the host between kernels, and the training step captures
+into hipGraphs with global-batch statistics in it (what RCCL collectives inside a capture did not allow on this stack:
+111 scenes/s eager, profiles/r04_bench_force_dist_sync_bn.json).  One node, <= 8 ranks.
 """
 import ctypes
 
@@ -88,29 +96,82 @@ def remove_fused_hook():
 
 
 def fused_hook_installed():
-    return _fused_hook is not None
+    return _fused_hook is not None or _native
 
 
-def enable(group=None, fused=True, single_rank_too=False):
+_native = False
+
+
+def native():
+    """True while the library's own kernels exchange the statistics (enable(native=True)): no site leaves its fused kernel."""
+    return _native
+
+
+def _connect_peers(group):
+    """Create this rank's slab, gather every rank's IPC handle, map the peers (csrc/peer.hip)."""
+    from . import _lib
+    L = _lib.lib()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    mine = ctypes.create_string_buffer(64)
+    _lib.check(L.eda_peer_create(mine), "eda_peer_create")
+    handles = [None] * world
+    if world > 1:
+        dist.all_gather_object(handles, bytes(mine.raw), group=group)
+    else:
+        handles[0] = bytes(mine.raw)
+    blob = ctypes.create_string_buffer(b"".join(handles), 64 * world)
+    _lib.check(L.eda_peer_connect(rank, world, blob), "eda_peer_connect")
+    if world > 1:
+        dist.barrier(group=group)          # every rank has mapped every slab before anyone's kernels write into them
+    return world
+
+
+def enable(group=None, fused=True, single_rank_too=False, native=False):
     """Use global-batch statistics in every BN+ReLU site (requires an initialised process group).  fused=True (and a
     GPU): the fused SA / FP calls stay fused and exchange their sums through the library hook.  single_rank_too: also
-    in a one-rank group (same results as without; exercises the collectives' code path on a one-GPU box)."""
-    global _enabled, _group, _single_rank_too
+    in a one-rank group (same results as without; exercises the collectives' code path on a one-GPU box).
+    native=True: the exchange happens inside the library's kernels through peer-mapped memory -- no collective, every
+    site stays fused, capturable (module docstring)."""
+    global _enabled, _group, _single_rank_too, _native
     if not dist.is_initialized():
         raise RuntimeError("sync_bn.enable() needs torch.distributed to be initialised")
     _enabled, _group, _single_rank_too = True, group, bool(single_rank_too)
+    if native:
+        if not torch.cuda.is_available():
+            raise RuntimeError("sync_bn.enable(native=True) needs the GPU library")
+        if dist.get_world_size(group) > 1 or single_rank_too:
+            from . import _lib
+            world = _connect_peers(group)
+            _lib.check(_lib.lib().eda_set_bn_sync_native(world), "eda_set_bn_sync_native")
+            _native = True
+        return
     if fused and torch.cuda.is_available() and (dist.get_world_size(group) > 1 or single_rank_too):
         install_fused_hook(dist.get_world_size(group))
 
 
 def disable():
-    global _enabled, _group, _single_rank_too
+    global _enabled, _group, _single_rank_too, _native
     _enabled, _group, _single_rank_too = False, None, False
+    if _native:
+        from . import _lib
+        _lib.lib().eda_set_bn_sync_native(0)
+        _native = False
     remove_fused_hook()
+
+
+def peer_timeouts():
+    """Exchanges that gave up their bounded spin since start-up (0 in a healthy run; host read, synchronises)."""
+    from . import _lib
+    return int(_lib.lib().eda_peer_timeouts())
 
 
 def enabled():
     return _enabled and dist.is_initialized() and (dist.get_world_size(_group) > 1 or _single_rank_too)
+
+
+def diverts():
+    """Do the small-row BN+ReLU sites have to leave their fused kernels for the torch ops below (a collective in the middle)?"""
+    return enabled() and not _native
 
 
 class _SyncBNReLU(Function):

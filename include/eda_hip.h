@@ -606,6 +606,31 @@ int eda_gemm_set_dma(int mode);
 typedef int (*eda_bn_sync_fn)(void *user, double *buf, long n, void *stream);
 int eda_set_bn_sync(eda_bn_sync_fn fn, void *user, int world);
 
+/* ---- SyncBatchNorm without collectives: the statistics exchange through peer-mapped memory (csrc/peer.h, peer.hip) ----
+ * The reference converts every BatchNorm to SyncBatchNorm at N > 1 (main_utils.py:336-338).  Here every rank (one process
+ * per GPU of ONE node, <= 8) owns a slab of device memory that the other processes map (hipIpc*); a kernel that has a
+ * channel's local sums writes them into every rank's slab with system-scope stores, polls its own slab for the others'
+ * and adds them in rank order -- inside the BatchNorm kernels themselves (single-launch heads / positional embeddings,
+ * the last block of the statistics kernel) or as a one-launch exchange of a vector (the fused set-abstraction calls'
+ * hook).  No host work between kernels, nothing a hipGraph capture cannot hold, every rank gets the same bits.  All ranks
+ * must issue the same exchanging launches in the same order.  Spins are bounded (~1 s): a rank that never arrives costs
+ * eda_peer_timeouts() > 0 and garbage statistics, not a hang.
+ *   eda_peer_create(handle)            allocate + zero this process's slab (once); handle: 64 bytes out (hipIpcMemHandle_t)
+ *   eda_peer_connect(rank, world, hs)  hs: world x 64 bytes, rank order, gathered by the host (any out-of-band channel)
+ *   eda_set_bn_sync_native(world)      BatchNorm statistics over the world (0 = per-GPU again); replaces eda_set_bn_sync
+ *   eda_peer_allreduce_f64(buf, n, s)  in-place sum of n <= 16384 doubles over the ranks, one launch on stream s
+ *   eda_peer_bn_hook                   the same as an eda_bn_sync_fn
+ * Over xGMI the protocol is unchanged but unmeasured in this repository (one-device box: two processes on one GPU). */
+size_t eda_peer_slab_bytes(void);
+int eda_peer_create(void *handle_out);
+int eda_peer_connect(int rank, int world, const void *handles);
+int eda_peer_disconnect(void);
+int eda_peer_connected(void);
+long eda_peer_timeouts(void);
+int eda_peer_allreduce_f64(double *buf, long n, void *stream);
+int eda_peer_bn_hook(void *user, double *buf, long n, void *stream);
+int eda_set_bn_sync_native(int world);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

@@ -87,3 +87,49 @@ def test_two_ranks_with_identical_rows_emulated(gather):
     rv_plain, rv_two = plain[-1], two[-1]
     expect = 0.9 + (rv_plain - 0.9) * ((rows - 1) / rows) * (2 * rows / (2 * rows - 1))
     torch.testing.assert_close(rv_two, expect, rtol=1e-5, atol=1e-6)
+
+
+def test_native_exchange_on_one_rank_equals_the_plain_kernels_bit_for_bit():
+    """`sync_bn.enable(native=True)` in a ONE-rank group: every BatchNorm kernel runs its peer exchange (csrc/peer.h) against
+    its own slab -- the N > 1 code path on one GPU.  The sums are the local ones, so the fused SA / FP call, the single-launch
+    BN+ReLU(+Dropout) kernels (R <= 4096), the multi-launch form (R > 4096, pooled too) and the stand-alone vector exchange
+    must reproduce the plain results exactly, forward and backward; no exchange may time out."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from eda_amd import _lib, sa_ops, sync_bn
+    dev = "cuda"
+
+    def small(R, C, pool=1, p=0.0):
+        torch.manual_seed(R + C)
+        z = torch.randn(R, C, device=dev, requires_grad=True)
+        g = (torch.rand(C, device=dev) + 0.5).requires_grad_(True)
+        b = (torch.randn(C, device=dev) * 0.1).requires_grad_(True)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        out = sa_ops.BNReLUCL.apply(z, g, b, rm, rv, 1e-5, 0.1, True, pool, p, 77)
+        (out * torch.linspace(0.5, 1.5, out.numel(), device=dev).view_as(out)).sum().backward()
+        return [out.detach(), z.grad, g.grad, b.grad, rm, rv]
+
+    def everything():
+        return _run(False) + _run(True) + small(2048, 288, p=0.1) + small(300, 64) + small(8192, 288) + small(8192, 128, pool=16)
+
+    plain = everything()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        sync_bn.enable(single_rank_too=True, native=True)
+        assert sync_bn.native() and not sync_bn.diverts() and _lib.lib().eda_peer_connected() == 1
+        native = everything()
+        buf = torch.arange(601, dtype=torch.float64, device=dev) * 0.25
+        _lib.check(_lib.lib().eda_peer_allreduce_f64(buf.data_ptr(), buf.numel(), torch.cuda.current_stream().cuda_stream), "peer")
+        assert torch.equal(buf, torch.arange(601, dtype=torch.float64, device=dev) * 0.25)
+        assert sync_bn.peer_timeouts() == 0
+    finally:
+        sync_bn.disable()
+        dist.destroy_process_group()
+    for i, (a, b) in enumerate(zip(plain, native)):
+        if a.dim() == 3:                                  # (scatter-add gradient of the gathered stack: fp32 atomics order)
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+        else:
+            assert torch.equal(a, b), i

@@ -21,10 +21,10 @@ def _free_port():
     return port
 
 
-def _run(world, out_dir, overlap, tag, deterministic=0):
+def _run(world, out_dir, overlap, tag, deterministic=0, sync="collective", graph=0):
     port = _free_port()
     procs, outs = [], []
-    env = dict(os.environ)
+    env = dict(os.environ, EDA_PEER_SPIN_LOG2="22")      # (a dead peer costs the test ~5 s, not the production default)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     for r in range(world):
@@ -32,7 +32,7 @@ def _run(world, out_dir, overlap, tag, deterministic=0):
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "two_rank_worker.py"), "--world", str(world),
                                        "--rank", str(r), "--port", str(port), "--overlap", str(overlap), "--out", out,
-                                       "--deterministic", str(deterministic)],
+                                       "--deterministic", str(deterministic), "--sync", sync, "--graph", str(graph)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
     for p in procs:
@@ -110,3 +110,27 @@ def test_two_ranks_equal_one_rank_to_rounding_in_the_deterministic_mode(tmp_path
     # three optimizer steps: 1 % of the update's norm (measured 0.97 %; the default mode's bound is 20 %): a wrong weight
     # decay or a 5 % scaling error in one range of the all-reduce no longer fits
     assert report["update_rel"] <= 0.03, report
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+def test_two_ranks_with_the_in_kernel_statistics_exchange(tmp_path, graph):
+    """SyncBatchNorm without a collective.  Two processes on device 0 map each other's slab
+    (csrc/peer.hip) and every BatchNorm kernel exchanges its sums there itself (csrc/peer.h): every site stays on its fused
+    kernel, and with graph = 1 steps 2 and 3 are REPLAYS of a captured forward + backward -- global-batch statistics inside a
+    hipGraph.  Against one rank on the global batch, in the deterministic mode (so that the bounds are the tight ones)."""
+    one, = _run(1, str(tmp_path), 0, "n1", deterministic=1)
+    two = _run(2, str(tmp_path), 0, f"n2g{graph}", deterministic=1, sync="native", graph=graph)
+    assert all(t["peer_timeouts"] == 0 for t in two), [t["peer_timeouts"] for t in two]
+    assert all(t["captured"] == bool(graph) for t in two)
+    assert all(t["fused_hook_calls"] == 0 for t in two)            # no collective ran for the statistics
+    assert torch.equal(two[0]["grad0"], two[1]["grad0"]) and torch.equal(two[0]["param"], two[1]["param"])
+    l2 = (two[0]["losses"] + two[1]["losses"]) / 2
+    g1, g2 = one["grad0"].double(), two[0]["grad0"].double()
+    p0, p1, p2 = one["param0"].double(), one["param"].double(), two[0]["param"].double()
+    report = dict(losses_two=l2.tolist(), losses_one=one["losses"].tolist(), grad_rel=float((g1 - g2).norm() / g1.norm()),
+                  update_rel=float((p1 - p2).norm() / (p1 - p0).norm()))
+    print("REPORT", report)
+    assert torch.allclose(l2, one["losses"], rtol=1e-4), report
+    assert report["grad_rel"] <= 5e-3 and report["update_rel"] <= 0.03, report
+    for k, v in one["bn"].items():
+        assert torch.allclose(two[0]["bn"][k], v, rtol=1e-4, atol=1e-6), k

@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--overlap", type=int, default=0)
     ap.add_argument("--deterministic", type=int, default=0)
+    ap.add_argument("--sync", choices=["collective", "native"], default="collective")
+    ap.add_argument("--graph", type=int, default=0, help="1: steps 2.. replayed from a captured hipGraph (native sync only)")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
 
@@ -46,7 +48,7 @@ def main():
         deterministic.enable(True)
     if a.world > 1:
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{a.port}", rank=a.rank, world_size=a.world)
-        sync_bn.enable()
+        sync_bn.enable(native=(a.sync == "native"))
         assert sync_bn.fused_hook_installed()
         parallel.reserve_cus_for_collectives(32)
         parallel.sampler_without_co_residency()
@@ -90,16 +92,41 @@ def main():
         sync_bn._reduce = counting          # (the hook's seam: same collective, counted)
 
     losses, grad0 = [], None
-    for step in range(a.steps):
+
+    def fwd_bwd():
         attention.advance_dropout_state(dev)
         loss = bench.synthetic_loss(model(inputs))
-        if a.overlap:
+        with flat.deferred_wgrad():
+            loss.backward()
+        flat.collect_grads()
+        return loss
+
+    graph, static_loss = None, None
+    side = torch.cuda.Stream()
+    for step in range(a.steps):
+        if a.graph and step >= 1:
+            # steps 2.. from a captured hipGraph: the statistics exchange lives INSIDE the kernels (sync native), so the
+            # forward + backward of a SyncBatchNorm model captures and replays; the flat all-reduce stays between graphs
+            if graph is None:
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                    static_loss = fwd_bwd()
+                if a.world > 1:
+                    dist.barrier()           # (capture is seconds of host work: start replaying together)
+            graph.replay()
+            loss = static_loss
+            flat.all_reduce_mean(a.world)
+        elif a.overlap:
+            attention.advance_dropout_state(dev)
+            loss = bench.synthetic_loss(model(inputs))
             handle = flat.backward_overlapped(loss, a.world)
             handle.wait()
         else:
-            with flat.deferred_wgrad():
-                loss.backward()
-            flat.collect_grads()
+            with torch.cuda.stream(side) if a.graph else torch.cuda.stream(torch.cuda.current_stream()):
+                loss = fwd_bwd()
+            if a.graph:
+                torch.cuda.current_stream().wait_stream(side)
             flat.all_reduce_mean(a.world)
         if step == 0:
             grad0 = flat.flat_grad.detach().cpu().clone()
@@ -107,10 +134,11 @@ def main():
             bn = {k: v.detach().cpu().clone() for k, v in model.state_dict().items() if "running_" in k and "backbone_net.sa1" in k}
         flat.clip_grad_norm_(0.1)
         opt.step()
-        losses.append(loss.detach().cpu())
+        losses.append(loss.detach().cpu().clone())
     torch.cuda.synchronize()
     torch.save({"losses": torch.stack(losses), "grad0": grad0, "param": flat.flat_param.detach().cpu(), "bn": bn, "param0": param0,
-                "fused_hook_calls": hooks[0]}, a.out)
+                "fused_hook_calls": hooks[0], "peer_timeouts": sync_bn.peer_timeouts() if a.sync == "native" and a.world > 1 else 0,
+                "captured": graph is not None}, a.out)
     if a.world > 1:
         dist.barrier()
         dist.destroy_process_group()
