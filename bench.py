@@ -1052,6 +1052,14 @@ def main():
         if os.environ.get("EDA_BENCH_KERNELS_FILE"):       # the complete per-op table (the line carries the first 40 rows)
             with open(os.environ["EDA_BENCH_KERNELS_FILE"], "w") as f:
                 json.dump(kernels, f)
+        # the JSON line is the LAST line of stdout: RCCL prints a version banner through C stdio (buffered until exit when
+        # stdout is a pipe) -- flush it out first
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.barrier()
