@@ -55,6 +55,8 @@ const KnobRow kKnobs[EDA_K_COUNT] = {
     {"EDA_GEMM_SPLITK", -1},        // 0: no split contraction; n >= 2: n slices for every eligible launch (unset: by shape)
     {"EDA_MHA2_PRIO", 1},
     {"EDA_MHA2_KSPLIT", -1},        // 0: no key-split forward; n >= 2: n key slices for every eligible launch (unset: by shape)
+    {"EDA_MHA3", 1},                // 0: the long-key attention forward stays on mha2.hip's fp32-MFMA kernel (mha3.hip: bf16 x 3)
+    {"EDA_MHA3_DBG", 0},            // ablation bits of mha3.hip (timing experiments; wrong results)
     {"EDA_BN_SMALL_CQ", 4},
     {"EDA_SA_LAYER_FUSE", 1},
     {"EDA_SA_BNBWD_FUSE", 1},

@@ -33,6 +33,7 @@ struct Mha2Args {
   // over keys_per_split keys (a multiple of the chunk); their (O, m, l) partials meet in `fwd_part` and the LAST arriver
   // of a block (ticket in `fwd_tickets`, left at zero again) merges them in split order and writes out / lse
   int n_ksplit, keys_per_split;
+  int dbg3;                  // mha3.hip ablation bits (EDA_MHA3_DBG; results are then wrong): 1 convert once, 2 no softmax, 4 no PV, 8 no QK^T, 16 no dropout
   float *fwd_part;           // [block][split][NQ][64 lanes][16 floats]
   unsigned *fwd_tickets;     // [block], zero before the first call
 };
@@ -40,6 +41,8 @@ struct Mha2Args {
 // 0 = launched, EDA_ERR_* otherwise.  Both enqueue on `stream` only, allocate nothing, never synchronise.
 int eda_mha2_fwd_launch(Mha2Args &a, void *ws, size_t ws_bytes, hipStream_t stream);
 size_t eda_mha2_fwd_workspace_bytes(int B, int H, int Lq, int Lk);
+// mha3.hip: the long-key forward on v_mfma_f32_16x16x32_bf16 (bf16 x 3 for F32, plain for BF16); -1 = not its shape
+int eda_mha3_fwd_launch(Mha2Args &a, hipStream_t stream);
 int eda_mha2_qproj_fwd_launch(Mha2Args &a, hipStream_t stream);      // Lk <= 192
 int eda_mha2_bwd_launch(Mha2Args &a, void *ws, size_t ws_bytes, hipStream_t stream);
 size_t eda_mha2_bwd_workspace_bytes(int B, int H, int Lq, int Lk);

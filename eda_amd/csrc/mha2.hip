@@ -1241,6 +1241,10 @@ int eda_mha2_fwd_launch(Mha2Args &a, void *ws, size_t ws_bytes, hipStream_t stre
       return one ? launch_fwd<4, 4, FWD_SPLIT_CHK, 1, true>(a, stream) : launch_fwd<4, 4, FWD_SPLIT_CHK, 2, true>(a, stream);
     }
   }
+  {
+    const int rc3 = eda_mha3_fwd_launch(a, stream);                  // >= 512 keys, >= 192 queries: the bf16-pipe kernel
+    if (rc3 >= 0) return rc3;
+  }
   const bool short_q = (long)BH * ((a.Lq + 255) / 256) < 192;        // 16-query waves alone would leave CUs idle
   if (a.Lk <= 144) {
     if (short_q) return launch_fwd<4, 2, 192, 1>(a, stream);
