@@ -808,6 +808,49 @@ def main():
             del src_c, dst_c
         except torch.OutOfMemoryError:
             copy_gbs = None
+        # ---- the same SA1 level in INFERENCE mode: one launch, nothing but the pooled output written (csrc/sa_eval.hip) --
+        # SURVEY 8d's "fused SA layer fwd" bytes are reachable only there (training keeps every pre-activation for the
+        # BatchNorm backward); priced on those bytes AND as matrix work (it is compute-bound: 1 166 FLOP per byte)
+        roofline_hbm_eval = None
+        try:
+            from eda_amd import pointnet2_utils as _PU, sa_ops as _so
+            sa1 = model.backbone_net.sa1
+            with torch.no_grad():
+                pcs = inputs["point_clouds"]
+                xyz_e = pcs[..., :3].contiguous(); feats_e = pcs[..., 3:6].contiguous()
+                inds_e = _PU.furthest_point_sample(xyz_e, sa1.npoint)
+                nx_e = _PU.gather_operation(xyz_e.transpose(1, 2).contiguous(), inds_e).transpose(1, 2).contiguous()
+                idx_e = _PU.ball_query(sa1.radius, sa1.nsample, xyz_e, nx_e)
+                lay_e = sa1.mlp_module.layers(); bns_e = [l_.bn.bn for l_ in lay_e]
+                cfg_e = dict(gather=True, radius=sa1.radius, normalize_xyz=True, pool=sa1.nsample, training=False, eps=bns_e[0].eps,
+                             momentum=bns_e[0].momentum, running=[(b_.running_mean, b_.running_var) for b_ in bns_e])
+                fn_e = lambda: _so._one_pass_eval(cfg_e, xyz_e, nx_e, feats_e, idx_e, lay_e, bns_e, sa1.nsample)
+                if fn_e() is not None:
+                    torch.cuda.synchronize()
+                    ee0, ee1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ee0.record()
+                    for _ in range(10):
+                        fn_e()
+                    ee1.record()
+                    torch.cuda.synchronize()
+                    ms_e = ee0.elapsed_time(ee1) / 10
+                    Bq, mq, nsq = xyz_e.shape[0], sa1.npoint, sa1.nsample
+                    alg_e = Bq * (12 * xyz_e.shape[1] + 12 * xyz_e.shape[1] + 12 * mq + 4 * (6 * 64 + 64 * 64 + 64 * 128) + 4 * mq * nsq + 4 * 128 * mq)
+                    fl_e = 2.0 * Bq * mq * nsq * (6 * 64 + 64 * 64 + 64 * 128)
+                    key_e = ("sa_fused_eval", (Bq * mq * nsq, nsq, 6, 64, 64, 128))
+                    roofline_hbm_eval = {"kernel": "sa_fused_eval(%d rows, 6 -> 64 -> 64 -> 128, pool %d): one launch, inference" % (Bq * mq * nsq, nsq),
+                                         "bound": "hbm (as SURVEY 8d prices it) / mfma (what it is: %.0f FLOP per byte)" % (fl_e / alg_e),
+                                         "ms_per_launch": round(ms_e, 4), "alg_bytes_per_launch": alg_e,
+                                         "achieved": round(alg_e / (ms_e * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": round(alg_e / (ms_e * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                         "traffic": pmc_traffic.get(key_e),
+                                         "traffic_over_alg_bytes": round(pmc_traffic[key_e] / alg_e, 2) if pmc_traffic.get(key_e) else None,
+                                         "fp32_equivalent_tflops": round(fl_e / (ms_e * 1e-3) / 1e12, 1),
+                                         "frac_of_fp32_mfma_peak": round(fl_e / (ms_e * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 3),
+                                         "arithmetic": "layer 1 fp32 MFMA; layers 2, 3 bf16 x 3 on v_mfma_f32_16x16x32_bf16 (fp32 accuracy)",
+                                         "timing": "HIP events around 10 launches"}
+        except Exception as exc:      # a measurement aid: never lose the line to it
+            roofline_hbm_eval = {"error": f"{type(exc).__name__}: {exc}"[:200]}
         roofline_hbm = None
         if dom:
             roofline_hbm = {"kernel": f"{dom['op']}{tuple(dom['dims'])}", "bound": "hbm",
@@ -1033,6 +1076,7 @@ def main():
             "roofline": roofline,
             "launch_bound_gemm": launch_bound_gemm,
             "roofline_hbm": roofline_hbm,
+            "roofline_hbm_eval": roofline_hbm_eval,
             "roofline_mfma": roofline_mfma,
             "roofline_gemm": roofline_gemm,
             "in_step": in_step,

@@ -112,6 +112,8 @@ SIGNATURES = {
     "eda_bn_relu_grouped_bwd_multi_f32": (_i, [_i, _p, _p, _l, _i, _i, _p, _p, _i, _p, _p, _f, _p, _p, _p]),
     "eda_sa_fused_fwd_f32": (_i, [_p, _l, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _l, _i, _p, _p, _p, _p, _p, _p,
                                  _f, _f, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "eda_sa_fused_eval_supported": (_i, [_i, _i, _p, _i]),
+    "eda_sa_fused_eval_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p]),
     "eda_sa_fused_bwd_workspace_bytes": (_sz, [_l, _i, _p, _i]),
     "eda_sa_fused_bwd_f32": (_i, [_p, _p, _p, _l, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _l, _i, _p, _p, _p,
                                  _p, _p, _i, _i, _p, _p, _p, _sz, _p, _p, _p, _p, _l, _p, _p]),

@@ -305,6 +305,36 @@ class FusedMLP(Function):
         return (None, dx, None, None, dfeats, None, *grads)
 
 
+_ONE_PASS_EVAL = os.environ.get("EDA_SA_ONE_PASS_EVAL", "1") != "0"
+
+
+def _one_pass_eval(cfg, xyz, new_xyz, feats_cl, idx, layers, bns, pool):
+    """Inference (running statistics, no autograd): gather -> 3 x (conv1x1 + BN + ReLU) -> max over the neighbourhood in ONE
+    launch that writes only the pooled output (csrc/sa_eval.hip; SURVEY section 8d's fused-layer byte count).  Returns None
+    when the stack is not the one the kernel is built for (SA1: 3 feature channels, 6 -> 64 -> 64 -> 128)."""
+    if feats_cl is None or not all(bn.track_running_stats for bn in bns):
+        return None
+    B, N, _ = xyz.shape
+    m, ns = idx.shape[1], idx.shape[2]
+    C = feats_cl.shape[2]
+    Ws = [l.conv.weight.reshape(l.conv.weight.shape[0], -1).contiguous() for l in layers]
+    chans = [3 + C] + [w.shape[0] for w in Ws]
+    chan_arr = (ctypes.c_int * len(chans))(*chans)
+    lib = _lib.lib()
+    if pool != ns or not lib.eda_sa_fused_eval_supported(C, len(layers), chan_arr, ns):
+        return None
+    xyz, new_xyz, feats_cl, idx = xyz.contiguous(), new_xyz.contiguous(), feats_cl.contiguous(), idx.contiguous()
+    out = torch.empty((B * m, chans[-1]), dtype=torch.float32, device=xyz.device)
+    with torch.cuda.device(xyz.device), _timed('sa_fused_eval', (B * m * ns, pool) + tuple(chans)):
+        rc = lib.eda_sa_fused_eval_f32(
+            xyz.data_ptr(), new_xyz.data_ptr(), feats_cl.data_ptr(), idx.data_ptr(), B, N, m, ns, C, float(cfg["radius"]),
+            int(bool(cfg["normalize_xyz"])), len(layers), chan_arr, _ptr_array(Ws), _ptr_array([bn.weight for bn in bns]),
+            _ptr_array([bn.bias for bn in bns]), _ptr_array([bn.running_mean for bn in bns]),
+            _ptr_array([bn.running_var for bn in bns]), float(cfg["eps"]), out.data_ptr(), _stream())
+    _lib.check(rc, "eda_sa_fused_eval_f32")
+    return out
+
+
 def _fusable(layers):
     from . import sync_bn
     if sync_bn.enabled() and not sync_bn.fused_hook_installed():
@@ -326,6 +356,10 @@ def fused_mlp(mlp, pool, x_rows=None, xyz=None, new_xyz=None, feats_cl=None, idx
     params = []
     for layer, bn in zip(layers, bns):
         params += [layer.conv.weight, bn.weight, bn.bias]
+    if idx is not None and not cfg["training"] and not torch.is_grad_enabled() and _ONE_PASS_EVAL:
+        out = _one_pass_eval(cfg, xyz, new_xyz, feats_cl, idx, layers, bns, pool)
+        if out is not None:
+            return out
     out = FusedMLP.apply(cfg, x_rows, xyz, new_xyz, feats_cl, idx, *params)
     if training:
         for bn in bns:

@@ -606,6 +606,20 @@ int eda_gemm_set_dma(int mode);
 typedef int (*eda_bn_sync_fn)(void *user, double *buf, long n, void *stream);
 int eda_set_bn_sync(eda_bn_sync_fn fn, void *user, int world);
 
+/* ---- inference: a whole set-abstraction level in ONE launch (csrc/sa_eval.hip) ----
+ * QueryAndGroup rows (pointnet2/pointnet2_utils.py:317-376) -> 3 x [conv1x1, BatchNorm on RUNNING statistics, ReLU]
+ * (pointnet2/pytorch_utils.py:67-120 in eval mode) -> max over the nsample rows of a centre
+ * (pointnet2/pointnet2_modules.py:251-257); only out (b*m, channels[3]) is written -- SURVEY 8d's fused-layer bytes.
+ * Built for the backbone's SA1: c_feat = 3, channels = {6, 64, 64, 128} (eda_sa_fused_eval_supported() says so; other
+ * stacks take eda_sa_fused_fwd_f32 with training = 0).  Layers 2 and 3 run as bf16 x 3 on the bf16 matrix pipe (fp32
+ * accuracy).  weight[l]: (channels[l+1], channels[l]) row-major, xyz columns first. */
+int eda_sa_fused_eval_supported(int c_feat, int nlayers, const int *channels, int ns);
+int eda_sa_fused_eval_f32(const float *xyz, const float *new_xyz, const float *feats_cl, const int *idx, int b, int n, int m,
+                          int ns, int c_feat, float radius, int normalize_xyz, int nlayers, const int *channels,
+                          const float *const *weight, const float *const *gamma, const float *const *beta,
+                          const float *const *running_mean, const float *const *running_var, float eps, float *out,
+                          void *stream);
+
 /* ---- SyncBatchNorm without collectives: the statistics exchange through peer-mapped memory (csrc/peer.h, peer.hip) ----
  * The reference converts every BatchNorm to SyncBatchNorm at N > 1 (main_utils.py:336-338).  Here every rank (one process
  * per GPU of ONE node, <= 8) owns a slab of device memory that the other processes map (hipIpc*); a kernel that has a

@@ -56,6 +56,28 @@ torch.cuda.synchronize()
 ''' % ROOT
 
 
+DRIVER_SA1_EVAL = r'''
+import sys, os
+sys.path.insert(0, %r)
+os.environ["ITERS"] = "4"
+sys.argv = ["bench_sa_eval.py"]
+sys.path.insert(0, os.path.join(%r, "tools"))
+import bench_sa_eval
+bench_sa_eval.main()
+''' % (ROOT, ROOT)
+
+DRIVER_GEMM = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from eda_amd import gemm
+for R, K, N in ((2048, 288, 288), (8192, 288, 288)):
+    x = torch.randn(R, K, device="cuda"); w = torch.randn(N, K, device="cuda"); b = torch.randn(N, device="cuda")
+    for _ in range(6):
+        gemm.linear_fwd(x, w, b)
+torch.cuda.synchronize()
+''' % ROOT
+
+
 def run_pass(counter, script):
     d = tempfile.mkdtemp(prefix="pmc_")
     subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, script],
@@ -97,6 +119,32 @@ def main():
         {"op": "sa_fused_fwd", "dims": [1048576, 64, 1, 6, 64, 64, 128], "bytes_per_launch": sum(sa_parts.values()),
          "kernels": {k[:90]: v for k, v in sorted(sa_parts.items())}},
     ]
+    # round 5: the one-launch inference SA1 (csrc/sa_eval.hip) and the dominant critical-path row product
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(DRIVER_SA1_EVAL)
+        script_ev = f.name
+    fetch_ev, write_ev = run_pass("FETCH_SIZE", script_ev), run_pass("WRITE_SIZE", script_ev)
+    ev = [k for k in set(fetch_ev) | set(write_ev) if "sa_eval_kernel" in k]
+    if ev:
+        entries.append({"op": "sa_fused_eval", "dims": [8 * 2048 * 64, 64, 6, 64, 64, 128],
+                        "bytes_per_launch": sum((2.0 * fetch_ev.get(k, 0.0) + write_ev.get(k, 0.0)) * 1024.0 for k in ev)})
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(DRIVER_GEMM)
+        script_g = f.name
+    fetch_g, write_g = run_pass("FETCH_SIZE", script_g), run_pass("WRITE_SIZE", script_g)
+    # (both shapes run the same 32 x 32-tile kernel template; the two launches of a process are told apart by grid size:
+    # per-launch averages are taken per (kernel name) -- so one process per shape)
+    for (R_, K_, N_) in ((2048, 288, 288),):
+        drv = DRIVER_GEMM.replace("((2048, 288, 288), (8192, 288, 288))", "((%d, %d, %d),)" % (R_, K_, N_))
+        with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+            f.write(drv)
+            sg = f.name
+        fg, wg = run_pass("FETCH_SIZE", sg), run_pass("WRITE_SIZE", sg)
+        gk = [k for k in set(fg) | set(wg) if "gemm_rows_kernel" in k or "gemm_dma_kernel" in k]
+        if gk:
+            entries.append({"op": "gemm_fwd", "dims": [R_, K_, N_],
+                            "bytes_per_launch": sum((2.0 * fg.get(k, 0.0) + wg.get(k, 0.0)) * 1024.0 for k in gk),
+                            "kernels": {k[:90]: (2.0 * fg.get(k, 0.0) + wg.get(k, 0.0)) * 1024.0 for k in gk}})
     out = {"source_hash": bench.source_hash(),
            "how": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate passes, KiB -> bytes, per launch "
                   "(tools/measure_traffic.py)", "entries": entries}
