@@ -160,6 +160,14 @@ struct EdaDetScatter {
 };
 int eda_det_scatter_launch(const EdaDetScatter &a, hipStream_t stream);
 
+// __syncthreads() that also retires THIS wave's LDS-DMA (global_load_lds / buffer_load ... lds).  The compiler orders a
+// DMA only against the issuing wave's own later LDS reads: its s_waitcnt vmcnt lands in front of that read -- possibly
+// BEHIND the barrier the other waves rely on (mha3's loop-top barrier compiled to `s_waitcnt lgkmcnt(0); s_barrier` with
+// the vmcnt(0) after it), and a wave that does not read at all never waits.  Every barrier that publishes DMA'd LDS
+// data goes through this (round 5: the long-key attention forward gave 1e-4-off results once two processes shared the
+// GPU, exact on an idle one).
+#define EDA_SYNC_DMA() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
+
 // Zero-fill on the stream with a kernel (not hipMemsetAsync): memset NODES of a captured
 // HIP graph were observed to race with the kernel nodes that consume the zeroed buffer
 // on ROCm 7.2 (ball-query cell table corrupted under graph replay), kernel nodes are not.

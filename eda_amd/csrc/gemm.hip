@@ -1529,11 +1529,21 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_dma_kernel(const GemmArgs
   const int kbase = c_lo * KC;
   constexpr int AHEAD = NST - 1;
   constexpr int KEEP_HI = (NST - 2) * NPW, KEEP_LO = (NST - 2) * (NPW - 1);
+  // lgkmcnt(0) rides with every one of these waits: the barrier behind it hands the stage this chunk was READ from to
+  // the DMA of chunk ci + NST - 1 (issued right after it), and nothing orders a landing DMA piece behind a ds_read that is
+  // issued but not yet executed (guide: "restage a buffer 1 phase after its last ds_read only when an lgkmcnt before the
+  // barrier retired those reads").  The scheduler parks the chunk's last ds_read + MFMAs behind the s_barrier, so without
+  // the count that read crossed the barrier in flight: on a CU shared with another queue's LDS-heavy workgroups it came
+  // back with bytes of the next-but-one chunk's weight piece (round 5: the text encoder's 48-row products on the second
+  // stream of the pipelined step off by 1e-1 in 8-column stripes, one in three replays; never on an otherwise idle GPU,
+  // never at the 640-row shapes -- tools/dbg_pipeline_gemm.py is the reproducer).  The empty asm keeps the compiler from
+  // moving the reads across.
   auto wait_keep = [&]() {
-    if (REM != 0 && wave >= REM) __builtin_amdgcn_s_waitcnt((KEEP_LO & 15) | (7 << 4) | (15 << 8) | ((KEEP_LO >> 4) << 14));
-    else __builtin_amdgcn_s_waitcnt((KEEP_HI & 15) | (7 << 4) | (15 << 8) | ((KEEP_HI >> 4) << 14));
+    asm volatile("" ::: "memory");
+    if (REM != 0 && wave >= REM) __builtin_amdgcn_s_waitcnt((KEEP_LO & 15) | (7 << 4) | (0 << 8) | ((KEEP_LO >> 4) << 14));
+    else __builtin_amdgcn_s_waitcnt((KEEP_HI & 15) | (7 << 4) | (0 << 8) | ((KEEP_HI >> 4) << 14));
   };
-  constexpr int WAIT_ALL = (7 << 4) | (15 << 8);
+  constexpr int WAIT_ALL = (7 << 4) | (0 << 8);
 #pragma unroll
   for (int p = 0; p < AHEAD; ++p)
     if (p < nchunks) issue(kbase + p * KC, p);
@@ -1547,7 +1557,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_dma_kernel(const GemmArgs
     GSTAMP(1);
     multiply(smem + st_cur * STAGE);
     GSTAMP(2);
-    if (more && NST > 2) wait_keep(); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+    if (more && NST > 2) wait_keep(); else { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(WAIT_ALL); }
     GSTAMP(3);
     __builtin_amdgcn_s_barrier();
     GSTAMP(4);

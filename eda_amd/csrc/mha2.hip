@@ -398,20 +398,20 @@ __global__ __launch_bounds__(NQ * KS * 64) void mha2_fwd_kernel(const Mha2Args a
   const int c_lo = SPLIT ? sp * (a.keys_per_split / CHK) : 0;
   const int nchunks = SPLIT ? min((a.Lk + CHK - 1) / CHK, c_lo + a.keys_per_split / CHK) : (a.Lk + CHK - 1) / CHK;
   if (nchunks > c_lo) stage(Ks0, Vs0, dead_s[0], c_lo * CHK);
-  __syncthreads();
+  EDA_SYNC_DMA();
   for (int ci = c_lo; ci < nchunks; ci += NBUF) {
     // even chunk in buffer 0 (the next one is fetched into buffer 1 meanwhile), odd chunk in buffer 1
     if (NBUF == 2 && ci + 1 < nchunks) stage(Ks1, Vs1, dead_s[1], (ci + 1) * CHK);
     compute(Ks0, Vs0, dead_s[0], ci * CHK);
-    __syncthreads();
+    EDA_SYNC_DMA();
     if (NBUF == 2) {
       if (ci + 1 >= nchunks) break;
       if (ci + 2 < nchunks) stage(Ks0, Vs0, dead_s[0], (ci + 2) * CHK);
       compute(Ks1, Vs1, dead_s[1], (ci + 1) * CHK);
-      __syncthreads();
+      EDA_SYNC_DMA();
     } else if (ci + 1 < nchunks) {
       stage(Ks0, Vs0, dead_s[0], (ci + 1) * CHK);
-      __syncthreads();
+      EDA_SYNC_DMA();
     }
   }
 
@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args
   // DMA) during phase B instead of everybody doing it in front of phase A.
   constexpr bool STAGE_IN_B = NBUF == 2 && NW == 16 && 3 * NSUBQ <= 12;
   if (nchunks > 0) stage(Qs0, Ds0, lse_s[0], del_s[0], qbeg, 0, NW);
-  __syncthreads();
+  EDA_SYNC_DMA();
   PSTAMP(0);
   for (int ci = 0; ci < nchunks; ci += NBUF) {
     const int q0 = qbeg + ci * QC;
@@ -1015,35 +1015,35 @@ __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args
       PSTAMP(1);
       phase_a(Qs0, Ds0, lse_s[0], del_s[0], q0);
       PSTAMP(2);
-      __syncthreads();
+      EDA_SYNC_DMA();
       PSTAMP(3);
       if (STAGE_IN_B && ci + 1 < nchunks && wave >= 12) stage(Qs1, Ds1, lse_s[1], del_s[1], q0 + QC, 12, 4);
       phase_b(q0);
       PSTAMP(4);
-      __syncthreads();
+      EDA_SYNC_DMA();
       PSTAMP(5);
       if (ci + 1 >= nchunks) break;
       if (!STAGE_IN_B && ci + 2 < nchunks) stage(Qs0, Ds0, lse_s[0], del_s[0], q0 + 2 * QC, 0, NW);
       PSTAMP(1);
       phase_a(Qs1, Ds1, lse_s[1], del_s[1], q0 + QC);
       PSTAMP(2);
-      __syncthreads();
+      EDA_SYNC_DMA();
       PSTAMP(3);
       if (STAGE_IN_B && ci + 2 < nchunks && wave >= 12) stage(Qs0, Ds0, lse_s[0], del_s[0], q0 + 2 * QC, 12, 4);
       phase_b(q0 + QC);
       PSTAMP(4);
-      __syncthreads();
+      EDA_SYNC_DMA();
       PSTAMP(5);
     } else {
       phase_a(Qs0, Ds0, lse_s[0], del_s[0], q0);
       PSTAMP(2);
-      __syncthreads();
+      EDA_SYNC_DMA();
       PSTAMP(3);
       phase_b(q0);
       PSTAMP(4);
       if (ci + 1 < nchunks) stage(Qs0, Ds0, lse_s[0], del_s[0], q0 + QC, 0, NW);      // (Q / dO of this chunk are dead)
       PSTAMP(1);
-      __syncthreads();
+      EDA_SYNC_DMA();
       PSTAMP(5);
     }
   }

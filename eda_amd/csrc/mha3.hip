@@ -368,7 +368,7 @@ __global__ __launch_bounds__(NQ * KS * 64) void mha3_fwd_kernel(const Mha2Args a
   for (int ci = 0; ci < nchunks; ++ci) {
     float *cur = (ci & 1) ? stage1 : stage0, *nxt = (ci & 1) ? stage0 : stage1;
     unsigned *dcur = dead0 + (ci & 1) * (CHK / 4), *dnxt = dead0 + ((ci + 1) & 1) * (CHK / 4);
-    __syncthreads();                  // chunk ci has landed (the barrier's fence drains the DMA), the planes are free
+    EDA_SYNC_DMA();                   // chunk ci has landed (every wave waited for its own pieces), the planes are free
     if (!(DBG3 & 1) || ci == 0) convert(cur);
     __syncthreads();                  // planes ready; nothing in flight: the next chunk's DMA may start
     if (ci + 1 < nchunks) stage(nxt, dnxt, (ci + 1) * CHK);
