@@ -1370,16 +1370,28 @@ __device__ unsigned long long gemm_prof[64 * 8];
 // tile's ticket, and the last workgroup to arrive re-reads ALL slices with sc1 loads and adds them IN SLICE ORDER (so the
 // result does not depend on who arrives last: bit-reproducible), then runs the plain epilogue.  No fences
 // (cdna_hip_programming.md G16 form R1; MI355X_MICROARCH.md rows publish-large / splitk-seam).
-template <int BM, int BN, int NWM, int NWN, int WMODE, int NST, bool LN = false, bool SK = false>
+// KCT: the chunk length.  96 (three of the 32-wide chunks per barrier phase; every contraction length of the decoder is a
+// multiple: 288, 576, 864) is for the launches with so few tiles that the per-chunk barrier + DMA round trip is what they
+// spend their time on.  The MFMA sequence (16-wide k blocks in ascending order) does not depend on KCT: bitwise the same
+// results.  A row is KCT / 4 granules; the XOR stays inside a group of 8 granules (32 floats = 32 banks), rows alternate
+// between the two halves of the banks when KCT = 96 (96 floats = 1.5 x 64 banks): 16 rows x one granule still hit every
+// bank once.
+template <int BM, int BN, int NWM, int NWN, int WMODE, int NST, bool LN = false, bool SK = false, int KCT = 32>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_dma_kernel(const GemmArgs a) {
   static_assert(!(LN && SK), "the LayerNorm epilogue is not built for a split contraction");
-  constexpr int KC = 32, NW = NWM * NWN;
+  static_assert(KCT % 32 == 0 && (BM * KCT) % 256 == 0 && (BN * KCT) % 256 == 0, "whole 1 KB pieces");
+  static_assert(!SK || KCT == 32, "the slice plan counts 32-wide chunks");
+  constexpr int KC = KCT, GR = KC / 4, NW = NWM * NWN;
   constexpr int WR = BM / NWM / 16, WC = BN / NWN / 16;
   static_assert(WR * 16 * NWM == BM && WC * 16 * NWN == BN, "wave tiles must be multiples of 16");
   constexpr int XF = BM * KC, WF = BN * KC, STAGE = XF + WF;      // floats
-  constexpr int XP = BM / 8, WP = BN / 8, NP = XP + WP;           // 1 KB pieces of the row / weight tile
+  constexpr int XP = BM * KC / 256, WP = BN * KC / 256, NP = XP + WP;   // 1 KB pieces of the row / weight tile
   constexpr int NPW = (NP + NW - 1) / NW, REM = NP % NW;          // pieces per wave (waves >= REM: one less if REM)
-  __shared__ __attribute__((aligned(1024))) float smem[NST * STAGE];
+  // (more than 64 KB of stages: dynamic LDS, the launcher raises the limit)
+  constexpr bool DYN_LDS = (size_t)NST * STAGE * 4 > 65536;
+  __shared__ __attribute__((aligned(1024))) float smem_static[DYN_LDS ? 256 : NST * STAGE];
+  extern __shared__ __attribute__((aligned(1024))) float smem_dyn[];
+  float *smem = DYN_LDS ? smem_dyn : smem_static;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_m = wave / NWN, wave_n = wave % NWN;
   const int xcd = blockIdx.x & 7;
@@ -1418,13 +1430,13 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_dma_kernel(const GemmArgs
     dst[i] = p * 256;
     src[i] = a.x;
     if (p < XP) {
-      const int r = 8 * p + (lane >> 3), g = (lane & 7) ^ ((r >> 1) & 7);
+      const int gi = 64 * p + lane, r = gi / GR, gs = gi - GR * r, g = (gs & ~7) | ((gs & 7) ^ ((r >> 1) & 7));
       long row = row0 + r;
       if (row > R - 1) row = R - 1;
       src[i] = a.x + row * a.ldx + 4 * g;
     } else if (p < NP) {
       if (WMODE == W_NT) {
-        const int r = 8 * (p - XP) + (lane >> 3), g = (lane & 7) ^ ((r >> 1) & 7);
+        const int gi = 64 * (p - XP) + lane, r = gi / GR, gs = gi - GR * r, g = (gs & ~7) | ((gs & 7) ^ ((r >> 1) & 7));
         int n = n0 + r;
         if (n > N - 1) n = N - 1;
         src[i] = a.w + (long)n * a.ldw + 4 * g;
@@ -1498,15 +1510,15 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_dma_kernel(const GemmArgs
   }
   auto multiply = [&](const float *st) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < KC / 16; ++h) {               // k block h = granules 4 h .. 4 h + 3: group h >> 1 of 8 granules, half h & 1
       f32x4 xv[WR], wv[WC];
 #pragma unroll
-      for (int i = 0; i < WR; ++i) xv[i] = *reinterpret_cast<const f32x4 *>(st + xo[i][h]);
+      for (int i = 0; i < WR; ++i) xv[i] = *reinterpret_cast<const f32x4 *>(st + xo[i][h & 1] + 32 * (h >> 1));
 #pragma unroll
       for (int j = 0; j < WC; ++j) {
-        if (WMODE == W_NT) wv[j] = *reinterpret_cast<const f32x4 *>(st + wo[j][h]);
+        if (WMODE == W_NT) wv[j] = *reinterpret_cast<const f32x4 *>(st + wo[j][h & 1] + 32 * (h >> 1));
         else {
-          const float *wp = st + wo[j][h];
+          const float *wp = st + wo[j][h & 1] + 32 * (h >> 1) * BN;
           wv[j][0] = wp[0]; wv[j][1] = wp[BN]; wv[j][2] = wp[2 * BN]; wv[j][3] = wp[3 * BN];
         }
       }
@@ -1848,6 +1860,13 @@ size_t splitk_bytes(long R, int N, int slices) {
   return SK_TICKET_BYTES + (size_t)tiles * slices * c.bm * c.bn * sizeof(float);
 }
 
+// 96-wide chunks (gemm_dma_kernel KCT = 96): which tile for which launch.  0 = none.
+int kc96_config(const GemmArgs &a) {
+  const long env = eda_knob(EDA_K_GEMM_KC96);
+  if (env >= 0) return (int)env;
+  return 0;
+}
+
 template <int BM, int BN, int NWM, int NWN, int NST>
 int launch_dma1_sk(GemmArgs &a, int wmode, int slices, void *ws, hipStream_t stream) {
   a.row_blocks = (a.R + BM - 1) / BM;
@@ -1872,11 +1891,23 @@ int launch_dma1_sk(GemmArgs &a, int wmode, int slices, void *ws, hipStream_t str
   return 0;
 }
 
-template <int BM, int BN, int NWM, int NWN, int NST>
+template <int BM, int BN, int NWM, int NWN, int NST, int KCT = 32>
 int launch_dma1(GemmArgs &a, int wmode, hipStream_t stream) {
   a.row_blocks = (a.R + BM - 1) / BM;
   a.col_tiles = (a.N + BN - 1) / BN;
   const int force_map = (int)eda_knob(EDA_K_GEMM_DMA_MAP);
+  constexpr size_t LDSB = (size_t)NST * (BM + BN) * KCT * 4;
+  constexpr unsigned DYN = LDSB > 65536 ? (unsigned)LDSB : 0u;
+  if (DYN) {
+    static bool raised[2] = {false, false};
+    if (!raised[wmode == W_NN]) {
+      hipError_t e = wmode == W_NN
+          ? eda_set_max_dynamic_lds(reinterpret_cast<const void *>(gemm_dma_kernel<BM, BN, NWM, NWN, W_NN, NST, false, false, KCT>), DYN)
+          : eda_set_max_dynamic_lds(reinterpret_cast<const void *>(gemm_dma_kernel<BM, BN, NWM, NWN, W_NT, NST, false, false, KCT>), DYN);
+      if (e != hipSuccess) { eda_set_error("gemm: cannot raise the LDS limit: %s", hipGetErrorString(e)); return (int)e; }
+      raised[wmode == W_NN] = true;
+    }
+  }
   {
     // bytes an XCD pulls through its L2 under either mapping
     const double xb = 4.0 * a.R * a.K, wb = 4.0 * a.N * a.K;
@@ -1886,8 +1917,8 @@ int launch_dma1(GemmArgs &a, int wmode, hipStream_t stream) {
                                        : (long)((a.col_tiles + 7) / 8) * 8 * a.row_blocks;
   if (blocks > 0x7fffffffL) { eda_set_error("gemm: grid too large"); return EDA_ERR_INVALID_ARG; }
   const dim3 grid((unsigned)blocks), block(64 * NWM * NWN);
-  if (wmode == W_NN) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, NWM, NWN, W_NN, NST>), grid, block, 0, stream, a);
-  else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, NWM, NWN, W_NT, NST>), grid, block, 0, stream, a);
+  if (wmode == W_NN) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, NWM, NWN, W_NN, NST, false, false, KCT>), grid, block, DYN, stream, a);
+  else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, NWM, NWN, W_NT, NST, false, false, KCT>), grid, block, DYN, stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { eda_set_error("gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
   return 0;
@@ -2099,6 +2130,20 @@ int eda_gemm_launch(GemmArgs &a, int wmode, hipStream_t stream) {
     const int slices = splitk_slices(a.R, a.K, a.N);
     if (slices > 1 && a.sk_ws_bytes >= splitk_bytes(a.R, a.N, slices) && (reinterpret_cast<uintptr_t>(a.sk_ws) & 15u) == 0)
       return launch_dma1_sk<32, 96, 2, 2, 2>(a, wmode, slices, a.sk_ws, stream);
+  }
+  if (g_dma_mode() != 0 && a.K % 96 == 0 && dma_eligible(a)) {
+    const int cfg = kc96_config(a);
+    switch (cfg) {
+      case 1: return launch_dma1<32, 32, 2, 2, 2, 96>(a, wmode, stream);
+      case 2: return launch_dma1<32, 32, 2, 2, 3, 96>(a, wmode, stream);
+      case 3: return launch_dma1<32, 96, 2, 2, 2, 96>(a, wmode, stream);
+      case 4: return launch_dma1<32, 48, 2, 3, 2, 96>(a, wmode, stream);
+      case 5: return launch_dma1<32, 48, 2, 3, 3, 96>(a, wmode, stream);
+      case 6: return launch_dma1<64, 96, 2, 2, 2, 96>(a, wmode, stream);
+      case 7: return launch_dma1<16, 96, 1, 2, 3, 96>(a, wmode, stream);
+      case 8: return launch_dma1<32, 96, 2, 6, 2, 96>(a, wmode, stream);
+      default: break;
+    }
   }
   if (dma_takes(a, wmode)) return launch_dma(a, wmode, stream);
   // measured on MI355X (tools/bench_gemm.py, profiles/r02a_gemm_tiles.txt): the 64x64 tile at 5-6

@@ -91,6 +91,33 @@ def test_dma_staged_kernel_equals_register_staged_kernel(R, K, N, monkeypatch):
     assert float((base[0].double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("R,K,N", [(2048, 288, 288), (100, 288, 96), (640, 576, 288), (8192, 288, 576), (33, 96, 36), (2048, 864, 288)])
+def test_96_wide_chunks_equal_32_wide_chunks(R, K, N, monkeypatch):
+    """gemm_dma_kernel with KCT = 96 (EDA_GEMM_KC96 = tile configuration): three 32-wide chunks per barrier phase, the
+    same MFMA sequence -- forward (bias, ReLU / dropout / gate epilogues) and dX bit for bit equal to the kernels of
+    EDA_GEMM_KC96=0, for every tile configuration the dispatch can pick."""
+    from eda_amd import _lib, gemm
+    monkeypatch.setenv("EDA_GEMM_SPLITK", "0")
+    L = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(R + K + N)
+    x = torch.randn(R, K, device="cuda", generator=g); w = torch.randn(N, K, device="cuda", generator=g)
+    b = torch.randn(N, device="cuda", generator=g); dy = torch.randn(R, N, device="cuda", generator=g)
+    seed = torch.tensor([99], dtype=torch.int64, device="cuda")
+    gate = torch.randn(R, N, device="cuda", generator=g)
+
+    def run():
+        return (gemm.linear_fwd(x, w, b), gemm.linear_fwd(x, w, None, True), gemm.linear_dgrad(dy, w),
+                gemm.linear_ex(x, w, b, relu=True, drop=(0.1, seed, 7)), gemm.linear_ex(x, w, None, gate=(gate, 1.25)))
+    monkeypatch.setenv("EDA_GEMM_KC96", "0"); L.eda_reload_env()
+    base = run()
+    for cfg in range(1, 9):
+        monkeypatch.setenv("EDA_GEMM_KC96", str(cfg)); L.eda_reload_env()
+        for i, (got, want) in enumerate(zip(run(), base)):
+            assert torch.equal(got, want), (cfg, i, float((got - want).abs().max()))
+    ref = x.double() @ w.double().t() + b.double()
+    assert float((base[0].double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
 def test_strided_operands_and_outputs():
     """Column views of packed projection buffers (row stride 864) as inputs and outputs."""
     from eda_amd import gemm

@@ -22,7 +22,14 @@ EDA_FPS_BUCKET=1 python bench.py --in-step-steps 0 > $O/bench_fps_bucket.json 2>
 EDA_FPS_BUCKET=1 python bench.py --fps-prefetch 0 --in-step-steps 0 > $O/bench_fps_bucket_in_step.json 2> $O/bench_fps_bucket_in_step.err
 python bench.py --force-dist --in-step-steps 0 > $O/bench_force_dist.json 2> $O/bench_force_dist.err
 python bench.py --force-dist --overlap-allreduce 1 --in-step-steps 0 > $O/bench_force_dist_overlap.json 2> $O/bench_force_dist_overlap.err
-python bench.py --force-dist --sync-bn --in-step-steps 0 > $O/bench_force_dist_sync_bn.json 2> $O/bench_force_dist_sync_bn.err
+python bench.py --force-dist --sync-bn native --in-step-steps 0 > $O/bench_force_dist_sync_bn_native.json 2> $O/bench_force_dist_sync_bn_native.err
+python bench.py --force-dist --sync-bn collective --in-step-steps 0 > $O/bench_force_dist_sync_bn_collective.json 2> $O/bench_force_dist_sync_bn_collective.err
+# round 5: ordered scatter sums, split contraction / key split / bf16x3 forward off, the races' reproducer, queue gaps
+python bench.py --deterministic 1 --in-step-steps 0 > $O/bench_deterministic.json 2> $O/bench_deterministic.err
+EDA_GEMM_SPLITK=0 python bench.py --in-step-steps 0 > $O/bench_splitk_off.json 2> $O/bench_splitk_off.err
+EDA_MHA3=0 EDA_MHA2_KSPLIT=0 python bench.py --in-step-steps 0 > $O/bench_mha3_ksplit_off.json 2> $O/bench_mha3_ksplit_off.err
+python tools/dbg_pipeline_gemm.py 12 > $O/dbg_pipeline_gemm.txt 2>&1
+python tools/bench_sa_eval.py > $O/sa_eval.txt 2>&1
 EDA_MHA_QPROJ=0 python bench.py --in-step-steps 0 > $O/bench_qproj_off.json 2> $O/bench_qproj_off.err
 EDA_WGRAD_BF16X3=0 python bench.py --in-step-steps 0 > $O/bench_wgrad_fp32_mfma.json 2> $O/bench_wgrad_fp32_mfma.err
 EDA_BATCHED_HEADS=0 python bench.py --in-step-steps 0 > $O/bench_heads_per_head.json 2> $O/bench_heads_per_head.err
@@ -35,6 +42,10 @@ rm -rf /tmp/pe
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pe -o eager -- python bench.py --steps 20 --warmup 3 --graph 0 --cpu-scenes 0 > $O/bench_eager_under_rocprof.json 2> $O/bench_eager.err
 find /tmp/pe -name "*kernel_stats.csv" -exec cp {} $O/bench_eager_kernel_stats_rocprofv3.csv \;
 python tools/summarize_profile.py $tag 23 $O/bench_eager_kernel_stats_rocprofv3.csv $O/bench_default.json $O/bench_eager_under_rocprof.json > $O/summary.md 2> $O/summary.err
+rm -rf /tmp/kt
+rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -- python bench.py --steps 10 --warmup 3 --in-step-steps 0 --cpu-scenes 0 > $O/bench_under_trace.json 2>/dev/null
+python tools/queue_gaps.py /tmp/kt 10 > $O/queue_gaps.txt 2>&1
+tools/prof_gemm_shapes.sh ${tag} > /dev/null 2>&1
 tools/prof_mha.sh ${tag}_f32 > /dev/null 2>&1
 ATTN_DTYPE=bf16 tools/prof_mha.sh ${tag}_bf16 > /dev/null 2>&1
 python - "$O" <<'PY'
