@@ -1387,11 +1387,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_dma_kernel(const GemmArgs
   constexpr int XF = BM * KC, WF = BN * KC, STAGE = XF + WF;      // floats
   constexpr int XP = BM * KC / 256, WP = BN * KC / 256, NP = XP + WP;   // 1 KB pieces of the row / weight tile
   constexpr int NPW = (NP + NW - 1) / NW, REM = NP % NW;          // pieces per wave (waves >= REM: one less if REM)
-  // (more than 64 KB of stages: dynamic LDS, the launcher raises the limit)
-  constexpr bool DYN_LDS = (size_t)NST * STAGE * 4 > 65536;
-  __shared__ __attribute__((aligned(1024))) float smem_static[DYN_LDS ? 256 : NST * STAGE];
-  extern __shared__ __attribute__((aligned(1024))) float smem_dyn[];
-  float *smem = DYN_LDS ? smem_dyn : smem_static;
+  __shared__ __attribute__((aligned(1024))) float smem[NST * STAGE];      // (static LDS may exceed 64 KB on gfx950: up to 160 KB)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_m = wave / NWN, wave_n = wave % NWN;
   const int xcd = blockIdx.x & 7;
@@ -1864,6 +1860,12 @@ size_t splitk_bytes(long R, int N, int slices) {
 int kc96_config(const GemmArgs &a) {
   const long env = eda_knob(EDA_K_GEMM_KC96);
   if (env >= 0) return (int)env;
+  // measured (tools/bench_gemm_kc96.py, profiles/r05_gemm_kc96.txt; us per launch inside a replayed graph): the 32 x 32 tile
+  // with two 96-wide stages wins wherever the contraction is short and the launch small -- 2048 x 288 -> 288: 9.7 -> 7.9,
+  // 640 x 288 -> 288: 6.1 -> 4.8, 2048 x 288 -> 576: 13.1 -> 11.5 -- and loses from 8192 rows on (16.0 -> 18.6: there the
+  // 32 x 96 tile's smaller L2 -> LDS traffic counts)
+  const long tiles32 = ((a.R + 31) / 32) * ((a.N + 31) / 32);
+  if (a.K <= 384 && tiles32 <= 1152) return 1;
   return 0;
 }
 
@@ -1896,18 +1898,7 @@ int launch_dma1(GemmArgs &a, int wmode, hipStream_t stream) {
   a.row_blocks = (a.R + BM - 1) / BM;
   a.col_tiles = (a.N + BN - 1) / BN;
   const int force_map = (int)eda_knob(EDA_K_GEMM_DMA_MAP);
-  constexpr size_t LDSB = (size_t)NST * (BM + BN) * KCT * 4;
-  constexpr unsigned DYN = LDSB > 65536 ? (unsigned)LDSB : 0u;
-  if (DYN) {
-    static bool raised[2] = {false, false};
-    if (!raised[wmode == W_NN]) {
-      hipError_t e = wmode == W_NN
-          ? eda_set_max_dynamic_lds(reinterpret_cast<const void *>(gemm_dma_kernel<BM, BN, NWM, NWN, W_NN, NST, false, false, KCT>), DYN)
-          : eda_set_max_dynamic_lds(reinterpret_cast<const void *>(gemm_dma_kernel<BM, BN, NWM, NWN, W_NT, NST, false, false, KCT>), DYN);
-      if (e != hipSuccess) { eda_set_error("gemm: cannot raise the LDS limit: %s", hipGetErrorString(e)); return (int)e; }
-      raised[wmode == W_NN] = true;
-    }
-  }
+  static_assert((size_t)NST * (BM + BN) * KCT * 4 <= 160 * 1024, "stages must fit the LDS");
   {
     // bytes an XCD pulls through its L2 under either mapping
     const double xb = 4.0 * a.R * a.K, wb = 4.0 * a.N * a.K;
@@ -1917,8 +1908,8 @@ int launch_dma1(GemmArgs &a, int wmode, hipStream_t stream) {
                                        : (long)((a.col_tiles + 7) / 8) * 8 * a.row_blocks;
   if (blocks > 0x7fffffffL) { eda_set_error("gemm: grid too large"); return EDA_ERR_INVALID_ARG; }
   const dim3 grid((unsigned)blocks), block(64 * NWM * NWN);
-  if (wmode == W_NN) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, NWM, NWN, W_NN, NST, false, false, KCT>), grid, block, DYN, stream, a);
-  else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, NWM, NWN, W_NT, NST, false, false, KCT>), grid, block, DYN, stream, a);
+  if (wmode == W_NN) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, NWM, NWN, W_NN, NST, false, false, KCT>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, NWM, NWN, W_NT, NST, false, false, KCT>), grid, block, 0, stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { eda_set_error("gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
   return 0;
