@@ -71,6 +71,11 @@ def _packed_like(tensors):
     return buf, views
 
 
+# TIMING EXPERIMENTS ONLY (the step then trains on stale prefetch results): EDA_TIMING_SKIP_SIDE=fps,text leaves the second
+# stream's graphs out of step() -- what the main stream costs alone (profiles/r05_side_stream_interference.md)
+_TIMING_SKIP = os.environ.get("EDA_TIMING_SKIP_SIDE", "").split(",")
+
+
 class PipelinedTrainStep:
     def __init__(self, model, first_batch, loss_fn, backward_fn, update_fn, *, stream=None, all_reduce=None,
                  split_update=False, prefetch="sa1", text_prefetch=True, after_loss=None, sa1_samples=2048,
@@ -230,9 +235,9 @@ class PipelinedTrainStep:
                 self.ev_text.record(self.side)
             if next_batch is not None:
                 self._feed(next_batch)
-            if self.g_fps is not None:
+            if self.g_fps is not None and "fps" not in _TIMING_SKIP:
                 self.g_fps.replay()
-            if self.text_prefetch:
+            if self.text_prefetch and "text" not in _TIMING_SKIP:
                 self.g_text.replay()
             self.ev_fps.record(self.side)          # (one event: the next point graph waits for all of it)
         if not self.text_prefetch:
