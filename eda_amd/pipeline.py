@@ -21,6 +21,8 @@ Every step executes exactly one sampling and one text-encoder pass (nothing is c
 with alternating batches and checks, per step, that the indices used are the FPS of the batch being trained and that
 the loss history equals eager training on the same sequence.
 """
+import os
+
 import torch
 
 from . import attention, ext, pointnet2_utils
