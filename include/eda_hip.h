@@ -171,7 +171,11 @@ int eda_three_interpolate_grad_f32(const float *grad_out, const int *idx,
  * Dropout (p_drop > 0): keep mask = hash(*seed_ptr, salt, b,h,q,k), regenerated
  * identically by the backward; seed_ptr is a DEVICE counter so that a replayed
  * HIP graph draws a fresh mask whenever the host bumps the counter.
- * fp32 in / fp32 accumulate on v_mfma_f32_16x16x4_f32.                      */
+ * fp32 in / fp32 accumulate on v_mfma_f32_16x16x4_f32 (csrc/mha2.hip); the forward
+ * for >= 512 queries against >= 512 keys runs on v_mfma_f32_16x16x32_bf16 with
+ * the operands split into three bf16 planes (h + m + l = the fp32 value exactly,
+ * six plane products, fp32 softmax and accumulators: csrc/mha3.hip; same error
+ * bounds against fp64, EDA_MHA3=0 keeps the fp32-MFMA kernel).               */
 int eda_mha_fwd_f32(const float *q, const float *k, const float *v, long q_sb, long q_sl,
                     long k_sb, long k_sl, long v_sb, long v_sl,
                     const unsigned char *key_padding_mask, int B, int H, int Lq, int Lk,

@@ -160,7 +160,7 @@ def run_full_model(dev, butd, tag=None, attn_dtype="f32"):
     """Full BeaUTyDETR forward against the reference's golden `model_full_<tag>.npz`.
 
     attn_dtype "bf16" / "f16" (GPU only): BASELINE.json configs[2] / configs[4] -- the QK^T / PV contractions of every
-    attention run on the 16-bit MFMA path (csrc/mha16.hip), everything else stays fp32.  Decision recorded here: the
+    attention run on the 16-bit MFMA path (csrc/mha2.hip, ArBf16 / ArF16), everything else stays fp32.  Decision recorded here: the
     seed objectness / query top-k is NOT special-cased -- it reads encoder features that went through the 16-bit
     attention, exactly as a mixed-precision run of the reference would.  The test therefore (1) counts how many of
     the selected queries differ from the golden's (the fixtures have a gap of >= 2e-4 in sigmoid space at the k / k+1

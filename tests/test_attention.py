@@ -2,7 +2,7 @@
 CPU: the torch restatement (oracle/attention_ref.py) is pinned against
 torch.nn.MultiheadAttention -- the module the reference instantiates -- through
 this repo's MultiheadAttention (same parameters, batch-first).
-GPU: the fused HIP kernels (csrc/mha.hip) against that restatement: outputs and
+GPU: the fused HIP kernels (csrc/mha2.hip; the long-key forward csrc/mha3.hip) against that restatement: outputs and
 gradients <= 1e-4 relative (fp32 MFMA), masks, ragged lengths, strided (packed
 QKV) inputs, and the dropout path (keep rate, fwd/bwd mask consistency)."""
 import numpy as np
@@ -241,7 +241,7 @@ def test_module_on_gpu_matches_torch_multiheadattention(case, batch_first):
         assert (g - e).abs().max().item() <= 2e-4 * scale + 1e-6, (name, (g - e).abs().max().item(), scale)
 
 
-# ------------------------------------------------------------------ 16-bit MFMA variants (csrc/mha16.hip)
+# ------------------------------------------------------------------ 16-bit MFMA variants (csrc/mha2.hip, ArBf16 / ArF16)
 # Tolerance (documented, BASELINE.json configs[2]/[4]): the contractions take bf16 / fp16 OPERANDS (8 / 11
 # significant bits: unit roundoff 3.9e-3 / 4.9e-4) and accumulate in fp32; Q, K, V, P, dS and dO are each
 # rounded once, so scores carry ~2u relative error, probabilities ~2u|s|, outputs / gradients a few u of the
