@@ -1172,8 +1172,10 @@ BwdPlan bwd_plan(int B, int H, int Lq, int Lk) {
   p.n_kb = (Lk + 16 * ksub - 1) / (16 * ksub);
   if (p.n_kb < 1) p.n_kb = 1;
   const int chunks = Lq > 0 ? (Lq + qc - 1) / qc : 1;
-  // enough workgroups to fill 256 CUs (x 2 where two fit a CU), but no more query splits than chunks
-  const long want_wgs = p.variant == 0 ? 256 : 512;
+  // enough workgroups to fill 256 CUs, but no more query splits than chunks
+  // (one workgroup per CU and ONE round of them: the short-key variants planned for 512 until round 5 -- 1024 x 80 then ran
+  //  384 workgroups of 15 waves in two rounds, 54.3 us; 256: 41.6 us, 1024 x 132 67.8 -> 61.6; profiles/r05_mha_bwd_wgs.txt)
+  const long want_wgs = 256;
   long n_qs = (want_wgs + BH * p.n_kb - 1) / (BH * p.n_kb);
   if (n_qs < 1) n_qs = 1;
   if (n_qs > chunks) n_qs = chunks;
