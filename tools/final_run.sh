@@ -27,6 +27,8 @@ python bench.py --force-dist --sync-bn collective --in-step-steps 0 > $O/bench_f
 # round 5: ordered scatter sums, split contraction / key split / bf16x3 forward off, the races' reproducer, queue gaps
 python bench.py --deterministic 1 --in-step-steps 0 > $O/bench_deterministic.json 2> $O/bench_deterministic.err
 EDA_GEMM_SPLITK=0 python bench.py --in-step-steps 0 > $O/bench_splitk_off.json 2> $O/bench_splitk_off.err
+EDA_GEMM_KC96=0 python bench.py --in-step-steps 0 > $O/bench_kc96_off.json 2> $O/bench_kc96_off.err
+EDA_TIMING_SKIP_SIDE=fps,text python bench.py --in-step-steps 0 > $O/bench_main_stream_alone_TIMING_ONLY.json 2> /dev/null
 EDA_MHA3=0 EDA_MHA2_KSPLIT=0 python bench.py --in-step-steps 0 > $O/bench_mha3_ksplit_off.json 2> $O/bench_mha3_ksplit_off.err
 python tools/dbg_pipeline_gemm.py 12 > $O/dbg_pipeline_gemm.txt 2>&1
 python tools/bench_sa_eval.py > $O/sa_eval.txt 2>&1
