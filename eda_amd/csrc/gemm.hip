@@ -1865,7 +1865,7 @@ int kc96_config(const GemmArgs &a) {
   // 640 x 288 -> 288: 6.1 -> 4.8, 2048 x 288 -> 576: 13.1 -> 11.5 -- and loses from 8192 rows on (16.0 -> 18.6: there the
   // 32 x 96 tile's smaller L2 -> LDS traffic counts)
   const long tiles32 = ((a.R + 31) / 32) * ((a.N + 31) / 32);
-  if (a.K <= 384 && tiles32 <= 1152) return 1;
+  if (a.K <= 864 && tiles32 <= 1152) return 1;
   return 0;
 }
 
@@ -2117,7 +2117,11 @@ int eda_gemm_launch(GemmArgs &a, int wmode, hipStream_t stream) {
     if (rc >= 0) return rc;
   }
   if (!gemm_vec_ok(a, wmode)) return launch_cfg<1, 4, false>(a, wmode, stream);
-  if (a.sk_ws && g_dma_mode() != 0 && dma_eligible(a)) {
+  // (a contraction of <= 864 with few tiles: the 96-wide chunks unsplit beat the split 32-wide ones -- 640 x 768 -> 768 14.2 ->
+  //  11.3 us, 2048 x 576 -> 288 14.6 -> 12.1, 640 x 576 -> 288 9.4 -> 6.5; from 3072 on the two are level and the split stays)
+  const bool kc96_first = g_dma_mode() != 0 && a.K % 96 == 0 && a.K <= 864 && dma_eligible(a) && kc96_config(a) == 1 &&
+                          eda_knob(EDA_K_GEMM_SPLITK) <= 0;        // (a forced slice count keeps the split: tests)
+  if (!kc96_first && a.sk_ws && g_dma_mode() != 0 && dma_eligible(a)) {
     const int slices = splitk_slices(a.R, a.K, a.N);
     if (slices > 1 && a.sk_ws_bytes >= splitk_bytes(a.R, a.N, slices) && (reinterpret_cast<uintptr_t>(a.sk_ws) & 15u) == 0)
       return launch_dma1_sk<32, 96, 2, 2, 2>(a, wmode, slices, a.sk_ws, stream);
