@@ -33,7 +33,7 @@ def timed(fn, n=50, reps=20):
 def main():
     shapes = [tuple(int(v) for v in s.split("x")) for s in (sys.argv[1] if len(sys.argv) > 1 else DEFAULT).split()]
     L = _lib.lib()
-    cfgs = [-1, 0] + list(range(1, 9))
+    cfgs = [-1, 0] + [int(c) for c in os.environ.get("CFGS", "1 2 3 4 5 6 7 8").split()]
     print("%-16s %-6s " % ("R x K x N", "form") + " ".join("%7s" % ("dflt" if c < 0 else "kc96=%d" % c) for c in cfgs))
     for R, K, N in shapes:
         x = torch.randn(R, K, device="cuda"); w = torch.randn(N, K, device="cuda"); b = torch.randn(N, device="cuda")
