@@ -263,6 +263,8 @@ def cpu_baseline(args):
 def run_cpu_baseline(args):
     """Host-CPU leg in a child process (own thread pools, hard time limit)."""
     import subprocess
+    if args.cpu_scenes <= 0:
+        return {"value": None, "unit": "scenes/s", "cores": None, "kind": "port", "sample": "skipped (--cpu-scenes 0)"}
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only",
            "--cpu-scenes", str(args.cpu_scenes), "--cpu-threads", str(args.cpu_threads),
            "--points", str(args.points), "--queries", str(args.queries), "--tokens", str(args.tokens)]
