@@ -49,6 +49,9 @@ SIGNATURES = {
     "eda_linear_add_dropout_ln_supported": (_i, [_i, _i]),
     "eda_linear_add_dropout_ln_fwd_f32": (_i, [_p, _l, _l, _i, _p, _l, _i, _p, _p, _p, _p, _f, _f, _p, _u, _p, _p, _p, _p,
                                                _p, _p, _p]),
+    "eda_linear_add_dropout_ln_workspace_bytes": (_sz, [_l, _i, _i]),
+    "eda_linear_add_dropout_ln_fwd_ws_f32": (_i, [_p, _l, _l, _i, _p, _l, _i, _p, _p, _p, _p, _f, _f, _p, _u, _p, _p, _p, _p,
+                                                  _p, _p, _p, _sz, _p]),
     "eda_add_dropout_ln_bwd_workspace_bytes": (_sz, [_l, _i]),
     "eda_add_dropout_ln_bwd_blocks": (_i, [_l]),
     "eda_ln_reduce_grouped_f32": (_i, [_p, _i, _i, _p]),

@@ -1378,7 +1378,6 @@ __device__ unsigned long long gemm_prof[64 * 8];
 // bank once.
 template <int BM, int BN, int NWM, int NWN, int WMODE, int NST, bool LN = false, bool SK = false, int KCT = 32>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_dma_kernel(const GemmArgs a) {
-  static_assert(!(LN && SK), "the LayerNorm epilogue is not built for a split contraction");
   static_assert(KCT % 32 == 0 && (BM * KCT) % 256 == 0 && (BN * KCT) % 256 == 0, "whole 1 KB pieces");
   static_assert(!SK || KCT == 32, "the slice plan counts 32-wide chunks");
   constexpr int KC = KCT, GR = KC / 4, NW = NWM * NWN;
@@ -2194,12 +2193,39 @@ static void gemm_defaults(GemmArgs &a) {
 // ---- C ABI: linear layer + residual + Dropout + LayerNorm in one launch ----------------------------------
 extern "C" int eda_linear_add_dropout_ln_supported(int K, int N) { return N == 288 && K >= 32 && K % 32 == 0; }
 
+// Up to 2048 rows the 16-row blocks are at most 128 workgroups of a kernel that streams the WHOLE weight per block (2048 rows:
+// 128 workgroups on 256 CUs): with scratch, two workgroups share a block's contraction (split as in gemm_dma_kernel SK: ordered,
+// reproducible) and the last one to arrive runs the LayerNorm epilogue.
+static int ln_splitk_slices(long R, int K) {
+  const long env = eda_knob(EDA_K_GEMM_SPLITK);
+  if (env == 0 || K < 256 || eda_knob(EDA_K_GEMM_LN_VAR) == 1) return 1;      // (EDA_GEMM_LN_VAR=1: this split alone off)
+  // measured (tools/time_linear_ln.py, us per launch in a replayed graph, K = 288): 640 rows 14.6 -> 13.0, 1024 14.7 -> 13.3,
+  // 2048 15.2 -> 14.0; 3072 rows (384 workgroups of 6 waves, 78 KB each) 15.7 -> 20.7: up to 128 row blocks only
+  if ((R + 15) / 16 > 128) return 1;
+  return 2;
+}
+extern "C" size_t eda_linear_add_dropout_ln_workspace_bytes(long R, int K, int N) {
+  if (R <= 0 || !eda_linear_add_dropout_ln_supported(K, N)) return 0;
+  const int s = ln_splitk_slices(R, K);
+  return s > 1 ? SK_TICKET_BYTES + (size_t)((R + 15) / 16) * s * 16 * 288 * sizeof(float) : 0;
+}
+
 extern "C" int eda_linear_add_dropout_ln_fwd_f32(const float *x, long ldx, long R, int K, const float *w, long ldw, int N,
                                                  const float *bias, const float *resid, const float *gamma,
                                                  const float *beta, float eps, float drop_p,
                                                  const unsigned long long *drop_seed, unsigned drop_salt, float *z,
                                                  float *out, float *mean, float *rstd, const float *pos, float *out_pos,
                                                  void *stream_) {
+  return eda_linear_add_dropout_ln_fwd_ws_f32(x, ldx, R, K, w, ldw, N, bias, resid, gamma, beta, eps, drop_p, drop_seed, drop_salt, z,
+                                              out, mean, rstd, pos, out_pos, nullptr, 0, stream_);
+}
+
+extern "C" int eda_linear_add_dropout_ln_fwd_ws_f32(const float *x, long ldx, long R, int K, const float *w, long ldw, int N,
+                                                    const float *bias, const float *resid, const float *gamma,
+                                                    const float *beta, float eps, float drop_p,
+                                                    const unsigned long long *drop_seed, unsigned drop_salt, float *z,
+                                                    float *out, float *mean, float *rstd, const float *pos, float *out_pos,
+                                                    void *ws, size_t ws_bytes, void *stream_) {
   EDA_CHECK_ARG(R >= 0 && ldx >= K && ldw >= K, "bad dimension");
   EDA_CHECK_ARG(eda_linear_add_dropout_ln_supported(K, N), "the fused kernel exists for N = 288 and K a multiple of 32");
   EDA_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || drop_seed), "dropout needs 0 <= p < 1 and a seed");
@@ -2230,6 +2256,18 @@ extern "C" int eda_linear_add_dropout_ln_fwd_f32(const float *x, long ldx, long 
   } else {
     a.row_blocks = (R + 15) / 16;
     const long blocks = (a.row_blocks + 7) / 8 * 8;
+    const int slices = ln_splitk_slices(R, K);
+    if (slices > 1 && ws && ws_bytes >= eda_linear_add_dropout_ln_workspace_bytes(R, K, N) && (reinterpret_cast<uintptr_t>(ws) & 15u) == 0) {
+      a.sk_tickets = reinterpret_cast<unsigned *>(ws);
+      a.sk_part = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(ws) + SK_TICKET_BYTES);
+      a.sk_slices = slices;
+      a.sk_cps = (K / 32 + slices - 1) / slices;
+      a.sk_per = blocks / 8;
+      hipLaunchKernelGGL((gemm_dma_kernel<16, 288, 1, 6, W_NT, 2, true, true>), dim3((unsigned)(blocks * slices)), dim3(384), 0, stream, a);
+      hipError_t e2 = hipGetLastError();
+      if (e2 != hipSuccess) { eda_set_error("linear_add_dropout_ln: launch failed: %s", hipGetErrorString(e2)); return (int)e2; }
+      return 0;
+    }
     // experiment switch (tools/bench_linear_ln.py): ring depth x waves of the 16-row variant
     const int var = (int)eda_knob(EDA_K_GEMM_LN_VAR);
     if (var == 63) hipLaunchKernelGGL((gemm_dma_kernel<16, 288, 1, 6, W_NT, 3, true>), dim3((unsigned)blocks), dim3(384), 0, stream, a);

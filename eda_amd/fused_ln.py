@@ -154,15 +154,20 @@ def _linear_ln_forward(inp2, W, b, x2, gamma, beta, eps, p_drop, salt, pos2, wan
     z = torch.empty_like(x2) if want_z else None
     stats = torch.empty((2, R), dtype=torch.float32, device=dev)
     seed = dropout_state(dev) if p_drop > 0 else None
+    # scratch of the split contraction (below 4096 rows two workgroups share a row block: include/eda_hip.h) -- the same
+    # persistent per-stream buffer the split row products use
+    need = int(_lib.lib().eda_linear_add_dropout_ln_workspace_bytes(R, inp2.shape[1], C))
+    ws = gemm.workspace(dev, need) if need else None
     with torch.cuda.device(dev), _timed("linear_add_dropout_ln_fwd", (R, inp2.shape[1], C)):
-        rc = _lib.lib().eda_linear_add_dropout_ln_fwd_f32(
+        rc = _lib.lib().eda_linear_add_dropout_ln_fwd_ws_f32(
             inp2.data_ptr(), gemm._ld(inp2), R, inp2.shape[1], W.data_ptr(), gemm._ld(W), C,
             b.data_ptr() if b is not None else None, x2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps),
             float(p_drop), seed.data_ptr() if seed is not None else None, int(salt),
             z.data_ptr() if z is not None else None, out.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
             pos2.data_ptr() if pos2 is not None else None, out_pos.data_ptr() if out_pos is not None else None,
+            ws.data_ptr() if ws is not None else None, ws.numel() * 4 if ws is not None else 0,
             torch.cuda.current_stream().cuda_stream)
-    _lib.check(rc, "eda_linear_add_dropout_ln_fwd_f32")
+    _lib.check(rc, "eda_linear_add_dropout_ln_fwd_ws_f32")
     return out, out_pos, z, stats
 
 

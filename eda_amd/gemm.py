@@ -37,6 +37,17 @@ def splitk_workspace(dev, R, K, N):
     return ws
 
 
+def workspace(dev, nbytes):
+    """The persistent zero-initialised scratch of the current stream (the one splitk_workspace hands out) if `nbytes` fit."""
+    if nbytes > _SK_BYTES:
+        return None
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _sk_ws_cache.get(key)
+    if ws is None:
+        ws = _sk_ws_cache[key] = torch.zeros(_SK_BYTES // 4, dtype=torch.int32, device=dev)
+    return ws
+
+
 def linear_fwd(x2, w, bias=None, relu=False, out=None):
     """y = x2 @ w.T (+ bias) (ReLU) for fp32 GPU matrices."""
     x2, w = _rows2d(x2), _rows2d(w)

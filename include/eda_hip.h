@@ -336,6 +336,17 @@ int eda_linear_add_dropout_ln_fwd_f32(const float *x, long ldx, long R, int K, c
                                       const float *bias, const float *resid, const float *gamma, const float *beta,
                                       float eps, float p_drop, const unsigned long long *seed_ptr, unsigned salt, float *z,
                                       float *out, float *mean, float *rstd, const float *pos, float *out_pos, void *stream);
+/* The same launch with scratch for a SPLIT contraction: up to 2048 rows two workgroups share each 16-row block's contraction
+ * and the last one to arrive adds the two partial tiles in slice order (bit-reproducible) and runs the LayerNorm epilogue --
+ * 2048 rows then occupy 256 CUs instead of 128.  ws: eda_linear_add_dropout_ln_workspace_bytes(R, K, N) bytes (0: the shape is
+ * not split, ws may be NULL), 16-byte aligned, zeroed once (every call leaves its ticket words zero), one per stream; it may be
+ * the scratch of eda_linear_ex_ws_f32.  ws == NULL = eda_linear_add_dropout_ln_fwd_f32. */
+size_t eda_linear_add_dropout_ln_workspace_bytes(long R, int K, int N);
+int eda_linear_add_dropout_ln_fwd_ws_f32(const float *x, long ldx, long R, int K, const float *w, long ldw, int N,
+                                      const float *bias, const float *resid, const float *gamma, const float *beta,
+                                      float eps, float p_drop, const unsigned long long *seed_ptr, unsigned salt, float *z,
+                                      float *out, float *mean, float *rstd, const float *pos, float *out_pos, void *ws, size_t ws_bytes,
+                                         void *stream);
 
 /* Deferred form: with grads3 == NULL eda_add_dropout_ln_bwd_f32 leaves its per-block partial sums
  * in `ws` (eda_add_dropout_ln_bwd_blocks(R) rows of 3*C floats); eda_ln_reduce_grouped_f32 then

@@ -242,6 +242,44 @@ def test_linear_layer_in_the_layer_norm_launch(R, K, p, with_pos, monkeypatch):
         assert _close(o1, ref)
 
 
+@pytest.mark.parametrize("R,K", [(2048, 288), (1030, 256), (2000, 2048), (17, 288)])
+def test_split_contraction_of_the_layer_norm_launch_is_reproducible_and_close_to_unsplit(R, K, monkeypatch):
+    """Up to 2048 rows two workgroups share a 16-row block's contraction and the last one to arrive adds the partial tiles in
+    slice order before the LayerNorm epilogue (eda_linear_add_dropout_ln_fwd_ws_f32): 20 launches are bit-identical, the result
+    is the unsplit launch's up to the association of one fp32 sum, and a replayed graph returns the same bits."""
+    from eda_amd import _lib, fused_ln
+    C = 288
+    assert _lib.lib().eda_linear_add_dropout_ln_workspace_bytes(R, K, C) > 0
+    g = torch.Generator(device="cuda").manual_seed(R * 7 + K)
+    inp = torch.randn(R, K, device="cuda", generator=g); W = torch.randn(C, K, device="cuda", generator=g) * K ** -0.5
+    b = torch.randn(C, device="cuda", generator=g); x = torch.randn(R, C, device="cuda", generator=g)
+    gamma = torch.rand(C, device="cuda", generator=g) + 0.5; beta = torch.randn(C, device="cuda", generator=g)
+    pos = torch.randn(R, C, device="cuda", generator=g)
+
+    def run():
+        out, out_pos, z, stats = fused_ln._linear_ln_forward(inp, W, b, x, gamma, beta, 1e-5, 0.1, 5, pos)
+        return out, out_pos, z, stats
+    first = run()
+    for _ in range(20):
+        for a_, b_ in zip(run(), first):
+            assert torch.equal(a_, b_)
+    s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        run(); torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s):
+            captured = run()
+        for _ in range(3):
+            gr.replay()
+        torch.cuda.synchronize()
+    for a_, b_ in zip(captured, first):
+        assert torch.equal(a_, b_)
+    monkeypatch.setenv("EDA_GEMM_SPLITK", "0")
+    assert _lib.lib().eda_linear_add_dropout_ln_workspace_bytes(R, K, C) == 0
+    for a_, b_ in zip(run(), first):
+        assert _close(a_, b_, 1e-5)
+
+
 @pytest.mark.parametrize("R", [2048, 640, 1030])
 @pytest.mark.parametrize("p", [0.0, 0.1])
 def test_ffn_block_as_one_node(R, p, monkeypatch):
