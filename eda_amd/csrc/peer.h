@@ -46,9 +46,12 @@ __device__ __forceinline__ void eda_peer_exchange2(const EdaPeer &P, unsigned lo
     __hip_atomic_store(dst, ua, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(dst + 1, ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the pairs have left before any tag does
+  // the pairs have left before any tag does: the wait retires this lane's write-through stores, and the tag is a system-scope
+  // RELEASE store (over xGMI a store is posted: the release is what orders the tag behind the pair at the peer; on one device
+  // it costs one cache write-back instruction on one lane)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   for (int r = 0; r < P.world; ++r)
-    __hip_atomic_store(P.slab[r] + base + (size_t)P.rank * 4 + 2, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(P.slab[r] + base + (size_t)P.rank * 4 + 2, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   double sa = 0.0, sb = 0.0;
   unsigned long long *mine = P.slab[P.rank];
   const unsigned limit = __hip_atomic_load(mine + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull ? 0u : P.spin_limit;
@@ -62,6 +65,7 @@ __device__ __forceinline__ void eda_peer_exchange2(const EdaPeer &P, unsigned lo
       }
       __builtin_amdgcn_s_sleep(2);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");             // (system scope: pairs with the tag's release)
     const unsigned long long va = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned long long vb = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     sa += __builtin_bit_cast(double, va);
