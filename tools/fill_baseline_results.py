@@ -30,14 +30,21 @@ for name, what in [("default", "headline: fp32, B = 8 x 50 000 points, 256 queri
                    ("fps_bucket", "single-workgroup bucket sampler instead of the cluster kernels (`EDA_FPS_BUCKET=1`)"),
                    ("wgrad_fp32_mfma", "grouped weight gradients on fp32 MFMA (`EDA_WGRAD_BF16X3=0`)"),
                    ("heads_per_head", "prediction heads' backward per head (`EDA_BATCHED_HEADS=0`)"),
-                   ("stock_roberta", "stock Hugging Face text-encoder forward (`EDA_FAST_ROBERTA=0`)")]:
+                   ("stock_roberta", "stock Hugging Face text-encoder forward (`EDA_FAST_ROBERTA=0`)"),
+                   ("force_dist_sync_bn_native", "`--force-dist --sync-bn native`: SyncBatchNorm statistics exchanged inside the kernels through peer-mapped memory, the step stays one captured graph"),
+                   ("force_dist_sync_bn_collective", "`--force-dist --sync-bn collective`: one RCCL micro-collective per BatchNorm layer and direction (eager launches)"),
+                   ("deterministic", "`--deterministic 1`: ordered scatter sums, bit-identical runs"),
+                   ("splitk_off", "split contraction of the row products off (`EDA_GEMM_SPLITK=0`)"),
+                   ("kc96_off", "96-wide chunks off (`EDA_GEMM_KC96=0`)"),
+                   ("mha3_ksplit_off", "key-split and bf16 x 3 attention forward off (`EDA_MHA3=0 EDA_MHA2_KSPLIT=0`)"),
+                   ("main_stream_alone_TIMING_ONLY", "TIMING ONLY (stale prefetch results): the main stream with nothing underneath it (`EDA_TIMING_SKIP_SIDE=fps,text`)")]:
     x = line(name)
     if x:
         rows.append(f"| {what} | {x['value']:.1f} | {x['ms_per_step']:.2f} |")
 r, rh, rm = d["roofline"], d["roofline_hbm"], d["roofline_mfma"]
 cb = d.get("cpu_baseline") or {}
 ins = d.get("in_step") or {}
-txt = f"""## 5. Results (round 4, one MI355X; `profiles/{tag}_*`)
+txt = f"""## 5. Results (round {int(tag[1:])}, one MI355X; `profiles/{tag}_*`)
 
 No multi-GPU node was available to any round: the 2 / 4 / 8-GPU points of the metric are UNMEASURED (the N > 1 step is
 exercised by `tests/test_two_rank_gpu.py`, `--force-dist` and `--split-graphs` on the one GPU there is).
@@ -52,11 +59,10 @@ CPU baseline, same run (kind "{cb.get('kind')}": the reference has no CPU op pat
 ({cb.get('cpu')}; {cb.get('sample')}).
 
 Roofline objects of the line:
-* `roofline` (the family with the most time per step: own tiled row GEMMs): `{r['kernel']}` {r['achieved']} TFLOP/s = {r['frac']} of the
-  fp32 MFMA peak from a HIP-event bracket around one eager launch, {r.get('achieved_graph_replay')} TFLOP/s = {r.get('frac_graph_replay')} from 50 launches
-  replayed back to back in a graph (rocprofv3's average duration in `profiles/{tag}_summary.md` is the third view); the family
-  as a whole: {r.get('family_tflops')} TFLOP/s = {r.get('family_frac')}.  These launches are bound by the launch floor and by operand bytes into
-  the CUs, not by the matrix pipe.
+* `roofline` (fixed rule since round 5: the roof-priced single-shape launch with the most MAIN-stream time per step): `{r['kernel']}`
+  {r['achieved']} TFLOP/s = {r['frac']} of the fp32 MFMA peak, timed as {r.get('timing')}; PMC traffic {r.get('traffic')} bytes per launch
+  against {r.get('alg_flops_per_launch')} flops; {r.get('calls_per_step')} launches = {r.get('ms_per_step')} ms of the step, its family {r.get('family_ms_per_step')} ms.
+  rocprofv3's per-shape durations, own kernel next to hipBLASLt: `profiles/{tag}_gemm_shapes.txt`.
 * `roofline_hbm`: `{rh['kernel']}` {rh['achieved']} GB/s = {rh['frac']} of 8 TB/s ({rh.get('frac_of_achievable')} of the device-copy kernel's
   {rh.get('achievable_copy_gbs')} GB/s) on the bytes of the training formulation (SURVEY §8d's fused bytes + the pre-activations kept for the
   backward); on SURVEY §8d's algorithmic bytes alone: {rh.get('frac_algorithmic')}.
