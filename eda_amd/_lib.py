@@ -73,6 +73,7 @@ SIGNATURES = {
     "eda_peer_bn_hook": (_i, [_p, _p, _l, _p]),
     "eda_set_bn_sync_native": (_i, [_i]),
     "eda_fps_set_cu_reserve": (_i, [_i]),
+    "eda_fps_set_background": (_i, [_i]),
     "eda_fps_set_policy": (_i, [_i]),
     "eda_add_n_f32": (_i, [_p, _i, _sz, _p, _p]),
     "eda_gemm_set_dma": (_i, [_i]),

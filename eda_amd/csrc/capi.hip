@@ -54,6 +54,7 @@ const KnobRow kKnobs[EDA_K_COUNT] = {
     {"EDA_GEMM_LN_VAR", 0},
     {"EDA_GEMM_SPLITK", -1},        // 0: no split contraction; n >= 2: n slices for every eligible launch (unset: by shape)
     {"EDA_GEMM_KC96", -1},          // 0: no 96-wide chunks; n >= 1: tile configuration n for every eligible launch (unset: by shape)
+    {"EDA_FPS_BACKGROUND", 0},      // 1: the cluster sampler polls one granule per record (eda_fps_set_background)
     {"EDA_MHA2_PRIO", 1},
     {"EDA_MHA2_KSPLIT", -1},        // 0: no key-split forward; n >= 2: n key slices for every eligible launch (unset: by shape)
     {"EDA_MHA3", 1},                // 0: the long-key attention forward stays on mha2.hip's fp32-MFMA kernel (mha3.hip: bf16 x 3)

@@ -37,6 +37,8 @@
 namespace {
 
 constexpr int kRecWords = 8;          // u64 words per mailbox record (5 used, 64-byte record)
+int g_fps_background = -1;            // -1: from EDA_FPS_BACKGROUND (eda_fps_set_background overrides)
+int fps_background() { return g_fps_background < 0 ? (int)(eda_knob(EDA_K_FPS_BACKGROUND) != 0) : g_fps_background; }
 int g_fps_cu_reserve = INT_MIN;       // INT_MIN: from EDA_FPS_CU_RESERVE (eda_fps_set_cu_reserve overrides)
 int fps_cu_reserve() { return g_fps_cu_reserve == INT_MIN ? (int)eda_knob(EDA_K_FPS_CU_RESERVE) : g_fps_cu_reserve; }
 constexpr int kMaxG = 64;             // workgroups per scene (one poll lane each)
@@ -334,7 +336,7 @@ __device__ __forceinline__ u64 fps_key(int bits, unsigned k, int p_log2) {
 template <int MODE, int T, int P, int K>
 __global__ __launch_bounds__(T) void fps_spec_kernel(const float *__restrict__ xyz_all, int n, int m,
                                                      int *__restrict__ idx_all, int S, int G, int p_log2,
-                                                     u64 *mail_all, int *status) {
+                                                     u64 *mail_all, int *status, int background) {
   static_assert(K == 4, "record layout and poll-lane mapping are written for K = 4");
   constexpr int NW = T / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -481,12 +483,28 @@ __global__ __launch_bounds__(T) void fps_spec_kernel(const float *__restrict__ x
       for (;;) {
         if (!ok) {
           const u64 *rec = box + (size_t)(lane / K) * kSpecRecWords + (size_t)(lane % K) * 5;
-          const u64 g0 = granule_load(rec + 0), g1 = granule_load(rec + 1);
-          const u64 g2 = granule_load(rec + 2), g3 = granule_load(rec + 3);
-          const u64 g4 = granule_load(rec + 4);
-          v0 = (unsigned)g0; v1 = (unsigned)g1; v2 = (unsigned)g2; v3 = (unsigned)g3; v4 = (unsigned)g4;
-          ok = ((unsigned)(g0 >> 32) == h) & ((unsigned)(g1 >> 32) == h) & ((unsigned)(g2 >> 32) == h) &
-               ((unsigned)(g3 >> 32) == h) & ((unsigned)(g4 >> 32) == h);
+          if (background) {
+            // the sampler as a PREFETCH underneath other work (eda_fps_set_background): poll ONE granule, the record's
+            // last-written one, and fetch the other four only once its tag is there -- a fifth of the polling traffic.  104
+            // resident workgroups polling five granules each took enough HBM / fabric bandwidth from the other stream's
+            // kernels to cost the step 0.2 ms (profiles/r05_side_stream_interference.md); the second, dependent fetch
+            // costs THIS kernel ~0.1 us per round (3.07 -> 3.29 ms), which is why the in-step form keeps the wide poll.
+            const u64 g4 = granule_load(rec + 4);
+            if ((unsigned)(g4 >> 32) == h) {
+              const u64 g0 = granule_load(rec + 0), g1 = granule_load(rec + 1);
+              const u64 g2 = granule_load(rec + 2), g3 = granule_load(rec + 3);
+              v0 = (unsigned)g0; v1 = (unsigned)g1; v2 = (unsigned)g2; v3 = (unsigned)g3; v4 = (unsigned)g4;
+              ok = ((unsigned)(g0 >> 32) == h) & ((unsigned)(g1 >> 32) == h) & ((unsigned)(g2 >> 32) == h) &
+                   ((unsigned)(g3 >> 32) == h);
+            }
+          } else {
+            const u64 g0 = granule_load(rec + 0), g1 = granule_load(rec + 1);
+            const u64 g2 = granule_load(rec + 2), g3 = granule_load(rec + 3);
+            const u64 g4 = granule_load(rec + 4);
+            v0 = (unsigned)g0; v1 = (unsigned)g1; v2 = (unsigned)g2; v3 = (unsigned)g3; v4 = (unsigned)g4;
+            ok = ((unsigned)(g0 >> 32) == h) & ((unsigned)(g1 >> 32) == h) & ((unsigned)(g2 >> 32) == h) &
+                 ((unsigned)(g3 >> 32) == h) & ((unsigned)(g4 >> 32) == h);
+          }
         }
         if (__all(ok)) break;
         if (++spins > kSpinLimit) { failed = true; break; }
@@ -574,7 +592,7 @@ int launch_fps_spec(const float *xyz, int n, int m, int *idx, int S, int G, int 
       return (int)e;
     }
   }
-  hipLaunchKernelGGL(kern, dim3(S * G), dim3(T), lds, stream, xyz, n, m, idx, S, G, p_log2, mail, status);
+  hipLaunchKernelGGL(kern, dim3(S * G), dim3(T), lds, stream, xyz, n, m, idx, S, G, p_log2, mail, status, fps_background());
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     eda_set_error("fps: launch failed: %s", hipGetErrorString(e));
@@ -725,7 +743,7 @@ int round_up_pow2(int v) {
 
 }  // namespace
 
-void eda_fps_env_reset() { g_fps_cu_reserve = INT_MIN; g_fps_policy = EDA_FPS_AUTO; }
+void eda_fps_env_reset() { g_fps_cu_reserve = INT_MIN; g_fps_policy = EDA_FPS_AUTO; g_fps_background = -1; }
 
 // status block + mailboxes of the cluster kernels (zeroed per call), then the sorted points of the bucket sampler
 static size_t fps_mail_bytes(int b) {
@@ -880,6 +898,11 @@ extern "C" int eda_furthest_point_sampling_f32(const float *xyz, int b, int n, i
 extern "C" int eda_fps_set_policy(int policy) {
   EDA_CHECK_ARG(policy == EDA_FPS_AUTO || policy == EDA_FPS_CLUSTER || policy == EDA_FPS_BUCKET, "policy must be EDA_FPS_AUTO / CLUSTER / BUCKET");
   g_fps_policy = policy;
+  return 0;
+}
+
+extern "C" int eda_fps_set_background(int on) {
+  g_fps_background = on != 0;
   return 0;
 }
 

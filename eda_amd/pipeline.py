@@ -140,14 +140,21 @@ class PipelinedTrainStep:
         self.g_fps, self.g_text = None, torch.cuda.CUDAGraph()
         if prefetch is not None:
             self.g_fps = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_fps, stream=self.side, **mode):
-                xyz_next = self.nxt["point_clouds"][..., 0:3].contiguous()
-                if prefetch_geometry:
-                    outs = list(model.backbone_net.geometry(xyz_next).values())
-                else:
-                    outs = [pointnet2_utils.furthest_point_sample(xyz_next, sa1_samples)]
-                for v, t in zip(self.inds_next, outs):     # (side stream: off the critical path)
-                    v.copy_(t)
+            # the sampler as a prefetch: lean polling, so that its ~100 resident workgroups leave the memory system to the
+            # step's kernels (include/eda_hip.h: eda_fps_set_background; a launch parameter, so the captured nodes keep it)
+            from . import _lib
+            _lib.check(_lib.lib().eda_fps_set_background(1), "eda_fps_set_background")
+            try:
+                with torch.cuda.graph(self.g_fps, stream=self.side, **mode):
+                    xyz_next = self.nxt["point_clouds"][..., 0:3].contiguous()
+                    if prefetch_geometry:
+                        outs = list(model.backbone_net.geometry(xyz_next).values())
+                    else:
+                        outs = [pointnet2_utils.furthest_point_sample(xyz_next, sa1_samples)]
+                    for v, t in zip(self.inds_next, outs):     # (side stream: off the critical path)
+                        v.copy_(t)
+            finally:
+                _lib.check(_lib.lib().eda_fps_set_background(0), "eda_fps_set_background")
         with torch.cuda.graph(self.g_text, stream=self.side, **mode):
             hidden = model.encode_text_frozen(tok["input_ids"], tok["attention_mask"])
             if text_prefetch:

@@ -26,6 +26,7 @@
  *    values are not per device and not per thread):
  *      eda_set_fma_mode          arithmetic form of the squared distances
  *      eda_fps_set_cu_reserve    CUs the cluster sampler leaves to other streams
+ *      eda_fps_set_background    cluster sampler as a prefetch underneath other work
  *      eda_fps_set_policy        cluster / bucket / auto sampler
  *      eda_gemm_set_dma          kernel selection of the plain row products
  *      eda_wgrad_set_arith       fp32 MFMA or bf16 x 3 weight gradients
@@ -574,6 +575,14 @@ int eda_transpose_batch_f32(const long long *desc, int count, long long total_ti
  * (CUs - reserve) / workgroups-per-scene scenes per launch.  Default 0 (or EDA_FPS_CU_RESERVE).  Replaces nothing in
  * the reference (its sampler is one workgroup per scene, sampling_gpu.cu:74-178). */
 int eda_fps_set_cu_reserve(int cus);
+
+/* 1: the multi-workgroup sampler runs as a PREFETCH on a second stream underneath other work (eda_amd/pipeline.py): its
+ * workgroups poll one granule per hand-off record instead of five, so that ~100 resident polling workgroups do not take
+ * memory bandwidth from the step's kernels (-0.2 ms per step; the sampler itself 3.07 -> 3.29 ms).  0 (default, or
+ * EDA_FPS_BACKGROUND): the sampler is on the critical path and polls wide.  Same indices either way (a launch parameter:
+ * captured graph nodes keep the value they were captured with).  Replaces nothing in the reference (its sampler runs
+ * inside the step, pointnet2_modules.py:128). */
+int eda_fps_set_background(int on);
 
 /* Which sampler eda_furthest_point_sampling_f32 runs for scenes of 8193..65536 points (csrc/fps.hip, csrc/fps_bucket.hip;
  * identical indices either way; replaces nothing in the reference, whose sampler is one workgroup per scene,

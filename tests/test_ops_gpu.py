@@ -338,3 +338,29 @@ def test_fps_bucket_sampler_equals_the_cluster_kernels_and_needs_no_co_residency
     again = ext.furthest_point_sampling(xyz, 2048)
     torch.cuda.synchronize()
     assert torch.equal(again, got) and ext.fps_status() == 0
+
+
+def test_fps_background_polling_gives_the_same_indices(ext, monkeypatch):
+    """eda_fps_set_background / EDA_FPS_BACKGROUND=1 (the sampler as a prefetch underneath other work: one polled granule per
+    hand-off record instead of five) changes the polling traffic, not the result: bench geometry, cluster kernels, bit-equal
+    indices, no give-up -- also while another stream keeps the memory system busy."""
+    from eda_amd import _lib, synthetic
+    xyz = torch.from_numpy(synthetic.batch(range(60, 68), 50000)[:, :, :3].copy()).cuda()
+    monkeypatch.setenv("EDA_FPS_BUCKET", "0")
+    wide = ext.furthest_point_sampling(xyz, 2048)
+    L = _lib.lib()
+    try:
+        assert L.eda_fps_set_background(1) == 0
+        lean = ext.furthest_point_sampling(xyz, 2048)
+        busy = torch.cuda.Stream()
+        big = torch.empty(1 << 27, device="cuda"); big2 = torch.empty_like(big)
+        with torch.cuda.stream(busy):
+            for _ in range(12):
+                big2.copy_(big)
+        lean_busy = ext.furthest_point_sampling(xyz, 2048)
+        torch.cuda.synchronize()
+    finally:
+        L.eda_fps_set_background(0)
+    assert torch.equal(lean, wide) and torch.equal(lean_busy, wide) and ext.fps_status() == 0
+    monkeypatch.setenv("EDA_FPS_BACKGROUND", "1")
+    assert torch.equal(ext.furthest_point_sampling(xyz, 2048), wide)
