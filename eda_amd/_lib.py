@@ -103,6 +103,8 @@ SIGNATURES = {
     "eda_linear_splitk_workspace_bytes": (_sz, [_l, _i, _i]),
     "eda_linear_ex_ws_f32": (_i, [_p, _l, _l, _i, _p, _l, _i, _p, _i, _f, _p, _u, _p, _l, _f, _p, _l, _p, _sz, _p]),
     "eda_linear_dgrad_ws_f32": (_i, [_p, _l, _l, _i, _p, _l, _i, _p, _l, _p, _sz, _p]),
+    "eda_linear_addend_ws_f32": (_i, [_p, _l, _l, _i, _p, _l, _i, _p, _p, _l, _p, _l, _p, _sz, _p]),
+    "eda_linear_dgrad_addend_ws_f32": (_i, [_p, _l, _l, _i, _p, _l, _i, _p, _l, _p, _l, _p, _sz, _p]),
     "eda_l2norm_rows_fwd_f32": (_i, [_p, _l, _i, _f, _p, _p, _p]),
     "eda_l2norm_rows_bwd_f32": (_i, [_p, _p, _p, _l, _i, _f, _p, _p]),
     "eda_linear_fwd_f32": (_i, [_p, _l, _l, _i, _p, _l, _i, _p, _i, _p, _l, _p]),

@@ -15,6 +15,7 @@ backward is one more kernel (dQ, dK, dV in one pass) that recomputes them.
 restatement used by CPU-side tests lives in oracle/attention_ref.py.
 """
 import itertools
+import os
 
 import torch
 from torch import nn
@@ -215,6 +216,27 @@ def _qproj_core_fwd(x, Wq, bq, k, v, m8, num_heads, p_drop, salt):
     return q, out, lse
 
 
+class ResidualLink:
+    """One post-norm block's residual gradient, handed from the residual LayerNorm's backward to the attention node's
+    instead of to autograd: the block's input x feeds the attention branch AND the residual sum
+    (models/encoder_decoder_layers.py:231-245, :87-93), so autograd would add the two gradients in a launch of its own;
+    with a link the LayerNorm node returns no gradient for x and leaves it here, and the attention node's input-gradient
+    product for x adds it in its epilogue (gemm.linear_dgrad(addend=...)) -- the same terms (where a third gradient meets them,
+    in another association: one fp32 rounding), one launch less per block.  Armed by MultiheadAttention.forward only
+    when that product will run (x requires grad, is
+    one of the node's inputs); the LayerNorm node (which always runs first in a backward pass: it consumes the attention
+    node's output) checks `armed`."""
+    __slots__ = ("armed", "dx")
+    taken = 0          # gradients handed over so far (tests)
+
+    def __init__(self):
+        self.armed, self.dx = False, None
+
+
+def residual_links_enabled():
+    return os.environ.get("EDA_RESIDUAL_LINK", "1") != "0"
+
+
 class _ProjectedMHA(Function):
     """In-projection + attention core as ONE autograd node (GPU training path of
     MultiheadAttention).  `groups` lists, per distinct input tensor, the row range [lo, hi) of
@@ -227,8 +249,9 @@ class _ProjectedMHA(Function):
     the GEMMs are the repo's own MFMA row GEMMs (csrc/gemm.hip)."""
 
     @staticmethod
-    def forward(ctx, W, b, mask, num_heads, p_drop, salt, groups, *xs):
+    def forward(ctx, W, b, mask, num_heads, p_drop, salt, groups, link, *xs):
         d = W.shape[1]
+        ctx.link = link                      # None or (ResidualLink, index into xs of the block's residual input)
         dev = W.device
         B = xs[0].shape[0]
         x2s, Ps, cols = [], [], {}
@@ -312,8 +335,17 @@ class _ProjectedMHA(Function):
                       want_db=db is not None)
             elif db is not None:
                 colsum(dP2, out=db[lo:hi])
-            dxs.append(gemm.linear_dgrad(dP2, W[lo:hi]).view(shapes[i]) if ctx.needs_input_grad[7 + i] else None)
-        return (dW, db, None, None, None, None, None, *dxs)
+            if not ctx.needs_input_grad[8 + i]:
+                dxs.append(None)
+                continue
+            res = None
+            if ctx.link is not None and ctx.link[1] == i and ctx.link[0].dx is not None:
+                res, ctx.link[0].dx = ctx.link[0].dx, None       # the residual LayerNorm's d(x): added in the product's epilogue
+                ResidualLink.taken += 1
+            dxs.append(gemm.linear_dgrad(dP2, W[lo:hi], out=res, addend=res).view(shapes[i]))
+        if ctx.link is not None and ctx.link[0].dx is not None:
+            raise RuntimeError("residual link: the LayerNorm node left a gradient that no input-gradient product took")
+        return (dW, db, None, None, None, None, None, None, *dxs)
 
 
 class KVSink:
@@ -527,7 +559,8 @@ class MultiheadAttention(nn.Module):
         return query.is_cuda and _core is _hip_core
 
     def forward(self, query, key, value, key_padding_mask=None, need_weights=False,
-                attn_mask=None, batch_first=False, defer_out_bias=False, skip_out_proj=False, pre_kv=None):
+                attn_mask=None, batch_first=False, defer_out_bias=False, skip_out_proj=False, pre_kv=None,
+                residual=None):
         """Returns (output, None).  Inputs are (L,B,F) unless batch_first (then (B,L,F)).
         With defer_out_bias the out-projection is applied WITHOUT its bias and (output, bias) is
         returned: the caller's fused residual+LayerNorm kernel adds it (fused_ln.py).
@@ -558,8 +591,18 @@ class MultiheadAttention(nn.Module):
                 groups, xs = ((0, 2 * d), (2 * d, 3 * d)), (query, value)
             else:
                 groups, xs = ((0, d), (d, 2 * d), (2 * d, 3 * d)), (query, key, value)
+            link = None
+            if residual is not None:
+                # residual = (ResidualLink, x): x is the block's residual input; arm the link when x is one of this node's
+                # inputs and its input-gradient product will run (see ResidualLink)
+                rl, rx = residual
+                gi = next((i for i, t in enumerate(xs) if t is rx), None)
+                if (gi is not None and batch_first and skip_out_proj and rx.requires_grad and torch.is_grad_enabled()
+                        and rx.dtype == torch.float32):
+                    rl.armed = True
+                    link = (rl, gi)
             o = _ProjectedMHA.apply(W, b, key_padding_mask, self.num_heads,
-                                    self.dropout if self.training else 0.0, self._salt, groups, *xs)
+                                    self.dropout if self.training else 0.0, self._salt, groups, link, *xs)
             if skip_out_proj:
                 return (o if batch_first else o.transpose(0, 1)), None
             o = linear_rows(o, self.out_proj.weight, None if defer_out_bias else self.out_proj.bias)

@@ -47,6 +47,8 @@ struct GemmArgs {
   // whose activated output `gate` is, applied to the input gradient that flows into it
   float drop_p; const unsigned long long *drop_seed; unsigned drop_salt;
   const float *gate; long ldgate; float gate_scale;
+  int gate_mode;        // 0: the gate above; 1: `gate` is an ADDEND, y = acc (+ bias, ...) + gate[row][col] (the second term of
+                        // an input gradient: eda_linear_addend_ws_f32; gate == y allowed: a lane reads its four floats first)
   // gemm_dma_kernel<..., LN = true> (eda_linear_add_dropout_ln_fwd_f32): the row block spans all N columns and the
   // epilogue is  z = resid + Dropout(acc + bias),  out = LayerNorm(z) * gamma + beta  (+ out_pos = out + pos); y is unused
   const float *ln_resid, *ln_gamma, *ln_beta, *ln_pos; float ln_eps;

@@ -502,7 +502,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_rows_kernel(const GemmArgs a_i
             const float *gp = a.gate + row * a.ldgate + col;
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-              if (col + u < N) o[u] = gp[u] > 0.f ? o[u] * a.gate_scale : 0.f;
+              if (col + u < N) o[u] = a.gate_mode == 1 ? o[u] + gp[u] : (gp[u] > 0.f ? o[u] * a.gate_scale : 0.f);
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) { t1[u] += o[u]; t2[u] += o[u] * o[u]; }
@@ -1734,7 +1734,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_dma_kernel(const GemmArgs
         const float4 gv = *reinterpret_cast<const float4 *>(a.gate + row * a.ldgate + col);
         const float g4[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) o[u] = g4[u] > 0.f ? o[u] * a.gate_scale : 0.f;
+        for (int u = 0; u < 4; ++u) o[u] = a.gate_mode == 1 ? o[u] + g4[u] : (g4[u] > 0.f ? o[u] * a.gate_scale : 0.f);
       }
       *reinterpret_cast<float4 *>(a.y + row * a.ldy + col) = make_float4(o[0], o[1], o[2], o[3]);
     }
@@ -2361,6 +2361,45 @@ extern "C" int eda_linear_dgrad_ws_f32(const float *dy, long lddy, long R, int N
   a.xmode = X_PLAIN; a.epi = E_PLAIN;
   a.x = dy; a.ldx = lddy; a.R = R; a.K = N;      // contraction over the layer's output channels
   a.w = w; a.ldw = ldw; a.N = K;                 // W (N, K) read as (contraction, output column)
+  a.y = dx; a.ldy = lddx;
+  a.sk_ws = ws; a.sk_ws_bytes = ws_bytes;
+  return eda_gemm_launch(a, W_NN, (hipStream_t)stream_);
+}
+
+// The same two products with a second TERM in the epilogue: y = x W^T (+ bias) + addend, dx = dy W + addend -- an input
+// gradient that has another contribution (the residual branch of a post-norm block, models/encoder_decoder_layers.py:
+// 87-105, 231-245) leaves the product's launch complete instead of meeting the other term in an element-wise add.
+// addend == y / dx is allowed (a lane reads its four floats before it writes them).  Same order as launch + add:
+// acc, + bias, + addend -- bitwise equal to the two-launch form.
+extern "C" int eda_linear_addend_ws_f32(const float *x, long ldx, long R, int K, const float *w, long ldw, int N,
+                                        const float *bias, const float *addend, long ldadd, float *y, long ldy, void *ws,
+                                        size_t ws_bytes, void *stream_) {
+  EDA_CHECK_ARG(R >= 0 && K > 0 && N > 0 && ldx >= K && ldw >= K && ldy >= N && ldadd >= N, "bad dimension");
+  if (R == 0) return 0;
+  EDA_CHECK_ARG(x && w && y && addend, "null pointer");
+  GemmArgs a;
+  gemm_defaults(a);
+  a.xmode = X_PLAIN; a.epi = E_PLAIN;
+  a.x = x; a.ldx = ldx; a.R = R; a.K = K;
+  a.w = w; a.ldw = ldw; a.N = N; a.bias = bias;
+  a.gate = addend; a.ldgate = ldadd; a.gate_scale = 1.f; a.gate_mode = 1;
+  a.y = y; a.ldy = ldy;
+  a.sk_ws = ws; a.sk_ws_bytes = ws_bytes;
+  return eda_gemm_launch(a, W_NT, (hipStream_t)stream_);
+}
+
+extern "C" int eda_linear_dgrad_addend_ws_f32(const float *dy, long lddy, long R, int N, const float *w, long ldw, int K,
+                                              const float *addend, long ldadd, float *dx, long lddx, void *ws,
+                                              size_t ws_bytes, void *stream_) {
+  EDA_CHECK_ARG(R >= 0 && K > 0 && N > 0 && lddy >= N && ldw >= K && lddx >= K && ldadd >= K, "bad dimension");
+  if (R == 0) return 0;
+  EDA_CHECK_ARG(dy && w && dx && addend, "null pointer");
+  GemmArgs a;
+  gemm_defaults(a);
+  a.xmode = X_PLAIN; a.epi = E_PLAIN;
+  a.x = dy; a.ldx = lddy; a.R = R; a.K = N;
+  a.w = w; a.ldw = ldw; a.N = K;
+  a.gate = addend; a.ldgate = ldadd; a.gate_scale = 1.f; a.gate_mode = 1;
   a.y = dx; a.ldy = lddx;
   a.sk_ws = ws; a.sk_ws_bytes = ws_bytes;
   return eda_gemm_launch(a, W_NN, (hipStream_t)stream_);

@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .attention import MultiheadAttention
+from .attention import MultiheadAttention, ResidualLink, residual_links_enabled
 from .fused_ln import (_FFNAddDropoutLN, add_dropout_layer_norm, fuses_bias, fuses_linear, linear_add_dropout_layer_norm,
                        new_salt_base)
 from .nn_utils import Conv1dK1, Linear, bn_relu_rows, fan_out, linear_rows, mlp_chain, rows_ok
@@ -51,9 +51,15 @@ def _attn_residual_norm(attn, x, q, k, v, mask, norm, p_drop, training, salt, ba
     pre_kv = (kv, sink, slot): K | V of this module already projected (attention.StackedKV); k, v are then not read."""
     if batch_first and attn.hip_path(q) and fuses_linear(x, norm, attn.embed_dim):
         # the out-projection rides in the residual LayerNorm's launch
-        o, _ = attn(q, k, v, key_padding_mask=mask, batch_first=True, skip_out_proj=True, pre_kv=pre_kv)
+        # x feeds the attention branch too (self-attention: value / everything; text <- points: the query): its residual
+        # gradient rides in the branch's input-gradient product instead of an accumulation launch (attention.ResidualLink)
+        link = None
+        if pre_kv is None and training and residual_links_enabled() and (x is q or x is k or x is v):
+            link = ResidualLink()
+        o, _ = attn(q, k, v, key_padding_mask=mask, batch_first=True, skip_out_proj=True, pre_kv=pre_kv,
+                    residual=(link, x) if link is not None else None)
         return linear_add_dropout_layer_norm(o, attn.out_proj.weight, attn.out_proj.bias, x, norm, p_drop, training,
-                                             salt, pos=pos)
+                                             salt, pos=pos, link=link)
     y, y_bias = attn(q, k, v, key_padding_mask=mask, batch_first=batch_first,
                      defer_out_bias=fuses_bias(x, norm))
     return add_dropout_layer_norm(x, y, norm, p_drop, training, salt, y_bias=y_bias, pos=pos)

@@ -177,8 +177,9 @@ class _LinearAddDropoutLN(Function):
     sum (d(gamma), d(beta) and d(b) ride in it), then the linear layer's own dX GEMM and queued weight gradient."""
 
     @staticmethod
-    def forward(ctx, inp, W, b, x, gamma, beta, eps, p_drop, salt, pos=None):
+    def forward(ctx, inp, W, b, x, gamma, beta, eps, p_drop, salt, pos=None, link=None):
         shape = x.shape
+        ctx.link = link if (link is not None and link.armed) else None      # attention.ResidualLink: d(x) goes to the attention node
         C = shape[-1]
         x2 = x.reshape(-1, C).contiguous()
         inp2 = inp.reshape(-1, inp.shape[-1])
@@ -206,9 +207,13 @@ class _LinearAddDropoutLN(Function):
         q = wgrad_queue.active
         if ctx.needs_input_grad[1] and not (q is not None and q.submit(W, None, dy, inp2)):
             dW, _ = wgrad(dy, inp2, want_db=False)
+        if ctx.link is not None and ctx.needs_input_grad[3]:
+            ctx.link.dx, dxo = dx, None         # added in the epilogue of the attention node's input-gradient product for x
+        else:
+            dxo = dx.view(shape)
         if g3 is None:
-            return dinp, dW, None, dx.view(shape), None, None, None, None, None, dpos
-        return (dinp, dW, g3[2] if b is not None else None, dx.view(shape), g3[0], g3[1], None, None, None, dpos)
+            return dinp, dW, None, dxo, None, None, None, None, None, dpos, None
+        return (dinp, dW, g3[2] if b is not None else None, dxo, g3[0], g3[1], None, None, None, dpos, None)
 
 
 class _FFNAddDropoutLN(Function):
@@ -259,7 +264,8 @@ class _FFNAddDropoutLN(Function):
                 grads["b1"] = colsum(dh)
         dxin = None
         if ctx.needs_input_grad[0]:
-            dxin = gemm.linear_dgrad(dh, W1).add_(dx).view(shape)
+            dx2 = dx.reshape(-1, x2.shape[1])
+            dxin = gemm.linear_dgrad(dh, W1, out=dx2, addend=dx2).view(shape)     # residual term in the product's epilogue
         if g3 is None:
             return (dxin, grads.get("W1"), grads.get("b1"), grads.get("W2"), None, None, None, None, None, None, None, None, dpos)
         return (dxin, grads.get("W1"), grads.get("b1"), grads.get("W2"), g3[2] if b2 is not None else None, g3[0], g3[1],
@@ -273,13 +279,11 @@ def fuses_linear(x, norm, K):
             and bool(_lib.lib().eda_linear_add_dropout_ln_supported(int(K), int(x.shape[-1]))))
 
 
-def linear_add_dropout_layer_norm(inp, weight, bias, x, norm, p_drop, training, salt, pos=None):
+def linear_add_dropout_layer_norm(inp, weight, bias, x, norm, p_drop, training, salt, pos=None, link=None):
     """norm(x + dropout(inp @ weight.T + bias)) (+ pos): one launch on the GPU when fuses_linear(x, norm, K)."""
     p = float(p_drop) if training else 0.0
     if fuses_linear(x, norm, weight.shape[1]) and inp.dtype == torch.float32:
-        if pos is not None:
-            return _LinearAddDropoutLN.apply(inp, weight, bias, x, norm.weight, norm.bias, norm.eps, p, salt, pos)
-        return _LinearAddDropoutLN.apply(inp, weight, bias, x, norm.weight, norm.bias, norm.eps, p, salt)
+        return _LinearAddDropoutLN.apply(inp, weight, bias, x, norm.weight, norm.bias, norm.eps, p, salt, pos, link)
     from .nn_utils import linear_rows
     fb = fuses_bias(x, norm)
     y = linear_rows(inp, weight, None if fb else bias)

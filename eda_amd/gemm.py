@@ -115,13 +115,40 @@ def linear_dgrad_gated(dy2, w, gate, scale, out=None):
     return dx.mul_(scale).mul_(gate > 0) if scale != 1.0 else dx.mul_(gate > 0)
 
 
-def linear_dgrad(dy2, w, out=None):
-    """dx = dy2 @ w for fp32 GPU matrices dy2 (R,N), w (N,K)."""
+def _addend_ok(addend, R, C):
+    return (addend.dtype == torch.float32 and addend.is_cuda and addend.dim() == 2 and tuple(addend.shape) == (R, C)
+            and addend.stride(1) == 1 and addend.stride(0) >= C)
+
+
+def linear_addend(x2, w, addend, bias=None, out=None):
+    """y = x2 @ w.T (+ bias) + addend in one launch (include/eda_hip.h: eda_linear_addend_ws_f32); out may be `addend`."""
+    x2, w, addend = _rows2d(x2), _rows2d(w), _rows2d(addend)
+    R, K = x2.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and _addend_ok(addend, R, N)
+    if out is None:
+        out = torch.empty((R, N), dtype=torch.float32, device=x2.device)
+    if R == 0:
+        return out
+    with torch.cuda.device(x2.device), _timed("gemm_fwd", (R, K, N)):
+        ws = splitk_workspace(x2.device, R, K, N)
+        rc = _lib.lib().eda_linear_addend_ws_f32(x2.data_ptr(), _ld(x2), R, K, w.data_ptr(), _ld(w), N,
+                                                 bias.data_ptr() if bias is not None else None, addend.data_ptr(),
+                                                 _ld(addend), out.data_ptr(), _ld(out),
+                                                 ws.data_ptr() if ws is not None else None,
+                                                 ws.numel() * 4 if ws is not None else 0,
+                                                 torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "eda_linear_addend_ws_f32")
+    return out
+
+
+def linear_dgrad(dy2, w, out=None, addend=None):
+    """dx = dy2 @ w (+ addend, in the same launch) for fp32 GPU matrices dy2 (R,N), w (N,K), addend (R,K)."""
     from . import wt_shadow
     if wt_shadow.active is not None:
         wt = wt_shadow.active.lookup(w)
         if wt is not None:                       # W^T is at hand: the forward's GEMM form on it
-            return linear_fwd(dy2, wt, out=out)
+            return linear_fwd(dy2, wt, out=out) if addend is None else linear_addend(dy2, wt, addend, out=out)
     dy2, w = _rows2d(dy2), _rows2d(w)
     R, N = dy2.shape
     K = w.shape[1]
@@ -129,6 +156,18 @@ def linear_dgrad(dy2, w, out=None):
     if out is None:
         out = torch.empty((R, K), dtype=torch.float32, device=dy2.device)
     if R == 0:
+        return out
+    if addend is not None:
+        addend = _rows2d(addend)
+        assert _addend_ok(addend, R, K)
+        with torch.cuda.device(dy2.device), _timed("gemm_dgrad", (R, N, K)):
+            ws = splitk_workspace(dy2.device, R, N, K)
+            rc = _lib.lib().eda_linear_dgrad_addend_ws_f32(dy2.data_ptr(), _ld(dy2), R, N, w.data_ptr(), _ld(w), K,
+                                                           addend.data_ptr(), _ld(addend), out.data_ptr(), _ld(out),
+                                                           ws.data_ptr() if ws is not None else None,
+                                                           ws.numel() * 4 if ws is not None else 0,
+                                                           torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "eda_linear_dgrad_addend_ws_f32")
         return out
     with torch.cuda.device(dy2.device), _timed("gemm_dgrad", (R, N, K)):
         ws = splitk_workspace(dy2.device, R, N, K)

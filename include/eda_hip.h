@@ -614,6 +614,19 @@ int eda_linear_ex_ws_f32(const float *x, long ldx, long R, int K, const float *w
 int eda_linear_dgrad_ws_f32(const float *dy, long lddy, long R, int N, const float *w, long ldw, int K, float *dx, long lddx,
                             void *ws, size_t ws_bytes, void *stream);
 
+/* The two products with a second TERM added in the epilogue: y = x W^T (+ bias) + addend, dx = dy W + addend.  The
+ * reference's post-norm blocks feed one tensor to an attention / feed-forward branch AND to the residual sum
+ * (models/encoder_decoder_layers.py:87-105 cross-attention, :231-245 encoder layer, :340-401 decoder layer), so its
+ * backward adds two gradients per block in a separate element-wise kernel (autograd's accumulation); here the residual
+ * gradient rides in the epilogue of the branch's input-gradient product.  addend: (R, columns) rows, 16-byte aligned
+ * with a stride that is a multiple of 4 for the fast kernels; addend == y / dx allowed.  Same operation order as
+ * product + add: bitwise equal to the two launches.  ws as for eda_linear_ex_ws_f32 (NULL: no split contraction). */
+int eda_linear_addend_ws_f32(const float *x, long ldx, long R, int K, const float *w, long ldw, int N, const float *bias,
+                             const float *addend, long ldadd, float *y, long ldy, void *ws, size_t ws_bytes, void *stream);
+int eda_linear_dgrad_addend_ws_f32(const float *dy, long lddy, long R, int N, const float *w, long ldw, int K,
+                                   const float *addend, long ldadd, float *dx, long lddx, void *ws, size_t ws_bytes,
+                                   void *stream);
+
 /* Kernel selection of the plain row products (eda_linear_fwd_f32 / _ex_f32 / _dgrad_f32): -1 the library's own choice
  * (the DMA-staged kernel of csrc/gemm.hip for launches of >= 400 tiles of 32 x 96, else the register-staged one), 0 the
  * DMA-staged kernel off, 1..4 one of its configurations for every eligible launch (tests, experiments).  Process-wide;
