@@ -54,6 +54,7 @@ const KnobRow kKnobs[EDA_K_COUNT] = {
     {"EDA_GEMM_LN_VAR", 0},
     {"EDA_GEMM_SPLITK", -1},        // 0: no split contraction; n >= 2: n slices for every eligible launch (unset: by shape)
     {"EDA_GEMM_KC96", -1},          // 0: no 96-wide chunks; n >= 1: tile configuration n for every eligible launch (unset: by shape)
+    {"EDA_GEMM_B3ROWS", 1},         // 0: the many-row plain products stay on the fp32 matrix pipe; 1: bf16 x 3 where measured faster; 2: every eligible shape
     {"EDA_FPS_BACKGROUND", 0},      // 1: the cluster sampler polls one granule per record (eda_fps_set_background)
     {"EDA_MHA2_PRIO", 1},
     {"EDA_MHA2_KSPLIT", -1},        // 0: no key-split forward; n >= 2: n key slices for every eligible launch (unset: by shape)

@@ -937,6 +937,15 @@ __device__ __forceinline__ void b3_split(float a, float b, unsigned &h, unsigned
   a -= __uint_as_float(m << 16); b -= __uint_as_float(m & 0xffff0000u);
   l = b3_pk(a, b);
 }
+// the same split with the two subtractions of a pair as ONE packed fp32 instruction (v_pk_add_f32)
+__device__ __forceinline__ void b3_split_pk(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
+  b3_f32x2 v = {a, b};
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, b3_bf16x2));
+  v = v - b3_f32x2{__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(v, b3_bf16x2));
+  v = v - b3_f32x2{__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(v, b3_bf16x2));
+}
 __device__ __forceinline__ f32x4 b3_mma(const uint4 &a, const uint4 &b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b3_bf16x8, a), __builtin_bit_cast(b3_bf16x8, b), c, 0, 0, 0);
 }
@@ -2012,6 +2021,217 @@ int launch_stream_b3(GemmArgs &a, hipStream_t stream) {
   return -1;
 }
 
+// ---- bf16 x 3 for the many-row PLAIN products (linear layers on 8192 rows: the point features of the cross-modal encoder,
+// models/encoder_decoder_layers.py:87-105, 231-245) ----------------------------------------------------------------------
+// gemm_dma_kernel runs them at 47-56 % of the fp32 matrix pipe and is bound by what a 32 x 96 tile has to ingest (147 KB for
+// 1.8 MFLOP).  Here a workgroup keeps a WHOLE-contraction weight tile (NT columns x KT) in LDS as three bf16 planes, split
+// once, and every wave streams 32-row strips of the row operand straight from global memory into the B-operand layout of
+// v_mfma_f32_16x16x32_bf16 (lane (g, i) needs k = 8 g .. 8 g + 7 of row i: two 16-byte loads, the four lanes of a row cover
+// one 128-byte line per 32-deep step) -- no LDS round trip and no barrier after the weight tile stands; the lane splits its
+// own eight values (v = h + m + l) and the step is six MFMAs per 16 x 16 pair (b3_mma, smallest terms first), the two
+// 16-row halves of the strip sharing every weight fragment read.  fp32 accuracy (tests/test_gemm_gpu.py: same bounds).
+// Block id -> (column tile, slot) as in the streaming kernels: the column tiles of a slot share an XCD's L2.
+template <int KT>
+constexpr int b3r_wss() { return KT + ((4 - (KT / 2) % 32 + 32) % 32) * 2; }   // row stride (bf16): words = 4 (mod 32), 16-byte rows
+template <int KT, int NT>
+constexpr size_t b3r_lds_bytes() { return (size_t)3 * NT * b3r_wss<KT>() * 2; }
+
+template <int KT, int NT, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void gemm_b3_rows_kernel(const GemmArgs a) {
+  constexpr int WSS = b3r_wss<KT>(), WPL = NT * WSS, NJ = NT / 16, KS = KT / 32, PF = 3;
+  static_assert(KT % 32 == 0 && NT % 16 == 0 && WSS % 8 == 0 && KS % PF == 0, "shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned short b3r_smem[];
+  unsigned short *Wp = b3r_smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const long R = a.R;
+  const int N = a.N;
+  const unsigned xq = blockIdx.x >> 3;
+  const int ct = (int)(xq % (unsigned)a.col_tiles), n0 = ct * NT;
+  const long slot = (long)(xq / (unsigned)a.col_tiles) * 8 + (blockIdx.x & 7), nslots = gridDim.x / (unsigned)a.col_tiles;
+  const long ntiles = (R + 31) >> 5;
+  const long tstride = nslots * NW;
+  const long t0 = slot * NW + wave;
+  float4 xr[PF][2][2];
+  auto row_ptrs = [&](long t, const float *&pa, const float *&pb) {
+    const long ra = t * 32 + r16, rb = ra + 16;
+    pa = a.x + (ra < R ? ra : R - 1) * a.ldx + 8 * g;
+    pb = a.x + (rb < R ? rb : R - 1) * a.ldx + 8 * g;
+  };
+  auto prologue = [&](const float *pa, const float *pb) {
+#pragma unroll
+    for (int s = 0; s < PF - 1; ++s) {
+      xr[s][0][0] = *reinterpret_cast<const float4 *>(pa + 32 * s); xr[s][0][1] = *reinterpret_cast<const float4 *>(pa + 32 * s + 4);
+      xr[s][1][0] = *reinterpret_cast<const float4 *>(pb + 32 * s); xr[s][1][1] = *reinterpret_cast<const float4 *>(pb + 32 * s + 4);
+    }
+  };
+  {
+    // the weight tile: every load of the thread in flight at once (a rolled loop paid one memory round trip per iteration),
+    // the first strip's rows requested before they are consumed
+    constexpr int KQ = KT / 4, WIT = (NT * KQ + 64 * NW - 1) / (64 * NW);
+    float4 wv[WIT];
+#pragma unroll
+    for (int i = 0; i < WIT; ++i) {
+      const int e = tid + i * 64 * NW;
+      const int n = e / KQ, kq = e % KQ;
+      wv[i] = e < NT * KQ ? *reinterpret_cast<const float4 *>(a.w + (long)(n0 + n) * a.ldw + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (t0 < ntiles) {
+      const float *pa, *pb;
+      row_ptrs(t0, pa, pb);
+      prologue(pa, pb);
+    }
+#pragma unroll
+    for (int i = 0; i < WIT; ++i) {
+      const int e = tid + i * 64 * NW;
+      if (e >= NT * KQ) break;
+      const int n = e / KQ, kq = e % KQ;
+      unsigned h0, m0, l0, h1, m1, l1;
+      b3_split_pk(wv[i].x, wv[i].y, h0, m0, l0);
+      b3_split_pk(wv[i].z, wv[i].w, h1, m1, l1);
+      *reinterpret_cast<uint2 *>(&Wp[n * WSS + 4 * kq]) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2 *>(&Wp[WPL + n * WSS + 4 * kq]) = make_uint2(m0, m1);
+      *reinterpret_cast<uint2 *>(&Wp[2 * WPL + n * WSS + 4 * kq]) = make_uint2(l0, l1);
+    }
+  }
+  // epilogue constants (the plain epilogue of gemm_dma_kernel: bias, ReLU / GELU, Dropout, gate / addend)
+  unsigned dseed = 0, dthresh = 0;
+  float dinv = 1.f;
+  const bool drop = a.drop_p > 0.f;
+  if (drop) {
+    dseed = gemm_hash32((unsigned)(*a.drop_seed) * 0x9E3779B1u + a.drop_salt);
+    dthresh = (unsigned)((double)a.drop_p * 4294967296.0);
+    dinv = 1.f / (1.f - a.drop_p);
+  }
+  float4 bias_v[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+    bias_v[j] = a.bias ? *reinterpret_cast<const float4 *>(a.bias + n0 + 16 * j + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+
+  const unsigned short *wf = Wp + r16 * WSS + 8 * g;          // lane (g, i): k = 8 g .. 8 g + 7 of weight row (= output column) i
+  for (long t = t0; t < ntiles; t += tstride) {
+    const long ra = t * 32 + r16, rb = ra + 16;
+    const float *pa, *pb;
+    row_ptrs(t, pa, pb);
+    f32x4 acc[2][NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    if (t != t0) prologue(pa, pb);
+    // a ring of PF steps, unrolled by PF inside a rolled loop: the loads of step s + PF - 1 are issued while step s is
+    // multiplied (a fully unrolled loop let the scheduler hoist every load of the strip: 256 registers + scratch)
+#pragma unroll 1
+    for (int s0 = 0; s0 < KS; s0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int s = s0 + u, sn = s + PF - 1;
+        if (sn < KS) {
+          constexpr int dummy = 0; (void)dummy;
+          float4 *d = &xr[(u + PF - 1) % PF][0][0];
+          d[0] = *reinterpret_cast<const float4 *>(pa + 32 * sn); d[1] = *reinterpret_cast<const float4 *>(pa + 32 * sn + 4);
+          d[2] = *reinterpret_cast<const float4 *>(pb + 32 * sn); d[3] = *reinterpret_cast<const float4 *>(pb + 32 * sn + 4);
+        }
+        uint4 bh[2], bm[2], bl[2];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const float4 v0 = xr[u][st][0], v1 = xr[u][st][1];
+          b3_split_pk(v0.x, v0.y, bh[st].x, bm[st].x, bl[st].x);
+          b3_split_pk(v0.z, v0.w, bh[st].y, bm[st].y, bl[st].y);
+          b3_split_pk(v1.x, v1.y, bh[st].z, bm[st].z, bl[st].z);
+          b3_split_pk(v1.z, v1.w, bh[st].w, bm[st].w, bl[st].w);
+        }
+        const unsigned short *ws = wf + 32 * s;
+        uint4 ah[NJ], am[NJ], al[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          ah[j] = *reinterpret_cast<const uint4 *>(ws + 16 * j * WSS);
+          am[j] = *reinterpret_cast<const uint4 *>(ws + WPL + 16 * j * WSS);
+          al[j] = *reinterpret_cast<const uint4 *>(ws + 2 * WPL + 16 * j * WSS);
+        }
+        // six of the nine products (what is dropped -- m l, l m, l l -- is below 2^-24 of the full product), smallest first;
+        // product-major: the 2 NJ accumulators take turns, so that no MFMA waits for the one before it (accumulator-major
+        // order left up to five dependent MFMAs back to back, each stalling for the full pipeline latency)
+#define B3R_ROUND(A_, B_)                                                                    \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                     \
+          acc[0][j] = b3_mma(A_[j], B_[0], acc[0][j]); acc[1][j] = b3_mma(A_[j], B_[1], acc[1][j]); \
+        }
+        B3R_ROUND(al, bh) B3R_ROUND(ah, bl) B3R_ROUND(am, bm) B3R_ROUND(am, bh) B3R_ROUND(ah, bm) B3R_ROUND(ah, bh)
+#undef B3R_ROUND
+      }
+    }
+    // D = W-fragment (rows = output columns) x row fragment: lane (g, i) holds columns 4 g .. 4 g + 3 of row i
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const long row = st ? rb : ra;
+      if (row >= R) continue;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int col = n0 + 16 * j + 4 * g;
+        const float b4[4] = {bias_v[j].x, bias_v[j].y, bias_v[j].z, bias_v[j].w};
+        float o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          o[u] = acc[st][j][u] + b4[u];
+          if (a.relu == 1) o[u] = fmaxf(o[u], 0.f);
+          else if (a.relu == 2) o[u] = 0.5f * o[u] * (1.f + erff(o[u] * 0.70710678118654752f));
+        }
+        if (drop) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            o[u] = gemm_hash32(dseed ^ (unsigned)(row * N + col + u)) >= dthresh ? o[u] * dinv : 0.f;
+        }
+        if (a.gate) {
+          const float4 gv = *reinterpret_cast<const float4 *>(a.gate + row * a.ldgate + col);
+          const float g4[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) o[u] = a.gate_mode == 1 ? o[u] + g4[u] : (g4[u] > 0.f ? o[u] * a.gate_scale : 0.f);
+        }
+        *reinterpret_cast<float4 *>(a.y + row * a.ldy + col) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+}
+
+template <int KT, int NT, int NW>
+int launch_b3_rows1(GemmArgs &a, hipStream_t stream) {
+  constexpr size_t lds = b3r_lds_bytes<KT, NT>();
+  static_assert(lds + 64 <= 160 * 1024, "weight planes must fit LDS");
+  a.col_tiles = a.N / NT;
+  int slots = 256 / a.col_tiles / 8 * 8;               // one workgroup per CU, a multiple of 8 slots (slot % 8 = XCD)
+  if (slots < 8) slots = 8;
+  const long need = ((a.R + 31) / 32 + NW - 1) / NW;
+  while (slots > 8 && slots - 8 >= need) slots -= 8;
+  const int grid = slots * a.col_tiles;
+  auto kern = gemm_b3_rows_kernel<KT, NT, NW>;
+  hipError_t e = eda_set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+  if (e != hipSuccess) { eda_set_error("gemm: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, a);
+  e = hipGetLastError();
+  if (e != hipSuccess) { eda_set_error("gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+// which launches: plain rows (W_NT), plain epilogue, >= 4096 rows against a 288- or 576-deep contraction.  Returns -1 otherwise.
+int try_b3_rows(GemmArgs &a, int wmode, hipStream_t stream) {
+  if (wmode != W_NT || a.xmode != X_PLAIN || a.epi != E_PLAIN || a.ngroups > 1 || a.R < 4096) return -1;
+  if (eda_knob(EDA_K_GEMM_B3ROWS) == 0) return -1;
+  if (!gemm_vec_ok(a, wmode)) return -1;
+  auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  if (a.N % 4 != 0 || a.ldy % 4 != 0 || !al16(a.y) || (a.bias && !al16(a.bias))) return -1;
+  if (a.gate && (a.ldgate % 4 != 0 || !al16(a.gate))) return -1;
+  if ((long)a.R * a.ldx >= 0x7fffffffL * 2) return -1;
+  // Measured (tools/bench_gemm_b3rows.py, us per launch in a replayed graph, fp32 MFMA -> bf16 x 3; profiles/r05_gemm_b3rows.txt):
+  //   8192 x 288 -> 288  17.1 -> 16.4    8192 x 288 -> 576  31.8 -> 26.3    8192 x 288 -> 864  42.1 -> 46.4 (144 workgroups)
+  //   8192 x 576 -> 288  27.5 -> 39.1    4096 x 288 -> 288  11.6 -> 15.1   16384 x 288 -> 288  31.9 -> 26.6
+  // The matrix pipe is no longer the bound (the MFMA phase of a strip is ~2.5 us); what a CU can INGEST is: 48-column tiles
+  // re-read the rows six times (70 MB per launch at the ~6.7 TB/s all CUs together take in: profiles/r03c_gemm_dma.md), and
+  // 96-column planes (189 KB) do not fit LDS.  So: by default only where it wins; EDA_GEMM_B3ROWS=2 takes every eligible shape.
+  const bool all = eda_knob(EDA_K_GEMM_B3ROWS) == 2;
+  if (a.K == 288 && a.N % 48 == 0 && (all || (a.N == 576 && a.R >= 8192) || (a.N <= 576 && a.R >= 16384)))
+    return launch_b3_rows1<288, 48, 8>(a, stream);
+  if (a.K == 576 && a.N % 32 == 0 && all) return launch_b3_rows1<576, 32, 8>(a, stream);
+  return -1;
+}
+
 // NW waves per workgroup, MINW waves per SIMD the register allocation aims at (8 x 4: 128 registers, two
 // workgroups per CU; 8 x 2: one workgroup per CU with up to 256 registers.  Measured on SA1, B = 8: the
 // latter beats two 6-wave workgroups at <= 168 registers: 64 -> 128: 230 vs 269 us, 128 -> 64 with the
@@ -2113,6 +2333,10 @@ int eda_gemm_launch(GemmArgs &a, int wmode, hipStream_t stream) {
   }
   {
     const int rc = try_stream(a, wmode, stream);
+    if (rc >= 0) return rc;
+  }
+  {
+    const int rc = try_b3_rows(a, wmode, stream);          // >= 4096 plain rows x 288 / 576: the bf16 pipe at fp32 accuracy
     if (rc >= 0) return rc;
   }
   if (!gemm_vec_ok(a, wmode)) return launch_cfg<1, 4, false>(a, wmode, stream);

@@ -68,6 +68,7 @@ def test_dma_staged_kernel_equals_register_staged_kernel(R, K, N, monkeypatch):
     dX agree bit for bit.  (Unsplit contraction: the split form adds slice partials, another association.)"""
     from eda_amd import _lib, gemm
     monkeypatch.setenv("EDA_GEMM_SPLITK", "0")
+    monkeypatch.setenv("EDA_GEMM_B3ROWS", "0")          # (8192 rows: the fp32 kernels under comparison, not the bf16 x 3 one)
     L = _lib.lib()
     g = torch.Generator(device="cuda").manual_seed(R + K + N)
     x = torch.randn(R, K, device="cuda", generator=g); w = torch.randn(N, K, device="cuda", generator=g)
@@ -98,6 +99,7 @@ def test_96_wide_chunks_equal_32_wide_chunks(R, K, N, monkeypatch):
     EDA_GEMM_KC96=0, for every tile configuration the dispatch can pick."""
     from eda_amd import _lib, gemm
     monkeypatch.setenv("EDA_GEMM_SPLITK", "0")
+    monkeypatch.setenv("EDA_GEMM_B3ROWS", "0")          # (8192 rows: the fp32 kernels under comparison, not the bf16 x 3 one)
     L = _lib.lib()
     g = torch.Generator(device="cuda").manual_seed(R + K + N)
     x = torch.randn(R, K, device="cuda", generator=g); w = torch.randn(N, K, device="cuda", generator=g)
@@ -300,3 +302,52 @@ def test_split_contraction_input_gradient_form():
     ref = dy.double() @ w.double()
     tol = 2e-6 * (N ** 0.5) * (dy.abs().double() @ w.abs().double()) + 1e-30
     assert bool(((dx.double() - ref).abs() <= tol + 1e-6 * ref.abs()).all())
+
+
+B3_SHAPES = [(8192, 288, 288), (8192, 288, 576), (8192, 576, 288), (8200, 288, 864), (4097, 288, 48), (40000, 288, 288),
+             (5000, 576, 32)]
+
+
+@pytest.mark.parametrize("R,K,N", B3_SHAPES)
+def test_many_row_products_on_the_bf16_pipe_keep_fp32_accuracy(R, K, N, monkeypatch):
+    """gemm_b3_rows_kernel (>= 4096 plain rows against a 288- / 576-deep contraction: operands split into three bf16 terms,
+    six v_mfma_f32_16x16x32_bf16 per step): every epilogue (bias, ReLU, Dropout, gate, addend), ragged row counts; the error
+    against fp64 stays inside the fp32 kernels' bound (this file's _tol) and is not larger than 1.5 x the fp32-MFMA kernel's
+    own; the Dropout mask and the ReLU / gate decisions are the fp32 kernel's wherever the pre-activation is not within
+    rounding of zero."""
+    from eda_amd import _lib, gemm
+    L = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(R + 5 * K + 11 * N)
+    x = torch.randn(R, K, device="cuda", generator=g); w = torch.randn(N, K, device="cuda", generator=g) * K ** -0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    seed = torch.tensor([99], dtype=torch.int64, device="cuda")
+    gate = torch.randn(R, N, device="cuda", generator=g)
+    big = torch.randn(R, K + 64, device="cuda", generator=g)
+    xs = big[:, 32:32 + K]                                   # strided rows (16-byte aligned)
+
+    def run():
+        return (gemm.linear_fwd(x, w, b), gemm.linear_fwd(x, w, None, True), gemm.linear_fwd(xs, w, b),
+                gemm.linear_ex(x, w, b, relu=True, drop=(0.1, seed, 7)), gemm.linear_ex(x, w, None, gate=(gate, 1.25)),
+                gemm.linear_addend(x, w, gate, bias=b))
+    try:
+        monkeypatch.setenv("EDA_GEMM_B3ROWS", "0"); L.eda_reload_env()
+        base = run()
+        monkeypatch.setenv("EDA_GEMM_B3ROWS", "2"); L.eda_reload_env()          # (2: every eligible shape, not only where it wins)
+        got = run()
+    finally:
+        monkeypatch.delenv("EDA_GEMM_B3ROWS"); L.eda_reload_env()
+    ref = x.double() @ w.double().t()
+    refs = (ref + b.double(), ref.relu(), xs.double() @ w.double().t() + b.double(), None, None, ref + b.double() + gate.double())
+    tol = _tol(x, w, K)
+    assert not torch.equal(got[0], base[0])                  # (the other kernel did run)
+    for i in (0, 1, 2, 5):
+        e_new = (got[i].double() - refs[i]).abs()
+        e_old = (base[i].double() - refs[i]).abs()
+        assert bool((e_new <= (_tol(xs, w, K) if i == 2 else tol) + 1e-6 * refs[i].abs()).all()), (i, float(e_new.max()))
+        assert float(e_new.max()) <= 1.5 * float(e_old.max()) + 1e-7, (i, float(e_new.max()), float(e_old.max()))
+    # Dropout / gate epilogues: same mask (a counter-based hash of the element), same values to fp32 rounding
+    for i in (3, 4):
+        d = (got[i] - base[i]).abs()
+        flips = (got[i] == 0) != (base[i] == 0)              # a ReLU decision within rounding of zero
+        assert float(flips.float().mean()) < 1e-4
+        assert bool((d[~flips] <= 2 * tol[~flips].float() + 1e-6).all()), (i, float(d[~flips].max()))
