@@ -2036,9 +2036,10 @@ constexpr int b3r_wss() { return KT + ((4 - (KT / 2) % 32 + 32) % 32) * 2; }   /
 template <int KT, int NT>
 constexpr size_t b3r_lds_bytes() { return (size_t)3 * NT * b3r_wss<KT>() * 2; }
 
-template <int KT, int NT, int NW>
+// ST: 16-row halves per strip (2: every weight fragment read feeds two MFMAs); PF: steps of the strip in flight (a ring)
+template <int KT, int NT, int NW, int ST, int PF>
 __global__ __launch_bounds__(64 * NW, 1) void gemm_b3_rows_kernel(const GemmArgs a) {
-  constexpr int WSS = b3r_wss<KT>(), WPL = NT * WSS, NJ = NT / 16, KS = KT / 32, PF = 3;
+  constexpr int WSS = b3r_wss<KT>(), WPL = NT * WSS, NJ = NT / 16, KS = KT / 32, RS = 16 * ST;
   static_assert(KT % 32 == 0 && NT % 16 == 0 && WSS % 8 == 0 && KS % PF == 0, "shape");
   extern __shared__ __attribute__((aligned(16))) unsigned short b3r_smem[];
   unsigned short *Wp = b3r_smem;
@@ -2049,12 +2050,12 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_b3_rows_kernel(const GemmArgs
   const unsigned xq = blockIdx.x >> 3;
   const int ct = (int)(xq % (unsigned)a.col_tiles), n0 = ct * NT;
   const long slot = (long)(xq / (unsigned)a.col_tiles) * 8 + (blockIdx.x & 7), nslots = gridDim.x / (unsigned)a.col_tiles;
-  const long ntiles = (R + 31) >> 5;
+  const long ntiles = (R + RS - 1) / RS;
   const long tstride = nslots * NW;
   const long t0 = slot * NW + wave;
-  float4 xr[PF][2][2];
+  float4 xr[PF][ST][2];
   auto row_ptrs = [&](long t, const float *&pa, const float *&pb) {
-    const long ra = t * 32 + r16, rb = ra + 16;
+    const long ra = t * RS + r16, rb = ST == 2 ? ra + 16 : ra;
     pa = a.x + (ra < R ? ra : R - 1) * a.ldx + 8 * g;
     pb = a.x + (rb < R ? rb : R - 1) * a.ldx + 8 * g;
   };
@@ -2062,7 +2063,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_b3_rows_kernel(const GemmArgs
 #pragma unroll
     for (int s = 0; s < PF - 1; ++s) {
       xr[s][0][0] = *reinterpret_cast<const float4 *>(pa + 32 * s); xr[s][0][1] = *reinterpret_cast<const float4 *>(pa + 32 * s + 4);
-      xr[s][1][0] = *reinterpret_cast<const float4 *>(pb + 32 * s); xr[s][1][1] = *reinterpret_cast<const float4 *>(pb + 32 * s + 4);
+      if (ST == 2) { xr[s][ST - 1][0] = *reinterpret_cast<const float4 *>(pb + 32 * s); xr[s][ST - 1][1] = *reinterpret_cast<const float4 *>(pb + 32 * s + 4); }
     }
   };
   {
@@ -2111,12 +2112,12 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_b3_rows_kernel(const GemmArgs
 
   const unsigned short *wf = Wp + r16 * WSS + 8 * g;          // lane (g, i): k = 8 g .. 8 g + 7 of weight row (= output column) i
   for (long t = t0; t < ntiles; t += tstride) {
-    const long ra = t * 32 + r16, rb = ra + 16;
+    const long ra = t * RS + r16, rb = ra + 16;
     const float *pa, *pb;
     row_ptrs(t, pa, pb);
-    f32x4 acc[2][NJ];
+    f32x4 acc[ST][NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) { acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int j = 0; j < NJ; ++j) { acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[ST - 1][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     if (t != t0) prologue(pa, pb);
     // a ring of PF steps, unrolled by PF inside a rolled loop: the loads of step s + PF - 1 are issued while step s is
     // multiplied (a fully unrolled loop let the scheduler hoist every load of the strip: 256 registers + scratch)
@@ -2129,11 +2130,11 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_b3_rows_kernel(const GemmArgs
           constexpr int dummy = 0; (void)dummy;
           float4 *d = &xr[(u + PF - 1) % PF][0][0];
           d[0] = *reinterpret_cast<const float4 *>(pa + 32 * sn); d[1] = *reinterpret_cast<const float4 *>(pa + 32 * sn + 4);
-          d[2] = *reinterpret_cast<const float4 *>(pb + 32 * sn); d[3] = *reinterpret_cast<const float4 *>(pb + 32 * sn + 4);
+          if (ST == 2) { d[2] = *reinterpret_cast<const float4 *>(pb + 32 * sn); d[3] = *reinterpret_cast<const float4 *>(pb + 32 * sn + 4); }
         }
-        uint4 bh[2], bm[2], bl[2];
+        uint4 bh[ST], bm[ST], bl[ST];
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
+        for (int st = 0; st < ST; ++st) {
           const float4 v0 = xr[u][st][0], v1 = xr[u][st][1];
           b3_split_pk(v0.x, v0.y, bh[st].x, bm[st].x, bl[st].x);
           b3_split_pk(v0.z, v0.w, bh[st].y, bm[st].y, bl[st].y);
@@ -2153,7 +2154,8 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_b3_rows_kernel(const GemmArgs
         // order left up to five dependent MFMAs back to back, each stalling for the full pipeline latency)
 #define B3R_ROUND(A_, B_)                                                                    \
         _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                     \
-          acc[0][j] = b3_mma(A_[j], B_[0], acc[0][j]); acc[1][j] = b3_mma(A_[j], B_[1], acc[1][j]); \
+          acc[0][j] = b3_mma(A_[j], B_[0], acc[0][j]);                                       \
+          if (ST == 2) acc[ST - 1][j] = b3_mma(A_[j], B_[ST - 1], acc[ST - 1][j]);                 \
         }
         B3R_ROUND(al, bh) B3R_ROUND(ah, bl) B3R_ROUND(am, bm) B3R_ROUND(am, bh) B3R_ROUND(ah, bm) B3R_ROUND(ah, bh)
 #undef B3R_ROUND
@@ -2161,7 +2163,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_b3_rows_kernel(const GemmArgs
     }
     // D = W-fragment (rows = output columns) x row fragment: lane (g, i) holds columns 4 g .. 4 g + 3 of row i
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
+    for (int st = 0; st < ST; ++st) {
       const long row = st ? rb : ra;
       if (row >= R) continue;
 #pragma unroll
@@ -2192,17 +2194,17 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_b3_rows_kernel(const GemmArgs
   }
 }
 
-template <int KT, int NT, int NW>
+template <int KT, int NT, int NW, int ST, int PF>
 int launch_b3_rows1(GemmArgs &a, hipStream_t stream) {
   constexpr size_t lds = b3r_lds_bytes<KT, NT>();
   static_assert(lds + 64 <= 160 * 1024, "weight planes must fit LDS");
   a.col_tiles = a.N / NT;
   int slots = 256 / a.col_tiles / 8 * 8;               // one workgroup per CU, a multiple of 8 slots (slot % 8 = XCD)
   if (slots < 8) slots = 8;
-  const long need = ((a.R + 31) / 32 + NW - 1) / NW;
+  const long need = ((a.R + 16 * ST - 1) / (16 * ST) + NW - 1) / NW;
   while (slots > 8 && slots - 8 >= need) slots -= 8;
   const int grid = slots * a.col_tiles;
-  auto kern = gemm_b3_rows_kernel<KT, NT, NW>;
+  auto kern = gemm_b3_rows_kernel<KT, NT, NW, ST, PF>;
   hipError_t e = eda_set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
   if (e != hipSuccess) { eda_set_error("gemm: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, a);
@@ -2220,15 +2222,18 @@ int try_b3_rows(GemmArgs &a, int wmode, hipStream_t stream) {
   if (a.gate && (a.ldgate % 4 != 0 || !al16(a.gate))) return -1;
   if ((long)a.R * a.ldx >= 0x7fffffffL * 2) return -1;
   // Measured (tools/bench_gemm_b3rows.py, us per launch in a replayed graph, fp32 MFMA -> bf16 x 3; profiles/r05_gemm_b3rows.txt):
-  //   8192 x 288 -> 288  17.1 -> 16.4    8192 x 288 -> 576  31.8 -> 26.3    8192 x 288 -> 864  42.1 -> 46.4 (144 workgroups)
-  //   8192 x 576 -> 288  27.5 -> 39.1    4096 x 288 -> 288  11.6 -> 15.1   16384 x 288 -> 288  31.9 -> 26.6
-  // The matrix pipe is no longer the bound (the MFMA phase of a strip is ~2.5 us); what a CU can INGEST is: 48-column tiles
-  // re-read the rows six times (70 MB per launch at the ~6.7 TB/s all CUs together take in: profiles/r03c_gemm_dma.md), and
-  // 96-column planes (189 KB) do not fit LDS.  So: by default only where it wins; EDA_GEMM_B3ROWS=2 takes every eligible shape.
+  //   8192 x 288 -> 288  17.2 -> 15.4    8192 x 288 -> 576  32.1 -> 24.1    8192 x 288 -> 864  42.1 -> 46.4 (144 workgroups)
+  //   8192 x 576 -> 288  27.5 -> 39.1    4096 x 288 -> 288  11.4 -> 13.4   16384 x 288 -> 288  31.5 -> 24.4
+  // (16 waves of 16-row strips: with 8 waves of 32-row strips the split arithmetic of a wave -- 176 VALU instructions per
+  // strip and step, redone for each of the N / 48 column tiles -- and its MFMAs ran one after the other: 16.4 / 26.2 / 26.4.)
+  // ~11 us of a launch are a serial chain -- launch, weight tile (load, split, barrier), first rows, one strip, store -- so
+  // the gain is bounded; 576-deep contractions need 32-column tiles (three MFMAs per split value: slower than fp32).
+  // Inside the training step the 33 launches of 8192 x 288 -> 288 showed nothing (17.58 vs 17.60 ms, three alternating runs):
+  // by default only where the isolated gain is >= 20 %; EDA_GEMM_B3ROWS=2 takes every eligible shape.
   const bool all = eda_knob(EDA_K_GEMM_B3ROWS) == 2;
   if (a.K == 288 && a.N % 48 == 0 && (all || (a.N == 576 && a.R >= 8192) || (a.N <= 576 && a.R >= 16384)))
-    return launch_b3_rows1<288, 48, 8>(a, stream);
-  if (a.K == 576 && a.N % 32 == 0 && all) return launch_b3_rows1<576, 32, 8>(a, stream);
+    return launch_b3_rows1<288, 48, 16, 1, 3>(a, stream);
+  if (a.K == 576 && a.N % 32 == 0 && all) return launch_b3_rows1<576, 32, 8, 2, 3>(a, stream);
   return -1;
 }
 
