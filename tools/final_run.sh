@@ -35,6 +35,9 @@ python tools/bench_sa_eval.py > $O/sa_eval.txt 2>&1
 EDA_MHA_QPROJ=0 python bench.py --in-step-steps 0 > $O/bench_qproj_off.json 2> $O/bench_qproj_off.err
 EDA_WGRAD_BF16X3=0 python bench.py --in-step-steps 0 > $O/bench_wgrad_fp32_mfma.json 2> $O/bench_wgrad_fp32_mfma.err
 EDA_BATCHED_HEADS=0 python bench.py --in-step-steps 0 > $O/bench_heads_per_head.json 2> $O/bench_heads_per_head.err
+EDA_RESIDUAL_LINK=0 python bench.py --in-step-steps 0 > $O/bench_residual_link_off.json 2> $O/bench_residual_link_off.err
+EDA_GEMM_B3ROWS=0 python bench.py --in-step-steps 0 > $O/bench_b3rows_off.json 2> $O/bench_b3rows_off.err
+python tools/bench_gemm_b3rows.py > $O/gemm_b3rows_tool.txt 2>&1
 python tools/bench_wgrad_grouped.py > $O/wgrad_grouped.txt 2>&1
 python tools/time_qproj_site.py > $O/qproj_site.txt 2>&1
 python tools/time_linear_ln.py 2048 288 > $O/linear_ln.txt 2>&1
