@@ -431,6 +431,11 @@ def main():
             args.graph = 0
         sync_bn.enable(single_rank_too=(world == 1), native=(args.sync_bn == "native"))        # fused SA / FP calls keep their fusion (library hook); no host synchronisation anywhere, so the
         # step is captured like the default one (a capture failure falls back to eager launches below)
+        if args.sync_bn == "native" and not sync_bn.native() and args.graph:
+            # the peer-memory self-test failed on some rank (sync_bn logged it): the statistics go through collectives, which
+            # cannot live inside a captured step (above)
+            print("[bench] --sync-bn native fell back to collectives: eager launches", file=sys.stderr, flush=True)
+            args.graph = 0
     from eda_amd.bdetr import BeaUTyDETR
     from eda_amd.parallel import FlatParams, reference_lr_groups
     if args.blas != "default":
@@ -544,11 +549,32 @@ def main():
             w_.wait()
         ar_works.clear()                             # (the 1/world rides in the clip's multiplication, update())
 
-    def all_reduce():
+    # Collectives issued BEFORE the step is captured run on a stream of their own that never captures.  RCCL's watchdog thread
+    # polls the completion events of the collectives issued so far; synchronous collectives record those events on the stream
+    # they were issued on, and on this ROCm an event query on a stream that has since entered capture fails with "operation
+    # not permitted on an event last recorded in a capturing stream", which aborts the process from the watchdog thread (seen
+    # in 2 of 6 --force-dist runs of round 4, worked around with a sleep until round 5).  Stream order is kept with
+    # wait_stream on both sides; after the capture the collectives run between the graphs on the replay stream itself.
+    coll_stream = torch.cuda.Stream() if dist_on else None
+    pre_capture = [bool(args.graph)]
+
+    def on_coll_stream(fn):
+        if not (dist_on and pre_capture[0]):
+            return fn()
+        cur = torch.cuda.current_stream()
+        coll_stream.wait_stream(cur)
+        with torch.cuda.stream(coll_stream):
+            fn()
+        cur.wait_stream(coll_stream)
+
+    def all_reduce_now():
         if overlap_ar:
             reduce_a(); stage_b(); reduce_b()
         elif dist_on:
             dist.all_reduce(flat.flat_grad)
+
+    def all_reduce():
+        on_coll_stream(all_reduce_now)
 
     def record_loss(loss):
         if ingraph_hist is not None:                 # debugging aid: loss history written by the graph itself
@@ -576,6 +602,14 @@ def main():
         load_batch()
         return core_step()
 
+    def sync_bn_native_on():
+        from eda_amd import sync_bn as _s
+        return _s.native()
+
+    def _lib_peer_kind():
+        from eda_amd import _lib as _l
+        return _l.lib().eda_peer_alloc_kind()
+
     def log(msg):
         if rank == 0:
             print(f"[bench +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
@@ -594,16 +628,9 @@ def main():
             for _ in range(2):
                 eager_step()
         torch.cuda.current_stream().wait_stream(side)
-        barrier_sync = (lambda: (dist.barrier() if dist_on else None, torch.cuda.synchronize()))
+        barrier_sync = (lambda: (on_coll_stream(dist.barrier) if dist_on else None, torch.cuda.synchronize()))
         barrier_sync()
-        if dist_on:
-            # RCCL's watchdog thread polls the events of the collectives issued so far (the barrier just now) every ~100 ms
-            # until it has seen them complete.  Synchronous collectives record those events on the CURRENT stream -- the
-            # stream the capture below starts on -- and on this ROCm an event query on a stream that has since entered capture
-            # fails with "operation not permitted on an event last recorded in a capturing stream", which ABORTS the process
-            # from the watchdog thread (seen in 2 of 6 --force-dist runs).  Everything is complete on the GPU here: give the
-            # watchdog one poll interval to retire it before any stream starts capturing.
-            time.sleep(1.0)
+        # (no collective's completion event sits on a stream that captures below: on_coll_stream above)
         # thread-local capture mode: calls from other threads (RCCL's watchdog) must not
         # invalidate the capture.
         mode = dict(capture_error_mode="thread_local")
@@ -661,11 +688,13 @@ def main():
                         all_reduce()
                     g_up.replay()
                     return static_loss
+            pre_capture[0] = False
             log("step captured in HIP graph(s)")
         except Exception as exc:     # never lose the run to a capture problem: fall back to eager launches
             log(f"graph capture failed ({type(exc).__name__}: {exc}); falling back to eager launches")
             torch.cuda.synchronize()
             args.graph = 0
+            pre_capture[0] = False
             step = eager_step
 
     trace_loss = os.environ.get("EDA_BENCH_TRACE_LOSS") == "1"      # debugging aid: loss of every warm-up step
@@ -756,6 +785,11 @@ def main():
     if fps_giveups:
         raise SystemExit(f"furthest point sampling gave up its inter-workgroup spin in {fps_giveups} workspace(s): "
                          "the sampled indices of this run are not the FPS result (include/eda_hip.h)")
+    if args.sync_bn and dist_on:
+        # the in-kernel BatchNorm statistics exchange never hangs -- a poll that ran into its bound is COUNTED and the statistics
+        # are garbage from then on (csrc/peer.h): a run with a non-zero count measured a broken training step
+        from eda_amd import sync_bn as _sbn
+        _sbn.check()
     log(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step")
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -1050,7 +1084,11 @@ def main():
                                               "two ranges of the flat fp32 buffer, the first in flight underneath the second "
                                               "range's grouped weight-gradient kernel" if overlap_ar else
                                               "one all-reduce of the flat fp32 buffer after the backward"),
-                       "batchnorm": ("global-batch statistics (sync_bn, %s%s)" % (args.sync_bn, "; one rank: the N > 1 code path" if world == 1 else ""))
+                       "batchnorm": ("global-batch statistics (sync_bn, %s%s%s)" % (
+                           args.sync_bn, "; one rank: the N > 1 code path" if world == 1 else "",
+                           ("; in-kernel exchange, slab memory kind %d, self-test passed, 0 timed-out polls"
+                            % _lib_peer_kind()) if sync_bn_native_on() else
+                           ("; FELL BACK to collectives: the peer-memory self-test failed" if args.sync_bn == "native" else "")))
                        if (args.sync_bn and dist_on) else "per-GPU statistics",
                        "launch": ("eager" if not args.graph else
                                   ("three hipGraphs on two streams (frozen text encoder underneath the point backbone | "

@@ -66,6 +66,9 @@ SIGNATURES = {
     "eda_peer_slab_bytes": (_sz, []),
     "eda_peer_create": (_i, [_p]),
     "eda_peer_connect": (_i, [_i, _i, _p]),
+    "eda_peer_alloc_kind": (_i, []),
+    "eda_peer_reset": (_i, []),
+    "eda_peer_selftest": (_i, [_p, _i]),
     "eda_peer_disconnect": (_i, []),
     "eda_peer_connected": (_i, []),
     "eda_peer_timeouts": (_l, []),
@@ -151,6 +154,11 @@ def lib():
             raise EdaHipError(f"libeda_hip.so ABI version {L.eda_version()} != 1")
         _lib = L
     return _lib
+
+
+def last_error():
+    msg = lib().eda_last_error_string()
+    return msg.decode() if msg else ""
 
 
 def check(rc, what):

@@ -106,8 +106,22 @@ def _fwd_workspace(dev, B, H, Lq, Lk):
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, n)
     ws = _fwd_ws_cache.get(key)
     if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            # (a buffer born inside a capture lives in that graph's pool and is zeroed only when that graph replays, yet this
+            # cache would hand it to eager calls and other graphs: ADVICE r05)
+            raise RuntimeError("eda_amd.attention: no key-split workspace for this (device, stream, size) yet -- run the "
+                               "step once eagerly on the stream before capturing it in a HIP graph")
         ws = _fwd_ws_cache[key] = torch.zeros((n + 3) // 4, dtype=torch.int32, device=dev)
     return ws
+
+
+def reset_workspaces():
+    """Re-zero every key-split workspace handed out so far (their ticket words must be zero between launches; an aborted
+    launch can leave a count behind).  Synchronises."""
+    torch.cuda.synchronize()
+    for ws in _fwd_ws_cache.values():
+        ws.zero_()
+    torch.cuda.synchronize()
 
 
 def _mha_fwd_call(q, k, v, m8, B, num_heads, Lq, Lk, hd, p_drop, salt, out, lse):

@@ -4,7 +4,8 @@
 // captured step on this stack and costs a launch each; here the exchange is a few 8-byte stores and
 // polls INSIDE the kernel that has the local sums in registers.
 //
-// Every rank owns one slab (device memory, mapped into every peer process with hipIpc*); slab words are u64:
+// Every rank owns one slab (FINE-GRAINED device memory -- it is polled and written by other GPUs while kernels run, csrc/peer.hip
+// alloc_slab -- mapped into every peer process with hipIpc*); slab words are u64:
 //   [0] seq   number of exchanging launches this rank has completed (every rank runs the same launches in the same order)
 //   [1] done  arrival ticket of the current launch's workgroups (the last one bumps seq)
 //   [2] timeouts (sticky count of bounded spins that gave up: results are then garbage, never a hang)
@@ -36,8 +37,8 @@ __device__ __forceinline__ unsigned long long eda_peer_seq(const EdaPeer &P) {
   return __hip_atomic_load(P.slab[P.rank], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// one thread, one granule: (a, b) <- sums over the ranks, rank order
-__device__ __forceinline__ void eda_peer_exchange2(const EdaPeer &P, unsigned long long seq, int g, double &a, double &b) {
+// one thread, one granule, first half: this rank's pair into every rank's slab, then the tag
+__device__ __forceinline__ void eda_peer_publish2(const EdaPeer &P, unsigned long long seq, int g, double a, double b) {
   const unsigned long long tag = seq + 1;
   const size_t base = PEER_HDR + (((seq & 1) * PEER_MAXG + (size_t)g) * PEER_MAXW) * 4;
   const unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
@@ -52,6 +53,12 @@ __device__ __forceinline__ void eda_peer_exchange2(const EdaPeer &P, unsigned lo
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   for (int r = 0; r < P.world; ++r)
     __hip_atomic_store(P.slab[r] + base + (size_t)P.rank * 4 + 2, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// second half: wait for every source rank's tag in the OWN slab, add the pairs in rank order
+__device__ __forceinline__ void eda_peer_poll2(const EdaPeer &P, unsigned long long seq, int g, double &a, double &b) {
+  const unsigned long long tag = seq + 1;
+  const size_t base = PEER_HDR + (((seq & 1) * PEER_MAXG + (size_t)g) * PEER_MAXW) * 4;
   double sa = 0.0, sb = 0.0;
   unsigned long long *mine = P.slab[P.rank];
   const unsigned limit = __hip_atomic_load(mine + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull ? 0u : P.spin_limit;
@@ -72,6 +79,12 @@ __device__ __forceinline__ void eda_peer_exchange2(const EdaPeer &P, unsigned lo
     sb += __builtin_bit_cast(double, vb);
   }
   a = sa; b = sb;
+}
+
+// one thread, one granule: (a, b) <- sums over the ranks, rank order
+__device__ __forceinline__ void eda_peer_exchange2(const EdaPeer &P, unsigned long long seq, int g, double &a, double &b) {
+  eda_peer_publish2(P, seq, g, a, b);
+  eda_peer_poll2(P, seq, g, a, b);
 }
 
 // every workgroup of an exchanging launch, once, after its last exchange (one thread): the last arriver bumps seq

@@ -102,6 +102,7 @@ BnSync bn_sync_native_arg() {
   if (g_sync_native && P) { S.P = *P; S.world = g_sync_world; }
   return S;
 }
+bool bn_sync_native_on() { return g_sync_native && eda_peer_active() != nullptr; }
 struct BnFinalize {          // what the last block of bn_stats_kernel needs to finish the statistics
   const float *gamma, *beta;
   float eps, momentum;
@@ -1469,6 +1470,7 @@ extern "C" int eda_bn_relu_grouped_fwd_f32(const float *z, long R, int ngroups, 
     G.salt[g] = salts ? salts[g] : 0u;
   }
   const int C = ngroups * cpg;
+  EDA_CHECK_ARG(!bn_sync_native_on() || C <= PEER_MAXG, "more channels than the peer slab has granules (PEER_MAXG)");
   hipLaunchKernelGGL(bn_relu_small_fwd_kernel<4>, dim3(C / 16), dim3(SM_THREADS), 0, stream, z, (int)R, C, G, eps,
                      momentum, training, mean, rstd, scale, shift, out, p_drop, seed_ptr, bn_sync_native_arg());
   EDA_CHECK_LAUNCH();
@@ -1495,6 +1497,7 @@ extern "C" int eda_bn_relu_grouped_bwd_f32(const float *dout, const float *z, lo
   memset(&G, 0, sizeof(G));
   G.cpg = cpg;
   for (int g = 0; g < ngroups; ++g) { EDA_CHECK_ARG(gamma[g], "null pointer"); G.gamma[g] = gamma[g]; G.salt[g] = salts ? salts[g] : 0u; }
+  EDA_CHECK_ARG(!bn_sync_native_on() || C <= PEER_MAXG, "more channels than the peer slab has granules (PEER_MAXG)");
   hipLaunchKernelGGL(bn_relu_small_bwd_kernel<4>, dim3(C / 16), dim3(SM_THREADS), 0, stream, dout, z, (int)R, C, G, mean,
                      rstd, scale, shift, training, nullptr, nullptr, dgamma, dbeta, dz, p_drop, seed_ptr, bn_sync_native_arg());
   EDA_CHECK_LAUNCH();
@@ -1524,6 +1527,9 @@ extern "C" int eda_bn_relu_grouped_bwd_multi_f32(int nmat, const float *const *d
       M.grp[m].salt[g] = salts ? salts[m * ngroups + g] : 0u;
     }
   }
+  // granule index of the in-kernel statistics exchange = matrix * C + channel: it must stay inside one parity's region of
+  // the slab (csrc/peer.h), or the stores land in the other parity / past the end of every peer's mapped slab
+  EDA_CHECK_ARG(!bn_sync_native_on() || (long)nmat * C <= PEER_MAXG, "nmat * channels beyond the peer slab's granules (PEER_MAXG)");
   hipLaunchKernelGGL(bn_relu_small_bwd_multi_kernel<4>, dim3(C / 16, nmat), dim3(SM_THREADS), 0, stream, M, (int)R, C, training,
                      p_drop, seed_ptr, bn_sync_native_arg());
   EDA_CHECK_LAUNCH();

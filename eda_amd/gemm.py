@@ -23,6 +23,36 @@ _SK_BYTES = 16 << 20
 _sk_ws_cache = {}
 
 
+def _stream_workspace(dev):
+    """The persistent 16 MiB scratch of (device, current stream).  Its leading ticket words must be ZERO before a split
+    launch and every launch leaves them zero.  It is created OUTSIDE any capture: a buffer first allocated while a hipGraph
+    is being captured would live in that graph's private pool and be zeroed by a captured fill -- i.e. only when THAT graph
+    replays -- while this cache hands it to eager calls and other graphs as well."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _sk_ws_cache.get(key)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("eda_amd.gemm: no split-launch workspace for this (device, stream) yet -- run the step once "
+                               "eagerly on the stream (or call eda_amd.gemm.prepare_workspace()) before capturing it")
+        ws = _sk_ws_cache[key] = torch.zeros(_SK_BYTES // 4, dtype=torch.int32, device=dev)
+    return ws
+
+
+def prepare_workspace(dev=None):
+    """Create the current stream's workspace (outside a capture); returns it."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if dev is None else torch.device(dev)
+    return _stream_workspace(dev)
+
+
+def reset_workspaces():
+    """Re-zero the ticket words of every workspace handed out so far (after a failed or aborted launch left an arrival
+    count behind, every later split product on that stream would merge at the wrong arrival).  Synchronises."""
+    torch.cuda.synchronize()
+    for ws in _sk_ws_cache.values():
+        ws.zero_()
+    torch.cuda.synchronize()
+
+
 def splitk_workspace(dev, R, K, N):
     """Scratch of the split-contraction launches (include/eda_hip.h: eda_linear_ex_ws_f32) for a product with R rows,
     contraction K, N columns, or None when the library does not split that shape: one persistent 16 MiB buffer per
@@ -30,22 +60,14 @@ def splitk_workspace(dev, R, K, N):
     n = int(_lib.lib().eda_linear_splitk_workspace_bytes(R, K, N))
     if n == 0 or n > _SK_BYTES:
         return None
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-    ws = _sk_ws_cache.get(key)
-    if ws is None:
-        ws = _sk_ws_cache[key] = torch.zeros(_SK_BYTES // 4, dtype=torch.int32, device=dev)
-    return ws
+    return _stream_workspace(dev)
 
 
 def workspace(dev, nbytes):
     """The persistent zero-initialised scratch of the current stream (the one splitk_workspace hands out) if `nbytes` fit."""
     if nbytes > _SK_BYTES:
         return None
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-    ws = _sk_ws_cache.get(key)
-    if ws is None:
-        ws = _sk_ws_cache[key] = torch.zeros(_SK_BYTES // 4, dtype=torch.int32, device=dev)
-    return ws
+    return _stream_workspace(dev)
 
 
 def linear_fwd(x2, w, bias=None, relu=False, out=None):

@@ -108,7 +108,7 @@ def native():
 
 
 def _connect_peers(group):
-    """Create this rank's slab, gather every rank's IPC handle, map the peers (csrc/peer.hip)."""
+    """Create this rank's slab, gather every rank's IPC handle, map the peers, start a clean session (csrc/peer.hip)."""
     from . import _lib
     L = _lib.lib()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -121,9 +121,35 @@ def _connect_peers(group):
         handles[0] = bytes(mine.raw)
     blob = ctypes.create_string_buffer(b"".join(handles), 64 * world)
     _lib.check(L.eda_peer_connect(rank, world, blob), "eda_peer_connect")
+    # a new session starts from sequence number 0 on every rank, with no counted timeout and no stale tag: every rank zeroes
+    # its own slab, and nobody's kernels write into a slab before every rank has done so and mapped all of them
+    _lib.check(L.eda_peer_reset(), "eda_peer_reset")
     if world > 1:
-        dist.barrier(group=group)          # every rank has mapped every slab before anyone's kernels write into them
+        dist.barrier(group=group)
     return world
+
+
+def peer_selftest(group=None, inject_wrong_tag=False):
+    """One exchange of a known vector through the peer slabs by EVERY rank of the group (csrc/peer.hip: eda_peer_selftest);
+    True when every rank got the right sums with no timed-out poll.  After a failure the slabs are reset (a counted
+    timeout is sticky and a wrong tag may be left behind), so the result is the same on every rank and the exchange can
+    be tried again."""
+    from . import _lib
+    L = _lib.lib()
+    rc = L.eda_peer_selftest(torch.cuda.current_stream().cuda_stream, int(bool(inject_wrong_tag)))
+    ok = rc == 0
+    world = dist.get_world_size(group)
+    if world > 1:
+        flag = torch.tensor([0 if ok else 1], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        ok = int(flag.item()) == 0
+    if not ok:
+        if world > 1:
+            dist.barrier(group=group)          # nobody is still polling
+        _lib.check(L.eda_peer_reset(), "eda_peer_reset")
+        if world > 1:
+            dist.barrier(group=group)
+    return ok
 
 
 def enable(group=None, fused=True, single_rank_too=False, native=False):
@@ -131,7 +157,13 @@ def enable(group=None, fused=True, single_rank_too=False, native=False):
     GPU): the fused SA / FP calls stay fused and exchange their sums through the library hook.  single_rank_too: also
     in a one-rank group (same results as without; exercises the collectives' code path on a one-GPU box).
     native=True: the exchange happens inside the library's kernels through peer-mapped memory -- no collective, every
-    site stays fused, capturable (module docstring)."""
+    site stays fused, capturable (module docstring).  The peer path is only trusted after a self-test exchange on THIS
+    set of GPUs (peer_selftest); if that fails on any rank, every rank logs one line and falls back to the collective
+    hook (fused=True semantics).
+
+    Preconditions of native=True (csrc/peer.h; they make the per-rank sequence numbers agree): every rank issues the same
+    BatchNorm launches in the same order on ONE stream, with the same shapes -- equal batch per rank (drop_last), the
+    same launch-structure knobs on every rank.  `check()` is the host-side guard: call it once per step or per epoch."""
     global _enabled, _group, _single_rank_too, _native
     if not dist.is_initialized():
         raise RuntimeError("sync_bn.enable() needs torch.distributed to be initialised")
@@ -142,11 +174,31 @@ def enable(group=None, fused=True, single_rank_too=False, native=False):
         if dist.get_world_size(group) > 1 or single_rank_too:
             from . import _lib
             world = _connect_peers(group)
-            _lib.check(_lib.lib().eda_set_bn_sync_native(world), "eda_set_bn_sync_native")
-            _native = True
-        return
+            if peer_selftest(group, inject_wrong_tag=_selftest_inject):
+                _lib.check(_lib.lib().eda_set_bn_sync_native(world), "eda_set_bn_sync_native")
+                _native = True
+                return
+            import sys
+            print("[eda_amd.sync_bn] rank %d: the peer-memory self-test failed (%s); BatchNorm statistics go through "
+                  "collectives instead" % (dist.get_rank(group), _lib.last_error()), file=sys.stderr, flush=True)
+            _lib.lib().eda_peer_disconnect()
+        else:
+            return
     if fused and torch.cuda.is_available() and (dist.get_world_size(group) > 1 or single_rank_too):
         install_fused_hook(dist.get_world_size(group))
+
+
+_selftest_inject = False    # test seam: enable(native=True) runs its self-test with an injected wrong tag
+
+
+def check():
+    """Raise if an in-kernel statistics exchange ever ran into its poll bound (the statistics since then are garbage).
+    A host read: it synchronises the device, so call it once per step at most -- bench.py does after its timed region."""
+    if _native:
+        n = peer_timeouts()
+        if n != 0:
+            raise RuntimeError("sync_bn: %d in-kernel BatchNorm statistics exchanges timed out -- the ranks' launch "
+                               "sequences diverged or a peer died; statistics are invalid from that point on" % n)
 
 
 def disable():
@@ -155,6 +207,7 @@ def disable():
     if _native:
         from . import _lib
         _lib.lib().eda_set_bn_sync_native(0)
+        _lib.lib().eda_peer_disconnect()       # the next enable() maps its own group's slabs and starts a clean session
         _native = False
     remove_fused_hook()
 

@@ -54,6 +54,7 @@ extern "C" {
 #define EDA_ERR_INVALID_ARG   10001
 #define EDA_ERR_WORKSPACE     10002
 #define EDA_ERR_UNSUPPORTED   10003
+#define EDA_ERR_PEER_SELFTEST 10004
 
 int         eda_version(void);
 const char *eda_last_error_string(void);
@@ -664,17 +665,30 @@ int eda_sa_fused_eval_f32(const float *xyz, const float *new_xyz, const float *f
  * and adds them in rank order -- inside the BatchNorm kernels themselves (single-launch heads / positional embeddings,
  * the last block of the statistics kernel) or as a one-launch exchange of a vector (the fused set-abstraction calls'
  * hook).  No host work between kernels, nothing a hipGraph capture cannot hold, every rank gets the same bits.  All ranks
- * must issue the same exchanging launches in the same order.  Spins are bounded (~1 s): a rank that never arrives costs
- * eda_peer_timeouts() > 0 and garbage statistics, not a hang.
+ * must issue the same exchanging launches in the same order ON ONE STREAM with the same shapes (equal rows per rank:
+ * drop_last).  Spins are bounded (EDA_PEER_SPIN_LOG2): a rank that never arrives costs eda_peer_timeouts() > 0 and garbage
+ * statistics, not a hang -- the host MUST read eda_peer_timeouts() (per step or per epoch) and stop on a non-zero value
+ * (bench.py, eda_amd/sync_bn.check()).  The slab is FINE-GRAINED device memory (hipExtMallocWithFlags): it is written and
+ * polled by other GPUs while this GPU's kernels run, and coarse-grained memory is coherent between agents at kernel
+ * boundaries only.
  *   eda_peer_create(handle)            allocate + zero this process's slab (once); handle: 64 bytes out (hipIpcMemHandle_t)
- *   eda_peer_connect(rank, world, hs)  hs: world x 64 bytes, rank order, gathered by the host (any out-of-band channel)
+ *   eda_peer_alloc_kind()              0 fine-grained, 1 uncached, 2 plain device memory (one-device use only), -1 none yet
+ *   eda_peer_connect(rank, world, hs)  hs: world x 64 bytes, rank order, gathered by the host (any out-of-band channel);
+ *                                      a peer whose handle changed since the last connect is re-opened
+ *   eda_peer_reset()                   zero the own slab (every rank, nothing in flight, host barrier behind it)
+ *   eda_peer_selftest(s, inject)       one exchange of a known vector by EVERY rank; host-checked sums and timeout word:
+ *                                      0 or EDA_ERR_PEER_SELFTEST (inject != 0: publish a wrong tag -- test seam)
  *   eda_set_bn_sync_native(world)      BatchNorm statistics over the world (0 = per-GPU again); replaces eda_set_bn_sync
  *   eda_peer_allreduce_f64(buf, n, s)  in-place sum of n <= 16384 doubles over the ranks, one launch on stream s
  *   eda_peer_bn_hook                   the same as an eda_bn_sync_fn
- * Over xGMI the protocol is unchanged but unmeasured in this repository (one-device box: two processes on one GPU). */
+ * Over xGMI the protocol is unchanged but unmeasured in this repository (one-device box: two processes on one GPU);
+ * eda_peer_selftest() is what tells a process at start-up whether its slabs really carry data between the GPUs. */
 size_t eda_peer_slab_bytes(void);
 int eda_peer_create(void *handle_out);
+int eda_peer_alloc_kind(void);
 int eda_peer_connect(int rank, int world, const void *handles);
+int eda_peer_reset(void);
+int eda_peer_selftest(void *stream, int inject_wrong_tag);
 int eda_peer_disconnect(void);
 int eda_peer_connected(void);
 long eda_peer_timeouts(void);

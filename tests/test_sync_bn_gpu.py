@@ -133,3 +133,84 @@ def test_native_exchange_on_one_rank_equals_the_plain_kernels_bit_for_bit():
             torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
         else:
             assert torch.equal(a, b), i
+
+
+def test_peer_self_test_passes_detects_an_injected_wrong_tag_and_recovers():
+    """csrc/peer.hip eda_peer_selftest, one rank against its own slab: (1) the slab is fine-grained or
+    uncached device memory and exports an IPC handle; (2) the exchange of the known vector passes; (3) with a wrong tag
+    injected the polls run into their bound, the call returns EDA_ERR_PEER_SELFTEST, `sync_bn.check()`-style reading of the
+    timeout word is non-zero until the reset; (4) after the reset it passes again; (5) `enable(native=True)` with the
+    injected fault logs and falls back to the collective hook instead of switching the kernels to the peer exchange."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from eda_amd import _lib, sync_bn
+    L = _lib.lib()
+    old = os.environ.get("EDA_PEER_SPIN_LOG2")
+    os.environ["EDA_PEER_SPIN_LOG2"] = "10"
+    L.eda_reload_env()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        sync_bn.enable(single_rank_too=True, native=True)
+        assert sync_bn.native()
+        assert L.eda_peer_alloc_kind() in (0, 1), L.eda_peer_alloc_kind()
+        stream = torch.cuda.current_stream().cuda_stream
+        assert L.eda_peer_selftest(stream, 0) == 0
+        assert L.eda_peer_selftest(stream, 1) == 10004 and b"timed-out" in L.eda_last_error_string()
+        assert sync_bn.peer_timeouts() > 0
+        try:
+            sync_bn.check()
+            raise AssertionError("sync_bn.check() must raise on a counted timeout")
+        except RuntimeError as e:
+            assert "timed out" in str(e)
+        _lib.check(L.eda_peer_reset(), "reset")
+        assert sync_bn.peer_timeouts() == 0 and L.eda_peer_selftest(stream, 0) == 0
+        sync_bn.disable()
+        assert L.eda_peer_connected() == 0
+        # the same fault at enable(): no native exchange, the collective hook instead
+        sync_bn._selftest_inject = True
+        sync_bn.enable(single_rank_too=True, native=True)
+        assert not sync_bn.native() and sync_bn.fused_hook_installed() and sync_bn.diverts()
+        assert sync_bn.peer_timeouts() == 0
+    finally:
+        sync_bn._selftest_inject = False
+        sync_bn.disable()
+        dist.destroy_process_group()
+        if old is None:
+            os.environ.pop("EDA_PEER_SPIN_LOG2", None)
+        else:
+            os.environ["EDA_PEER_SPIN_LOG2"] = old
+        L.eda_reload_env()
+
+
+def test_grouped_batchnorm_rejects_more_channels_than_the_peer_slab_has_granules():
+    """granule index = matrix * C + channel must stay below PEER_MAXG (8192) when the kernels exchange their
+    statistics through the slab -- 8 matrices x 4 groups x 288 channels = 9216 would write past one parity's region."""
+    import ctypes
+    import os
+    import socket
+    import torch.distributed as dist
+    from eda_amd import _lib, sync_bn
+    L = _lib.lib()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        sync_bn.enable(single_rank_too=True, native=True)
+        nmat, ng, cpg, R = 8, 4, 288, 64
+        C = ng * cpg
+        dev = "cuda"
+        z = [torch.randn(R, C, device=dev) for _ in range(nmat)]
+        dz = [torch.empty(R, C, device=dev) for _ in range(nmat)]
+        gam = [torch.ones(cpg, device=dev) for _ in range(nmat * ng)]
+        st = [torch.zeros(4 * C, device=dev) for _ in range(nmat)]
+        dgb = [torch.zeros(2 * C, device=dev) for _ in range(nmat)]
+        arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        rc = L.eda_bn_relu_grouped_bwd_multi_f32(nmat, arr(z), arr(z), R, ng, cpg, arr(gam), arr(st), 1, arr(dgb), arr(dz), 0.0,
+                                                 None, None, torch.cuda.current_stream().cuda_stream)
+        assert rc == 10001 and b"PEER_MAXG" in L.eda_last_error_string()
+    finally:
+        sync_bn.disable()
+        dist.destroy_process_group()

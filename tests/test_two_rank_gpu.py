@@ -21,10 +21,10 @@ def _free_port():
     return port
 
 
-def _run(world, out_dir, overlap, tag, deterministic=0, sync="collective", graph=0):
+def _run(world, out_dir, overlap, tag, deterministic=0, sync="collective", graph=0, inject_rank=-1, spin_log2="22"):
     port = _free_port()
     procs, outs = [], []
-    env = dict(os.environ, EDA_PEER_SPIN_LOG2="22")      # (a dead peer costs the test ~5 s, not the production default)
+    env = dict(os.environ, EDA_PEER_SPIN_LOG2=spin_log2)      # (a dead peer costs the test ~5 s, not the production default)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     for r in range(world):
@@ -32,7 +32,8 @@ def _run(world, out_dir, overlap, tag, deterministic=0, sync="collective", graph
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "two_rank_worker.py"), "--world", str(world),
                                        "--rank", str(r), "--port", str(port), "--overlap", str(overlap), "--out", out,
-                                       "--deterministic", str(deterministic), "--sync", sync, "--graph", str(graph)],
+                                       "--deterministic", str(deterministic), "--sync", sync, "--graph", str(graph),
+                                       "--selftest-inject-rank", str(inject_rank)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
     for p in procs:
@@ -121,6 +122,8 @@ def test_two_ranks_with_the_in_kernel_statistics_exchange(tmp_path, graph):
     one, = _run(1, str(tmp_path), 0, "n1", deterministic=1)
     two = _run(2, str(tmp_path), 0, f"n2g{graph}", deterministic=1, sync="native", graph=graph)
     assert all(t["peer_timeouts"] == 0 for t in two), [t["peer_timeouts"] for t in two]
+    # the slab other GPUs write and poll while kernels run is fine-grained (or uncached) device memory, never plain hipMalloc
+    assert all(t["native"] and t["peer_alloc_kind"] in (0, 1) for t in two), [(t["native"], t["peer_alloc_kind"]) for t in two]
     assert all(t["captured"] == bool(graph) for t in two)
     assert all(t["fused_hook_calls"] == 0 for t in two)            # no collective ran for the statistics
     assert torch.equal(two[0]["grad0"], two[1]["grad0"]) and torch.equal(two[0]["param"], two[1]["param"])
@@ -134,3 +137,19 @@ def test_two_ranks_with_the_in_kernel_statistics_exchange(tmp_path, graph):
     assert report["grad_rel"] <= 5e-3 and report["update_rel"] <= 0.03, report
     for k, v in one["bn"].items():
         assert torch.allclose(two[0]["bn"][k], v, rtol=1e-4, atol=1e-6), k
+
+
+def test_a_failed_peer_self_test_on_one_rank_sends_both_ranks_to_the_collective_hook(tmp_path):
+    """`sync_bn.enable(native=True)` trusts the peer slabs only after one exchange of a known vector.
+    Rank 1 publishes a WRONG tag in that self-test: rank 0's polls of rank 1's granules (and rank 1's own) run into their
+    bound, the timeout word counts them, the ranks agree on the failure, reset their slabs and BOTH fall back to the
+    collective hook -- training then equals one rank on the global batch as in the collective test, with statistics
+    exchanged through `dist.all_reduce` (hook calls > 0) and no counted timeout left behind."""
+    one, = _run(1, str(tmp_path), 0, "f1", deterministic=1)
+    two = _run(2, str(tmp_path), 0, "f2", deterministic=1, sync="native", graph=0, inject_rank=1, spin_log2="12")
+    assert all(not t["native"] for t in two)
+    assert all(t["fused_hook_calls"] > 0 for t in two)
+    assert all(t["peer_timeouts"] == 0 for t in two)                 # (reset after the failed self-test)
+    assert torch.equal(two[0]["grad0"], two[1]["grad0"]) and torch.equal(two[0]["param"], two[1]["param"])
+    l2 = (two[0]["losses"] + two[1]["losses"]) / 2
+    assert torch.allclose(l2, one["losses"], rtol=1e-4), (l2, one["losses"])

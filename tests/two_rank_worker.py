@@ -22,6 +22,11 @@ import torch
 import torch.distributed as dist
 
 
+def _peer_kind():
+    from eda_amd import _lib
+    return int(_lib.lib().eda_peer_alloc_kind())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--world", type=int, required=True)
@@ -34,6 +39,8 @@ def main():
     ap.add_argument("--deterministic", type=int, default=0)
     ap.add_argument("--sync", choices=["collective", "native"], default="collective")
     ap.add_argument("--graph", type=int, default=0, help="1: steps 2.. replayed from a captured hipGraph (native sync only)")
+    ap.add_argument("--selftest-inject-rank", type=int, default=-1,
+                    help="this rank publishes a wrong tag in the peer-memory self-test of sync_bn.enable(native=True)")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
 
@@ -48,8 +55,10 @@ def main():
         deterministic.enable(True)
     if a.world > 1:
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{a.port}", rank=a.rank, world_size=a.world)
+        sync_bn._selftest_inject = (a.rank == a.selftest_inject_rank)
         sync_bn.enable(native=(a.sync == "native"))
         assert sync_bn.fused_hook_installed()
+        assert sync_bn.native() == (a.sync == "native" and a.selftest_inject_rank < 0)
         parallel.reserve_cus_for_collectives(32)
         parallel.sampler_without_co_residency()
 
@@ -138,7 +147,8 @@ def main():
     torch.cuda.synchronize()
     torch.save({"losses": torch.stack(losses), "grad0": grad0, "param": flat.flat_param.detach().cpu(), "bn": bn, "param0": param0,
                 "fused_hook_calls": hooks[0], "peer_timeouts": sync_bn.peer_timeouts() if a.sync == "native" and a.world > 1 else 0,
-                "captured": graph is not None}, a.out)
+                "captured": graph is not None, "native": sync_bn.native(),
+                "peer_alloc_kind": _peer_kind() if a.sync == "native" and a.world > 1 else -1}, a.out)
     if a.world > 1:
         dist.barrier()
         dist.destroy_process_group()
