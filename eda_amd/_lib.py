@@ -91,6 +91,9 @@ SIGNATURES = {
                               _p, _l, _l, _p, _p, _i, _p]),
     "eda_mha_bwd": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _l, _p, _i, _i, _i, _i, _i, _f, _f,
                         _p, _u, _p, _p, _p, _l, _l, _p, _p, _p, _p, _l, _l, _l, _l, _l, _l, _p, _sz, _i, _p]),
+    "eda_mha_bwd_ticket_bytes": (_sz, [_i, _i, _i, _i]),
+    "eda_mha_bwd_tk": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _l, _p, _i, _i, _i, _i, _i, _f, _f,
+                           _p, _u, _p, _p, _p, _l, _l, _p, _p, _p, _p, _l, _l, _l, _l, _l, _l, _p, _sz, _p, _sz, _i, _p]),
     "eda_wgrad_workspace_bytes": (_sz, [_l, _i, _i]),
     "eda_wgrad_f32": (_i, [_p, _l, _p, _l, _l, _i, _i, _p, _p, _p, _sz, _p]),
     "eda_wgrad_grouped_f32": (_i, [_p, _i, _p, _p, _p]),

@@ -119,9 +119,46 @@ def reset_workspaces():
     """Re-zero every key-split workspace handed out so far (their ticket words must be zero between launches; an aborted
     launch can leave a count behind).  Synchronises."""
     torch.cuda.synchronize()
-    for ws in _fwd_ws_cache.values():
+    for ws in list(_fwd_ws_cache.values()) + list(_bwd_tk_cache.values()):
         ws.zero_()
     torch.cuda.synchronize()
+
+
+_bwd_tk_cache = {}
+
+
+def _bwd_tickets(dev, nbytes):
+    """Arrival tickets of the split backward (include/eda_hip.h: eda_mha_bwd_tk): one persistent ZERO buffer per (device,
+    stream) -- every launch leaves it zero -- created outside any capture (same reason as _fwd_workspace)."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    tk = _bwd_tk_cache.get(key)
+    if tk is None or tk.numel() * 4 < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("eda_amd.attention: no backward ticket buffer for this (device, stream) yet -- run the step "
+                               "once eagerly on the stream before capturing it in a HIP graph")
+        tk = _bwd_tk_cache[key] = torch.zeros(max(16384, (nbytes + 3) // 4), dtype=torch.int32, device=dev)
+    return tk
+
+
+def _mha_bwd_call(q, k, v, m8, B, num_heads, Lq, Lk, hd, p_drop, seed, salt, out, lse, dout, dq, dk, dv, dtype_code):
+    dev = q.device
+    L = _lib.lib()
+    with torch.cuda.device(dev), _timed('mha_bwd', (B, num_heads, Lq, Lk)):
+        ws_bytes = L.eda_mha_bwd_workspace_bytes(B, num_heads, Lq, Lk)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
+        tk_bytes = L.eda_mha_bwd_ticket_bytes(B, num_heads, Lq, Lk)
+        tk = _bwd_tickets(dev, tk_bytes) if tk_bytes else None
+        rc = L.eda_mha_bwd_tk(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
+            k.stride(1), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else None,
+            B, num_heads, Lq, Lk, hd, hd ** -0.5, p_drop,
+            seed.data_ptr() if seed is not None else None, salt, out.data_ptr(), lse.data_ptr(),
+            dout.data_ptr(), dout.stride(0), dout.stride(1), None, dq.data_ptr(),
+            dk.data_ptr(), dv.data_ptr(), dq.stride(0), dq.stride(1), dk.stride(0), dk.stride(1),
+            dv.stride(0), dv.stride(1), ws.data_ptr() if ws is not None else None, ws_bytes,
+            tk.data_ptr() if tk is not None else None, tk.numel() * 4 if tk is not None else 0,
+            dtype_code, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "eda_mha_bwd_tk")
 
 
 def _mha_fwd_call(q, k, v, m8, B, num_heads, Lq, Lk, hd, p_drop, salt, out, lse):
@@ -171,22 +208,9 @@ class _FusedMHA(Function):
         dq = torch.empty((B, Lq, D), dtype=torch.float32, device=q.device)
         dk = torch.empty((B, Lk, D), dtype=torch.float32, device=q.device)
         dv = torch.empty((B, Lk, D), dtype=torch.float32, device=q.device)
-        delta = torch.empty((B, num_heads, Lq), dtype=torch.float32, device=q.device)
         m8 = ctx.mask8
         seed = dropout_state(q.device) if p_drop > 0 else None
-        ws_bytes = _lib.lib().eda_mha_bwd_workspace_bytes(B, num_heads, Lq, Lk)
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=q.device) if ws_bytes else None
-        with torch.cuda.device(q.device), _timed('mha_bwd', (B, num_heads, Lq, Lk)):
-            rc = _lib.lib().eda_mha_bwd(
-                q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
-                k.stride(1), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else None,
-                B, num_heads, Lq, Lk, hd, hd ** -0.5, p_drop,
-                seed.data_ptr() if seed is not None else None, salt, out.data_ptr(), lse.data_ptr(),
-                dout.data_ptr(), dout.stride(0), dout.stride(1), delta.data_ptr(), dq.data_ptr(),
-                dk.data_ptr(), dv.data_ptr(), dq.stride(0), dq.stride(1), dk.stride(0), dk.stride(1),
-                dv.stride(0), dv.stride(1), ws.data_ptr() if ws is not None else None, ws_bytes,
-                ctx.dtype_code, torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "eda_mha_bwd")
+        _mha_bwd_call(q, k, v, m8, B, num_heads, Lq, Lk, hd, p_drop, seed, salt, out, lse, dout, dq, dk, dv, ctx.dtype_code)
         return dq, dk, dv, None, None, None, None
 
 
@@ -311,22 +335,9 @@ class _ProjectedMHA(Function):
         hd = d // num_heads
         dPs = [torch.empty_like(P) for P in Ps]
         dq, dk, dv = (dPs[g][..., c:c + d] for g, c in (cols[0], cols[1], cols[2]))
-        delta = torch.empty((B, num_heads, Lq), dtype=torch.float32, device=dev)
         m8 = ctx.mask8
         seed = dropout_state(dev) if p_drop > 0 else None
-        ws_bytes = _lib.lib().eda_mha_bwd_workspace_bytes(B, num_heads, Lq, Lk)
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
-        with torch.cuda.device(dev), _timed('mha_bwd', (B, num_heads, Lq, Lk)):
-            rc = _lib.lib().eda_mha_bwd(
-                q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
-                k.stride(1), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else None,
-                B, num_heads, Lq, Lk, hd, hd ** -0.5, p_drop,
-                seed.data_ptr() if seed is not None else None, salt, out.data_ptr(), lse.data_ptr(),
-                dout.data_ptr(), dout.stride(0), dout.stride(1), delta.data_ptr(), dq.data_ptr(),
-                dk.data_ptr(), dv.data_ptr(), dq.stride(0), dq.stride(1), dk.stride(0), dk.stride(1),
-                dv.stride(0), dv.stride(1), ws.data_ptr() if ws is not None else None, ws_bytes,
-                ctx.dtype_code, torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "eda_mha_bwd")
+        _mha_bwd_call(q, k, v, m8, B, num_heads, Lq, Lk, hd, p_drop, seed, salt, out, lse, dout, dq, dk, dv, ctx.dtype_code)
         from . import wgrad_queue
         qd = wgrad_queue.active
         deferred = False
@@ -493,22 +504,9 @@ class _ProjectedMHAPreKV(Function):
         dq = torch.empty_like(q)
         dkv = sink.slot(slot, B, Lk, dev) if sink is not None else torch.empty((B, Lk, 2 * d), dtype=torch.float32, device=dev)
         dk, dv = dkv[..., :d], dkv[..., d:]
-        delta = torch.empty((B, num_heads, Lq), dtype=torch.float32, device=dev)
         m8 = ctx.mask8
         seed = dropout_state(dev) if p_drop > 0 else None
-        ws_bytes = _lib.lib().eda_mha_bwd_workspace_bytes(B, num_heads, Lq, Lk)
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
-        with torch.cuda.device(dev), _timed('mha_bwd', (B, num_heads, Lq, Lk)):
-            rc = _lib.lib().eda_mha_bwd(
-                q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0),
-                k.stride(1), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else None,
-                B, num_heads, Lq, Lk, hd, hd ** -0.5, p_drop,
-                seed.data_ptr() if seed is not None else None, salt, out.data_ptr(), lse.data_ptr(),
-                dout.data_ptr(), dout.stride(0), dout.stride(1), delta.data_ptr(), dq.data_ptr(),
-                dk.data_ptr(), dv.data_ptr(), dq.stride(0), dq.stride(1), dk.stride(0), dk.stride(1),
-                dv.stride(0), dv.stride(1), ws.data_ptr() if ws is not None else None, ws_bytes,
-                ctx.dtype_code, torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "eda_mha_bwd")
+        _mha_bwd_call(q, k, v, m8, B, num_heads, Lq, Lk, hd, p_drop, seed, salt, out, lse, dout, dq, dk, dv, ctx.dtype_code)
         from . import wgrad_queue
         qd = wgrad_queue.active
         dq2 = dq.view(-1, d)

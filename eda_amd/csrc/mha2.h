@@ -23,6 +23,8 @@ struct Mha2Args {
   int dtype;         // EDA_DTYPE_F32 (exact fp32 MFMA: the parity path) / BF16 / F16 contractions, fp32 accumulate
   float *dq_part;    // bwd: [key block][B][Lq][H*36] dense partials of dQ (n_kb > 1)
   float *dkv_part;   // bwd: [query split][dk | dv][B][Lk][H*36] dense partials (n_qs > 1)
+  unsigned *bwd_tickets;   // bwd: [B*H][n_qs] arrivals of the key blocks at a dQ range, then [B*H][n_kb] of the query splits at a
+                           // key block's dK | dV: zero before the launch, left zero (the last arriver merges and re-arms)
   // q-projection fused in front of the forward (eda_mha_qproj_fwd): q = xq Wq^T + bq is computed per (query block, head)
   // inside the attention launch and WRITTEN to q_out (the backward reads it like any projected q)
   const float *xq; long xq_sb, xq_sl;         // (B, Lq, H*36) input rows of the q-projection
@@ -44,5 +46,6 @@ size_t eda_mha2_fwd_workspace_bytes(int B, int H, int Lq, int Lk);
 // mha3.hip: the long-key forward on v_mfma_f32_16x16x32_bf16 (bf16 x 3 for F32, plain for BF16); -1 = not its shape
 int eda_mha3_fwd_launch(Mha2Args &a, hipStream_t stream);
 int eda_mha2_qproj_fwd_launch(Mha2Args &a, hipStream_t stream);      // Lk <= 192
-int eda_mha2_bwd_launch(Mha2Args &a, void *ws, size_t ws_bytes, hipStream_t stream);
+int eda_mha2_bwd_launch(Mha2Args &a, void *ws, size_t ws_bytes, unsigned *tickets, size_t tickets_bytes, hipStream_t stream);
 size_t eda_mha2_bwd_workspace_bytes(int B, int H, int Lq, int Lk);
+size_t eda_mha2_bwd_ticket_bytes(int B, int H, int Lq, int Lk);

@@ -743,6 +743,8 @@ __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args
   float *dq_out = a.dq + (long)b * a.dq_sb + h * HD;
   long dq_sl = a.dq_sl;
   if (a.n_kb > 1) { dq_out = a.dq_part + ((long)kb * a.B + b) * a.Lq * D + h * HD; dq_sl = D; }
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rs_dq = __builtin_amdgcn_make_buffer_rsrc(dq_out, 0, a.Lq * D * 4, 0x00020000);
 
   // stage one chunk: lse (log2 domain, +inf for rows outside the range: their P is exactly 0) and
   // delta = rowsum(dO o O) with ordinary loads, then Q and dO by LDS-DMA
@@ -995,8 +997,11 @@ __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args
       const int gq = q0 + 16 * j + c;
       if (gq < qend && (full || g == 0)) {
         const float sc = a.scale;
-        *reinterpret_cast<float4 *>(dq_out + (long)gq * dq_sl + 16 * n + 4 * g) =
-            make_float4(r[0] * sc, r[1] * sc, r[2] * sc, r[3] * sc);
+        const f32x4 val = {r[0] * sc, r[1] * sc, r[2] * sc, r[3] * sc};
+        if (a.n_kb > 1)        // this key block's partial: WRITE-THROUGH, the last-arriving key block of the rows merges (below)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rs_dq, (gq * D + 16 * n + 4 * g) * 4, 0, 16);
+        else
+          *reinterpret_cast<f32x4 *>(dq_out + (long)gq * dq_sl + 16 * n + 4 * g) = val;
       }
     }
   };
@@ -1067,22 +1072,95 @@ __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args
     }
   }
   if (wave_live && qg == 0) { dk[2] = grp_sum4(dk[2]); dv[2] = grp_sum4(dv[2]); }
+  const long kv_per = (long)a.B * a.Lk * D;                 // one tensor of one query split's dense partial
   if (kvalid && wave_live && qg == 0) {
     const float sc = a.scale, ik = dc.inv_keep;
-    float *ok = a.dk + (long)b * a.dk_sb + (long)ki * a.dk_sl + h * HD;
-    float *ov = a.dv + (long)b * a.dv_sb + (long)ki * a.dv_sl + h * HD;
-    if (a.n_qs > 1) {          // dense partial of this query split: [split][dk | dv][B][Lk][D]
-      const long per = (long)a.B * a.Lk * D;
-      ok = a.dkv_part + (long)qsp * 2 * per + ((long)b * a.Lk + ki) * D + h * HD;
-      ov = ok + per;
+    if (a.n_qs > 1) {          // dense partial of this query split: [split][dk | dv][B][Lk][D], WRITE-THROUGH (merged below)
+      const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+          a.dkv_part + (long)qsp * 2 * kv_per + ((long)b * a.Lk + ki) * D + h * HD, 0, HD * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+          a.dkv_part + (long)qsp * 2 * kv_per + kv_per + ((long)b * a.Lk + ki) * D + h * HD, 0, HD * 4, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dk[0] * sc), rk, 16 * g, 0, 16);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dk[1] * sc), rk, 64 + 16 * g, 0, 16);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dv[0] * ik), rv, 16 * g, 0, 16);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dv[1] * ik), rv, 64 + 16 * g, 0, 16);
+      if (g == 0) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dk[2] * sc), rk, 128, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dv[2] * ik), rv, 128, 0, 16);
+      }
+    } else {
+      float *ok = a.dk + (long)b * a.dk_sb + (long)ki * a.dk_sl + h * HD;
+      float *ov = a.dv + (long)b * a.dv_sb + (long)ki * a.dv_sl + h * HD;
+      *reinterpret_cast<f32x4 *>(ok + 4 * g) = dk[0] * sc;
+      *reinterpret_cast<f32x4 *>(ok + 16 + 4 * g) = dk[1] * sc;
+      *reinterpret_cast<f32x4 *>(ov + 4 * g) = dv[0] * ik;
+      *reinterpret_cast<f32x4 *>(ov + 16 + 4 * g) = dv[1] * ik;
+      if (g == 0) {
+        *reinterpret_cast<f32x4 *>(ok + 32) = dk[2] * sc;
+        *reinterpret_cast<f32x4 *>(ov + 32) = dv[2] * ik;
+      }
     }
-    *reinterpret_cast<float4 *>(ok + 4 * g) = make_float4(dk[0][0] * sc, dk[0][1] * sc, dk[0][2] * sc, dk[0][3] * sc);
-    *reinterpret_cast<float4 *>(ok + 16 + 4 * g) = make_float4(dk[1][0] * sc, dk[1][1] * sc, dk[1][2] * sc, dk[1][3] * sc);
-    *reinterpret_cast<float4 *>(ov + 4 * g) = make_float4(dv[0][0] * ik, dv[0][1] * ik, dv[0][2] * ik, dv[0][3] * ik);
-    *reinterpret_cast<float4 *>(ov + 16 + 4 * g) = make_float4(dv[1][0] * ik, dv[1][1] * ik, dv[1][2] * ik, dv[1][3] * ik);
-    if (g == 0) {
-      *reinterpret_cast<float4 *>(ok + 32) = make_float4(dk[2][0] * sc, dk[2][1] * sc, dk[2][2] * sc, dk[2][3] * sc);
-      *reinterpret_cast<float4 *>(ov + 32) = make_float4(dv[2][0] * ik, dv[2][1] * ik, dv[2][2] * ik, dv[2][3] * ik);
+  }
+  // ---- cross-workgroup merge of the split ranges (round 6; until round 5 a second launch, mha2_part_reduce_kernel, summed the
+  // dense partials: 36 launches x 5 us per training step).  Same hand-off as the key-split forward: the partials left with
+  // write-through (sc1) stores, every wave drains its stores, one lane takes the range's ticket, and the LAST arriver sums
+  // all partials of the range IN SPLIT ORDER from sc1 loads (so the bits do not depend on who is last) and writes the
+  // gradient.  dQ rows [qbeg, qend) of head h: ticket (bh, query split), n_kb arrivals.  dK / dV rows of key block kb: ticket
+  // (bh, key block), n_qs arrivals.
+  if (a.n_kb > 1 || a.n_qs > 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned *flag = reinterpret_cast<unsigned *>(lse_s);
+    if (tid == 0) {
+      unsigned lq = 0u, lkv = 0u;
+      if (a.n_kb > 1) {
+        unsigned *tk = a.bwd_tickets + (long)bh * a.n_qs + qsp;
+        lq = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)a.n_kb - 1u;
+        if (lq) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            // re-armed
+      }
+      if (a.n_qs > 1) {
+        unsigned *tk = a.bwd_tickets + (long)BH * a.n_qs + (long)bh * a.n_kb + kb;
+        lkv = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)a.n_qs - 1u;
+        if (lkv) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      flag[0] = lq; flag[1] = lkv;
+    }
+    __syncthreads();
+    if (flag[0]) {
+      const long per = (long)a.B * a.Lq * D;                   // floats between two key blocks' partials
+      const float *p0 = a.dq_part + (long)b * a.Lq * D + h * HD;
+      float *dq_fin = a.dq + (long)b * a.dq_sb + h * HD;
+      for (int i = tid; i < (qend - qbeg) * 9; i += NT) {
+        const int row = i / 9, c4 = i - row * 9;
+        const int off = ((qbeg + row) * D + 4 * c4) * 4;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int z = 0; z < a.n_kb; ++z) {
+          const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p0 + z * per), 0, a.Lq * D * 4, 0x00020000);
+          t += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, off, 0, 16));
+        }
+        *reinterpret_cast<f32x4 *>(dq_fin + (long)(qbeg + row) * a.dq_sl + 4 * c4) = t;
+      }
+    }
+    if (flag[1]) {
+      const int nkeys = min(KB, a.Lk - kblock0);
+      for (int which = 0; which < 2; ++which) {
+        const float *p0 = a.dkv_part + which * kv_per + ((long)b * a.Lk + kblock0) * D + h * HD;
+        float *fin = which ? a.dv + (long)b * a.dv_sb + (long)kblock0 * a.dv_sl + h * HD
+                           : a.dk + (long)b * a.dk_sb + (long)kblock0 * a.dk_sl + h * HD;
+        const long fin_sl = which ? a.dv_sl : a.dk_sl;
+        for (int i = tid; i < nkeys * 9; i += NT) {
+          const int row = i / 9, c4 = i - row * 9;
+          const int off = (row * D + 4 * c4) * 4;
+          f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+          for (int z = 0; z < a.n_qs; ++z) {
+            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p0 + z * 2 * kv_per), 0, KB * D * 4, 0x00020000);
+            t += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, off, 0, 16));
+          }
+          *reinterpret_cast<f32x4 *>(fin + row * fin_sl + 4 * c4) = t;
+        }
+      }
     }
   }
 #ifdef EDA_MHA2_PROFILE
@@ -1091,29 +1169,6 @@ __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args
   if (lane == 0)
     for (int i = 0; i < 8; ++i) atomicAdd(&mha2_prof[((blockIdx.x * 16 + wave) & 63) * 8 + i], prof_acc[i]);
 #endif
-}
-
-// out tensors (1: dq; 2: dk, dv) = sum over the splits of the dense partials [split][tensor][B][L][D], written
-// with the outputs' strides, in split order (deterministic)
-__global__ __launch_bounds__(256) void mha2_part_reduce_kernel(const float *__restrict__ part, int nsplit, int ntens,
-                                                               int B, int L, int D, float *__restrict__ o0, long o0_sb,
-                                                               long o0_sl, float *__restrict__ o1, long o1_sb,
-                                                               long o1_sl) {
-  const long per = (long)B * L * D, n4 = per / 4;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= ntens * n4) return;
-  const int which = i >= n4;
-  const long e = (i - which * n4) * 4;
-  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int z = 0; z < nsplit; ++z) {
-    const float4 v = *reinterpret_cast<const float4 *>(part + ((long)z * ntens + which) * per + e);
-    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
-  }
-  const long row = e / D;
-  const int col = (int)(e - row * D);
-  const long bb = row / L, l = row - bb * L;
-  float *o = which ? o1 + bb * o1_sb + l * o1_sl + col : o0 + bb * o0_sb + l * o0_sl + col;
-  *reinterpret_cast<float4 *>(o) = t;
 }
 
 template <int NQ, int KS, int CHK, int NBUF, bool SPLIT = false>
@@ -1191,6 +1246,10 @@ size_t bwd_workspace_floats(const BwdPlan &p, int B, int H, int Lq, int Lk) {
   if (p.n_kb > 1) n += (size_t)p.n_kb * B * Lq * H * HD;
   if (p.n_qs > 1) n += (size_t)p.n_qs * 2 * B * Lk * H * HD;
   return n;
+}
+// arrival tickets of the split ranges: [B*H][n_qs] for dQ, then [B*H][n_kb] for dK | dV (zero before a launch, left zero)
+size_t bwd_ticket_words(const BwdPlan &p, int B, int H) {
+  return (p.n_kb > 1 || p.n_qs > 1) ? (size_t)B * H * (p.n_qs + p.n_kb) : 0;
 }
 
 template <int KSUB, int QG, int QC, int NBUF>
@@ -1288,42 +1347,41 @@ extern "C" int eda_mha2_profile_read(unsigned long long *out16) {
 }
 #endif
 
+// The scratch of a backward: [tickets (eda_mha2_bwd_ticket_bytes, 256-byte rounded) | dense partials].  The ticket words must
+// be ZERO before the launch and are left zero; a caller with a PERSISTENT zeroed ticket buffer passes it separately
+// (eda_mha2_bwd_launch tickets != nullptr) and the kernel never needs a fill launch; with tickets == nullptr the leading
+// ticket area of `ws` is zeroed by a fill kernel first.
+size_t eda_mha2_bwd_ticket_bytes(int B, int H, int Lq, int Lk) {
+  if (B <= 0 || Lq <= 0 || Lk <= 0) return 0;
+  return (sizeof(unsigned) * bwd_ticket_words(bwd_plan(B, H, Lq, Lk), B, H) + 255) / 256 * 256;
+}
 size_t eda_mha2_bwd_workspace_bytes(int B, int H, int Lq, int Lk) {
   if (B <= 0 || Lq <= 0 || Lk <= 0) return 0;
-  return sizeof(float) * bwd_workspace_floats(bwd_plan(B, H, Lq, Lk), B, H, Lq, Lk);
+  return eda_mha2_bwd_ticket_bytes(B, H, Lq, Lk) + sizeof(float) * bwd_workspace_floats(bwd_plan(B, H, Lq, Lk), B, H, Lq, Lk);
 }
 
-int eda_mha2_bwd_launch(Mha2Args &a, void *ws, size_t ws_bytes, hipStream_t stream) {
+int eda_mha2_bwd_launch(Mha2Args &a, void *ws, size_t ws_bytes, unsigned *tickets, size_t tickets_bytes, hipStream_t stream) {
   if (a.B == 0) return 0;
   a.prio_mode = (int)eda_knob(EDA_K_MHA2_PRIO);
   const BwdPlan p = bwd_plan(a.B, a.H, a.Lq, a.Lk);
   a.n_kb = p.n_kb; a.n_qs = p.n_qs; a.q_per_wg = p.q_per_wg;
-  const size_t need = sizeof(float) * bwd_workspace_floats(p, a.B, a.H, a.Lq, a.Lk);
+  const size_t tk = eda_mha2_bwd_ticket_bytes(a.B, a.H, a.Lq, a.Lk);
+  const size_t need = tk + sizeof(float) * bwd_workspace_floats(p, a.B, a.H, a.Lq, a.Lk);
   EDA_CHECK_ARG(need == 0 || (ws && ws_bytes >= need && (reinterpret_cast<uintptr_t>(ws) & 15u) == 0),
                 "workspace of eda_mha_bwd_workspace_bytes() required (16-byte aligned)");
-  float *w = reinterpret_cast<float *>(ws);
-  a.dq_part = nullptr; a.dkv_part = nullptr;
+  EDA_CHECK_ARG(!tickets || tickets_bytes >= tk, "ticket buffer of eda_mha_bwd_ticket_bytes() required");
+  float *w = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(ws) + tk);
+  a.dq_part = nullptr; a.dkv_part = nullptr; a.bwd_tickets = nullptr;
   if (p.n_kb > 1) { a.dq_part = w; w += (size_t)p.n_kb * a.B * a.Lq * a.H * HD; }
   if (p.n_qs > 1) a.dkv_part = w;
-  int rc;
-  if (p.variant == 0) rc = launch_bwd<16, 1, 64, 2>(a, stream);
-  else if (p.variant == 1) rc = launch_bwd<9, 1, 64, 1>(a, stream);
-  else rc = launch_bwd<5, 3, 96, 1>(a, stream);
-  if (rc) return rc;
-  const int D = a.H * HD;
-  if (p.n_kb > 1) {
-    const long items = (long)a.B * a.Lq * D / 4;
-    hipLaunchKernelGGL(mha2_part_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream,
-                       a.dq_part, p.n_kb, 1, a.B, a.Lq, D, a.dq, a.dq_sb, a.dq_sl, a.dq, a.dq_sb, a.dq_sl);
-    EDA_CHECK_LAUNCH();
+  if (tk) {
+    a.bwd_tickets = tickets ? tickets : reinterpret_cast<unsigned *>(ws);
+    if (!tickets)
+      if (int rc = eda_zero_async(ws, tk, stream)) return rc;
   }
-  if (p.n_qs > 1) {
-    const long items = 2L * a.B * a.Lk * D / 4;
-    hipLaunchKernelGGL(mha2_part_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream,
-                       a.dkv_part, p.n_qs, 2, a.B, a.Lk, D, a.dk, a.dk_sb, a.dk_sl, a.dv, a.dv_sb, a.dv_sl);
-    EDA_CHECK_LAUNCH();
-  }
-  return 0;
+  if (p.variant == 0) return launch_bwd<16, 1, 64, 2>(a, stream);
+  if (p.variant == 1) return launch_bwd<9, 1, 64, 1>(a, stream);
+  return launch_bwd<5, 3, 96, 1>(a, stream);
 }
 
 // ---------------------------------------------------------------------------------------- C entry points ----
@@ -1436,12 +1494,29 @@ extern "C" size_t eda_mha_bwd_workspace_bytes(int B, int H, int Lq, int Lk) {
 }
 
 // delta_ws: unused since round 3 (delta = rowsum(dO o O) is formed while a chunk is staged); may be NULL.
+extern "C" size_t eda_mha_bwd_ticket_bytes(int B, int H, int Lq, int Lk) { return eda_mha2_bwd_ticket_bytes(B, H, Lq, Lk); }
+
 extern "C" int eda_mha_bwd(const float *q, const float *k, const float *v, long q_sb, long q_sl, long k_sb, long k_sl,
                            long v_sb, long v_sl, const unsigned char *key_padding_mask, int B, int H, int Lq, int Lk,
                            int head_dim, float scale, float p_drop, const unsigned long long *seed_ptr, unsigned salt,
                            const float *out, const float *lse, const float *dout, long do_sb, long do_sl,
                            float *delta_ws, float *dq, float *dk, float *dv, long dq_sb, long dq_sl, long dk_sb,
                            long dk_sl, long dv_sb, long dv_sl, void *ws, size_t ws_bytes, int dtype, void *stream_) {
+  return eda_mha_bwd_tk(q, k, v, q_sb, q_sl, k_sb, k_sl, v_sb, v_sl, key_padding_mask, B, H, Lq, Lk, head_dim, scale, p_drop,
+                        seed_ptr, salt, out, lse, dout, do_sb, do_sl, delta_ws, dq, dk, dv, dq_sb, dq_sl, dk_sb, dk_sl, dv_sb,
+                        dv_sl, ws, ws_bytes, nullptr, 0, dtype, stream_);
+}
+
+// eda_mha_bwd with the arrival tickets of the split ranges in a PERSISTENT buffer of the caller (zero before its first use;
+// every launch leaves it zero): no fill launch in front of the kernel.  tickets == NULL: the leading
+// eda_mha_bwd_ticket_bytes() of `ws` are zeroed by a fill kernel first (what eda_mha_bwd does).
+extern "C" int eda_mha_bwd_tk(const float *q, const float *k, const float *v, long q_sb, long q_sl, long k_sb, long k_sl,
+                              long v_sb, long v_sl, const unsigned char *key_padding_mask, int B, int H, int Lq, int Lk,
+                              int head_dim, float scale, float p_drop, const unsigned long long *seed_ptr, unsigned salt,
+                              const float *out, const float *lse, const float *dout, long do_sb, long do_sl,
+                              float *delta_ws, float *dq, float *dk, float *dv, long dq_sb, long dq_sl, long dk_sb,
+                              long dk_sl, long dv_sb, long dv_sl, void *ws, size_t ws_bytes, void *tickets,
+                              size_t tickets_bytes, int dtype, void *stream_) {
   (void)delta_ws;
   hipStream_t stream = (hipStream_t)stream_;
   EDA_CHECK_ARG(dtype == EDA_DTYPE_F32 || dtype == EDA_DTYPE_BF16 || dtype == EDA_DTYPE_F16,
@@ -1469,7 +1544,7 @@ extern "C" int eda_mha_bwd(const float *q, const float *k, const float *v, long 
   m.dout = dout; m.do_sb = do_sb; m.do_sl = do_sl; m.dq = dq; m.dk = dk; m.dv = dv;
   m.dq_sb = dq_sb; m.dq_sl = dq_sl; m.dk_sb = dk_sb; m.dk_sl = dk_sl; m.dv_sb = dv_sb; m.dv_sl = dv_sl;
   m.dtype = dtype;
-  return eda_mha2_bwd_launch(m, ws, ws_bytes, stream);
+  return eda_mha2_bwd_launch(m, ws, ws_bytes, reinterpret_cast<unsigned *>(tickets), tickets_bytes, stream);
 }
 
 extern "C" int eda_mha_bwd_f32(const float *q, const float *k, const float *v, long q_sb, long q_sl,

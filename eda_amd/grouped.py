@@ -280,7 +280,7 @@ def block_linear(xp, weights, biases, pack_out, relu=False):
 
 def bn_relu_cfg(zp, bns, dropouts=None):
     """cfg tuple of the grouped BatchNorm+ReLU(+Dropout) launch for modules `bns` / `dropouts` on packed rows zp."""
-    from .nn_utils import _bn_drop_salts
+    from .nn_utils import dropout_salt
     G = len(bns)
     C = zp.shape[1] // G
     training = bns[0].training
@@ -289,11 +289,7 @@ def bn_relu_cfg(zp, bns, dropouts=None):
     if dropouts is not None and dropouts[0] is not None and dropouts[0].training and dropouts[0].p > 0:
         p = float(dropouts[0].p)
         for g, d in enumerate(dropouts):
-            s = _bn_drop_salts.get(id(d))
-            if s is None:
-                from .fused_ln import new_salt_base
-                s = _bn_drop_salts[id(d)] = new_salt_base() + 7
-            salts[g] = s
+            salts[g] = dropout_salt(d)
     return (G, C, training or not bns[0].track_running_stats, bns[0].eps, bns[0].momentum, p, salts,
             [(bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None) for bn in bns])
 

@@ -293,7 +293,16 @@ def bump_batches_tracked(bn):
         bn.num_batches_tracked.add_(1)
 
 
-_bn_drop_salts = {}
+def dropout_salt(dropout):
+    """The call-site salt of a Dropout module whose masks the library's kernels draw (fused into BN+ReLU): assigned on first
+    use and kept ON THE MODULE -- a deep copy of a model draws the same masks as the original for the same counter (until
+    round 5 a process-wide table keyed by id(module): two copies of one model trained differently, and a freed module's id
+    could hand its salt to an unrelated one)."""
+    salt = getattr(dropout, "_eda_salt", None)
+    if salt is None:
+        from .fused_ln import new_salt_base
+        salt = dropout._eda_salt = new_salt_base() + 7
+    return salt
 _bn_drop_rows = None
 
 
@@ -317,10 +326,7 @@ def bn_relu_rows(bn, z, dropout=None):
             _bn_drop_rows = _lib.lib().eda_bn_relu_dropout_max_rows()
         if z.shape[0] <= _bn_drop_rows:
             p = float(dropout.p)
-            salt = _bn_drop_salts.get(id(dropout))
-            if salt is None:
-                from .fused_ln import new_salt_base
-                salt = _bn_drop_salts[id(dropout)] = new_salt_base() + 7
+            salt = dropout_salt(dropout)
     out = sa_ops.BNReLUCL.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
                                 bn.momentum, bn.training, 1, p, salt)
     if bn.training and bn.track_running_stats:

@@ -205,9 +205,8 @@ int eda_mha_fwd_hd64_f32(const float *q, const float *k, const float *v, long q_
                          long v_sb, long v_sl, const unsigned char *key_padding_mask, int B, int H, int Lq, int Lk,
                          float scale, float *out, void *stream);
 
-/* ws: optional scratch of eda_mha_bwd_workspace_bytes() (0 = none needed): with it, short key
- * dimensions split the query range of the dK/dV kernel over more workgroups (partials summed in
- * split order); without it (NULL) the unsplit kernel runs.                                   */
+/* ws: scratch of eda_mha_bwd_workspace_bytes() (0 = none needed: ws may be NULL), required when non-zero:
+ * the split ranges' tickets and dense partials ("eda_mha_bwd and the split ranges" below).      */
 size_t eda_mha_bwd_workspace_bytes(int B, int H, int Lq, int Lk);
 
 /* The same two entry points with the arithmetic type of the QK^T / PV contractions as an argument
@@ -229,6 +228,22 @@ int eda_mha_bwd(const float *q, const float *k, const float *v, long q_sb, long 
                 const float *out, const float *lse, const float *dout, long do_sb, long do_sl,
                 float *delta_ws, float *dq, float *dk, float *dv, long dq_sb, long dq_sl, long dk_sb,
                 long dk_sl, long dv_sb, long dv_sl, void *ws, size_t ws_bytes, int dtype, void *stream);
+
+/* eda_mha_bwd and the split ranges (round 6).  When a shape's key range (Lk > 256: key blocks of 256) or query range (short
+ * key sets: query splits, so that every CU holds a workgroup) is divided, each workgroup leaves a dense partial in `ws` with
+ * write-through stores and takes an arrival ticket; the LAST workgroup of a range sums the partials in split order (the bits
+ * do not depend on who is last) and writes dq / dk / dv -- inside the same launch (until round 5 a second launch did).
+ * Layout of ws: [eda_mha_bwd_ticket_bytes() ticket words | partials]; eda_mha_bwd_workspace_bytes() covers both.  Ticket
+ * words must be ZERO before the launch and are left zero: eda_mha_bwd zeroes the leading area with a fill kernel;
+ * eda_mha_bwd_tk takes them from a PERSISTENT buffer of the caller (zeroed once; one per stream) and launches nothing else. */
+size_t eda_mha_bwd_ticket_bytes(int B, int H, int Lq, int Lk);
+int eda_mha_bwd_tk(const float *q, const float *k, const float *v, long q_sb, long q_sl, long k_sb, long k_sl,
+                   long v_sb, long v_sl, const unsigned char *key_padding_mask, int B, int H, int Lq, int Lk,
+                   int head_dim, float scale, float p_drop, const unsigned long long *seed_ptr, unsigned salt,
+                   const float *out, const float *lse, const float *dout, long do_sb, long do_sl,
+                   float *delta_ws, float *dq, float *dk, float *dv, long dq_sb, long dq_sl, long dk_sb,
+                   long dk_sl, long dv_sb, long dv_sl, void *ws, size_t ws_bytes, void *tickets, size_t tickets_bytes,
+                   int dtype, void *stream);
 
 /* eda_mha_fwd with scratch for the KEY-SPLIT forward (F32 contractions): for at most 256 queries against >= 512 keys
  * (the text -> point and query -> point cross-attention, models/encoder_decoder_layers.py:87-93, 393-399) the keys of a

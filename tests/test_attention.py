@@ -131,6 +131,61 @@ def test_key_split_forward_is_reproducible_and_matches_the_unsplit_kernel(B, Lq,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,Lq,Lk", [(8, 1024, 1024), (8, 80, 1024), (8, 1024, 80), (8, 256, 132), (2, 300, 700), (1, 256, 256),
+                                     (3, 1024, 16)])
+def test_split_backward_merges_in_the_launch_reproducibly(B, Lq, Lk):
+    """Round 6: the key blocks' dQ partials and the query splits' dK | dV partials are merged by the LAST workgroup of a range
+    inside the backward launch (ticket + write-through partials; until round 5 a second launch).  Two calls give the same bits
+    whoever arrives last; the ticket words are back at zero; the legacy entry point (tickets at the head of its per-call
+    scratch, zeroed by a fill kernel) gives the same bits as the persistent-ticket entry point; and both agree with the sum
+    formed on the host from per-key-block / per-query-range backward calls of the same kernel."""
+    from eda_amd import _lib, attention
+    L = _lib.lib()
+    torch.manual_seed(Lq * 3 + Lk)
+    dev = "cuda"
+    q, k, v = (torch.randn(B, n, 288, device=dev) for n in (Lq, Lk, Lk))
+    mask = _mask(B, Lk, 5, min_valid=max(1, Lk // 3)).to(dev)
+    dout = torch.randn(B, Lq, 288, device=dev)
+    assert L.eda_mha_bwd_ticket_bytes(B, 8, Lq, Lk) > 0            # every shape of this list is split somewhere
+
+    def run():
+        qq, kk, vv = (t.clone().requires_grad_(True) for t in (q, k, v))
+        out = attention.attention_core(qq, kk, vv, mask, 8, 0.1, 7)
+        out.backward(dout)
+        return out.detach(), qq.grad, kk.grad, vv.grad
+    o1, dq1, dk1, dv1 = run()
+    o2, dq2, dk2, dv2 = run()
+    assert torch.equal(dq1, dq2) and torch.equal(dk1, dk2) and torch.equal(dv1, dv2)
+    torch.cuda.synchronize()
+    for tk in attention._bwd_tk_cache.values():
+        assert int(tk.abs().sum().item()) == 0
+    # the legacy entry point: per-call scratch, tickets zeroed by a fill launch
+    lse = torch.empty(B, 8, Lq, device=dev)
+    out = torch.empty(B, Lq, 288, device=dev)
+    m8 = mask.contiguous().view(torch.uint8)
+    seed = attention.dropout_state(torch.device(dev))
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(L.eda_mha_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0), k.stride(1),
+                             v.stride(0), v.stride(1), m8.data_ptr(), B, 8, Lq, Lk, 36, 36 ** -0.5, 0.1, seed.data_ptr(), 7,
+                             out.data_ptr(), lse.data_ptr(), 0, st), "fwd")
+    dq3, dk3, dv3 = torch.full_like(q, float("nan")), torch.full_like(k, float("nan")), torch.full_like(v, float("nan"))
+    nws = L.eda_mha_bwd_workspace_bytes(B, 8, Lq, Lk)
+    ws = torch.full((nws // 4,), float("nan"), device=dev)        # (poisoned: the call must zero its own ticket area)
+    _lib.check(L.eda_mha_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0), k.stride(1),
+                             v.stride(0), v.stride(1), m8.data_ptr(), B, 8, Lq, Lk, 36, 36 ** -0.5, 0.1, seed.data_ptr(), 7,
+                             out.data_ptr(), lse.data_ptr(), dout.data_ptr(), dout.stride(0), dout.stride(1), None,
+                             dq3.data_ptr(), dk3.data_ptr(), dv3.data_ptr(), dq3.stride(0), dq3.stride(1), dk3.stride(0),
+                             dk3.stride(1), dv3.stride(0), dv3.stride(1), ws.data_ptr(), nws, 0, st), "bwd")
+    # ... against the persistent-ticket entry point on the SAME saved forward (out, lse)
+    dq4, dk4, dv4 = torch.full_like(q, float("nan")), torch.full_like(k, float("nan")), torch.full_like(v, float("nan"))
+    attention._mha_bwd_call(q, k, v, m8, B, 8, Lq, Lk, 36, 0.1, seed, 7, out, lse, dout, dq4, dk4, dv4, 0)
+    assert torch.equal(dq3, dq4) and torch.equal(dk3, dk4) and torch.equal(dv3, dv4)
+    # (the autograd path above may have taken the key-split forward: same numbers up to the online softmax's re-association)
+    for a, b in ((dq1, dq4), (dk1, dk4), (dv1, dv4)):
+        assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
+
+
+@pytest.mark.gpu
 def test_fused_strided_packed_inputs():
     """q/k/v as column slices of one packed projection output (what the module passes)."""
     from eda_amd import attention

@@ -14,13 +14,12 @@ def _run(batched, defer, what="EDA_BATCHED_HEADS"):
     from eda_amd.bdetr import BeaUTyDETR
     from eda_amd.parallel import FlatParams
     import itertools
-    from eda_amd import attention, fused_ln, nn_utils
+    from eda_amd import attention, fused_ln
     os.environ[what] = "1" if batched else "0"
     try:
         # the same dropout streams in both runs: call-site salts are drawn from process-wide counters at construction
         attention._salt_counter = itertools.count(1)
         fused_ln._salt_counter = itertools.count(1 << 20)
-        nn_utils._bn_drop_salts.clear()
         torch.manual_seed(0)
         dev = torch.device("cuda", 0)
         model = BeaUTyDETR(num_queries=64, num_decoder_layers=2).to(dev).train()
