@@ -57,6 +57,8 @@ const KnobRow kKnobs[EDA_K_COUNT] = {
     {"EDA_GEMM_B3ROWS", 1},         // 0: the many-row plain products stay on the fp32 matrix pipe; 1: bf16 x 3 where measured faster; 2: every eligible shape
     {"EDA_FPS_BACKGROUND", 0},      // 1: the cluster sampler polls one granule per record (eda_fps_set_background)
     {"EDA_MHA2_PRIO", 1},
+    {"EDA_MHA2_BWD_DBUF", 0},
+    {"EDA_MHA2_BWD_MERGE", -1},     // split backward: 0 = partials summed by a second launch, 1 = by the last arriver inside the launch (unset: by size)       // 1: the short-key backward variants double-buffer their query chunks
     {"EDA_MHA2_KSPLIT", -1},        // 0: no key-split forward; n >= 2: n key slices for every eligible launch (unset: by shape)
     {"EDA_MHA3", 1},                // 0: the long-key attention forward stays on mha2.hip's fp32-MFMA kernel (mha3.hip: bf16 x 3)
     {"EDA_MHA3_DBG", 0},            // ablation bits of mha3.hip (timing experiments; wrong results)

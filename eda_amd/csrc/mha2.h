@@ -23,6 +23,7 @@ struct Mha2Args {
   int dtype;         // EDA_DTYPE_F32 (exact fp32 MFMA: the parity path) / BF16 / F16 contractions, fp32 accumulate
   float *dq_part;    // bwd: [key block][B][Lq][H*36] dense partials of dQ (n_kb > 1)
   float *dkv_part;   // bwd: [query split][dk | dv][B][Lk][H*36] dense partials (n_qs > 1)
+  int bwd_merge;           // bwd: 1 = the split ranges are merged inside the launch (tickets), 0 = by mha2_part_reduce_kernel
   unsigned *bwd_tickets;   // bwd: [B*H][n_qs] arrivals of the key blocks at a dQ range, then [B*H][n_kb] of the query splits at a
                            // key block's dK | dV: zero before the launch, left zero (the last arriver merges and re-arms)
   // q-projection fused in front of the forward (eda_mha_qproj_fwd): q = xq Wq^T + bq is computed per (query block, head)

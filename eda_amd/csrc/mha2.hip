@@ -998,7 +998,7 @@ __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args
       if (gq < qend && (full || g == 0)) {
         const float sc = a.scale;
         const f32x4 val = {r[0] * sc, r[1] * sc, r[2] * sc, r[3] * sc};
-        if (a.n_kb > 1)        // this key block's partial: WRITE-THROUGH, the last-arriving key block of the rows merges (below)
+        if (a.n_kb > 1 && a.bwd_merge)   // this key block's partial: WRITE-THROUGH, the last-arriving key block of the rows merges (below)
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rs_dq, (gq * D + 16 * n + 4 * g) * 4, 0, 16);
         else
           *reinterpret_cast<f32x4 *>(dq_out + (long)gq * dq_sl + 16 * n + 4 * g) = val;
@@ -1075,7 +1075,7 @@ __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args
   const long kv_per = (long)a.B * a.Lk * D;                 // one tensor of one query split's dense partial
   if (kvalid && wave_live && qg == 0) {
     const float sc = a.scale, ik = dc.inv_keep;
-    if (a.n_qs > 1) {          // dense partial of this query split: [split][dk | dv][B][Lk][D], WRITE-THROUGH (merged below)
+    if (a.n_qs > 1 && a.bwd_merge) {   // dense partial of this query split: [split][dk | dv][B][Lk][D], WRITE-THROUGH (merged below)
       const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
           a.dkv_part + (long)qsp * 2 * kv_per + ((long)b * a.Lk + ki) * D + h * HD, 0, HD * 4, 0x00020000);
       const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
@@ -1091,6 +1091,10 @@ __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args
     } else {
       float *ok = a.dk + (long)b * a.dk_sb + (long)ki * a.dk_sl + h * HD;
       float *ov = a.dv + (long)b * a.dv_sb + (long)ki * a.dv_sl + h * HD;
+      if (a.n_qs > 1) {          // (merged by mha2_part_reduce_kernel)
+        ok = a.dkv_part + (long)qsp * 2 * kv_per + ((long)b * a.Lk + ki) * D + h * HD;
+        ov = ok + kv_per;
+      }
       *reinterpret_cast<f32x4 *>(ok + 4 * g) = dk[0] * sc;
       *reinterpret_cast<f32x4 *>(ok + 16 + 4 * g) = dk[1] * sc;
       *reinterpret_cast<f32x4 *>(ov + 4 * g) = dv[0] * ik;
@@ -1107,7 +1111,7 @@ __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args
   // all partials of the range IN SPLIT ORDER from sc1 loads (so the bits do not depend on who is last) and writes the
   // gradient.  dQ rows [qbeg, qend) of head h: ticket (bh, query split), n_kb arrivals.  dK / dV rows of key block kb: ticket
   // (bh, key block), n_qs arrivals.
-  if (a.n_kb > 1 || a.n_qs > 1) {
+  if (a.bwd_merge && (a.n_kb > 1 || a.n_qs > 1)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     unsigned *flag = reinterpret_cast<unsigned *>(lse_s);
@@ -1126,41 +1130,45 @@ __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args
       flag[0] = lq; flag[1] = lkv;
     }
     __syncthreads();
-    if (flag[0]) {
-      const long per = (long)a.B * a.Lq * D;                   // floats between two key blocks' partials
-      const float *p0 = a.dq_part + (long)b * a.Lq * D + h * HD;
-      float *dq_fin = a.dq + (long)b * a.dq_sb + h * HD;
-      for (int i = tid; i < (qend - qbeg) * 9; i += NT) {
-        const int row = i / 9, c4 = i - row * 9;
-        const int off = ((qbeg + row) * D + 4 * c4) * 4;
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int z = 0; z < a.n_kb; ++z) {
-          const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p0 + z * per), 0, a.Lq * D * 4, 0x00020000);
-          t += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, off, 0, 16));
+    // the merging workgroup is ALONE on this range and everybody else may already have left the chip: the sum is latency,
+    // so every thread keeps MU items x up to 4 splits = 16 sixteen-byte loads in flight
+    constexpr int MU = 4;
+    auto merge = [&](const float *p0, long zstride, int nz, int rows, int row0, float *fin, long fin_sl, int span_bytes) {
+      const int nitems = rows * 9;
+      for (int base = tid; base < nitems; base += NT * MU) {
+        f32x4 t[MU];
+        int off[MU];
+#pragma unroll
+        for (int u = 0; u < MU; ++u) {
+          const int i = min(base + u * NT, nitems - 1);
+          const int row = i / 9, c4 = i - row * 9;
+          off[u] = ((row0 + row) * D + 4 * c4) * 4;
+          t[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        *reinterpret_cast<f32x4 *>(dq_fin + (long)(qbeg + row) * a.dq_sl + 4 * c4) = t;
+#pragma unroll 4
+        for (int z = 0; z < nz; ++z) {
+          const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p0 + z * zstride), 0, span_bytes, 0x00020000);
+#pragma unroll
+          for (int u = 0; u < MU; ++u) t[u] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, off[u], 0, 16));
+        }
+#pragma unroll
+        for (int u = 0; u < MU; ++u) {
+          const int i = base + u * NT;
+          if (i < nitems) {
+            const int row = i / 9, c4 = i - row * 9;
+            *reinterpret_cast<f32x4 *>(fin + (long)(row0 + row) * fin_sl + 4 * c4) = t[u];
+          }
+        }
       }
-    }
+    };
+    if (flag[0])
+      merge(a.dq_part + (long)b * a.Lq * D + h * HD, (long)a.B * a.Lq * D, a.n_kb, qend - qbeg, qbeg,
+            a.dq + (long)b * a.dq_sb + h * HD, a.dq_sl, a.Lq * D * 4);
     if (flag[1]) {
       const int nkeys = min(KB, a.Lk - kblock0);
-      for (int which = 0; which < 2; ++which) {
-        const float *p0 = a.dkv_part + which * kv_per + ((long)b * a.Lk + kblock0) * D + h * HD;
-        float *fin = which ? a.dv + (long)b * a.dv_sb + (long)kblock0 * a.dv_sl + h * HD
-                           : a.dk + (long)b * a.dk_sb + (long)kblock0 * a.dk_sl + h * HD;
-        const long fin_sl = which ? a.dv_sl : a.dk_sl;
-        for (int i = tid; i < nkeys * 9; i += NT) {
-          const int row = i / 9, c4 = i - row * 9;
-          const int off = (row * D + 4 * c4) * 4;
-          f32x4 t = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-          for (int z = 0; z < a.n_qs; ++z) {
-            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p0 + z * 2 * kv_per), 0, KB * D * 4, 0x00020000);
-            t += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, off, 0, 16));
-          }
-          *reinterpret_cast<f32x4 *>(fin + row * fin_sl + 4 * c4) = t;
-        }
-      }
+      const float *p0 = a.dkv_part + (long)b * a.Lk * D + h * HD;
+      merge(p0, 2 * kv_per, a.n_qs, nkeys, kblock0, a.dk + (long)b * a.dk_sb + h * HD, a.dk_sl, a.Lk * D * 4);
+      merge(p0 + kv_per, 2 * kv_per, a.n_qs, nkeys, kblock0, a.dv + (long)b * a.dv_sb + h * HD, a.dv_sl, a.Lk * D * 4);
     }
   }
 #ifdef EDA_MHA2_PROFILE
@@ -1169,6 +1177,30 @@ __global__ __launch_bounds__(KSUB * QG * 64) void mha2_bwd_kernel(const Mha2Args
   if (lane == 0)
     for (int i = 0; i < 8; ++i) atomicAdd(&mha2_prof[((blockIdx.x * 16 + wave) & 63) * 8 + i], prof_acc[i]);
 #endif
+}
+
+// out tensors (1: dq; 2: dk, dv) = sum over the splits of the dense partials [split][tensor][B][L][D], written
+// with the outputs' strides, in split order (deterministic).  The second launch of a split backward whose ranges are too
+// large for the in-launch merge (bwd_merge_in_launch below).
+__global__ __launch_bounds__(256) void mha2_part_reduce_kernel(const float *__restrict__ part, int nsplit, int ntens,
+                                                               int B, int L, int D, float *__restrict__ o0, long o0_sb,
+                                                               long o0_sl, float *__restrict__ o1, long o1_sb,
+                                                               long o1_sl) {
+  const long per = (long)B * L * D, n4 = per / 4;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ntens * n4) return;
+  const int which = i >= n4;
+  const long e = (i - which * n4) * 4;
+  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z = 0; z < nsplit; ++z) {
+    const float4 v = *reinterpret_cast<const float4 *>(part + ((long)z * ntens + which) * per + e);
+    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+  }
+  const long row = e / D;
+  const int col = (int)(e - row * D);
+  const long bb = row / L, l = row - bb * L;
+  float *o = which ? o1 + bb * o1_sb + l * o1_sl + col : o0 + bb * o0_sb + l * o0_sl + col;
+  *reinterpret_cast<float4 *>(o) = t;
 }
 
 template <int NQ, int KS, int CHK, int NBUF, bool SPLIT = false>
@@ -1215,11 +1247,21 @@ FwdSplit fwd_ksplit(int B, int H, int Lq, int Lk) {
   return p;
 }
 
+// Who sums the split ranges' partials: the last-arriving workgroup of a range inside the backward launch (1), or a second
+// launch over the whole chip (0).  The in-launch merge is ONE workgroup reading n partials of its range while the rest of
+// the chip has gone idle, behind write-through partial stores that every workgroup has to drain: it wins while a range is a few
+// tens of KB (80 x 1024: 43.3 -> 41.1 us and one launch boundary less), loses when it is hundreds (256 x 256: 36.8 -> 46.5 us,
+// 1024 x 1024: 288.8 -> 297.7; profiles/r06_mha_bwd_merge.txt -- the same finding as the key-split forward's, whose partials
+// are a few KB).  EDA_MHA2_BWD_MERGE = 0 / 1 forces never / always.
+struct BwdPlan;
+int bwd_merge_in_launch(const BwdPlan &p, int Lq, int Lk, int kb_keys);
+
 // Backward decomposition of a shape: which kernel variant, how many key blocks / query splits.
-struct BwdPlan { int variant, n_kb, n_qs, q_per_wg; };
+constexpr long BWD_MERGE_MAX_BYTES = 64 << 10;
+struct BwdPlan { int variant, n_kb, n_qs, q_per_wg, merge; };
 BwdPlan bwd_plan(int B, int H, int Lq, int Lk) {
   const long BH = (long)B * H;
-  BwdPlan p = {0, 1, 1, 0};
+  BwdPlan p = {0, 1, 1, 0, 0};
   int ksub, qc;
   if (Lk <= 80) { p.variant = 2; ksub = 5; qc = 96; }          // text tokens: 5 key waves x 3 query groups
   else if (Lk <= 144) { p.variant = 1; ksub = 9; qc = 64; }    // detected boxes / long utterances: 9 key waves
@@ -1238,7 +1280,18 @@ BwdPlan bwd_plan(int B, int H, int Lq, int Lk) {
   p.q_per_wg = cpw * qc;
   p.n_qs = (Lq + p.q_per_wg - 1) / p.q_per_wg;
   if (p.n_qs < 1) p.n_qs = 1;
+  p.merge = bwd_merge_in_launch(p, Lq, Lk, 16 * ksub);
   return p;
+}
+
+int bwd_merge_in_launch(const BwdPlan &p, int Lq, int Lk, int kb_keys) {
+  if (p.n_kb <= 1 && p.n_qs <= 1) return 0;
+  const long env = eda_knob(EDA_K_MHA2_BWD_MERGE);
+  if (env >= 0) return env != 0;
+  // bytes the largest merging workgroup reads: n_kb partials of its query range (dQ), n_qs partials of its key block (dK | dV)
+  const long dq_bytes = p.n_kb > 1 ? (long)p.n_kb * (p.q_per_wg < Lq ? p.q_per_wg : Lq) * HD * 4 : 0;
+  const long kv_bytes = p.n_qs > 1 ? (long)p.n_qs * 2 * (kb_keys < Lk ? kb_keys : Lk) * HD * 4 : 0;
+  return (dq_bytes > kv_bytes ? dq_bytes : kv_bytes) <= BWD_MERGE_MAX_BYTES;
 }
 
 size_t bwd_workspace_floats(const BwdPlan &p, int B, int H, int Lq, int Lk) {
@@ -1249,7 +1302,7 @@ size_t bwd_workspace_floats(const BwdPlan &p, int B, int H, int Lq, int Lk) {
 }
 // arrival tickets of the split ranges: [B*H][n_qs] for dQ, then [B*H][n_kb] for dK | dV (zero before a launch, left zero)
 size_t bwd_ticket_words(const BwdPlan &p, int B, int H) {
-  return (p.n_kb > 1 || p.n_qs > 1) ? (size_t)B * H * (p.n_qs + p.n_kb) : 0;
+  return p.merge ? (size_t)B * H * (p.n_qs + p.n_kb) : 0;
 }
 
 template <int KSUB, int QG, int QC, int NBUF>
@@ -1379,9 +1432,29 @@ int eda_mha2_bwd_launch(Mha2Args &a, void *ws, size_t ws_bytes, unsigned *ticket
     if (!tickets)
       if (int rc = eda_zero_async(ws, tk, stream)) return rc;
   }
-  if (p.variant == 0) return launch_bwd<16, 1, 64, 2>(a, stream);
-  if (p.variant == 1) return launch_bwd<9, 1, 64, 1>(a, stream);
-  return launch_bwd<5, 3, 96, 1>(a, stream);
+  a.bwd_merge = p.merge;
+  // the next chunk's Q / dO staged underneath this chunk's phases -- also for the short-key variants from round 6 on (1024 x 80:
+  // 41.4 -> 40.3 us, 1024 x 132: 61.8 -> 61.0, one-chunk shapes unchanged; profiles/r06_mha_bwd_merge.txt)
+  const bool dbuf = eda_knob(EDA_K_MHA2_BWD_DBUF) != 0;
+  int rc;
+  if (p.variant == 0) rc = launch_bwd<16, 1, 64, 2>(a, stream);
+  else if (p.variant == 1) rc = dbuf ? launch_bwd<9, 1, 64, 2>(a, stream) : launch_bwd<9, 1, 64, 1>(a, stream);
+  else rc = dbuf ? launch_bwd<5, 3, 96, 2>(a, stream) : launch_bwd<5, 3, 96, 1>(a, stream);
+  if (rc || p.merge) return rc;
+  const int D = a.H * HD;
+  if (p.n_kb > 1) {
+    const long items = (long)a.B * a.Lq * D / 4;
+    hipLaunchKernelGGL(mha2_part_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream,
+                       a.dq_part, p.n_kb, 1, a.B, a.Lq, D, a.dq, a.dq_sb, a.dq_sl, a.dq, a.dq_sb, a.dq_sl);
+    EDA_CHECK_LAUNCH();
+  }
+  if (p.n_qs > 1) {
+    const long items = 2L * a.B * a.Lk * D / 4;
+    hipLaunchKernelGGL(mha2_part_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream,
+                       a.dkv_part, p.n_qs, 2, a.B, a.Lk, D, a.dk, a.dk_sb, a.dk_sl, a.dv, a.dv_sb, a.dv_sl);
+    EDA_CHECK_LAUNCH();
+  }
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------- C entry points ----

@@ -133,20 +133,26 @@ def test_key_split_forward_is_reproducible_and_matches_the_unsplit_kernel(B, Lq,
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,Lq,Lk", [(8, 1024, 1024), (8, 80, 1024), (8, 1024, 80), (8, 256, 132), (2, 300, 700), (1, 256, 256),
                                      (3, 1024, 16)])
-def test_split_backward_merges_in_the_launch_reproducibly(B, Lq, Lk):
-    """Round 6: the key blocks' dQ partials and the query splits' dK | dV partials are merged by the LAST workgroup of a range
-    inside the backward launch (ticket + write-through partials; until round 5 a second launch).  Two calls give the same bits
-    whoever arrives last; the ticket words are back at zero; the legacy entry point (tickets at the head of its per-call
-    scratch, zeroed by a fill kernel) gives the same bits as the persistent-ticket entry point; and both agree with the sum
-    formed on the host from per-key-block / per-query-range backward calls of the same kernel."""
+@pytest.mark.parametrize("mode", ["1", "0", None])
+def test_split_backward_merges_in_the_launch_reproducibly(B, Lq, Lk, mode, monkeypatch):
+    """Round 6: the key blocks' dQ partials and the query splits' dK | dV partials can be merged by the LAST workgroup of a
+    range inside the backward launch (ticket + write-through partials; EDA_MHA2_BWD_MERGE=1) instead of by a second launch
+    (=0); unset, the library decides by the size of a range (small ranges in the launch).  In every mode: two calls give the
+    same bits whoever arrives last; the ticket words are back at zero; the legacy entry point (tickets at the head of its
+    per-call scratch, zeroed by a fill kernel) gives the same bits as the persistent-ticket entry point; and the modes agree
+    bit for bit with each other (both sum the same partials in split order)."""
     from eda_amd import _lib, attention
     L = _lib.lib()
+    if mode is not None:
+        monkeypatch.setenv("EDA_MHA2_BWD_MERGE", mode)
     torch.manual_seed(Lq * 3 + Lk)
     dev = "cuda"
     q, k, v = (torch.randn(B, n, 288, device=dev) for n in (Lq, Lk, Lk))
     mask = _mask(B, Lk, 5, min_valid=max(1, Lk // 3)).to(dev)
     dout = torch.randn(B, Lq, 288, device=dev)
-    assert L.eda_mha_bwd_ticket_bytes(B, 8, Lq, Lk) > 0            # every shape of this list is split somewhere
+    assert L.eda_mha_bwd_workspace_bytes(B, 8, Lq, Lk) > 0         # every shape of this list is split somewhere
+    if mode is not None:
+        assert (L.eda_mha_bwd_ticket_bytes(B, 8, Lq, Lk) > 0) == (mode == "1")
 
     def run():
         qq, kk, vv = (t.clone().requires_grad_(True) for t in (q, k, v))
@@ -183,6 +189,12 @@ def test_split_backward_merges_in_the_launch_reproducibly(B, Lq, Lk):
     # (the autograd path above may have taken the key-split forward: same numbers up to the online softmax's re-association)
     for a, b in ((dq1, dq4), (dk1, dk4), (dv1, dv4)):
         assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
+    # the other merge mode on the same saved forward: the same partials summed in the same order
+    if mode is not None:
+        monkeypatch.setenv("EDA_MHA2_BWD_MERGE", "0" if mode == "1" else "1")
+        dq5, dk5, dv5 = torch.full_like(q, float("nan")), torch.full_like(k, float("nan")), torch.full_like(v, float("nan"))
+        attention._mha_bwd_call(q, k, v, m8, B, 8, Lq, Lk, 36, 0.1, seed, 7, out, lse, dout, dq5, dk5, dv5, 0)
+        assert torch.equal(dq5, dq4) and torch.equal(dk5, dk4) and torch.equal(dv5, dv4)
 
 
 @pytest.mark.gpu
