@@ -60,6 +60,7 @@ const KnobRow kKnobs[EDA_K_COUNT] = {
     {"EDA_MHA2_BWD_DBUF", 0},
     {"EDA_MHA2_BWD_MERGE", -1},     // split backward: 0 = partials summed by a second launch, 1 = by the last arriver inside the launch (unset: by size)       // 1: the short-key backward variants double-buffer their query chunks
     {"EDA_MHA2_KSPLIT", -1},        // 0: no key-split forward; n >= 2: n key slices for every eligible launch (unset: by shape)
+    {"EDA_MHA4", 0},                // 0 (default: measured no faster, profiles/r06_mha4_keys_per_wave.md): short query sets against >= 512 keys stay on mha2.hip's key-split forward; 1: <= 144 queries on mha4.hip (keys per wave); 2: <= 256
     {"EDA_MHA3", 1},                // 0: the long-key attention forward stays on mha2.hip's fp32-MFMA kernel (mha3.hip: bf16 x 3)
     {"EDA_MHA3_DBG", 0},            // ablation bits of mha3.hip (timing experiments; wrong results)
     {"EDA_BN_SMALL_CQ", 4},

@@ -46,6 +46,10 @@ int eda_mha2_fwd_launch(Mha2Args &a, void *ws, size_t ws_bytes, hipStream_t stre
 size_t eda_mha2_fwd_workspace_bytes(int B, int H, int Lq, int Lk);
 // mha3.hip: the long-key forward on v_mfma_f32_16x16x32_bf16 (bf16 x 3 for F32, plain for BF16); -1 = not its shape
 int eda_mha3_fwd_launch(Mha2Args &a, hipStream_t stream);
+// mha4.hip: a short query set (<= 144, on request <= 256) against >= 512 keys, keys per wave, fp32 MFMA; needs the workspace
+bool eda_mha4_takes(int dtype, int Lq, int Lk);
+size_t eda_mha4_fwd_workspace_bytes(int B, int H, int Lq, int Lk);
+int eda_mha4_fwd_launch(Mha2Args &a, void *ws, size_t ws_bytes, hipStream_t stream);
 int eda_mha2_qproj_fwd_launch(Mha2Args &a, hipStream_t stream);      // Lk <= 192
 int eda_mha2_bwd_launch(Mha2Args &a, void *ws, size_t ws_bytes, unsigned *tickets, size_t tickets_bytes, hipStream_t stream);
 size_t eda_mha2_bwd_workspace_bytes(int B, int H, int Lq, int Lk);

@@ -1327,6 +1327,7 @@ int launch_bwd(Mha2Args &a, hipStream_t stream) {
 
 size_t eda_mha2_fwd_workspace_bytes(int B, int H, int Lq, int Lk) {
   if (B <= 0 || Lq <= 0 || Lk <= 0) return 0;
+  if (eda_mha4_takes(EDA_DTYPE_F32, Lq, Lk)) return eda_mha4_fwd_workspace_bytes(B, H, Lq, Lk);
   const FwdSplit sp = fwd_ksplit(B, H, Lq, Lk);
   if (sp.ns <= 1) return 0;
   const size_t blocks = (size_t)B * H * ((Lq + 16 * sp.nq - 1) / (16 * sp.nq));
@@ -1338,6 +1339,7 @@ size_t eda_mha2_fwd_workspace_bytes(int B, int H, int Lq, int Lk) {
 int eda_mha2_fwd_launch(Mha2Args &a, void *ws, size_t ws_bytes, hipStream_t stream) {
   if (a.B == 0 || a.Lq == 0) return 0;
   const int BH = a.B * a.H;
+  if (ws && eda_mha4_takes(a.dtype, a.Lq, a.Lk)) return eda_mha4_fwd_launch(a, ws, ws_bytes, stream);     // keys per wave (mha4.hip)
   {
     const FwdSplit sp = ws ? fwd_ksplit(a.B, a.H, a.Lq, a.Lk) : FwdSplit{1, 4};
     if (sp.ns > 1) {

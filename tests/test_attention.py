@@ -106,6 +106,7 @@ def test_key_split_forward_is_reproducible_and_matches_the_unsplit_kernel(B, Lq,
     ticket words are back at zero for the second one); against the one-workgroup-per-block kernel (EDA_MHA2_KSPLIT=0)
     the result differs by the re-association of the online softmax only; forcing other split counts works too."""
     from eda_amd import _lib, attention
+    monkeypatch.setenv("EDA_MHA4", "0")                 # (this test is about mha2.hip's key split; mha4.hip has its own below)
     torch.manual_seed(Lq + Lk)
     dev = "cuda"
     q, k, v = (torch.randn(B, L, 288, device=dev) for L in (Lq, Lk, Lk))
@@ -128,6 +129,56 @@ def test_key_split_forward_is_reproducible_and_matches_the_unsplit_kernel(B, Lq,
     torch.cuda.synchronize()
     for ws in attention._fwd_ws_cache.values():          # every ticket word re-armed
         assert int(ws[:64].abs().sum().item()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Lq,Lk,mode", [(8, 80, 1024, "1"), (8, 130, 1024, "1"), (2, 80, 1024, "1"), (3, 64, 513, "1"),
+                                          (1, 144, 700, "1"), (2, 17, 512, "1"), (5, 1, 1000, "1"), (8, 256, 1024, "2"),
+                                          (1, 200, 700, "2")])
+@pytest.mark.parametrize("masked", [True, False])
+def test_keys_per_wave_forward_matches_the_query_per_wave_kernel(B, Lq, Lk, mode, masked, monkeypatch):
+    """csrc/mha4.hip (round 6): a wave owns 32 keys and walks over all query tiles; the waves' and the key splits' (O, m, l)
+    are merged in wave / split order.  Against mha2.hip's one-workgroup-per-block kernel (EDA_MHA4=0, EDA_MHA2_KSPLIT=0) the
+    output and lse differ by the re-association of the softmax sums only (same dropout mask: the hash is indexed by query and
+    key); two calls give the same bits whoever arrives last; the ticket words are back at zero."""
+    from eda_amd import _lib, attention
+    L = _lib.lib()
+    torch.manual_seed(Lq * 7 + Lk)
+    dev = "cuda"
+    q, k, v = (torch.randn(B, n, 288, device=dev) for n in (Lq, Lk, Lk))
+    m8 = _mask(B, Lk, 5, min_valid=Lk // 3).to(dev).contiguous().view(torch.uint8) if masked else None
+
+    def fwd():
+        out, lse = torch.full((B, Lq, 288), float("nan"), device=dev), torch.full((B, 8, Lq), float("nan"), device=dev)
+        attention._mha_fwd_call(q, k, v, m8, B, 8, Lq, Lk, 36, 0.1, 7, out, lse)
+        return out, lse
+    monkeypatch.setenv("EDA_MHA4", mode)
+    assert L.eda_mha_fwd_workspace_bytes(B, 8, Lq, Lk) >= B * 8 * ((Lk + 255) // 256) * ((Lq + 15) // 16) * 4096
+    o1, l1 = fwd()
+    o2, l2 = fwd()
+    assert torch.equal(o1, o2) and torch.equal(l1, l2)
+    torch.cuda.synchronize()
+    for ws in attention._fwd_ws_cache.values():
+        assert int(ws[:min(B * 8, ws.numel())].abs().sum().item()) == 0        # (one ticket word per (scene, head))
+    monkeypatch.setenv("EDA_MHA4", "0")
+    monkeypatch.setenv("EDA_MHA2_KSPLIT", "0")
+    o0, l0 = fwd()
+    assert torch.isfinite(o0).all() and torch.isfinite(l0).all()
+    assert (o1 - o0).abs().max().item() <= 2e-6 * o0.abs().max().item()
+    assert (l1 - l0).abs().max().item() <= 2e-6 * l0.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_keys_per_wave_forward_with_all_keys_of_a_scene_masked_gives_nan_like_the_reference(monkeypatch):
+    from eda_amd import attention
+    dev = "cuda"
+    torch.manual_seed(1)
+    q, k, v = (torch.randn(2, n, 288, device=dev) for n in (80, 1024, 1024))
+    mask = torch.zeros(2, 1024, dtype=torch.bool, device=dev)
+    mask[1] = True
+    monkeypatch.setenv("EDA_MHA4", "1")
+    out = attention.attention_core(q, k, v, mask, 8, 0.0, 3)
+    assert torch.isfinite(out[0]).all() and torch.isnan(out[1]).all()
 
 
 @pytest.mark.gpu
