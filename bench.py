@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA (v_mfma_f32_16x16x4_f32) dense peak
+MFMA_F32_MEASURED_TFLOPS = 126.0     # 2048 FLOP / 36 cycles x 1024 SIMDs x 2.17 GHz (profiles/r06_mha4_keys_per_wave.md)
 
 SA_LEVELS = [  # (N, npoint, radius, nsample, C_feat) -- models/backbone_module.py:44-78
     (50000, 2048, 0.2, 64, 3), (2048, 1024, 0.4, 32, 128), (1024, 512, 0.8, 16, 256), (512, 256, 1.2, 16, 256)]
@@ -957,18 +958,26 @@ def main():
             try:
                 from eda_amd import gemm as _g
                 r_, k_, n_ = topg["dims"]
-                x_ = torch.randn(r_, k_, device=device)
-                w_ = torch.randn((n_, k_) if topg["op"] == "gemm_fwd" else (k_, n_), device=device) * 0.05
-                fn_ = (lambda: _g.linear_fwd(x_, w_)) if topg["op"] == "gemm_fwd" else (lambda: _g.linear_dgrad(x_, w_))
+                # EIGHT distinct operand sets rotate through the 50 launches (with ONE set the operands
+                # stay L2-resident, a best case the step never sees -- there every launch of this shape reads activations
+                # another kernel has just written and weights it last saw a layer ago)
+                NSET_ = 8
+                xs_ = [torch.randn(r_, k_, device=device) for _ in range(NSET_)]
+                ws_ = [torch.randn((n_, k_) if topg["op"] == "gemm_fwd" else (k_, n_), device=device) * 0.05 for _ in range(NSET_)]
+                ys_ = [torch.empty(r_, n_ if topg["op"] == "gemm_fwd" else k_, device=device) for _ in range(NSET_)]
+                if topg["op"] == "gemm_fwd":
+                    fn_ = lambda i: _g.linear_fwd(xs_[i % NSET_], ws_[i % NSET_], out=ys_[i % NSET_])       # noqa: E731
+                else:
+                    fn_ = lambda i: _g.linear_dgrad(xs_[i % NSET_], ws_[i % NSET_])                          # noqa: E731
                 gs_ = torch.cuda.Stream()
                 gg_ = torch.cuda.CUDAGraph()
                 with torch.cuda.stream(gs_), torch.no_grad():
-                    for _ in range(3):
-                        fn_()
+                    for i_ in range(NSET_):
+                        fn_(i_)
                     torch.cuda.synchronize()
                     with torch.cuda.graph(gg_, stream=gs_, capture_error_mode="thread_local"):
-                        for _ in range(50):
-                            fn_()
+                        for i_ in range(50):
+                            fn_(i_)
                 for _ in range(3):
                     gg_.replay()
                 torch.cuda.synchronize()
@@ -1046,11 +1055,16 @@ def main():
                     roofline["ms_per_launch"] = t_
                     roofline["ms_per_launch_graph_replay"] = t_
                     roofline["ms_per_step"] = round(t_ * win["calls_per_step"], 4)
-                    roofline["timing"] = "50 launches back to back in a replayed hipGraph (HIP events around the replays)"
+                    roofline["timing"] = ("50 launches back to back in a replayed hipGraph, 8 distinct operand sets in rotation "
+                                          "(HIP events around the replays)")
                 else:
                     roofline["timing"] = "HIP events around each launch in the eager kernel-timing runs"
                 roofline["achieved"] = round(flops_ / (roofline["ms_per_launch"] * 1e-3) / 1e12, 2)
                 roofline["frac"] = round(roofline["achieved"] / MFMA_F32_PEAK_TFLOPS, 4)
+                # beside the guide's peak: the rate v_mfma_f32_16x16x4_f32 really issues at with the chip busy (one per 36
+                # cycles per SIMD at 2.17 GHz, tools/probe/mfma_f32_rate.hip, profiles/r06_mha4_keys_per_wave.md)
+                roofline["peak_measured_issue_rate"] = MFMA_F32_MEASURED_TFLOPS
+                roofline["frac_of_measured_issue_rate"] = round(roofline["achieved"] / MFMA_F32_MEASURED_TFLOPS, 4)
                 fam_k = [k for k in kernels if fam_pred(k) and k.get("stream") == "main" and k["tflops"]]
                 fam_ms = sum(k["ms"] * k["calls_per_step"] for k in fam_k)
                 fam_fl = sum(algorithmic_flops((k["op"],) + tuple(k["dims"])) * k["calls_per_step"] for k in fam_k)

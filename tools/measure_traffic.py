@@ -111,7 +111,8 @@ def main():
     def total(pred):
         return sum((2.0 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024.0 for k in set(fetch) | set(write) if pred(k))
     entries = [
-        {"op": "mha_fwd", "dims": [8, 8, 1024, 1024], "bytes_per_launch": total(lambda k: "mha_fwd_kernel" in k or "mha2_fwd_kernel" in k)},
+        {"op": "mha_fwd", "dims": [8, 8, 1024, 1024], "bytes_per_launch": total(lambda k: "mha_fwd_kernel" in k or "mha2_fwd_kernel" in k or "mha3_fwd_kernel" in k
+                                                                                      or "mha4_fwd_kernel" in k)},
         {"op": "mha_bwd", "dims": [8, 8, 1024, 1024],
          "bytes_per_launch": total(lambda k: "mha_bwd_dq_kernel" in k or "mha_bwd_dkv_kernel" in k or "mha_part_reduce" in k
                                    or "mha2_bwd_kernel" in k or "mha2_part_reduce" in k)},
