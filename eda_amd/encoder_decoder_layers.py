@@ -117,16 +117,18 @@ class CrossAttentionLayer(nn.Module):
             self.norm_d = nn.LayerNorm(d_model)
         self._salt = new_salt_base()
 
-    def forward(self, vis_feats, vis_key_padding_mask, text_feats, text_key_padding_mask,
-                pos_feats, detected_feats=None, detected_mask=None, vis_query=None, emit_pos=False):
-        """vis_query: vis_feats + pos_feats when the caller already has it (the producing LayerNorm launch emits it);
-        emit_pos: return (vis, text, vis + pos_feats) -- the next encoder layer's self-attention query / key."""
-        # text attends to points: no positional term on the keys (:80-93)
+    def text_branch(self, text_feats, vis_feats, vis_key_padding_mask):
+        """text attends to points (no positional term on the keys, :80-93), then its FFN: reads both inputs, writes text only."""
         tr, sb = self.training, self._salt
         text_out = _attn_residual_norm(self.cross_lv, text_feats, text_feats, vis_feats, vis_feats,
                                        vis_key_padding_mask, self.norm_lv, self.dropout_lv.p, tr, sb)
-        text_out = _ffn_residual_norm(text_out, self.ffn_lv, self.norm_lv2, tr, sb + 1)
-        # points attend to the ORIGINAL text (:99-105), position added to the query only
+        return _ffn_residual_norm(text_out, self.ffn_lv, self.norm_lv2, tr, sb + 1)
+
+    def vis_branch(self, vis_feats, text_feats, text_key_padding_mask, pos_feats, detected_feats=None, detected_mask=None,
+                   vis_query=None, emit_pos=False):
+        """points attend to the ORIGINAL text (:99-105, position added to the query only), then to the detected boxes, then
+        their FFN: reads both inputs, writes the points only.  emit_pos: (vis, vis + pos_feats)."""
+        tr, sb = self.training, self._salt
         vis = _attn_residual_norm(self.cross_vl, vis_feats, vis_query if vis_query is not None else vis_feats + pos_feats,
                                   text_feats, text_feats, text_key_padding_mask, self.norm_vl, self.dropout_vl.p,
                                   tr, sb + 2)
@@ -134,10 +136,17 @@ class CrossAttentionLayer(nn.Module):
             vis = _attn_residual_norm(self.cross_d, vis, vis, detected_feats, detected_feats,
                                       detected_mask, self.norm_d, self.dropout_d.p, tr, sb + 3)
         if emit_pos:
-            vis, vis_q = _ffn_residual_norm(vis, self.ffn_vl, self.norm_vl2, tr, sb + 4, pos=pos_feats)
-            return vis, text_out, vis_q
-        vis = _ffn_residual_norm(vis, self.ffn_vl, self.norm_vl2, tr, sb + 4)
-        return vis, text_out
+            return _ffn_residual_norm(vis, self.ffn_vl, self.norm_vl2, tr, sb + 4, pos=pos_feats)
+        return _ffn_residual_norm(vis, self.ffn_vl, self.norm_vl2, tr, sb + 4), None
+
+    def forward(self, vis_feats, vis_key_padding_mask, text_feats, text_key_padding_mask,
+                pos_feats, detected_feats=None, detected_mask=None, vis_query=None, emit_pos=False):
+        """vis_query: vis_feats + pos_feats when the caller already has it (the producing LayerNorm launch emits it);
+        emit_pos: return (vis, text, vis + pos_feats) -- the next encoder layer's self-attention query / key."""
+        text_out = self.text_branch(text_feats, vis_feats, vis_key_padding_mask)
+        vis, vis_q = self.vis_branch(vis_feats, text_feats, text_key_padding_mask, pos_feats, detected_feats, detected_mask,
+                                     vis_query, emit_pos)
+        return (vis, text_out, vis_q) if emit_pos else (vis, text_out)
 
 
 class TransformerEncoderLayerNoFFN(nn.Module):
@@ -220,6 +229,13 @@ class BiEncoder(nn.Module):
             vis_feats, text_feats = out[0], out[1]
             vis_q = out[2] if not last else None
         return vis_feats, text_feats
+
+
+    # (Round 6 measured the TEXT chain of every layer on a second HIP stream -- inside a layer the modalities only read each
+    # other, models/encoder_decoder_layers.py:231-245, so self_lang | self_vis and [cross_lv, ffn_lv] | [cross_vl, cross_d,
+    # ffn_vl] can overlap, ~130 us of 640-row launches per layer and direction.  Bit-identical results, but the fork / join
+    # edges inside the replayed hipGraph cost far more than the overlap returns on this ROCm: 17.6 -> 21.5 ms per step
+    # (profiles/r06_encoder_two_streams.md); not kept.  text_branch / vis_branch of the cross layer remain as the seam.)
 
 
 class BiDecoderLayer(nn.Module):
