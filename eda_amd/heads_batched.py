@@ -27,7 +27,7 @@ _MAXM = 8           # csrc/sa_cl.hip BN_MAXMAT
 
 class _Record:
     """Intermediates of one head's forward (rows x, packed z1 / a1 / z2 / a2, per-stack outputs, BatchNorm statistics)."""
-    __slots__ = ("x", "xd", "z1", "a1", "z2", "a2", "outs", "st1", "st2", "cfg1", "cfg2", "nets", "names")
+    __slots__ = ("x", "xd", "z1", "a1", "z2", "a2", "outs", "st1", "st2", "cfg1", "cfg2", "nets", "names", "center")
 
 
 def _bn_bwd_multi(douts, zs, stats, gammas, cfgs):
@@ -95,7 +95,10 @@ class _HeadsBatched(Function):
         ctx.shape = (H, S)
         outs = []
         for r in recs:
-            outs += [o.view_as(o) for o in r.outs]
+            # the centre stack hands out base_xyz + residual as computed in add() (base_xyz carries no gradient: the
+            # centre's gradient IS the residual's) -- not the residual for a second, recorded addition per head
+            outs += [(r.center if (r.center is not None and n == "center_residual_head") else o).view_as(o)
+                     for n, o in zip(r.names, r.outs)]
         return tuple(outs)
 
     @staticmethod
@@ -225,7 +228,10 @@ class HeadsBatch:
         self.recs.append(r)
         self.meta.append((head, base_xyz, end_points, prefix, B, Q))
         o = dict(zip(names, r.outs))
-        return base_xyz + o["center_residual_head"].view(B, Q, 3), o["size_pred_head"].view(B, Q, 3)
+        center = base_xyz + o["center_residual_head"].view(B, Q, 3)
+        # (kept for finalize(): the recorded output of the centre stack, unless base_xyz itself is differentiable)
+        r.center = center.view(B * Q, 3) if not base_xyz.requires_grad else None
+        return center, o["size_pred_head"].view(B, Q, 3)
 
     def finalize(self):
         if not self.recs:
@@ -243,7 +249,8 @@ class HeadsBatch:
             if head.objectness:
                 end_points[f"{prefix}objectness_scores"] = o["objectness_scores_head"].view(B, Q)
             end_points[f"{prefix}base_xyz"] = base_xyz
-            end_points[f"{prefix}center"] = base_xyz + o["center_residual_head"].view(B, Q, 3)
+            end_points[f"{prefix}center"] = (o["center_residual_head"].view(B, Q, 3) if self.recs[h].center is not None
+                                             else base_xyz + o["center_residual_head"].view(B, Q, 3))
             end_points[f"{prefix}pred_size"] = o["size_pred_head"].view(B, Q, 3)
             if head.compute_sem_scores:
                 end_points[f"{prefix}sem_cls_scores"] = o["sem_cls_scores_head"].view(B, Q, -1)
