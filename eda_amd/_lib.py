@@ -94,6 +94,10 @@ SIGNATURES = {
     "eda_mha_bwd_ticket_bytes": (_sz, [_i, _i, _i, _i]),
     "eda_mha_bwd_tk": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _l, _p, _i, _i, _i, _i, _i, _f, _f,
                            _p, _u, _p, _p, _p, _l, _l, _p, _p, _p, _p, _l, _l, _l, _l, _l, _l, _p, _sz, _p, _sz, _i, _p]),
+    "eda_bf16x3_planes_bytes": (_sz, [_i, _i]),
+    "eda_bf16x3_split_f32": (_i, [_p, _l, _i, _i, _p, _p]),
+    "eda_linear_frozen_b3_supported": (_i, [_l, _i, _i]),
+    "eda_linear_frozen_b3_f32": (_i, [_p, _l, _l, _i, _p, _i, _p, _i, _p, _l, _p]),
     "eda_wgrad_workspace_bytes": (_sz, [_l, _i, _i]),
     "eda_wgrad_f32": (_i, [_p, _l, _p, _l, _l, _i, _i, _p, _p, _p, _sz, _p]),
     "eda_wgrad_grouped_f32": (_i, [_p, _i, _p, _p, _p]),

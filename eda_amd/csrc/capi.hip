@@ -70,6 +70,7 @@ const KnobRow kKnobs[EDA_K_COUNT] = {
     {"EDA_WGRAD_BF16X3", 1},        // eda_wgrad_set_arith
     {"EDA_WGRAD_WGS", 144},
     {"EDA_DETERMINISTIC", 0},       // eda_set_deterministic
+    {"EDA_FROZEN_NW", 0},           // csrc/gemm_frozen.hip: 4 / 8 waves per workgroup for every launch (0: by shape)
     {"EDA_PEER_SPIN_LOG2", 24},     // log2 of the polls an in-kernel statistics exchange waits for a peer (csrc/peer.h)
     {"EDA_PEER_ALLOC", 0},          // pins the slab's allocation kind: 0 fine-grained, 1 uncached, 2 plain (unset: the first that exports an IPC handle)
 };

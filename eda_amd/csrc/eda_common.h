@@ -23,7 +23,7 @@ enum EdaKnob : int {
   EDA_K_FPS_TEST_GIVEUP, EDA_K_BQ_SCAN, EDA_K_GEMM_DBG, EDA_K_GEMM_DMA, EDA_K_GEMM_DMA_MAP, EDA_K_GEMM_STREAM_GRID,
   EDA_K_GEMM_STREAM_B3, EDA_K_GEMM_STREAM, EDA_K_GEMM_STREAM_MINR, EDA_K_GEMM_CFG, EDA_K_GEMM_LN_BM, EDA_K_GEMM_LN_VAR,
   EDA_K_GEMM_SPLITK, EDA_K_GEMM_KC96, EDA_K_GEMM_B3ROWS, EDA_K_FPS_BACKGROUND, EDA_K_MHA2_PRIO, EDA_K_MHA2_BWD_DBUF, EDA_K_MHA2_BWD_MERGE, EDA_K_MHA2_KSPLIT, EDA_K_MHA4, EDA_K_MHA3, EDA_K_MHA3_DBG, EDA_K_BN_SMALL_CQ, EDA_K_SA_LAYER_FUSE, EDA_K_SA_BNBWD_FUSE,
-  EDA_K_SA_BWD_B3, EDA_K_WGRAD_BF16X3, EDA_K_WGRAD_WGS, EDA_K_DETERMINISTIC, EDA_K_PEER_SPIN_LOG2, EDA_K_PEER_ALLOC, EDA_K_COUNT
+  EDA_K_SA_BWD_B3, EDA_K_WGRAD_BF16X3, EDA_K_WGRAD_WGS, EDA_K_DETERMINISTIC, EDA_K_FROZEN_NW, EDA_K_PEER_SPIN_LOG2, EDA_K_PEER_ALLOC, EDA_K_COUNT
 };
 struct EdaEnv {
   long val[EDA_K_COUNT];          // the variable's integer value, or the table's default when it is unset / empty

@@ -199,3 +199,38 @@ def linear_dgrad(dy2, w, out=None, addend=None):
                                                 torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "eda_linear_dgrad_ws_f32")
     return out
+
+
+def frozen_planes(w):
+    """The three bf16 planes (h | m | l, v = h + m + l exactly) of a FROZEN (N, K) fp32 weight, in the layout
+    `linear_frozen` consumes: (3, N, K) int16 storage (include/eda_hip.h: eda_bf16x3_split_f32).  Built once per weight."""
+    w = _rows2d(w.detach())
+    N, K = w.shape
+    planes = torch.empty((3, N, K), dtype=torch.int16, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = _lib.lib().eda_bf16x3_split_f32(w.data_ptr(), _ld(w), N, K, planes.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "eda_bf16x3_split_f32")
+    return planes
+
+
+def linear_frozen_supported(R, K, N):
+    return bool(_lib.lib().eda_linear_frozen_b3_supported(R, K, N))
+
+
+def linear_frozen(x2, planes, bias=None, act=0, out=None):
+    """act(x2 @ W.T + bias) for the frozen weight whose planes `frozen_planes` made: bf16 x 3 on v_mfma_f32_16x16x32_bf16,
+    fp32 accumulation, fp32 accuracy (csrc/gemm_frozen.hip).  act: 0 none, 1 ReLU, 2 GELU (erf).  Inference only."""
+    x2 = _rows2d(x2)
+    R, K = x2.shape
+    N = planes.shape[1]
+    assert planes.shape[2] == K
+    if out is None:
+        out = torch.empty((R, N), dtype=torch.float32, device=x2.device)
+    if R == 0:
+        return out
+    with torch.cuda.device(x2.device), _timed("gemm_frozen_b3", (R, K, N)):
+        rc = _lib.lib().eda_linear_frozen_b3_f32(x2.data_ptr(), _ld(x2), R, K, planes.data_ptr(), N,
+                                                 bias.data_ptr() if bias is not None else None, int(act), out.data_ptr(), _ld(out),
+                                                 torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "eda_linear_frozen_b3_f32")
+    return out

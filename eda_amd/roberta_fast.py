@@ -71,13 +71,21 @@ class FrozenRobertaFast:
         self.pad = int(hf_model.embeddings.padding_idx)
         self._versions = self._param_versions()
         self.layers = []
+        import os
+        # the encoder is FROZEN: its weights are split once into bf16 x 3 planes and every linear layer runs on the bf16
+        # matrix pipe at fp32 accuracy (csrc/gemm_frozen.hip; EDA_FROZEN_B3=0: the fp32-MFMA row products of csrc/gemm.hip)
+        b3 = os.environ.get("EDA_FROZEN_B3", "1") != "0"
         with torch.no_grad():
             for lyr in hf_model.encoder.layer:
                 sa = lyr.attention.self
-                self.layers.append({
-                    "wqkv": torch.cat([sa.query.weight, sa.key.weight, sa.value.weight], 0).contiguous(),
-                    "bqkv": torch.cat([sa.query.bias, sa.key.bias, sa.value.bias], 0).contiguous(),
-                    "lyr": lyr})
+                ent = {"wqkv": torch.cat([sa.query.weight, sa.key.weight, sa.value.weight], 0).contiguous(),
+                       "bqkv": torch.cat([sa.query.bias, sa.key.bias, sa.value.bias], 0).contiguous(),
+                       "lyr": lyr, "planes": None}
+                ws = [ent["wqkv"], lyr.attention.output.dense.weight, lyr.intermediate.dense.weight, lyr.output.dense.weight]
+                if b3 and all(gemm.linear_frozen_supported(64, w.shape[1], w.shape[0]) for w in ws):
+                    ent["planes"] = [gemm.frozen_planes(w) for w in ws]
+                    ent["w"] = ws
+                self.layers.append(ent)
 
     def _param_versions(self):
         return tuple(p._version for p in self.m.parameters()) + (next(self.m.parameters()).data_ptr(),)
@@ -102,15 +110,42 @@ class FrozenRobertaFast:
         scale = 64 ** -0.5
         for ent in self.layers:
             lyr = ent["lyr"]
+            pl = ent["planes"]
+            ao = lyr.attention.output
+            if pl is not None:
+                W = ent["w"]
+                qkv = _frozen_or_fp32(h, pl[0], W[0], ent["bqkv"], 0).view(B, L, 3 * d)
+                ctx = attention_hd64(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], kpm, self.heads, scale)
+                y = _frozen_or_fp32(ctx.view(B * L, d), pl[1], W[1], None, 0)   # (bias added by the LayerNorm kernel)
+                h = _ln_residual(h, y, ao.dense.bias, ao.LayerNorm.weight, ao.LayerNorm.bias, self.eps)
+                t = _frozen_or_fp32(h, pl[2], W[2], lyr.intermediate.dense.bias, 2)
+                y = _frozen_or_fp32(t, pl[3], W[3], None, 0)
+                h = _ln_residual(h, y, lyr.output.dense.bias, lyr.output.LayerNorm.weight, lyr.output.LayerNorm.bias, self.eps)
+                continue
             qkv = gemm.linear_fwd(h, ent["wqkv"], ent["bqkv"]).view(B, L, 3 * d)
             ctx = attention_hd64(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], kpm, self.heads, scale)
-            ao = lyr.attention.output
             y = gemm.linear_fwd(ctx.view(B * L, d), ao.dense.weight)            # (bias added by the LayerNorm kernel)
             h = _ln_residual(h, y, ao.dense.bias, ao.LayerNorm.weight, ao.LayerNorm.bias, self.eps)
             t = _gelu_linear(h, lyr.intermediate.dense.weight, lyr.intermediate.dense.bias)
             y = gemm.linear_fwd(t, lyr.output.dense.weight)
             h = _ln_residual(h, y, lyr.output.dense.bias, lyr.output.LayerNorm.weight, lyr.output.LayerNorm.bias, self.eps)
         return h.view(B, L, d)
+
+
+def _frozen_or_fp32(x2, planes, w, bias, act):
+    """The row product on the frozen weight's bf16 x 3 planes where that launch is the faster one, else on the fp32 matrix
+    instruction.  Measured (tools/bench_gemm_frozen.py, profiles/r06_gemm_frozen.txt, us per launch, planes | fp32 MFMA |
+    hipBLASLt): 640 x 768 -> 2304: 25.7 | 27.1 | 27.4; 640 x 768 -> 3072: 27.8 | 36.5 | 26.7; 640 x 768 -> 768: 20.9 | 11.6 |
+    10.0; 640 x 3072 -> 768: 71.0 | 35.3 | 27.2; 1040 rows (130 tokens): -> 2304 33.0 | 44.5 | 48.4, 3072 -> 768 73.7 | 85.9
+    | 47.5.  A 64-column tile of a 768-wide output gives 120 workgroups: the planes win where the output is wide or the rows
+    are many.  EDA_FROZEN_B3=2 takes the planes everywhere."""
+    import os
+    R = x2.shape[0]
+    N, K = planes.shape[1], planes.shape[2]
+    mode = os.environ.get("EDA_FROZEN_B3", "1")
+    if mode == "2" or N >= 2304 or (R >= 1024 and K >= 2304):
+        return gemm.linear_frozen(x2, planes, bias, act=act)
+    return gemm.linear_fwd(x2, w, bias, relu=act)
 
 
 def _gelu_linear(x2, w, bias):

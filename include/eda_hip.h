@@ -673,6 +673,21 @@ int eda_sa_fused_eval_f32(const float *xyz, const float *new_xyz, const float *f
                           const float *const *running_mean, const float *const *running_var, float eps, float *out,
                           void *stream);
 
+/* ---- Row products against a FROZEN weight on the bf16 matrix pipe at fp32 accuracy (csrc/gemm_frozen.hip) --------------------
+ * The reference freezes its text encoder (models/bdetr.py:77-80: requires_grad = False on every RobertaModel parameter) and runs
+ * its 48 linear layers once per step (:170-175).  A frozen weight is split ONCE into three bf16 planes (v = h + m + l exactly);
+ * the launch splits only the activation rows and forms every product from the six plane products of weight >= 2^-24 on
+ * v_mfma_f32_16x16x32_bf16 with fp32 accumulation: the fp32 kernels' error bound, 2.7 x their matrix-pipe rate.
+ *   eda_bf16x3_planes_bytes(N, K)            bytes of the plane buffer ([3][N][K] bf16)
+ *   eda_bf16x3_split_f32(w, ldw, N, K, p, s) write the planes of w (N, K) fp32 rows
+ *   eda_linear_frozen_b3_supported(R, K, N)  K % 64 == 0 and N % 64 == 0
+ *   eda_linear_frozen_b3_f32(...)            y = act(x W^T + bias); act 0 none / 1 ReLU / 2 GELU (erf); 16-byte aligned rows */
+size_t eda_bf16x3_planes_bytes(int N, int K);
+int eda_bf16x3_split_f32(const float *w, long ldw, int N, int K, void *planes, void *stream);
+int eda_linear_frozen_b3_supported(long R, int K, int N);
+int eda_linear_frozen_b3_f32(const float *x, long ldx, long R, int K, const void *wplanes, int N, const float *bias, int act,
+                             float *y, long ldy, void *stream);
+
 /* ---- SyncBatchNorm without collectives: the statistics exchange through peer-mapped memory (csrc/peer.h, peer.hip) ----
  * The reference converts every BatchNorm to SyncBatchNorm at N > 1 (main_utils.py:336-338).  Here every rank (one process
  * per GPU of ONE node, <= 8) owns a slab of device memory that the other processes map (hipIpc*); a kernel that has a
