@@ -37,6 +37,11 @@ EDA_WGRAD_BF16X3=0 python bench.py --in-step-steps 0 > $O/bench_wgrad_fp32_mfma.
 EDA_BATCHED_HEADS=0 python bench.py --in-step-steps 0 > $O/bench_heads_per_head.json 2> $O/bench_heads_per_head.err
 EDA_RESIDUAL_LINK=0 python bench.py --in-step-steps 0 > $O/bench_residual_link_off.json 2> $O/bench_residual_link_off.err
 EDA_GEMM_B3ROWS=0 python bench.py --in-step-steps 0 > $O/bench_b3rows_off.json 2> $O/bench_b3rows_off.err
+# round 6: in-launch merge of the split attention backward off, the frozen text encoder on fp32-MFMA products, the key-per-wave forward
+EDA_MHA2_BWD_MERGE=0 EDA_MHA2_BWD_DBUF=0 python bench.py --in-step-steps 0 > $O/bench_mha_bwd_r05_form.json 2> $O/bench_mha_bwd_r05_form.err
+EDA_FROZEN_B3=0 python bench.py --in-step-steps 0 > $O/bench_frozen_b3_off.json 2> $O/bench_frozen_b3_off.err
+EDA_MHA4=1 python bench.py --in-step-steps 0 > $O/bench_mha4_on.json 2> $O/bench_mha4_on.err
+python tools/bench_gemm_frozen.py > $O/gemm_frozen.txt 2>&1
 python tools/bench_gemm_b3rows.py > $O/gemm_b3rows_tool.txt 2>&1
 python tools/bench_wgrad_grouped.py > $O/wgrad_grouped.txt 2>&1
 python tools/time_qproj_site.py > $O/qproj_site.txt 2>&1
@@ -50,6 +55,8 @@ python tools/summarize_profile.py $tag 23 $O/bench_eager_kernel_stats_rocprofv3.
 rm -rf /tmp/kt
 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -- python bench.py --steps 10 --warmup 3 --in-step-steps 0 --cpu-scenes 0 > $O/bench_under_trace.json 2>/dev/null
 python tools/queue_gaps.py /tmp/kt 10 > $O/queue_gaps.txt 2>&1
+python tools/step_sequence.py /tmp/kt > $O/step_sequence.txt 2>&1
+python tools/step_sequence.py /tmp/kt --native 0 > $O/step_sequence_not_native.txt 2>&1
 tools/prof_gemm_shapes.sh ${tag} > /dev/null 2>&1
 tools/prof_mha.sh ${tag}_f32 > /dev/null 2>&1
 ATTN_DTYPE=bf16 tools/prof_mha.sh ${tag}_bf16 > /dev/null 2>&1

@@ -12,9 +12,9 @@ import glob
 import re
 import sys
 
-NATIVE = re.compile(r"^(fps_|gemm_|mha|wgrad|sa_|bn_|add_dropout_ln|ln_|gq_|ball_query|three_|gather_points|group_|zero_kernel|colsum|"
-                    r"wcolsum|tiny_out|rows_scatter|weight_transpose|transpose_batch|lsa_|peer_|det_scatter|scatter_det|index_add_rows|"
-                    r"group_concat|fill_rows|interp|eda_)")
+NATIVE = re.compile(r"^(add_dropout_ln|add_n_kernel|ball_query|bf16x3_split|bn_|colsum|copy_kernel|det_scatter|fps_|gather_points|gemm_|gq_|"
+                    r"group_|l2norm_|linear_frozen|ln_reduce|lsa_|mha|peer_|rows_scatter|sa_|three_|tiny_out|transpose_batch|wcolsum|"
+                    r"weight_transpose|wgrad|zero_kernel)")
 
 
 def short(n):
