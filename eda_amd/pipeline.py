@@ -264,6 +264,17 @@ class PipelinedTrainStep:
             self.g_up.replay()
         return self.loss
 
+    def check(self):
+        """Host-side health check of everything in the step that gives up instead of hanging (synchronises the device: call it
+        once per epoch, or per step while debugging): raises if the multi-workgroup sampler ever gave up its spin (the indices
+        of that step were not the FPS result) or an in-kernel BatchNorm statistics exchange timed out (the statistics are
+        invalid from that point on, eda_amd/sync_bn.py)."""
+        from . import sync_bn
+        n = self.fps_status()
+        if n:
+            raise RuntimeError(f"furthest point sampling gave up its inter-workgroup spin in {n} workspace(s)")
+        sync_bn.check()
+
     def fps_status(self):
         """Sticky give-up flag of the multi-workgroup sampler over all steps so far (0 = every sampling completed)."""
         return ext.fps_status(self.nxt["point_clouds"].device)
