@@ -6,13 +6,15 @@ import re
 import sys
 
 NATIVE = [
-    ("native: own row GEMMs fwd / dX, tiled (gemm_rows / gemm_dma: linear layers incl. the text encoder's and the LayerNorm-epilogue launches, small SA/FP layers)", r"^gemm_rows_kernel|^gemm_dma_kernel"),
+    ("native: own row GEMMs fwd / dX, tiled (gemm_rows / gemm_dma: linear layers incl. the text encoder's and the LayerNorm-epilogue launches, small SA/FP layers)", r"^gemm_rows_kernel|^gemm_dma_kernel|^gemm_b3_rows_kernel"),
+    ("native: the frozen text encoder's wide linear layers on pre-split bf16 x 3 weight planes (gemm_frozen.hip)", r"^linear_frozen_b3_kernel|^bf16x3_split"),
     ("native: own row GEMMs fwd / dX, streaming (gemm_stream, fp32 MFMA or bf16 x 3 / gemm_gather3: many-row SA layers)", r"^gemm_stream_kernel|^gemm_stream_b3_kernel|^gemm_gather3"),
     ("native: furthest point sampling", r"^fps_"),
-    ("native: fused attention (fwd, dQ, dK/dV)", r"^mha2?_"),
+    ("native: fused attention (fwd, dQ, dK/dV)", r"^mha[234]?_"),
     ("native: BN+ReLU(+pool) fwd/bwd", r"^bn_"),
     ("native: residual+dropout+LayerNorm", r"^add_dropout_ln|^ln_reduce"),
-    ("native: weight/bias gradients (grouped wgrad fp32 / bf16 x 3, wgrad_x, colsum, the heads' 3-channel layers) and the SA layers' one-launch backward (sa_layer_bwd: weight + input gradient)", r"^wgrad_|^colsum_|^wcolsum_|^weight_transpose|^tiny_out_|^sa_layer_bwd|^sa_gather_layer_bwd|^rows_scatter_add"),
+    ("native: weight/bias gradients (grouped wgrad fp32 / bf16 x 3, wgrad_x, colsum, the heads' 3-channel layers) and the SA layers' one-launch backward (sa_layer_bwd: weight + input gradient)", r"^wgrad_|^colsum_|^wcolsum_|^weight_transpose|^transpose_batch|^tiny_out_|^sa_layer_bwd|^sa_gather_layer_bwd|^rows_scatter_add"),
+    ("native: small fused kernels (ordered / n-ary adds, l2norm of the contrastive projections, device assignment, peer exchange)", r"^add_n_kernel|^l2norm_|^lsa_|^peer_|^det_scatter|^copy_kernel|^sa_eval"),
     ("native: ball query (grid build + query)", r"^gq_|^ball_query"),
     ("native: gather/group/3-NN", r"^group_|^gather_|^three_"),
     ("native: zero-fill", r"^zero_kernel"),
