@@ -157,13 +157,11 @@ def load_pmc_traffic():
 def synthetic_loss(end_points):
     """Scalar that reaches every trainable parameter the real loss reaches, with
     no host sync (SURVEY.md §8d 'Loss for bwd')."""
-    loss = end_points["seeds_obj_cls_logits"].pow(2).mean()
     proj_tokens = end_points["proj_tokens"]
     prefixes = [k[:-len("center")] for k in end_points if k.endswith("center")]   # proposal_, {i}head_, last_
-    # sum over the prediction heads p of
-    #   mean_bq |center_p|^2 + mean_bq |pred_size_p|^2 + mean(sem_cls_scores_p^2) + mean(proj_queries_p proj_tokens^T),
-    # evaluated on the heads STACKED along a new leading dimension: ~25 launches instead of 7 x 14 (the
-    # per-head form spent ~0.5 ms/step of the graph in 5 us reductions of (8,256,3) tensors)
+    # mean(seed logits^2) + sum over the prediction heads p of
+    #   mean_bq |center_p|^2 + mean_bq |pred_size_p|^2 + mean(sem_cls_scores_p^2) + mean(proj_queries_p proj_tokens^T)
+    loss = end_points["seeds_obj_cls_logits"].pow(2).mean() if os.environ.get("EDA_BENCH_LOSS_FORM") in ("perhead", "stacked") else None
     if os.environ.get("EDA_BENCH_LOSS_FORM") == "perhead":      # the original evaluation order (debugging aid)
         for p in prefixes:
             loss = loss + end_points[f"{p}center"].pow(2).sum(-1).mean() + end_points[f"{p}pred_size"].pow(2).sum(-1).mean()
@@ -173,11 +171,40 @@ def synthetic_loss(end_points):
 
     def stacked(name):
         return torch.stack([end_points[p + name] for p in prefixes])
-    centers, sizes, sem, pq = stacked("center"), stacked("pred_size"), stacked("sem_cls_scores"), stacked("proj_queries")
-    bq = float(centers.shape[1] * centers.shape[2])
-    loss = loss + centers.pow(2).sum() / bq + sizes.pow(2).sum() / bq + sem.pow(2).sum() / (bq * sem.shape[-1])
-    sim = torch.matmul(pq, proj_tokens.transpose(1, 2))              # (P, B, Q, L)
-    return loss + sim.sum() / (bq * sim.shape[-1])
+    if os.environ.get("EDA_BENCH_LOSS_FORM") == "stacked":      # the round 1-5 evaluation: one pow / sum / scale per term
+        centers, sizes, sem, pq = stacked("center"), stacked("pred_size"), stacked("sem_cls_scores"), stacked("proj_queries")
+        bq = float(centers.shape[1] * centers.shape[2])
+        loss = loss + centers.pow(2).sum() / bq + sizes.pow(2).sum() / bq + sem.pow(2).sum() / (bq * sem.shape[-1])
+        sim = torch.matmul(pq, proj_tokens.transpose(1, 2))              # (P, B, Q, L)
+        return loss + sim.sum() / (bq * sim.shape[-1])
+    # Round 6: the same sum of weighted squares as ONE weighted dot product over the concatenation of all squared terms
+    # (seed logits / numel, centres and sizes / (B Q), class scores / (B Q C)): cat + mul + dot instead of ~18 launches of
+    # 5 us each forward and as many backward (every term is `weight * sum(x^2)`; the weights are a constant vector)
+    seeds = end_points["seeds_obj_cls_logits"]
+    parts = [seeds] + [end_points[p + n] for n in ("center", "pred_size", "sem_cls_scores") for p in prefixes]
+    c0 = end_points[prefixes[0] + "center"]
+    bq = float(c0.shape[0] * c0.shape[1])
+    cw = float(end_points[prefixes[0] + "sem_cls_scores"].shape[-1])
+    wts = [1.0 / seeds.numel()] + [1.0 / bq] * (2 * len(prefixes)) + [1.0 / (bq * cw)] * len(prefixes)
+    v = torch.cat([t.reshape(-1) for t in parts])
+    w = _loss_weight_vector(tuple(t.numel() for t in parts), tuple(wts), v.device)
+    pq = stacked("proj_queries")
+    sim = torch.matmul(pq, proj_tokens.transpose(1, 2))                  # (P, B, Q, L)
+    return torch.dot(v * w, v) + sim.sum() / (bq * sim.shape[-1])
+
+
+_loss_w_cache = {}
+
+
+def _loss_weight_vector(sizes, weights, device):
+    """Constant per-element weights of synthetic_loss's squared terms (built once per layout, outside any capture)."""
+    key = (sizes, weights, str(device))
+    w = _loss_w_cache.get(key)
+    if w is None:
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("synthetic_loss: run one eager step before capturing (its weight vector is built on first use)")
+        w = _loss_w_cache[key] = torch.cat([torch.full((n,), wt, dtype=torch.float32) for n, wt in zip(sizes, weights)]).to(device)
+    return w
 
 
 def make_targets(rank, per_gpu, device, inputs):

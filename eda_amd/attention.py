@@ -125,6 +125,7 @@ def reset_workspaces():
 
 
 _bwd_tk_cache = {}
+_bwd_tk_retired = []
 
 
 def _bwd_tickets(dev, nbytes):
@@ -136,6 +137,8 @@ def _bwd_tickets(dev, nbytes):
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("eda_amd.attention: no backward ticket buffer for this (device, stream) yet -- run the step "
                                "once eagerly on the stream before capturing it in a HIP graph")
+        if tk is not None:
+            _bwd_tk_retired.append(tk)          # (a captured graph may still hold the smaller buffer's address: never freed)
         tk = _bwd_tk_cache[key] = torch.zeros(max(16384, (nbytes + 3) // 4), dtype=torch.int32, device=dev)
     return tk
 
