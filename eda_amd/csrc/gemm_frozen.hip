@@ -35,6 +35,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int FB_BN = 64, FB_KC = 64, FB_PF = 4;
+#ifndef EDA_FROZEN_NSTG
+#define EDA_FROZEN_NSTG 2
+#endif
+constexpr int FB_NSTG = EDA_FROZEN_NSTG;      // LDS ring slots of the weight chunks (2; 3 measured slower: 72 KB per workgroup = one workgroup less per CU)
 
 // two fp32 values -> their three bf16 planes, packed pairwise (first value in the low half)
 __device__ __forceinline__ void split_pk(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
@@ -76,8 +80,12 @@ struct FrozenArgs {
 template <int FB_NW>
 __global__ __launch_bounds__(64 * FB_NW) void linear_frozen_b3_kernel(const FrozenArgs a) {
   constexpr int FB_BM = 16 * FB_NW;
-  // LDS: [2 buffers][3 planes][64 columns][64 k] bf16, rows of 128 bytes = 8 granules of 16 bytes, granule q of row r at slot q ^ (r & 7)
-  __shared__ __attribute__((aligned(1024))) unsigned short Ws[2 * 3 * FB_BN * FB_KC];
+  // LDS (dynamic): [FB_NSTG ring slots][3 planes][64 columns][64 k] bf16, rows of 128 bytes = 8 granules of 16 bytes, granule q of
+  // row r at slot q ^ (r & 7).  Two slots.  (PMC, tools/frozen_pmc.py: waves sit in s_waitcnt / barriers for 46 % of their
+  // cycles, the matrix pipe is 21 % busy; a THIRD slot -- chunk c + 2 requested while chunk c is multiplied -- made it slower,
+  // 27.8 -> 29.0 us and 33 -> 46 us at 1040 rows: what hides the latency here is a third workgroup per CU, which 72 KB forbid.)
+  extern __shared__ __attribute__((aligned(1024))) unsigned short Ws[];
+  constexpr int STG = 3 * FB_BN * FB_KC, PW = 24 / FB_NW;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g = lane >> 4;
@@ -95,8 +103,8 @@ __global__ __launch_bounds__(64 * FB_NW) void linear_frozen_b3_kernel(const Froz
   const int nchunks = a.K / FB_KC, nsteps = a.K / 32;
 
   // weight chunk c -> buffer c & 1: 3 planes x 64 rows x 8 granules = 1536 granules = 24 pieces of 64; 24 / NW per wave
-  auto stage_w = [&](int c) {
-    unsigned short *dst = Ws + (c & 1) * (3 * FB_BN * FB_KC);
+  auto stage_w = [&](int c, int slot) {
+    unsigned short *dst = Ws + slot * STG;
 #pragma unroll
     for (int i = 0; i < 24 / FB_NW; ++i) {
       const int p = wave + FB_NW * i;                          // piece: 8 rows of one plane
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(64 * FB_NW) void linear_frozen_b3_kernel(const Froz
     xr[slot][1] = *reinterpret_cast<const float4 *>(xp + 32 * s + 4);
   };
 
-  stage_w(0);
+  stage_w(0, 0);
 #pragma unroll
   for (int s = 0; s < FB_PF - 1; ++s)
     if (s < nsteps) load_x(s, s);
@@ -122,24 +130,28 @@ __global__ __launch_bounds__(64 * FB_NW) void linear_frozen_b3_kernel(const Froz
 #pragma unroll
   for (int j = 0; j < 4; ++j)
     bias_v[j] = a.bias ? *reinterpret_cast<const float4 *>(a.bias + n0 + 16 * j + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  bool pre1 = false;
+  if (FB_NSTG == 3 && nchunks > 1) { stage_w(1, 1); pre1 = true; }     // chunk 1 is requested LAST: the wait below leaves only it in flight
   // acc: the running 128-deep partial on the matrix pipe; tot: the sum of the partials (one fp32 addition per 128 of
   // contraction keeps the rounding of a 3072-deep sum at the fp32 kernels' level: blocked summation)
   f32x4 acc[4], tot[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) { acc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; tot[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  EDA_SYNC_DMA();
+  if (pre1) { if (PW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 
   // one chunk = two 32-deep steps; two chunks per trip so that the ring slots (step % 4) are compile-time registers
+  int buf = 0;                                                 // ring slot of the chunk being multiplied
   auto chunk = [&](int c, auto parity) {
     constexpr int PAR = decltype(parity)::value;
-    const bool more = c + 1 < nchunks;
-    if (more) stage_w(c + 1);
-    const unsigned short *wb = Ws + PAR * (3 * FB_BN * FB_KC);
+    const bool ahead = c + FB_NSTG - 1 < nchunks;
+    if (ahead) stage_w(c + FB_NSTG - 1, (buf + FB_NSTG - 1) % FB_NSTG);
+    const unsigned short *wb = Ws + buf * STG;
     int young = 0;                                             // row loads issued behind this chunk's DMA (uniform)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int s = 2 * c + u;
-      constexpr int dummy = 0; (void)dummy;
       const int slot = 2 * PAR + u;                            // = s % 4
       if (s + FB_PF - 1 < nsteps) { load_x(s + FB_PF - 1, (slot + FB_PF - 1) % FB_PF); young += 2; }
       const float4 v0 = xr[slot][0], v1 = xr[slot][1];
@@ -162,12 +174,23 @@ __global__ __launch_bounds__(64 * FB_NW) void linear_frozen_b3_kernel(const Froz
       FB_ROUND(al, bh) FB_ROUND(ah, bl) FB_ROUND(am, bm) FB_ROUND(am, bh) FB_ROUND(ah, bm) FB_ROUND(ah, bh)
 #undef FB_ROUND
     }
-    // chunk c + 1 must have landed (this wave's six DMA pieces are OLDER than the row loads it issued since: wait for all but
-    // those), and everybody must be done reading chunk c's buffer before the chunk after next overwrites it
-    if (young == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (young == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // chunk c + 1 must have landed.  vmcnt counts in order: what this wave issued AFTER chunk c + 1's pieces may stay in
+    // flight -- the pieces of the chunk requested at the top of this one (three-slot ring: PW of them) and `young` row loads.
+    // Then the barrier: everybody has its pieces of chunk c + 1, and is done reading the slot the next request overwrites.
+    const int keep = ((FB_NSTG == 3 && ahead) ? PW : 0) + young;
+    switch (keep) {
+      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
     __syncthreads();
+    buf = buf + 1 == FB_NSTG ? 0 : buf + 1;
   };
 #pragma unroll 1
   for (int c = 0; c < nchunks; c += 2) {
@@ -234,8 +257,14 @@ extern "C" int eda_linear_frozen_b3_f32(const float *x, long ldx, long R, int K,
   const int ct_per = (a.col_tiles + 7) / 8;
   const long grid = (long)8 * ct_per * a.row_blocks;
   EDA_CHECK_ARG(grid <= 0x7fffffffL, "too many workgroups");
-  if (w8) hipLaunchKernelGGL(linear_frozen_b3_kernel<8>, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream_, a);
-  else hipLaunchKernelGGL(linear_frozen_b3_kernel<4>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream_, a);
+  constexpr size_t lds = (size_t)FB_NSTG * 3 * FB_BN * FB_KC * sizeof(unsigned short);
+  if (w8) {
+    EDA_CHECK_HIP(eda_set_max_dynamic_lds(reinterpret_cast<const void *>(&linear_frozen_b3_kernel<8>), lds));
+    hipLaunchKernelGGL(linear_frozen_b3_kernel<8>, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream_, a);
+  } else {
+    EDA_CHECK_HIP(eda_set_max_dynamic_lds(reinterpret_cast<const void *>(&linear_frozen_b3_kernel<4>), lds));
+    hipLaunchKernelGGL(linear_frozen_b3_kernel<4>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, a);
+  }
   EDA_CHECK_LAUNCH();
   return 0;
 }
