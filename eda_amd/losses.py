@@ -343,7 +343,11 @@ def compute_hungarian_loss(end_points, num_decoder_layers, set_criterion, query_
     same keys into end_points.  The reference runs matcher + criterion once per head; here the P
     heads are stacked into the batch dimension -- one (P*B, Q, G) cost, ONE assignment launch,
     one pass of each loss -- and the per-head values are read off the per-scene sums.
-    `assign`: optional {prefix: (B,G) assignment} (tests on CPU)."""
+    `assign`: optional {prefix: (B,G) assignment} (tests on CPU).  On CUDA tensors the same arithmetic runs as a handful
+    of fused launches (losses_fused.py / csrc/loss.hip) unless EDA_FUSED_LOSS=0."""
+    from . import losses_fused
+    if losses_fused.usable(end_points, set_criterion, assign):
+        return losses_fused.compute_hungarian_loss(end_points, num_decoder_layers, set_criterion, query_points_obj_topk)
     prefixes = ["proposal_", "last_"] + [f"{i}head_" for i in range(num_decoder_layers - 1)]
     P = len(prefixes)
     gt_box = torch.cat([end_points["center_label"][:, :, 0:3], end_points["size_gts"]], dim=-1)

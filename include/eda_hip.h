@@ -673,6 +673,39 @@ int eda_sa_fused_eval_f32(const float *xyz, const float *new_xyz, const float *f
                           const float *const *running_mean, const float *const *running_var, float eps, float *out,
                           void *stream);
 
+/* ---- The training loss's small-tensor arithmetic as a handful of launches (csrc/loss.hip) -----------------------
+ * The reference's SetCriterion (models/losses.py:339-647) is ~300 element-wise operations on tensors of a few thousand elements
+ * and twice that in its autograd backward: 690 launches per training step.  Each entry below is one launch; the *_fwd entries also
+ * form the gradient of their loss with respect to the predictions (grad0 / g_*), which the backward only scales by the upstream
+ * gradient.  PB = heads x scenes rows of predictions (heads stacked into the batch dimension), B scenes of targets: row pb uses the
+ * targets of scene pb % B.  num_boxes: ONE float on the device (losses.py:630-636).  All tensors dense unless strides are given.
+ *   eda_match_cost_f32      HungarianMatcher.cost_matrix (:262-318) for the real target slots g < ntargets[b] (0 beyond): class
+ *                           term from the token maps (pmap != NULL: soft-token) or from labels
+ *   eda_match_slots_i64     tq (PB, Q) = the target slot matched to each query, -1 for the others (inverse of eda_lsa_f32's result)
+ *   eda_box_loss_fwd/bwd    loss_boxes (:462-497): per-row sums of L1 (centre + 0.2 size) and 1 - GIoU over the valid matched pairs
+ *   eda_pos_align_fwd       loss_pos_align (:396-460): maps = positive, modify, pronoun, relation with weights w[4]
+ *   eda_sem_align_fwd       loss_sem_align (:499-608): maps = positive, modify, pronoun, other-entity, relation; logits = proj_queries
+ *                           . proj_tokens^T / temperature; guard eda_sem_align_supported(Q, L) (the scene's logits live in LDS)
+ *   eda_scale_by_scene_f32  out[pb][:] = grad0[pb][:] * w[pb] / num_boxes: the backward of pos_align / sem_align */
+int eda_match_cost_f32(const float *logits, const float *pred, const float *tgt_boxes, const float *pmap, long pm_sg,
+                       const long *labels, const int *ntargets, int PB, int B, int Q, int G, int C, float w_class, float w_bbox,
+                       float w_giou, float *cost, void *stream);
+int eda_match_slots_i64(const int *assign, const int *ntargets, int PB, int B, int Q, int G, long *tq, void *stream);
+int eda_box_loss_fwd_f32(const float *pred, long p_sb, long p_sq, const float *tgt, const int *assign, const unsigned char *valid,
+                         const float *num_boxes, int PB, int Bt, int Q, int G, float *loss_l1, float *loss_giou, float *g_l1,
+                         float *g_giou, void *stream);
+int eda_box_loss_bwd_f32(const float *g_l1, const float *g_giou, const long *tq, const float *w_l1, const float *w_giou,
+                         const float *num_boxes, int B, int Q, int G, float *dpred, void *stream);
+int eda_pos_align_fwd_f32(const float *logits, const long *tq, const float *const *maps, const float *w, long map_sb, long map_sg,
+                          const float *num_boxes, int PB, int B, int Q, int G, int C, float eos, float *loss, float *grad0,
+                          void *stream);
+int eda_scale_by_scene_f32(const float *g0, const float *w, const float *num_boxes, int PB, long per, float *out, void *stream);
+size_t eda_sem_align_lds_bytes(int Q, int L);
+int eda_sem_align_supported(int Q, int L);
+int eda_sem_align_fwd_f32(const float *logits, const long *tq, const float *const *maps, long map_sb, long map_sg,
+                          const long *attn_mask, const float *num_boxes, int PB, int B, int Q, int G, int L, float eos,
+                          float *loss, float *grad0, void *stream);
+
 /* ---- Row products against a FROZEN weight on the bf16 matrix pipe at fp32 accuracy (csrc/gemm_frozen.hip) --------------------
  * The reference freezes its text encoder (models/bdetr.py:77-80: requires_grad = False on every RobertaModel parameter) and runs
  * its 48 linear layers once per step (:170-175).  A frozen weight is split ONCE into three bf16 planes (v = h + m + l exactly);

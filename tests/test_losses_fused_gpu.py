@@ -1,0 +1,119 @@
+"""csrc/loss.hip (eda_amd/losses_fused.py) against the torch form of the same loss (eda_amd/losses.py, itself pinned to the
+reference's models/losses.py goldens in tests/test_losses.py): values of every part and head, the assignment, and the gradients
+with respect to every prediction tensor, on padded targets with empty scenes, full scenes and scattered valid slots."""
+import numpy as np
+import pytest
+import torch
+
+import loss_fixtures as LF
+
+pytestmark = pytest.mark.gpu
+
+
+def _criterion(soft=True, names=("boxes", "labels", "contrastive_align")):
+    from eda_amd import losses
+    return losses, losses.SetCriterion(losses.HungarianMatcher(1, 5, 2, soft), losses=list(names), eos_coef=0.1, temperature=0.07)
+
+
+def _end_points(seed, dataset, B, Q, L, counts):
+    ep = LF.make_end_points(seed, B=B, Q=Q, L=L, dataset=dataset)
+    rng = np.random.default_rng(seed + 100)
+    mask = torch.zeros(B, LF.G)
+    for b, n in enumerate(counts):
+        mask[b, torch.from_numpy(rng.permutation(LF.G)[:n].astype(np.int64))] = 1          # scattered valid slots
+    ep["box_label_mask"] = mask
+    ep = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in ep.items()}
+    ep["tokenized"] = {"attention_mask": ep["tokenized"]["attention_mask"].cuda()}
+    return ep
+
+
+def _run(ep, crit, losses, fused, monkeypatch):
+    monkeypatch.setenv("EDA_FUSED_LOSS", "1" if fused else "0")
+    ep = dict(ep)
+    for k in LF.GRAD_KEYS:
+        ep[k] = ep[k].detach().clone().requires_grad_(True)
+    loss, ep = losses.compute_hungarian_loss(ep, 2, crit, query_points_obj_topk=5)
+    loss.backward()
+    return loss, ep
+
+
+@pytest.mark.parametrize("dataset,B,Q,L,counts", [
+    ("scanrefer", 4, 256, 40, (0, 1, 37, 132)),
+    ("sr3d", 3, 32, 20, (2, 0, 5)),
+    ("scanrefer", 8, 256, 130, (3, 1, 2, 8, 1, 1, 4, 2)),
+    ("scanrefer", 2, 64, 256, (1, 6)),
+])
+def test_fused_loss_equals_torch_form(dataset, B, Q, L, counts, monkeypatch):
+    from eda_amd import losses_fused
+    losses, crit = _criterion()
+    ep0 = _end_points(21, dataset, B, Q, L, counts)
+    assert losses_fused.usable(ep0, crit, None)
+    lt, et = _run(ep0, crit, losses, False, monkeypatch)
+    lf, ef = _run(ep0, crit, losses, True, monkeypatch)
+    for p in LF.PREFIXES:
+        assert torch.equal(et[f"{p}assign"], ef[f"{p}assign"]), p
+        for k in ("loss_ce", "loss_bbox", "loss_giou", "loss_sem_align"):
+            torch.testing.assert_close(ef[f"{p}_{k}"], et[f"{p}_{k}"], rtol=3e-5, atol=1e-5, msg=lambda m: f"{p}{k}: {m}")
+    for k in ("loss_ce", "loss_bbox", "loss_giou", "loss_sem_align", "query_points_generation_loss"):
+        torch.testing.assert_close(ef[k], et[k], rtol=3e-5, atol=1e-5, msg=lambda m: f"{k}: {m}")
+    torch.testing.assert_close(lf, lt, rtol=2e-5, atol=1e-5)
+    for k in LF.GRAD_KEYS:
+        e, g = et[k].grad, ef[k].grad
+        torch.testing.assert_close(g, e, rtol=5e-4, atol=5e-6 * (float(e.abs().max()) + 1), msg=lambda m: f"grad {k}: {m}")
+
+
+@pytest.mark.parametrize("names", [("boxes",), ("labels",), ("boxes", "contrastive_align")])
+def test_fused_loss_subsets(names, monkeypatch):
+    losses, crit = _criterion(names=names)
+    ep0 = _end_points(5, "scanrefer", 3, 32, 20, (2, 1, 3))
+    lt, et = _run(ep0, crit, losses, False, monkeypatch)
+    lf, ef = _run(ep0, crit, losses, True, monkeypatch)
+    torch.testing.assert_close(lf, lt, rtol=2e-5, atol=1e-5)
+    for k in LF.GRAD_KEYS:
+        e, g = et[k].grad, ef[k].grad
+        if e is None:
+            assert g is None or float(g.abs().max()) == 0.0, k
+        else:
+            torch.testing.assert_close(g, e, rtol=5e-4, atol=5e-6 * (float(e.abs().max()) + 1), msg=lambda m: f"grad {k}: {m}")
+
+
+@pytest.mark.parametrize("soft", [True, False])
+def test_match_cost_and_slots(soft):
+    from eda_amd import losses_fused
+    losses, crit = _criterion(soft)
+    torch.manual_seed(3)
+    P, B, Q, G, C = 3, 4, 96, 20, 256
+    logits = torch.randn(P * B, Q, C, device="cuda")
+    pred = torch.cat([torch.randn(P * B, Q, 3, device="cuda"), torch.rand(P * B, Q, 3, device="cuda") + 0.2], -1)
+    tgt = torch.cat([torch.randn(B, G, 3, device="cuda"), torch.rand(B, G, 3, device="cuda") + 0.2], -1)
+    pmap = torch.rand(B, G, C, device="cuda") * (torch.rand(B, G, C, device="cuda") < 0.1)
+    labels = torch.randint(0, C, (B, G), device="cuda")
+    nt = torch.tensor([0, 20, 7, 1], dtype=torch.int32, device="cuda")
+    got = losses_fused.match_cost(logits, pred, tgt, nt, crit.matcher, pmap, labels)
+    rep = lambda t: t.unsqueeze(0).expand(P, *t.shape).reshape(P * t.shape[0], *t.shape[1:])       # noqa: E731
+    exp = crit.matcher.cost_matrix(logits, pred, rep(tgt), rep(pmap), rep(labels))
+    real = (torch.arange(G, device="cuda")[None, :] < rep(nt)[:, None])[:, None, :].expand_as(exp)
+    torch.testing.assert_close(got[real], exp[real], rtol=2e-5, atol=2e-5)
+    assert float(got[~real].abs().max()) == 0.0
+    # the same assignment from either matrix, and its inverse
+    a1 = losses.solve_assignment(got, rep(nt))
+    a2 = losses.solve_assignment(torch.nan_to_num(exp), rep(nt))
+    assert torch.equal(a1, a2)
+    tq = losses_fused.match_slots(a1, nt, Q).cpu()
+    a = a1.cpu()
+    exp_tq = torch.full((P * B, Q), -1, dtype=torch.long)
+    for pb in range(P * B):
+        for g in range(int(nt[pb % B])):
+            exp_tq[pb, a[pb, g]] = g
+    assert torch.equal(tq, exp_tq)
+
+
+def test_fused_path_is_what_the_bench_loss_runs(monkeypatch):
+    """usable() takes the bench's --loss hungarian inputs; a hand-given assignment or EDA_FUSED_LOSS=0 keeps the torch form."""
+    from eda_amd import losses_fused
+    losses, crit = _criterion()
+    ep = _end_points(9, "scanrefer", 2, 32, 20, (1, 2))
+    assert losses_fused.usable(ep, crit, None)
+    assert not losses_fused.usable(ep, crit, {"last_": None})
+    monkeypatch.setenv("EDA_FUSED_LOSS", "0")
+    assert not losses_fused.usable(ep, crit, None)
