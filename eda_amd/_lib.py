@@ -98,11 +98,17 @@ SIGNATURES = {
     "eda_match_slots_i64": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "eda_box_loss_fwd_f32": (_i, [_p, _l, _l, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "eda_box_loss_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p]),
-    "eda_pos_align_fwd_f32": (_i, [_p, _p, _p, _p, _l, _l, _p, _i, _i, _i, _i, _i, _f, _p, _p, _p]),
-    "eda_scale_by_scene_f32": (_i, [_p, _p, _p, _i, _l, _p, _p]),
+    "eda_pos_align_chunk": (_i, [_i, _i]),
+    "eda_pos_align_fwd_f32": (_i, [_p, _p, _p, _p, _l, _l, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p]),
+    "eda_scale_by_scene_f32": (_i, [_p, _p, _p, _i, _l, _l, _i, _p, _p]),
+    "eda_compact_targets": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p]),
+    "eda_loss_combine_fwd_f32": (_i, [_p, _p, _p, _p, _f, _f, _i, _i, _p, _p, _p, _p]),
+    "eda_loss_combine_bwd_f32": (_i, [_p, _p, _f, _f, _p, _p, _p, _i, _p]),
     "eda_sem_align_lds_bytes": (_sz, [_i, _i]),
     "eda_sem_align_supported": (_i, [_i, _i]),
     "eda_sem_align_fwd_f32": (_i, [_p, _p, _p, _l, _l, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p, _p]),
+    "eda_seed_objectness_lds_bytes": (_sz, [_i]),
+    "eda_seed_objectness_fwd_f32": (_i, [_p, _p, _p, _p, _l, _p, _l, _p, _l, _p, _i, _i, _i, _i, _p, _p, _p]),
     "eda_bf16x3_planes_bytes": (_sz, [_i, _i]),
     "eda_bf16x3_split_f32": (_i, [_p, _l, _i, _i, _p, _p]),
     "eda_linear_frozen_b3_supported": (_i, [_l, _i, _i]),

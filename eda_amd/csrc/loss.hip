@@ -76,15 +76,17 @@ __device__ __forceinline__ float giou_loss(const float (&a6)[6], const float (&t
   return loss;
 }
 
-// workgroup sum of two values (256 threads)
+// workgroup sum of two values (NW waves; red holds 2 * NW floats)
+template <int NW = 4>
 __device__ __forceinline__ void block_sum2(float &x, float &y, float *red) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) { x += __shfl_xor(x, o); y += __shfl_xor(y, o); }
   const int w = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { red[2 * w] = x; red[2 * w + 1] = y; }
   __syncthreads();
-  x = red[0] + red[2] + red[4] + red[6];
-  y = red[1] + red[3] + red[5] + red[7];
+  x = 0.f; y = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) { x += red[2 * i]; y += red[2 * i + 1]; }
   __syncthreads();
 }
 
@@ -286,24 +288,26 @@ __global__ __launch_bounds__(256) void match_cost_kernel(const float *__restrict
 
 struct PosAlignMaps { const float *m[4]; float w[4]; long sb, sg; };     // (B, G, >= C) maps, element strides
 
-// position-aligned soft-token cross entropy (loss_pos_align, losses.py:396-460): one workgroup per pb, a wave per query row;
-// loss[pb] = sum_q ce / num_boxes, grad0 (PB, Q, C) = d(sum_q ce) / d(logits)
+// position-aligned soft-token cross entropy (loss_pos_align, losses.py:396-460): workgroup (chunk, pb) takes the query rows
+// [chunk * QC, (chunk + 1) * QC) of scene pb, a wave per row; loss[pb][chunk] = sum over its rows of ce / num_boxes (the S chunk
+// sums of a scene add up to the reference's value), grad0 (PB, Q, C) = d(sum_q ce) / d(logits)
 __global__ __launch_bounds__(256) void pos_align_fwd_kernel(const float *__restrict__ logits, const long *__restrict__ tq,
                                                             const PosAlignMaps M, const float *__restrict__ num_boxes,
-                                                            int B, int Q, int G, int C, float eos, float *__restrict__ loss,
-                                                            float *__restrict__ grad0) {
+                                                            int B, int Q, int G, int C, int QC, float eos,
+                                                            float *__restrict__ loss, float *__restrict__ grad0) {
   __shared__ float red[8];
-  const int pb = blockIdx.x, b = pb % B;
+  const int pb = blockIdx.y, b = pb % B, S = gridDim.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q_end = min(Q, ((int)blockIdx.x + 1) * QC);
   float acc = 0.f;
-  for (int q = wave; q < Q; q += 4) {
+  for (int q = blockIdx.x * QC + wave; q < q_end; q += 4) {
     const long row = (long)pb * Q + q;
     float x[CE_MAXK], m, s;
     row_softmax(logits + row * C, C, lane, x, m, s);
     const float lse = m + __logf(s);
     const long g = tq[row];
     const bool matched = g >= 0 && g < G;
-    float sim[CE_MAXK], S = 0.f, ce = 0.f;
+    float sim[CE_MAXK], S_ = 0.f, ce = 0.f;
 #pragma unroll
     for (int k = 0; k < CE_MAXK; ++k) {
       const int c = lane + 64 * k;
@@ -318,133 +322,214 @@ __global__ __launch_bounds__(256) void pos_align_fwd_kernel(const float *__restr
         ce += __logf(v + 1e-6f) * v - (x[k] - lse) * v;
       }
       sim[k] = v;
-      S += v;
+      S_ += v;
     }
-    S = wave_sum(S);
+    S_ = wave_sum(S_);
     ce = wave_sum(ce);
     const float qw = matched ? 1.f : eos;
     acc += ce * qw;
 #pragma unroll
     for (int k = 0; k < CE_MAXK; ++k) {
       const int c = lane + 64 * k;
-      if (c < C) grad0[row * C + c] = qw * (__expf(x[k] - lse) * S - sim[k]);
+      if (c < C) grad0[row * C + c] = qw * (__expf(x[k] - lse) * S_ - sim[k]);
     }
   }
   float dummy = 0.f;
   if (lane != 0) acc = 0.f;                 // (every lane of a wave holds the same sum)
   block_sum2(acc, dummy, red);
-  if (threadIdx.x == 0) loss[pb] = acc / num_boxes[0];
+  if (threadIdx.x == 0) loss[(long)pb * S + blockIdx.x] = acc / num_boxes[0];
 }
 
-// out[pb][i] = g0[pb][i] * w[pb] / num_boxes  (the backward of every per-scene loss whose gradient was formed in the forward)
+// out[pb][i] = g0[pb][i] * w[pb][part of i] / num_boxes  (the backward of every per-scene loss whose gradient was formed in the
+// forward); a scene's `per` elements are S parts of per_part elements (the last one may be short)
 __global__ __launch_bounds__(256) void scale_by_scene_kernel(const float *__restrict__ g0, const float *__restrict__ w,
-                                                             const float *__restrict__ num_boxes, long per, long total,
-                                                             float *__restrict__ out) {
+                                                             const float *__restrict__ num_boxes, long per, long per_part, int S,
+                                                             long total, float *__restrict__ out) {
   const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= total) return;
-  const float sc = w[i / per] / num_boxes[0];           // (per % 4 == 0: the four elements share a scene)
+  const long pb = i / per;                              // (per % 4 == 0 and per_part % 4 == 0: the four elements share a part)
+  const float sc = w[pb * S + (i - pb * per) / per_part] / num_boxes[0];
   const float4 v = *reinterpret_cast<const float4 *>(g0 + i);
   *reinterpret_cast<float4 *>(out + i) = make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc);
 }
 
 struct SemMaps { const float *pos, *modi, *pron, *other, *rel; long sb, sg; };
 
-// semantic-alignment contrastive loss (loss_sem_align, losses.py:499-608): one workgroup per pb with the scene's (Q, L) logits in
-// LDS; phase 1 per query row (object -> text), phase 2 per token column (text -> object), phase 3 the gradient.
+// semantic-alignment contrastive loss (loss_sem_align, losses.py:499-608): one workgroup of 16 waves per pb with the scene's (Q, L)
+// logits in LDS.
+//   phase 1  object -> text: a wave per query row, lanes over the tokens (the maps are read for matched rows only -- a few per scene);
+//   phase 2a text -> object: the log-sum-exp of every token column over all queries, a wave per 8 columns x 8 row parts;
+//   phase 2b the map sums of every column over the MATCHED rows (compact list) + the closed form of the unmatched ones;
+//   phase 3  the gradient, a wave per query row (coalesced stores).
 // loss[pb] = (b2t + t2b) / 2 / num_boxes; grad0 (PB, Q, L) = d(b2t + t2b) / 2 / d(logits)
-__global__ __launch_bounds__(256) void sem_align_fwd_kernel(const float *__restrict__ logits, const long *__restrict__ tq,
-                                                            const SemMaps M, const long *__restrict__ attn_mask,
-                                                            const float *__restrict__ num_boxes, int B, int Q, int G, int L,
-                                                            float eos, float *__restrict__ loss, float *__restrict__ grad0) {
+constexpr int SEM_NW = 16;
+#ifdef EDA_LOSS_PROFILE
+// phase timeline (experiments only, tools/loss_phase_profile.py): wall-clock stamps (100 MHz) of thread 0 of every workgroup
+__device__ unsigned long long loss_prof[256 * 8];
+#define PL(slot) do { if (threadIdx.x == 0) loss_prof[(blockIdx.x & 255) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define PL(slot) do { } while (0)
+#endif
+constexpr int SEM_MAXK = 4;                 // token columns per lane: L <= 256
+constexpr size_t SEM_LDS_MAX = 160 * 1024 - 1024;
+
+__global__ __launch_bounds__(64 * SEM_NW) void sem_align_fwd_kernel(const float *__restrict__ logits, const long *__restrict__ tq,
+                                                                   const SemMaps M, const long *__restrict__ attn_mask,
+                                                                   const float *__restrict__ num_boxes, int B, int Q, int G, int L,
+                                                                   int R, float eos, float *__restrict__ loss,
+                                                                   float *__restrict__ grad0) {
+  PL(0);
   extern __shared__ __attribute__((aligned(16))) float sem_smem[];
+  constexpr int NT = 64 * SEM_NW;
   const int LS = L + 1;
   float *X = sem_smem;                      // [Q][LS]
   float *rowst = X + (size_t)Q * LS;        // [Q][8]: sp, sm, sr, srel, m1, s1, gq, -
-  float *colst = rowst + (size_t)Q * 8;     // [L][4]: nb, gl, mcol, scol
+  float *colst = rowst + (size_t)Q * 8;     // [L][4]: nb (phase 2a: sum of the unmatched rows' logits), gl, mcol, scol
   int *slot = reinterpret_cast<int *>(colst + (size_t)L * 4);       // [Q]: matched target slot or -1
-  __shared__ float red[8];
-  __shared__ int lastprev[2];
-  const int pb = blockIdx.x, b = pb % B, tid = threadIdx.x;
-  for (int i = tid; i < Q * L; i += 256) {
+  float *part_sums = reinterpret_cast<float *>(slot + Q);           // [R][L][8]: R waves' column sums at a time
+  __shared__ float red[2 * SEM_NW];
+  __shared__ int shared_i[3];               // last, prev, number of matched rows
+  const int pb = blockIdx.x, b = pb % B, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int i = tid; i < Q * L; i += NT) {
     const int q = i / L, l = i - q * L;
     X[q * LS + l] = logits[((long)pb * Q + q) * L + l];
   }
-  for (int q = tid; q < Q; q += 256) {
+  for (int q = tid; q < Q; q += NT) {
     const long g = tq[(long)pb * Q + q];
     slot[q] = (g >= 0 && g < G) ? (int)g : -1;
   }
-  if (tid < 64) {                           // number of real tokens -> the "not mentioned" token and the one before it
+  __syncthreads();
+  if (wv == 0) {                            // number of real tokens -> the "not mentioned" token and the one before it
     long n = 0;
-    for (int l = tid; l < L; l += 64) n += attn_mask[(long)b * L + l];
+    for (int l = lane; l < L; l += 64) n += attn_mask[(long)b * L + l];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o);
-    if (tid == 0) {
-      lastprev[0] = (int)((((n - 1) % L) + L) % L);
-      lastprev[1] = (int)((((n - 2) % L) + L) % L);
+    if (lane == 0) {
+      shared_i[0] = (int)((((n - 1) % L) + L) % L);
+      shared_i[1] = (int)((((n - 2) % L) + L) % L);
     }
+  } else if (wv == 1) {                     // number of matched rows
+    int nm = 0;
+    for (int q0 = 0; q0 < Q; q0 += 64) nm += __popcll(__ballot(q0 + lane < Q && slot[q0 + lane] >= 0));
+    if (lane == 0) shared_i[2] = nm;
   }
   __syncthreads();
-  const int last = lastprev[0], prev = lastprev[1];
+  PL(1);
+  const int last = shared_i[0], prev = shared_i[1], nmatched = shared_i[2];
   const float *mp = M.pos + (long)b * M.sb, *mm = M.modi + (long)b * M.sb, *mr = M.pron + (long)b * M.sb;
   const float *mo = M.other + (long)b * M.sb, *ml = M.rel + (long)b * M.sb;
-  // ---- phase 1: object -> text, one thread per query row ----
+  // ---- phase 1: object -> text, a wave per query row; lane owns the token columns lane + 64 k and keeps, over the wave's MATCHED
+  //      rows, the column sums phase 2b needs: counts of the four maps' set entries, the three maps' values, -sum(logit x sets) ----
   float b2t_acc = 0.f;
-  for (int q = tid; q < Q; q += 256) {
+  float pc[SEM_MAXK][8];
+#pragma unroll
+  for (int k = 0; k < SEM_MAXK; ++k)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pc[k][i] = 0.f;
+  for (int q = wv; q < Q; q += SEM_NW) {
     const int g = slot[q];
     const float *x = X + q * LS;
-    float sp = 0.f, sm = 0.f, sr = 0.f, sl = 0.f, dp = 0.f, dm = 0.f, dr = 0.f, dl = 0.f, m1 = -INFINITY;
-    for (int l = 0; l < L; ++l) {
-      float pm, mb = 0.f, rb = 0.f, lb = 0.f, ob = 0.f;
-      if (g >= 0) {
-        const long o = (long)g * M.sg + l;
-        pm = mp[o] > 0.f ? 1.f : 0.f; mb = mm[o] > 0.f ? 1.f : 0.f; rb = mr[o] > 0.f ? 1.f : 0.f;
-        lb = ml[o] > 0.f ? 1.f : 0.f; ob = mo[o] > 0.f ? 1.f : 0.f;
-      } else {
-        pm = (l == last || l == prev) ? 1.f : 0.f;
+    float sp = 0.f, sm = 0.f, sr = 0.f, sl = 0.f, dp = 0.f, dm = 0.f, dr = 0.f, dl = 0.f, m1 = -INFINITY, s1 = 0.f;
+    if (g >= 0) {
+      float vo[SEM_MAXK];                   // logit x (1 + other-entity bit)
+#pragma unroll
+      for (int k = 0; k < SEM_MAXK; ++k) {
+        const int l = lane + 64 * k;
+        vo[k] = -INFINITY;
+        if (l < L) {
+          const long o = (long)g * M.sg + l;
+          const float c = mm[o], d = mr[o], e = ml[o];
+          const float pm = mp[o] > 0.f ? 1.f : 0.f, mb = c > 0.f ? 1.f : 0.f, rb = d > 0.f ? 1.f : 0.f;
+          const float lb = e > 0.f ? 1.f : 0.f, ob = mo[o] > 0.f ? 1.f : 0.f;
+          const float v = x[l];
+          sp += pm; sm += mb; sr += rb; sl += lb;
+          dp += v * pm; dm += v * mb; dr += v * rb; dl += v * lb;
+          vo[k] = v + v * ob;
+          m1 = fmaxf(m1, vo[k]);
+          pc[k][0] += pm; pc[k][1] += mb; pc[k][2] += rb; pc[k][3] += lb;
+          pc[k][4] += c; pc[k][5] += d; pc[k][6] += e;
+          pc[k][7] -= v * (pm + mb + rb + lb);
+        }
       }
-      const float v = x[l];
-      sp += pm; sm += mb; sr += rb; sl += lb;
-      dp += v * pm; dm += v * mb; dr += v * rb; dl += v * lb;
-      m1 = fmaxf(m1, v + v * ob);
+      m1 = wave_max(m1);
+#pragma unroll
+      for (int k = 0; k < SEM_MAXK; ++k) s1 += lane + 64 * k < L ? __expf(vo[k] - m1) : 0.f;
+      sp = wave_sum(sp); sm = wave_sum(sm); sr = wave_sum(sr); sl = wave_sum(sl);
+      dp = wave_sum(dp); dm = wave_sum(dm); dr = wave_sum(dr); dl = wave_sum(dl);
+    } else {                                // unmatched: the two "not mentioned" tokens are the positives, nothing else is set
+      for (int l = lane; l < L; l += 64) m1 = fmaxf(m1, x[l]);
+      m1 = wave_max(m1);
+      for (int l = lane; l < L; l += 64) s1 += __expf(x[l] - m1);
+      sp = last == prev ? 1.f : 2.f;
+      dp = last == prev ? x[last] : x[last] + x[prev];
     }
-    float s1 = 0.f;
-    for (int l = 0; l < L; ++l) {
-      const float ob = (g >= 0 && mo[(long)g * M.sg + l] > 0.f) ? 1.f : 0.f;
-      s1 += __expf(x[l] + x[l] * ob - m1);
+    s1 = wave_sum(s1);
+    if (lane == 0) {
+      const float gq = (sp > 0.f ? 1.f : 0.f) * (g >= 0 ? 1.f : eos);
+      const float v = -dp / (sp + 1e-6f) - 0.2f * dm / (sm + 1e-6f) - 0.2f * dr / (sr + 1e-6f) - 0.1f * dl / (sl + 1e-6f) +
+                      (m1 + __logf(s1));
+      b2t_acc += v * gq;
+      float *rs = rowst + q * 8;
+      rs[0] = sp; rs[1] = sm; rs[2] = sr; rs[3] = sl; rs[4] = m1; rs[5] = s1; rs[6] = gq;
     }
-    const float gq = (sp > 0.f ? 1.f : 0.f) * (g >= 0 ? 1.f : eos);
-    const float v = -dp / (sp + 1e-6f) - 0.2f * dm / (sm + 1e-6f) - 0.2f * dr / (sr + 1e-6f) - 0.1f * dl / (sl + 1e-6f) +
-                    (m1 + __logf(s1));
-    b2t_acc += v * gq;
-    float *rs = rowst + q * 8;
-    rs[0] = sp; rs[1] = sm; rs[2] = sr; rs[3] = sl; rs[4] = m1; rs[5] = s1; rs[6] = gq;
   }
-  __syncthreads();
-  // ---- phase 2: text -> object, one thread per token column ----
-  float t2b_acc = 0.f;
-  for (int l = tid; l < L; l += 256) {
-    float cp = 0.f, vm = 0.f, vr = 0.f, vl = 0.f, post = 0.f, mc = -INFINITY;
-    bool anyp = false, anym = false, anyr = false, anyl = false;
-    for (int q = 0; q < Q; ++q) {
-      const int g = slot[q];
+  PL(2);
+  // ---- phase 2a: column log-sum-exp over all queries; lane = part * 8 + column of the wave's group of 8 ----
+  for (int l0 = wv * 8; l0 < L; l0 += SEM_NW * 8) {
+    const int l = l0 + (lane & 7), part = lane >> 3;
+    const bool on = l < L;
+    float mc = -INFINITY;
+    if (on) for (int q = part; q < Q; q += 8) mc = fmaxf(mc, X[q * LS + l]);
+    mc = fmaxf(mc, __shfl_xor(mc, 8)); mc = fmaxf(mc, __shfl_xor(mc, 16)); mc = fmaxf(mc, __shfl_xor(mc, 32));
+    float sc = 0.f, us = 0.f;
+    if (on) for (int q = part; q < Q; q += 8) {
       const float v = X[q * LS + l];
-      float pm, mb = 0.f, rb = 0.f, lb = 0.f;
-      if (g >= 0) {
-        const long o = (long)g * M.sg + l;
-        const float a = mp[o], c = mm[o], d = mr[o], e = ml[o];
-        pm = a > 0.f ? 1.f : 0.f; mb = c > 0.f ? 1.f : 0.f; rb = d > 0.f ? 1.f : 0.f; lb = e > 0.f ? 1.f : 0.f;
-        vm += c; vr += d; vl += e;
-      } else {
-        pm = (l == last || l == prev) ? 1.f : 0.f;
-      }
-      cp += pm;
-      anyp |= pm > 0.f; anym |= mb > 0.f; anyr |= rb > 0.f; anyl |= lb > 0.f;
-      post -= v * (pm + mb + rb + lb);
-      mc = fmaxf(mc, v);
+      sc += __expf(v - mc);
+      us += slot[q] < 0 ? v : 0.f;
     }
-    float sc = 0.f;
-    for (int q = 0; q < Q; ++q) sc += __expf(X[q * LS + l] - mc);
-    const float nb = cp + vm + vr + vl + 1e-6f;
+    sc += __shfl_xor(sc, 8); sc += __shfl_xor(sc, 16); sc += __shfl_xor(sc, 32);
+    us += __shfl_xor(us, 8); us += __shfl_xor(us, 16); us += __shfl_xor(us, 32);
+    if (on && part == 0) { float *cs = colst + l * 4; cs[0] = us; cs[2] = mc; cs[3] = sc; }
+  }
+  PL(3);
+  // ---- phase 2b: text -> object; the waves' column sums meet in LDS, R waves at a time, in wave order; thread l owns column l ----
+  float col[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r0 = 0; r0 < SEM_NW; r0 += R) {
+    if (wv >= r0 && wv < r0 + R) {
+#pragma unroll
+      for (int k = 0; k < SEM_MAXK; ++k) {
+        const int l = lane + 64 * k;
+        if (l < L) {
+          float *dst = part_sums + ((size_t)(wv - r0) * L + l) * 8;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) dst[i] = pc[k][i];
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < L) {
+      for (int w = 0; w < R && r0 + w < SEM_NW; ++w) {
+        const float *src = part_sums + ((size_t)w * L + tid) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) col[i] += src[i];
+      }
+    }
+    __syncthreads();
+  }
+  float t2b_acc = 0.f;
+  if (tid < L) {
+    const int l = tid;
+    float cp = col[0], post = col[7];
+    bool anyp = col[0] > 0.f;
+    const bool anym = col[1] > 0.f, anyr = col[2] > 0.f, anyl = col[3] > 0.f;
+    float *cs = colst + l * 4;
+    if ((l == last || l == prev) && nmatched < Q) {     // every unmatched row counts this token as its positive
+      cp += (float)(Q - nmatched);
+      anyp = true;
+      post -= cs[0];
+    }
+    const float mc = cs[2], sc = cs[3];
+    const float nb = cp + col[4] + col[5] + col[6] + 1e-6f;
     float tm = eos;                                        // overwritten in this order (losses.py:550-556)
     if (l == last) tm = 1.f;
     if (anyp) tm = 1.f;
@@ -453,19 +538,19 @@ __global__ __launch_bounds__(256) void sem_align_fwd_kernel(const float *__restr
     if (anyl) tm = 0.1f;
     if (l == prev) tm = 0.1f;
     const float gl = (anyp || anym || anyr || anyl) ? tm : 0.f;
-    t2b_acc += (-__logf(nb + 1e-6f) / nb + post / nb + (mc + __logf(sc))) * gl;
-    float *cs = colst + l * 4;
-    cs[0] = nb; cs[1] = gl; cs[2] = mc; cs[3] = sc;
+    t2b_acc = (-__logf(nb + 1e-6f) / nb + post / nb + (mc + __logf(sc))) * gl;
+    cs[0] = nb; cs[1] = gl;
   }
   __syncthreads();
-  // ---- phase 3: gradient, one thread per query row ----
-  for (int q = tid; q < Q; q += 256) {
+  PL(4);
+  // ---- phase 3: gradient, a wave per query row ----
+  for (int q = wv; q < Q; q += SEM_NW) {
     const int g = slot[q];
     const float *x = X + q * LS;
     const float *rs = rowst + q * 8;
     const float sp = rs[0], sm = rs[1], sr = rs[2], sl = rs[3], m1 = rs[4], s1 = rs[5], gq = rs[6];
     float *out = grad0 + ((long)pb * Q + q) * L;
-    for (int l = 0; l < L; ++l) {
+    for (int l = lane; l < L; l += 64) {
       float pm, mb = 0.f, rb = 0.f, lb = 0.f, ob = 0.f;
       if (g >= 0) {
         const long o = (long)g * M.sg + l;
@@ -482,8 +567,201 @@ __global__ __launch_bounds__(256) void sem_align_fwd_kernel(const float *__restr
       out[l] = 0.5f * (gq * row_t + cs[1] * col_t);
     }
   }
-  block_sum2(b2t_acc, t2b_acc, red);
+  PL(5);
+  block_sum2<SEM_NW>(b2t_acc, t2b_acc, red);
   if (tid == 0) loss[pb] = (b2t_acc + t2b_acc) * 0.5f / num_boxes[0];
+  PL(6);
+}
+
+// ---- seed objectness (losses.py:166-228, compute_points_obj_cls_loss_hard_topk) ------------------------------------------------
+// One workgroup per scene.  Positives = for every real target slot g the `topk` seeds with the smallest value of
+//   owned(k, g) ? sqrt(sum(((xyz_k - centre_g) / (size_g + 1e-6))^2) + 1e-6) : 100        (owner = instance id, background -> G - 1)
+// that are not background; the reference takes them with torch.topk, whose choice among EQUAL values (an instance with fewer than
+// `topk` seeds: the rest come from the 100s) is implementation-defined -- here the lowest seed index wins.  Then the sigmoid focal
+// loss (alpha 0.25, gamma 2; losses.py:100-164) of all K seeds with weight 1/K, divided by the number of scenes, and its gradient.
+constexpr int OBJ_MAXTOP = 8;
+
+__global__ __launch_bounds__(256) void seed_objectness_fwd_kernel(const float *__restrict__ logits, const float *__restrict__ seed_xyz,
+                                                                  const int *__restrict__ seed_inds,
+                                                                  const long *__restrict__ instance_label, long npoints,
+                                                                  const float *__restrict__ centre, long c_sg,
+                                                                  const float *__restrict__ size, long s_sg,
+                                                                  const float *__restrict__ mask, int B, int K, int G, int topk,
+                                                                  float *__restrict__ loss, float *__restrict__ grad0) {
+  extern __shared__ float obj_lds[];
+  float *sx = obj_lds;                                   // K x 3
+  int *owner = reinterpret_cast<int *>(obj_lds + 3 * (long)K);   // K: instance id, G - 1 for background, -1 - id kept in `fg`
+  int *label = owner + K;                                // K
+  __shared__ float red[8];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int k = tid; k < K; k += 256) {
+    const long inst = instance_label[(long)b * npoints + seed_inds[(long)b * K + k]];
+    // owner: background seeds belong to slot G - 1; ids beyond the slots match nothing.  Bit 30 marks "not background".
+    const int own = inst < 0 ? G - 1 : (inst < G ? (int)inst : G);
+    owner[k] = own | (inst >= 0 ? (1 << 30) : 0);
+    label[k] = 0;
+    const float *x = seed_xyz + ((long)b * K + k) * 3;
+    sx[3 * k] = x[0]; sx[3 * k + 1] = x[1]; sx[3 * k + 2] = x[2];
+  }
+  __syncthreads();
+  for (int g = wv; g < G; g += 4) {
+    if (mask[(long)b * G + g] == 0.f) continue;
+    const float *c = centre + ((long)b * G + g) * c_sg, *z = size + ((long)b * G + g) * s_sg;
+    const float c0 = c[0], c1 = c[1], c2 = c[2], z0 = z[0] + 1e-6f, z1 = z[1] + 1e-6f, z2 = z[2] + 1e-6f;
+    // each lane keeps its own `topk` smallest (value, index) keys in ascending order; value bits of a positive float order as integers
+    unsigned long long best[OBJ_MAXTOP];
+#pragma unroll
+    for (int i = 0; i < OBJ_MAXTOP; ++i) best[i] = ~0ull;
+    for (int k = lane; k < K; k += 64) {
+      float v = 100.f;
+      if ((owner[k] & ~(1 << 30)) == g) {
+        const float d0 = (sx[3 * k] - c0) / z0, d1 = (sx[3 * k + 1] - c1) / z1, d2 = (sx[3 * k + 2] - c2) / z2;
+        v = sqrtf(d0 * d0 + d1 * d1 + d2 * d2 + 1e-6f);
+      }
+      unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)k;
+#pragma unroll
+      for (int i = 0; i < OBJ_MAXTOP; ++i) {
+        if (i < topk && key < best[i]) { const unsigned long long t = best[i]; best[i] = key; key = t; }
+      }
+    }
+    for (int r = 0; r < topk; ++r) {
+      unsigned long long m = best[0];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned long long other = __shfl_xor(m, o);
+        m = other < m ? other : m;
+      }
+      if (m == ~0ull) break;                             // fewer than topk seeds in the scene
+      if (best[0] == m) {                                // exactly one lane holds this key (the index is part of it)
+        label[(int)(m & 0xffffffffu)] = 1;
+#pragma unroll
+        for (int i = 0; i + 1 < OBJ_MAXTOP; ++i) best[i] = best[i + 1];
+        best[OBJ_MAXTOP - 1] = ~0ull;
+      }
+    }
+  }
+  __syncthreads();
+  const float scale = 1.f / (float)(K > 1 ? K : 1) / (float)B;
+  float acc = 0.f, dummy = 0.f;
+  for (int k = tid; k < K; k += 256) {
+    const bool pos = label[k] != 0 && (owner[k] & (1 << 30));
+    const float x = logits[(long)b * K + k];
+    const float p = 1.f / (1.f + expf(-x));
+    const float sp = fmaxf(pos ? -x : x, 0.f) + log1pf(expf(-fabsf(x)));      // softplus(-x) for a positive, softplus(x) otherwise
+    float f, df;
+    if (pos) {
+      const float q = 1.f - p;
+      f = 0.25f * q * q * sp;
+      df = -0.25f * q * q * (2.f * p * sp + q);
+    } else {
+      f = 0.75f * p * p * sp;
+      df = 0.75f * p * p * (2.f * (1.f - p) * sp + p);
+    }
+    acc += f;
+    grad0[(long)b * K + k] = df * scale;
+  }
+  block_sum2(acc, dummy, red);
+  if (tid == 0) loss[b] = acc * scale;
+}
+
+// ---- the padded targets, valid slots first (eda_amd/losses.py compact_targets: what the reference's boolean indexing per scene does,
+// losses.py:660-690), as one launch: workgroup (part, b) orders scene b's slots (valid ones first, order kept) and moves its share of
+// the rows of up to 8 tensors; rows beyond the scene's count are zeroed (nothing reads them).  Also the per-scene counts, the valid
+// mask of the compacted layout and the batch's box count (the losses' normaliser before any all-reduce).
+constexpr int CT_MAXT = 8;
+struct CompactDesc { const unsigned *src; unsigned *dst; long src_sb, src_sg, dst_sg, dst_off; int words; };
+struct CompactArgs { CompactDesc d[CT_MAXT]; int n; };
+
+__global__ __launch_bounds__(256) void compact_targets_kernel(const float *__restrict__ mask, const CompactArgs A, int B, int G,
+                                                              int *__restrict__ ntargets, unsigned char *__restrict__ valid,
+                                                              float *__restrict__ num_boxes) {
+  extern __shared__ int ct_order[];                      // [G]
+  __shared__ int s_nt, s_all[4];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (wv == 0) {
+    int nt = 0;
+    for (int g0 = 0; g0 < G; g0 += 64) {
+      const int g = g0 + lane;
+      const bool v = g < G && mask[(long)b * G + g] > 0.f;
+      const unsigned long long bal = __ballot(v);
+      if (v) ct_order[nt + __popcll(bal & ((1ull << lane) - 1))] = g;
+      nt += __popcll(bal);
+    }
+    if (lane == 0) s_nt = nt;
+  }
+  if (blockIdx.x == 0 && b == 0) {                        // box count of the whole batch
+    int c = 0;
+    for (long i = tid; i < (long)B * G; i += 256) c += mask[i] > 0.f ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+    if (lane == 0) s_all[wv] = c;
+  }
+  __syncthreads();
+  const int nt = s_nt;
+  if (blockIdx.x == 0) {
+    if (tid == 0) ntargets[b] = nt;
+    for (int g = tid; g < G; g += 256) valid[(long)b * G + g] = g < nt ? 1 : 0;
+    if (b == 0 && tid == 0) num_boxes[0] = (float)(s_all[0] + s_all[1] + s_all[2] + s_all[3]);
+  }
+  const int rows_per = (G + gridDim.x - 1) / gridDim.x;
+  const int j0 = blockIdx.x * rows_per, j1 = min(G, j0 + rows_per);
+  for (int t = 0; t < A.n; ++t) {
+    const CompactDesc d = A.d[t];
+    const long n = (long)(j1 - j0) * d.words;
+    for (long i = tid; i < n; i += 256) {
+      const int j = j0 + (int)(i / d.words), w = (int)(i % d.words);
+      d.dst[((long)b * G + j) * d.dst_sg + d.dst_off + w] = j < nt ? d.src[(long)b * d.src_sb + (long)ct_order[j] * d.src_sg + w] : 0u;
+    }
+  }
+}
+
+// ---- the final weighted sum (losses.py:716-738): per-head and total values of the four criterion losses, the objectness sum, and
+//   loss = w_obj * objectness + inv * (w[0] ce + w[1] bbox + w[2] giou + w[3] sem)
+struct CombineArgs { const float *rows[4]; int parts[4]; float w[4]; float inv, w_obj; };
+
+__global__ __launch_bounds__(256) void loss_combine_fwd_kernel(const CombineArgs A, const float *__restrict__ obj, int P, int B,
+                                                               float *__restrict__ per_head, float *__restrict__ totals,
+                                                               float *__restrict__ loss) {
+  __shared__ float ph[4 * 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int pair = wv; pair < 4 * P; pair += 4) {
+    const int j = pair / P, p = pair - j * P;
+    float s = 0.f;
+    if (A.rows[j]) {
+      const int n = B * A.parts[j];
+      for (int i = lane; i < n; i += 64) s += A.rows[j][(long)p * n + i];
+      s = wave_sum(s);
+    }
+    if (lane == 0) { ph[pair] = s; per_head[pair] = s; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t[4];
+    for (int j = 0; j < 4; ++j) {
+      t[j] = 0.f;
+      for (int p = 0; p < P; ++p) t[j] += ph[j * P + p];
+      totals[j] = t[j];
+    }
+    float qp = 0.f;
+    if (obj) for (int b = 0; b < B; ++b) qp += obj[b];
+    totals[4] = qp;
+    loss[0] = A.w_obj * qp + A.inv * (A.w[0] * t[0] + A.w[1] * t[1] + A.w[2] * t[2] + A.w[3] * t[3]);
+  }
+}
+
+struct CombineGrads { float *rows[4]; int n[4]; float *obj; int B; };
+
+__global__ __launch_bounds__(256) void loss_combine_bwd_kernel(const float *__restrict__ g, const CombineArgs A, const CombineGrads D) {
+  const float up = g[0];
+  const int j = blockIdx.x;
+  if (j < 4) {
+    if (!D.rows[j]) return;
+    const float v = up * (A.inv * A.w[j]);
+    for (int i = threadIdx.x; i < D.n[j]; i += 256) D.rows[j][i] = v;
+  } else if (D.obj) {
+    const float v = up * A.w_obj;
+    for (int i = threadIdx.x; i < D.B; i += 256) D.obj[i] = v;
+  }
 }
 
 }  // namespace
@@ -513,37 +791,46 @@ extern "C" int eda_match_cost_f32(const float *logits, const float *pred, const 
 }
 
 // maps: the four (B, G, >= C) token maps (positive, modify, pronoun, relation) with element strides (map_sb, map_sg, 1) and their
-// weights w[4]; logits (PB, Q, C) dense; loss (PB); grad0 (PB, Q, C)
+// weights w[4]; logits (PB, Q, C) dense; loss (PB, S): S partial sums per scene, one per chunk of eda_pos_align_chunk(Q, S) query
+// rows (S >= 1 spreads a scene over S workgroups; the chunks of a scene add up to its loss); grad0 (PB, Q, C)
+extern "C" int eda_pos_align_chunk(int Q, int S) { return S > 0 ? ((Q + S - 1) / S + 3) / 4 * 4 : 0; }
 extern "C" int eda_pos_align_fwd_f32(const float *logits, const long *tq, const float *const *maps, const float *w, long map_sb,
-                                     long map_sg, const float *num_boxes, int PB, int B, int Q, int G, int C, float eos,
+                                     long map_sg, const float *num_boxes, int PB, int B, int Q, int G, int C, int S, float eos,
                                      float *loss, float *grad0, void *stream_) {
   EDA_CHECK_ARG(PB >= 0 && B > 0 && PB % B == 0 && Q > 0 && G > 0 && C > 0 && C <= 64 * CE_MAXK, "bad dimension (at most 512 classes)");
+  EDA_CHECK_ARG(S >= 1 && S <= 64, "1..64 chunks per scene");
   if (PB == 0) return 0;
   EDA_CHECK_ARG(logits && tq && maps && w && num_boxes && loss && grad0, "null pointer");
   PosAlignMaps M;
   for (int i = 0; i < 4; ++i) { EDA_CHECK_ARG(maps[i], "null pointer"); M.m[i] = maps[i]; M.w[i] = w[i]; }
   M.sb = map_sb; M.sg = map_sg;
-  hipLaunchKernelGGL(pos_align_fwd_kernel, dim3((unsigned)PB), dim3(256), 0, (hipStream_t)stream_, logits, tq, M, num_boxes, B, Q,
-                     G, C, eos, loss, grad0);
+  hipLaunchKernelGGL(pos_align_fwd_kernel, dim3((unsigned)S, (unsigned)PB), dim3(256), 0, (hipStream_t)stream_, logits, tq, M, num_boxes,
+                     B, Q, G, C, eda_pos_align_chunk(Q, S), eos, loss, grad0);
   EDA_CHECK_LAUNCH();
   return 0;
 }
 
-// out[pb][:] = g0[pb][:] * w[pb] / num_boxes[0]; per = elements per scene (a multiple of 4), 16-byte aligned buffers
-extern "C" int eda_scale_by_scene_f32(const float *g0, const float *w, const float *num_boxes, int PB, long per, float *out,
-                                      void *stream_) {
+// out[pb][i] = g0[pb][i] * w[pb][min(i / per_part, S - 1)] / num_boxes[0]; per = elements per scene, per_part = elements per part
+// (both multiples of 4; S = 1, per_part = per: one weight per scene), 16-byte aligned buffers
+extern "C" int eda_scale_by_scene_f32(const float *g0, const float *w, const float *num_boxes, int PB, long per, long per_part, int S,
+                                      float *out, void *stream_) {
   EDA_CHECK_ARG(PB >= 0 && per >= 0 && per % 4 == 0, "elements per scene must be a multiple of 4");
   if (PB == 0 || per == 0) return 0;
+  EDA_CHECK_ARG(S >= 1 && per_part > 0 && per_part % 4 == 0 && per_part * S >= per, "bad parts");
   EDA_CHECK_ARG(g0 && w && num_boxes && out, "null pointer");
   const long total = (long)PB * per;
   hipLaunchKernelGGL(scale_by_scene_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, g0, w,
-                     num_boxes, per, total, out);
+                     num_boxes, per, per_part, S, total, out);
   EDA_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" size_t eda_sem_align_lds_bytes(int Q, int L) { return sizeof(float) * ((size_t)Q * (L + 1) + (size_t)Q * 8 + (size_t)L * 4 + Q); }
-extern "C" int eda_sem_align_supported(int Q, int L) { return Q > 0 && L > 0 && eda_sem_align_lds_bytes(Q, L) <= 150 * 1024; }
+// LDS of the alignment kernel with room for R waves' column sums (R = 1: the least it runs with)
+static size_t sem_align_lds(int Q, int L, int R) {
+  return sizeof(float) * ((size_t)Q * (L + 1) + (size_t)Q * 8 + (size_t)L * 4 + (size_t)Q + (size_t)R * L * 8);
+}
+extern "C" size_t eda_sem_align_lds_bytes(int Q, int L) { return sem_align_lds(Q, L, 1); }
+extern "C" int eda_sem_align_supported(int Q, int L) { return Q > 0 && L > 0 && L <= 64 * SEM_MAXK && sem_align_lds(Q, L, 1) <= SEM_LDS_MAX; }
 
 // maps: positive, modify, pronoun, other-entity, relation (B, G, >= L) with element strides (map_sb, map_sg, 1); logits (PB, Q, L)
 // dense = proj_queries . proj_tokens^T / temperature; attn_mask (B, L) int64 (1 = token); loss (PB); grad0 (PB, Q, L)
@@ -558,10 +845,90 @@ extern "C" int eda_sem_align_fwd_f32(const float *logits, const long *tq, const 
   for (int i = 0; i < 5; ++i) EDA_CHECK_ARG(maps[i], "null pointer");
   M.pos = maps[0]; M.modi = maps[1]; M.pron = maps[2]; M.other = maps[3]; M.rel = maps[4];
   M.sb = map_sb; M.sg = map_sg;
-  const size_t lds = eda_sem_align_lds_bytes(Q, L);
-  EDA_CHECK_HIP(eda_set_max_dynamic_lds(reinterpret_cast<const void *>(&sem_align_fwd_kernel), 150 * 1024));
-  hipLaunchKernelGGL(sem_align_fwd_kernel, dim3((unsigned)PB), dim3(256), lds, (hipStream_t)stream_, logits, tq, M, attn_mask,
-                     num_boxes, B, Q, G, L, eos, loss, grad0);
+  int R = SEM_NW;
+  while (R > 1 && sem_align_lds(Q, L, R) > SEM_LDS_MAX) --R;
+  const size_t lds = sem_align_lds(Q, L, R);
+  EDA_CHECK_HIP(eda_set_max_dynamic_lds(reinterpret_cast<const void *>(&sem_align_fwd_kernel), SEM_LDS_MAX));
+  hipLaunchKernelGGL(sem_align_fwd_kernel, dim3((unsigned)PB), dim3(64 * SEM_NW), lds, (hipStream_t)stream_, logits, tq, M, attn_mask,
+                     num_boxes, B, Q, G, L, R, eos, loss, grad0);
   EDA_CHECK_LAUNCH();
   return 0;
 }
+
+// logits (B, K) dense; seed_xyz (B, K, 3) dense; seed_inds (B, K) int32 into instance_label (B, npoints) int64 (< 0 = background);
+// centre / size (B, G, >= 3) with slot strides c_sg / s_sg (elements); mask (B, G) float (0 = padded slot); loss (B): the scene's
+// share of the reference's scalar (their sum IS compute_points_obj_cls_loss_hard_topk); grad0 (B, K) = d sum(loss) / d logits
+extern "C" size_t eda_seed_objectness_lds_bytes(int K) { return (size_t)K * 20; }
+extern "C" int eda_seed_objectness_fwd_f32(const float *logits, const float *seed_xyz, const int *seed_inds, const long *instance_label,
+                                           long npoints, const float *centre, long c_sg, const float *size, long s_sg, const float *mask,
+                                           int B, int K, int G, int topk, float *loss, float *grad0, void *stream_) {
+  EDA_CHECK_ARG(B >= 0 && K > 0 && G > 0 && npoints > 0, "bad dimension");
+  EDA_CHECK_ARG(topk >= 1 && topk <= OBJ_MAXTOP, "topk must be 1..8");
+  EDA_CHECK_ARG(eda_seed_objectness_lds_bytes(K) <= 150 * 1024, "too many seeds for the LDS tile (at most 7680)");
+  if (B == 0) return 0;
+  EDA_CHECK_ARG(logits && seed_xyz && seed_inds && instance_label && centre && size && mask && loss && grad0, "null pointer");
+  EDA_CHECK_HIP(eda_set_max_dynamic_lds(reinterpret_cast<const void *>(&seed_objectness_fwd_kernel), 150 * 1024));
+  hipLaunchKernelGGL(seed_objectness_fwd_kernel, dim3((unsigned)B), dim3(256), eda_seed_objectness_lds_bytes(K), (hipStream_t)stream_,
+                     logits, seed_xyz, seed_inds, instance_label, npoints, centre, c_sg, size, s_sg, mask, B, K, G, topk, loss, grad0);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}
+
+// mask (B, G) float (> 0 = a real target); n <= 8 tensors of (B, G, words) 4-byte words: src[t] with element strides (src_sb[t],
+// src_sg[t], 1) in WORDS, moved to dst[t] (B, G, dst_sg[t]) at word offset dst_off[t] of each row (two sources can fill one row:
+// centre | size -> a box); ntargets (B) int32, valid (B, G) bytes (slot < count), num_boxes: one float = all real targets of the batch
+extern "C" int eda_compact_targets(const float *mask, int n, const void *const *src, const long *src_sb, const long *src_sg,
+                                   void *const *dst, const long *dst_sg, const long *dst_off, const int *words, int B, int G,
+                                   int *ntargets, unsigned char *valid, float *num_boxes, void *stream_) {
+  EDA_CHECK_ARG(B >= 0 && G > 0 && G <= 8192 && n >= 0 && n <= CT_MAXT, "bad dimension (at most 8 tensors, 8192 slots)");
+  if (B == 0) return 0;
+  EDA_CHECK_ARG(mask && ntargets && valid && num_boxes && (n == 0 || (src && src_sb && src_sg && dst && dst_sg && dst_off && words)),
+                "null pointer");
+  CompactArgs A;
+  A.n = n;
+  for (int t = 0; t < n; ++t) {
+    EDA_CHECK_ARG(src[t] && dst[t] && words[t] > 0 && dst_off[t] >= 0 && dst_off[t] + words[t] <= dst_sg[t], "bad tensor description");
+    A.d[t] = CompactDesc{static_cast<const unsigned *>(src[t]), static_cast<unsigned *>(dst[t]), src_sb[t], src_sg[t], dst_sg[t],
+                         dst_off[t], words[t]};
+  }
+  hipLaunchKernelGGL(compact_targets_kernel, dim3(16, (unsigned)B), dim3(256), sizeof(int) * (size_t)G, (hipStream_t)stream_, mask, A, B,
+                     G, ntargets, valid, num_boxes);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}
+
+// rows[j] (P * B, parts[j]) per-scene (partial) sums of loss j = ce, bbox, giou, sem-align, heads-major, or NULL (that loss is off);
+// obj (B) per-scene objectness shares or NULL; per_head (4, P), totals (5: the four + objectness), loss (1):
+//   loss = w_obj * sum(obj) + inv * (w[0] ce + w[1] bbox + w[2] giou + w[3] sem)
+extern "C" int eda_loss_combine_fwd_f32(const float *const *rows, const int *parts, const float *obj, const float *w, float inv,
+                                        float w_obj, int P, int B, float *per_head, float *totals, float *loss, void *stream_) {
+  EDA_CHECK_ARG(P > 0 && P <= 64 && B > 0, "bad dimension (at most 64 heads)");
+  EDA_CHECK_ARG(rows && parts && w && per_head && totals && loss, "null pointer");
+  CombineArgs A;
+  for (int j = 0; j < 4; ++j) { A.rows[j] = rows[j]; A.parts[j] = parts[j]; A.w[j] = w[j]; EDA_CHECK_ARG(!rows[j] || parts[j] > 0, "bad parts"); }
+  A.inv = inv; A.w_obj = w_obj;
+  hipLaunchKernelGGL(loss_combine_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, A, obj, P, B, per_head, totals, loss);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}
+
+// the gradient of eda_loss_combine's `loss` given its upstream gradient g (one float on the device): d_rows[j] (n[j] elements, or
+// NULL) filled with g * inv * w[j], d_obj (B, or NULL) with g * w_obj
+extern "C" int eda_loss_combine_bwd_f32(const float *g, const float *w, float inv, float w_obj, float *const *d_rows, const int *n,
+                                        float *d_obj, int B, void *stream_) {
+  EDA_CHECK_ARG(g && w && d_rows && n && B >= 0, "null pointer");
+  CombineArgs A;
+  CombineGrads D;
+  for (int j = 0; j < 4; ++j) { A.rows[j] = nullptr; A.parts[j] = 0; A.w[j] = w[j]; D.rows[j] = d_rows[j]; D.n[j] = n[j]; }
+  A.inv = inv; A.w_obj = w_obj;
+  D.obj = d_obj; D.B = B;
+  hipLaunchKernelGGL(loss_combine_bwd_kernel, dim3(5), dim3(256), 0, (hipStream_t)stream_, g, A, D);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}
+
+#ifdef EDA_LOSS_PROFILE
+extern "C" __attribute__((visibility("default"))) int eda_loss_profile_read(unsigned long long *out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(loss_prof), sizeof(unsigned long long) * (size_t)n) != hipSuccess;
+}
+#endif

@@ -686,7 +686,7 @@ int eda_sa_fused_eval_f32(const float *xyz, const float *new_xyz, const float *f
  *   eda_pos_align_fwd       loss_pos_align (:396-460): maps = positive, modify, pronoun, relation with weights w[4]
  *   eda_sem_align_fwd       loss_sem_align (:499-608): maps = positive, modify, pronoun, other-entity, relation; logits = proj_queries
  *                           . proj_tokens^T / temperature; guard eda_sem_align_supported(Q, L) (the scene's logits live in LDS)
- *   eda_scale_by_scene_f32  out[pb][:] = grad0[pb][:] * w[pb] / num_boxes: the backward of pos_align / sem_align */
+ *   eda_scale_by_scene_f32  out[pb][:] = grad0[pb][:] * w[pb][part] / num_boxes: the backward of pos_align (S parts) / sem_align (1) */
 int eda_match_cost_f32(const float *logits, const float *pred, const float *tgt_boxes, const float *pmap, long pm_sg,
                        const long *labels, const int *ntargets, int PB, int B, int Q, int G, int C, float w_class, float w_bbox,
                        float w_giou, float *cost, void *stream);
@@ -696,15 +696,36 @@ int eda_box_loss_fwd_f32(const float *pred, long p_sb, long p_sq, const float *t
                          float *g_giou, void *stream);
 int eda_box_loss_bwd_f32(const float *g_l1, const float *g_giou, const long *tq, const float *w_l1, const float *w_giou,
                          const float *num_boxes, int B, int Q, int G, float *dpred, void *stream);
+int eda_pos_align_chunk(int Q, int S);     /* query rows per chunk when a scene is spread over S workgroups */
 int eda_pos_align_fwd_f32(const float *logits, const long *tq, const float *const *maps, const float *w, long map_sb, long map_sg,
-                          const float *num_boxes, int PB, int B, int Q, int G, int C, float eos, float *loss, float *grad0,
-                          void *stream);
-int eda_scale_by_scene_f32(const float *g0, const float *w, const float *num_boxes, int PB, long per, float *out, void *stream);
+                          const float *num_boxes, int PB, int B, int Q, int G, int C, int S, float eos, float *loss /* (PB, S) */,
+                          float *grad0, void *stream);
+int eda_scale_by_scene_f32(const float *g0, const float *w /* (PB, S) */, const float *num_boxes, int PB, long per, long per_part,
+                           int S, float *out, void *stream);
 size_t eda_sem_align_lds_bytes(int Q, int L);
 int eda_sem_align_supported(int Q, int L);
 int eda_sem_align_fwd_f32(const float *logits, const long *tq, const float *const *maps, long map_sb, long map_sg,
                           const long *attn_mask, const float *num_boxes, int PB, int B, int Q, int G, int L, float eos,
                           float *loss, float *grad0, void *stream);
+/* compute_points_obj_cls_loss_hard_topk (models/losses.py:166-228): sigmoid focal loss of the K seed-objectness logits of each
+ * scene; positives = the topk (<= 8) seeds of each real target's instance nearest its centre in box-normalised distance (equal
+ * distances: lowest seed index -- the reference's torch.topk leaves that choice to the library).  loss (B) = per-scene shares of
+ * the reference's scalar; grad0 (B, K) = d sum(loss) / d logits. */
+/* compute_hungarian_loss's two ends (models/losses.py:650-738).  eda_compact_targets: the padded targets with the valid slots first
+ * (the reference's per-scene boolean indexing, :660-690) for up to 8 tensors of 4-byte words + counts, valid mask, box count.
+ * eda_loss_combine_*: per-head values, totals and loss = w_obj * objectness + inv * (w . [ce, bbox, giou, sem]) (:716-738) and its
+ * gradient. */
+int eda_compact_targets(const float *mask, int n, const void *const *src, const long *src_sb, const long *src_sg, void *const *dst,
+                        const long *dst_sg, const long *dst_off, const int *words, int B, int G, int *ntargets, unsigned char *valid,
+                        float *num_boxes, void *stream);
+int eda_loss_combine_fwd_f32(const float *const *rows, const int *parts, const float *obj, const float *w, float inv, float w_obj,
+                             int P, int B, float *per_head, float *totals, float *loss, void *stream);
+int eda_loss_combine_bwd_f32(const float *g, const float *w, float inv, float w_obj, float *const *d_rows, const int *n, float *d_obj,
+                             int B, void *stream);
+size_t eda_seed_objectness_lds_bytes(int K);
+int eda_seed_objectness_fwd_f32(const float *logits, const float *seed_xyz, const int *seed_inds, const long *instance_label,
+                                long npoints, const float *centre, long c_sg, const float *size, long s_sg, const float *mask,
+                                int B, int K, int G, int topk, float *loss, float *grad0, void *stream);
 
 /* ---- Row products against a FROZEN weight on the bf16 matrix pipe at fp32 accuracy (csrc/gemm_frozen.hip) --------------------
  * The reference freezes its text encoder (models/bdetr.py:77-80: requires_grad = False on every RobertaModel parameter) and runs

@@ -19,6 +19,9 @@ def count(fn):
         fn()
         torch.cuda.synchronize()
     ev = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    if "--list" in sys.argv:
+        for e in ev:
+            print("    %7.1f us  %s" % (e.device_time, e.name[:150]))
     return len(ev), sum(e.device_time for e in ev)
 
 
@@ -50,6 +53,8 @@ def main():
         loss.backward()
     n, t = count(whole)
     print("whole loss forward + backward: %d launches, %.1f us of kernels" % (n, t))
+    if "--list" in sys.argv:
+        return
     for parts in (["boxes"], ["labels"], ["contrastive_align"], []):
         c2 = L.SetCriterion(L.HungarianMatcher(1, 0, 2, True), losses=parts, eos_coef=0.1, temperature=0.07)
 
