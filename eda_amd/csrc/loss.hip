@@ -356,11 +356,14 @@ __global__ __launch_bounds__(256) void scale_by_scene_kernel(const float *__rest
 struct SemMaps { const float *pos, *modi, *pron, *other, *rel; long sb, sg; };
 
 // semantic-alignment contrastive loss (loss_sem_align, losses.py:499-608): one workgroup of 16 waves per pb with the scene's (Q, L)
-// logits in LDS.
-//   phase 1  object -> text: a wave per query row, lanes over the tokens (the maps are read for matched rows only -- a few per scene);
+// logits in LDS (row stride odd: a thread per row reads without bank conflicts).
+//   phase 1  object -> text.  Unmatched rows (nearly all): a thread per row, two passes over its tokens in LDS.  Matched rows (a few
+//            per scene): a wave per row, lanes over the tokens, the five maps read once; the lane also keeps the column sums of
+//            phase 2b over the wave's rows.
 //   phase 2a text -> object: the log-sum-exp of every token column over all queries, a wave per 8 columns x 8 row parts;
-//   phase 2b the map sums of every column over the MATCHED rows (compact list) + the closed form of the unmatched ones;
-//   phase 3  the gradient, a wave per query row (coalesced stores).
+//   phase 2b the map sums of every column over the matched rows (the waves' sums meet in LDS, in wave order) + the closed form of the
+//            unmatched ones;
+//   phase 3  the gradient, a wave per query row (coalesced stores); every divisor was inverted once per row / column.
 // loss[pb] = (b2t + t2b) / 2 / num_boxes; grad0 (PB, Q, L) = d(b2t + t2b) / 2 / d(logits)
 constexpr int SEM_NW = 16;
 #ifdef EDA_LOSS_PROFILE
@@ -372,6 +375,7 @@ __device__ unsigned long long loss_prof[256 * 8];
 #endif
 constexpr int SEM_MAXK = 4;                 // token columns per lane: L <= 256
 constexpr size_t SEM_LDS_MAX = 160 * 1024 - 1024;
+__host__ __device__ constexpr int sem_row_stride(int L) { return L + 1 + (L & 1); }
 
 __global__ __launch_bounds__(64 * SEM_NW) void sem_align_fwd_kernel(const float *__restrict__ logits, const long *__restrict__ tq,
                                                                    const SemMaps M, const long *__restrict__ attn_mask,
@@ -381,18 +385,45 @@ __global__ __launch_bounds__(64 * SEM_NW) void sem_align_fwd_kernel(const float 
   PL(0);
   extern __shared__ __attribute__((aligned(16))) float sem_smem[];
   constexpr int NT = 64 * SEM_NW;
-  const int LS = L + 1;
+  const int LS = sem_row_stride(L);
   float *X = sem_smem;                      // [Q][LS]
-  float *rowst = X + (size_t)Q * LS;        // [Q][8]: sp, sm, sr, srel, m1, s1, gq, -
-  float *colst = rowst + (size_t)Q * 8;     // [L][4]: nb (phase 2a: sum of the unmatched rows' logits), gl, mcol, scol
+  float *rowst = X + (size_t)Q * LS;        // [Q][8]: 1/(sp+e), .2/(sm+e), .2/(sr+e), .1/(srel+e), m1, 1/s1, gq, -
+  float *colst = rowst + (size_t)Q * 8;     // [4][L]: 1/nb (phase 2a: sum of the unmatched rows' logits), gl, mcol, 1/scol (2a: scol)
   int *slot = reinterpret_cast<int *>(colst + (size_t)L * 4);       // [Q]: matched target slot or -1
-  float *part_sums = reinterpret_cast<float *>(slot + Q);           // [R][L][8]: R waves' column sums at a time
+  int *mlist = slot + Q;                    // [Q]: the matched rows, ascending
+  float *part_sums = reinterpret_cast<float *>(mlist + Q);          // [R][8][L]: R waves' column sums at a time
   __shared__ float red[2 * SEM_NW];
   __shared__ int shared_i[3];               // last, prev, number of matched rows
   const int pb = blockIdx.x, b = pb % B, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  for (int i = tid; i < Q * L; i += NT) {
-    const int q = i / L, l = i - q * L;
-    X[q * LS + l] = logits[((long)pb * Q + q) * L + l];
+  {
+    const float *src = logits + (long)pb * Q * L;
+    const int n = Q * L;
+    if ((n & 3) == 0) {                     // four 16-byte loads in flight per thread
+      const int n4 = n >> 2;
+      for (int i0 = tid; i0 < n4; i0 += NT * 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (i0 + u * NT < n4) v[u] = reinterpret_cast<const float4 *>(src)[i0 + u * NT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (i0 + u * NT >= n4) continue;
+          const int i = (i0 + u * NT) * 4;
+          int q = i / L, l = i - q * L;
+          const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            X[q * LS + l] = e[j];
+            if (++l == L) { l = 0; ++q; }
+          }
+        }
+      }
+    } else {
+      for (int i = tid; i < n; i += NT) {
+        const int q = i / L, l = i - q * L;
+        X[q * LS + l] = src[i];
+      }
+    }
   }
   for (int q = tid; q < Q; q += NT) {
     const long g = tq[(long)pb * Q + q];
@@ -408,9 +439,15 @@ __global__ __launch_bounds__(64 * SEM_NW) void sem_align_fwd_kernel(const float 
       shared_i[0] = (int)((((n - 1) % L) + L) % L);
       shared_i[1] = (int)((((n - 2) % L) + L) % L);
     }
-  } else if (wv == 1) {                     // number of matched rows
+  } else if (wv == 1) {                     // ordered list of the matched rows
     int nm = 0;
-    for (int q0 = 0; q0 < Q; q0 += 64) nm += __popcll(__ballot(q0 + lane < Q && slot[q0 + lane] >= 0));
+    for (int q0 = 0; q0 < Q; q0 += 64) {
+      const int q = q0 + lane;
+      const bool mt = q < Q && slot[q] >= 0;
+      const unsigned long long bal = __ballot(mt);
+      if (mt) mlist[nm + __popcll(bal & ((1ull << lane) - 1))] = q;
+      nm += __popcll(bal);
+    }
     if (lane == 0) shared_i[2] = nm;
   }
   __syncthreads();
@@ -418,59 +455,79 @@ __global__ __launch_bounds__(64 * SEM_NW) void sem_align_fwd_kernel(const float 
   const int last = shared_i[0], prev = shared_i[1], nmatched = shared_i[2];
   const float *mp = M.pos + (long)b * M.sb, *mm = M.modi + (long)b * M.sb, *mr = M.pron + (long)b * M.sb;
   const float *mo = M.other + (long)b * M.sb, *ml = M.rel + (long)b * M.sb;
-  // ---- phase 1: object -> text, a wave per query row; lane owns the token columns lane + 64 k and keeps, over the wave's MATCHED
-  //      rows, the column sums phase 2b needs: counts of the four maps' set entries, the three maps' values, -sum(logit x sets) ----
+  // ---- phase 1, unmatched rows: the two "not mentioned" tokens are the positives, nothing else is set; four threads per row ----
   float b2t_acc = 0.f;
+  for (int q = tid >> 2; q < ((Q + 255) & ~255); q += NT / 4) {
+    const bool on = q < Q && slot[q] < 0;
+    const float *x = X + (on ? q : 0) * LS;
+    float m1 = -INFINITY, s1 = 0.f;
+    if (on) {
+#pragma unroll 4
+      for (int l = tid & 3; l < L; l += 4) m1 = fmaxf(m1, x[l]);
+    }
+    m1 = fmaxf(m1, __shfl_xor(m1, 1)); m1 = fmaxf(m1, __shfl_xor(m1, 2));
+    if (on) {
+#pragma unroll 4
+      for (int l = tid & 3; l < L; l += 4) s1 += __expf(x[l] - m1);
+    }
+    s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2);
+    if (on && (tid & 3) == 0) {
+      const float sp = last == prev ? 1.f : 2.f;
+      const float dp = last == prev ? x[last] : x[last] + x[prev];
+      b2t_acc += (-dp / (sp + 1e-6f) + (m1 + __logf(s1))) * eos;
+      float *rs = rowst + q * 8;
+      rs[0] = 1.f / (sp + 1e-6f); rs[1] = 0.f; rs[2] = 0.f; rs[3] = 0.f; rs[4] = m1; rs[5] = 1.f / s1; rs[6] = eos;
+    }
+  }
+  // ---- phase 1, matched rows: a wave per row; lane owns the token columns lane + 64 k and keeps, over the wave's rows, the column
+  //      sums phase 2b needs: counts of the four maps' set entries, the three maps' values, -sum(logit x sets) ----
   float pc[SEM_MAXK][8];
+  int keep[SEM_MAXK];                       // the map bits of the wave's first matched row, for phase 3
 #pragma unroll
-  for (int k = 0; k < SEM_MAXK; ++k)
+  for (int k = 0; k < SEM_MAXK; ++k) {
+    keep[k] = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) pc[k][i] = 0.f;
-  for (int q = wv; q < Q; q += SEM_NW) {
-    const int g = slot[q];
+  }
+  for (int mi = wv; mi < nmatched; mi += SEM_NW) {
+    const int q = mlist[mi], g = slot[q];
     const float *x = X + q * LS;
     float sp = 0.f, sm = 0.f, sr = 0.f, sl = 0.f, dp = 0.f, dm = 0.f, dr = 0.f, dl = 0.f, m1 = -INFINITY, s1 = 0.f;
-    if (g >= 0) {
-      float vo[SEM_MAXK];                   // logit x (1 + other-entity bit)
+    float vo[SEM_MAXK];                     // logit x (1 + other-entity bit)
 #pragma unroll
-      for (int k = 0; k < SEM_MAXK; ++k) {
-        const int l = lane + 64 * k;
-        vo[k] = -INFINITY;
-        if (l < L) {
-          const long o = (long)g * M.sg + l;
-          const float c = mm[o], d = mr[o], e = ml[o];
-          const float pm = mp[o] > 0.f ? 1.f : 0.f, mb = c > 0.f ? 1.f : 0.f, rb = d > 0.f ? 1.f : 0.f;
-          const float lb = e > 0.f ? 1.f : 0.f, ob = mo[o] > 0.f ? 1.f : 0.f;
-          const float v = x[l];
-          sp += pm; sm += mb; sr += rb; sl += lb;
-          dp += v * pm; dm += v * mb; dr += v * rb; dl += v * lb;
-          vo[k] = v + v * ob;
-          m1 = fmaxf(m1, vo[k]);
-          pc[k][0] += pm; pc[k][1] += mb; pc[k][2] += rb; pc[k][3] += lb;
-          pc[k][4] += c; pc[k][5] += d; pc[k][6] += e;
-          pc[k][7] -= v * (pm + mb + rb + lb);
-        }
+    for (int k = 0; k < SEM_MAXK; ++k) {
+      const int l = lane + 64 * k;
+      vo[k] = -INFINITY;
+      if (l < L) {
+        const long o = (long)g * M.sg + l;
+        const float c = mm[o], d = mr[o], e = ml[o];
+        const float pm = mp[o] > 0.f ? 1.f : 0.f, mb = c > 0.f ? 1.f : 0.f, rb = d > 0.f ? 1.f : 0.f;
+        const float lb = e > 0.f ? 1.f : 0.f, ob = mo[o] > 0.f ? 1.f : 0.f;
+        const float v = x[l];
+        sp += pm; sm += mb; sr += rb; sl += lb;
+        dp += v * pm; dm += v * mb; dr += v * rb; dl += v * lb;
+        vo[k] = v + v * ob;
+        m1 = fmaxf(m1, vo[k]);
+        pc[k][0] += pm; pc[k][1] += mb; pc[k][2] += rb; pc[k][3] += lb;
+        pc[k][4] += c; pc[k][5] += d; pc[k][6] += e;
+        pc[k][7] -= v * (pm + mb + rb + lb);
+        if (mi == wv) keep[k] = (int)pm | (int)mb << 1 | (int)rb << 2 | (int)lb << 3 | (int)ob << 4;
       }
-      m1 = wave_max(m1);
-#pragma unroll
-      for (int k = 0; k < SEM_MAXK; ++k) s1 += lane + 64 * k < L ? __expf(vo[k] - m1) : 0.f;
-      sp = wave_sum(sp); sm = wave_sum(sm); sr = wave_sum(sr); sl = wave_sum(sl);
-      dp = wave_sum(dp); dm = wave_sum(dm); dr = wave_sum(dr); dl = wave_sum(dl);
-    } else {                                // unmatched: the two "not mentioned" tokens are the positives, nothing else is set
-      for (int l = lane; l < L; l += 64) m1 = fmaxf(m1, x[l]);
-      m1 = wave_max(m1);
-      for (int l = lane; l < L; l += 64) s1 += __expf(x[l] - m1);
-      sp = last == prev ? 1.f : 2.f;
-      dp = last == prev ? x[last] : x[last] + x[prev];
     }
+    m1 = wave_max(m1);
+#pragma unroll
+    for (int k = 0; k < SEM_MAXK; ++k) s1 += lane + 64 * k < L ? __expf(vo[k] - m1) : 0.f;
+    sp = wave_sum(sp); sm = wave_sum(sm); sr = wave_sum(sr); sl = wave_sum(sl);
+    dp = wave_sum(dp); dm = wave_sum(dm); dr = wave_sum(dr); dl = wave_sum(dl);
     s1 = wave_sum(s1);
     if (lane == 0) {
-      const float gq = (sp > 0.f ? 1.f : 0.f) * (g >= 0 ? 1.f : eos);
+      const float gq = sp > 0.f ? 1.f : 0.f;
       const float v = -dp / (sp + 1e-6f) - 0.2f * dm / (sm + 1e-6f) - 0.2f * dr / (sr + 1e-6f) - 0.1f * dl / (sl + 1e-6f) +
                       (m1 + __logf(s1));
       b2t_acc += v * gq;
       float *rs = rowst + q * 8;
-      rs[0] = sp; rs[1] = sm; rs[2] = sr; rs[3] = sl; rs[4] = m1; rs[5] = s1; rs[6] = gq;
+      rs[0] = 1.f / (sp + 1e-6f); rs[1] = 0.2f / (sm + 1e-6f); rs[2] = 0.2f / (sr + 1e-6f); rs[3] = 0.1f / (sl + 1e-6f);
+      rs[4] = m1; rs[5] = 1.f / s1; rs[6] = gq;
     }
   }
   PL(2);
@@ -489,46 +546,45 @@ __global__ __launch_bounds__(64 * SEM_NW) void sem_align_fwd_kernel(const float 
     }
     sc += __shfl_xor(sc, 8); sc += __shfl_xor(sc, 16); sc += __shfl_xor(sc, 32);
     us += __shfl_xor(us, 8); us += __shfl_xor(us, 16); us += __shfl_xor(us, 32);
-    if (on && part == 0) { float *cs = colst + l * 4; cs[0] = us; cs[2] = mc; cs[3] = sc; }
+    if (on && part == 0) { colst[l] = us; colst[2 * L + l] = mc; colst[3 * L + l] = sc; }
   }
   PL(3);
   // ---- phase 2b: text -> object; the waves' column sums meet in LDS, R waves at a time, in wave order; thread l owns column l ----
   float col[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int r0 = 0; r0 < SEM_NW; r0 += R) {
+  const int nwaves_used = min(nmatched, SEM_NW);               // waves beyond the matched rows hold zeros
+  for (int r0 = 0; r0 < nwaves_used; r0 += R) {
     if (wv >= r0 && wv < r0 + R) {
 #pragma unroll
       for (int k = 0; k < SEM_MAXK; ++k) {
         const int l = lane + 64 * k;
         if (l < L) {
-          float *dst = part_sums + ((size_t)(wv - r0) * L + l) * 8;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) dst[i] = pc[k][i];
+          for (int i = 0; i < 8; ++i) part_sums[((size_t)(wv - r0) * 8 + i) * L + l] = pc[k][i];
         }
       }
     }
     __syncthreads();
     if (tid < L) {
-      for (int w = 0; w < R && r0 + w < SEM_NW; ++w) {
-        const float *src = part_sums + ((size_t)w * L + tid) * 8;
+      for (int w = 0; w < R && r0 + w < nwaves_used; ++w) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) col[i] += src[i];
+        for (int i = 0; i < 8; ++i) col[i] += part_sums[((size_t)w * 8 + i) * L + tid];
       }
     }
     __syncthreads();
   }
+  if (nwaves_used == 0) __syncthreads();                       // (phase 2a's column statistics)
   float t2b_acc = 0.f;
   if (tid < L) {
     const int l = tid;
     float cp = col[0], post = col[7];
     bool anyp = col[0] > 0.f;
     const bool anym = col[1] > 0.f, anyr = col[2] > 0.f, anyl = col[3] > 0.f;
-    float *cs = colst + l * 4;
     if ((l == last || l == prev) && nmatched < Q) {     // every unmatched row counts this token as its positive
       cp += (float)(Q - nmatched);
       anyp = true;
-      post -= cs[0];
+      post -= colst[l];
     }
-    const float mc = cs[2], sc = cs[3];
+    const float mc = colst[2 * L + l], sc = colst[3 * L + l];
     const float nb = cp + col[4] + col[5] + col[6] + 1e-6f;
     float tm = eos;                                        // overwritten in this order (losses.py:550-556)
     if (l == last) tm = 1.f;
@@ -539,32 +595,47 @@ __global__ __launch_bounds__(64 * SEM_NW) void sem_align_fwd_kernel(const float 
     if (l == prev) tm = 0.1f;
     const float gl = (anyp || anym || anyr || anyl) ? tm : 0.f;
     t2b_acc = (-__logf(nb + 1e-6f) / nb + post / nb + (mc + __logf(sc))) * gl;
-    cs[0] = nb; cs[1] = gl;
+    colst[l] = 1.f / nb; colst[L + l] = gl; colst[3 * L + l] = 1.f / sc;
   }
   __syncthreads();
   PL(4);
-  // ---- phase 3: gradient, a wave per query row ----
+  // ---- phase 3: gradient, a wave per query row: the unmatched rows, then the wave's matched rows (the first one's map bits are still
+  //      in registers from phase 1) ----
   for (int q = wv; q < Q; q += SEM_NW) {
-    const int g = slot[q];
+    if (slot[q] >= 0) continue;
     const float *x = X + q * LS;
     const float *rs = rowst + q * 8;
-    const float sp = rs[0], sm = rs[1], sr = rs[2], sl = rs[3], m1 = rs[4], s1 = rs[5], gq = rs[6];
+    const float a0 = rs[0], m1 = rs[4], r1 = rs[5], gq = rs[6];
     float *out = grad0 + ((long)pb * Q + q) * L;
     for (int l = lane; l < L; l += 64) {
-      float pm, mb = 0.f, rb = 0.f, lb = 0.f, ob = 0.f;
-      if (g >= 0) {
-        const long o = (long)g * M.sg + l;
-        pm = mp[o] > 0.f ? 1.f : 0.f; mb = mm[o] > 0.f ? 1.f : 0.f; rb = mr[o] > 0.f ? 1.f : 0.f;
-        lb = ml[o] > 0.f ? 1.f : 0.f; ob = mo[o] > 0.f ? 1.f : 0.f;
-      } else {
-        pm = (l == last || l == prev) ? 1.f : 0.f;
-      }
       const float v = x[l];
-      const float *cs = colst + l * 4;
-      const float row_t = -pm / (sp + 1e-6f) - 0.2f * mb / (sm + 1e-6f) - 0.2f * rb / (sr + 1e-6f) - 0.1f * lb / (sl + 1e-6f) +
-                          __expf(v + v * ob - m1) / s1 * (1.f + ob);
-      const float col_t = -(pm + mb + rb + lb) / cs[0] + __expf(v - cs[2]) / cs[3];
-      out[l] = 0.5f * (gq * row_t + cs[1] * col_t);
+      const float pm = (l == last || l == prev) ? 1.f : 0.f;
+      const float row_t = -pm * a0 + __expf(v - m1) * r1;
+      const float col_t = -pm * colst[l] + __expf(v - colst[2 * L + l]) * colst[3 * L + l];
+      out[l] = 0.5f * (gq * row_t + colst[L + l] * col_t);
+    }
+  }
+  for (int mi = wv; mi < nmatched; mi += SEM_NW) {
+    const int q = mlist[mi], g = slot[q];
+    const float *x = X + q * LS;
+    const float *rs = rowst + q * 8;
+    const float a0 = rs[0], a1 = rs[1], a2 = rs[2], a3 = rs[3], m1 = rs[4], r1 = rs[5], gq = rs[6];
+    float *out = grad0 + ((long)pb * Q + q) * L;
+#pragma unroll
+    for (int k = 0; k < SEM_MAXK; ++k) {
+      const int l = lane + 64 * k;
+      if (l >= L) continue;
+      int bits = keep[k];
+      if (mi != wv) {
+        const long o = (long)g * M.sg + l;
+        bits = (mp[o] > 0.f ? 1 : 0) | (mm[o] > 0.f ? 2 : 0) | (mr[o] > 0.f ? 4 : 0) | (ml[o] > 0.f ? 8 : 0) | (mo[o] > 0.f ? 16 : 0);
+      }
+      const float pm = (float)(bits & 1), mb = (float)(bits >> 1 & 1), rb = (float)(bits >> 2 & 1), lb = (float)(bits >> 3 & 1);
+      const float ob = (float)(bits >> 4 & 1);
+      const float v = x[l];
+      const float row_t = -pm * a0 - mb * a1 - rb * a2 - lb * a3 + __expf(v + v * ob - m1) * r1 * (1.f + ob);
+      const float col_t = -(pm + mb + rb + lb) * colst[l] + __expf(v - colst[2 * L + l]) * colst[3 * L + l];
+      out[l] = 0.5f * (gq * row_t + colst[L + l] * col_t);
     }
   }
   PL(5);
@@ -827,7 +898,7 @@ extern "C" int eda_scale_by_scene_f32(const float *g0, const float *w, const flo
 
 // LDS of the alignment kernel with room for R waves' column sums (R = 1: the least it runs with)
 static size_t sem_align_lds(int Q, int L, int R) {
-  return sizeof(float) * ((size_t)Q * (L + 1) + (size_t)Q * 8 + (size_t)L * 4 + (size_t)Q + (size_t)R * L * 8);
+  return sizeof(float) * ((size_t)Q * sem_row_stride(L) + (size_t)Q * 8 + (size_t)L * 4 + 2 * (size_t)Q + (size_t)R * L * 8);
 }
 extern "C" size_t eda_sem_align_lds_bytes(int Q, int L) { return sem_align_lds(Q, L, 1); }
 extern "C" int eda_sem_align_supported(int Q, int L) { return Q > 0 && L > 0 && L <= 64 * SEM_MAXK && sem_align_lds(Q, L, 1) <= SEM_LDS_MAX; }

@@ -6,6 +6,7 @@ O=gpurun_out/$tag; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; tail -2 $O/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
 python tools/measure_traffic.py > $O/traffic.txt 2>&1
+cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json      # (this box's copy: the bench lines below carry the traffic of THIS build)
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --fps-prefetch 0 --in-step-steps 0 > $O/bench_fps_in_step.json 2> $O/bench_fps_in_step.err
 python bench.py --fps-prefetch 1 --in-step-steps 0 > $O/bench_sa1_prefetch_only.json 2> $O/bench_sa1_prefetch_only.err
@@ -37,10 +38,15 @@ EDA_WGRAD_BF16X3=0 python bench.py --in-step-steps 0 > $O/bench_wgrad_fp32_mfma.
 EDA_BATCHED_HEADS=0 python bench.py --in-step-steps 0 > $O/bench_heads_per_head.json 2> $O/bench_heads_per_head.err
 EDA_RESIDUAL_LINK=0 python bench.py --in-step-steps 0 > $O/bench_residual_link_off.json 2> $O/bench_residual_link_off.err
 EDA_GEMM_B3ROWS=0 python bench.py --in-step-steps 0 > $O/bench_b3rows_off.json 2> $O/bench_b3rows_off.err
-# round 6: in-launch merge of the split attention backward off, the frozen text encoder on fp32-MFMA products, the key-per-wave forward
+# round 6: in-launch merge of the split attention backward off, the frozen text encoder on fp32-MFMA products, the key-per-wave forward,
+# the training loss in its element-wise torch form
 EDA_MHA2_BWD_MERGE=0 EDA_MHA2_BWD_DBUF=0 python bench.py --in-step-steps 0 > $O/bench_mha_bwd_r05_form.json 2> $O/bench_mha_bwd_r05_form.err
 EDA_FROZEN_B3=0 python bench.py --in-step-steps 0 > $O/bench_frozen_b3_off.json 2> $O/bench_frozen_b3_off.err
 EDA_MHA4=1 python bench.py --in-step-steps 0 > $O/bench_mha4_on.json 2> $O/bench_mha4_on.err
+EDA_FUSED_LOSS=0 python bench.py --loss hungarian --in-step-steps 0 > $O/bench_hungarian_loss_torch_form.json 2> $O/bench_hungarian_loss_torch_form.err
+python tools/loss_census.py > $O/loss_census.txt 2>&1
+EDA_FUSED_LOSS=0 python tools/loss_census.py > $O/loss_census_torch_form.txt 2>&1
+python tools/loss_phase_profile.py > $O/loss_phase_profile.txt 2>&1
 python tools/bench_gemm_frozen.py > $O/gemm_frozen.txt 2>&1
 python tools/bench_gemm_b3rows.py > $O/gemm_b3rows_tool.txt 2>&1
 python tools/bench_wgrad_grouped.py > $O/wgrad_grouped.txt 2>&1
