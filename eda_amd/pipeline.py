@@ -21,6 +21,7 @@ Every step executes exactly one sampling and one text-encoder pass (nothing is c
 with alternating batches and checks, per step, that the indices used are the FPS of the batch being trained and that
 the loss history equals eager training on the same sequence.
 """
+import ctypes
 import os
 
 import torch
@@ -78,6 +79,36 @@ def _packed_like(tensors):
 _TIMING_SKIP = os.environ.get("EDA_TIMING_SKIP_SIDE", "").split(",")
 
 
+def _side_stream(device):
+    """The second stream.  EDA_SIDE_CU_MASK (experiments: profiles/r06_side_cu_mask.md) restricts it to a set of CUs
+    (hipExtStreamCreateWithCUMask): "N" = N CUs spread evenly over the mask's 256 bits, "lowN" = the first N bits, "0x..." = the
+    mask itself (bit i = CU i in the runtime's numbering).  The cluster sampler is told to plan for that many CUs."""
+    spec = os.environ.get("EDA_SIDE_CU_MASK", "")
+    if not spec:
+        return torch.cuda.Stream()
+    total = torch.cuda.get_device_properties(device).multi_processor_count
+    if spec.startswith("0x"):
+        mask = int(spec, 16)
+    elif spec.startswith("low"):
+        mask = (1 << int(spec[3:])) - 1
+    else:
+        n = int(spec)
+        mask = 0
+        for i in range(n):
+            mask |= 1 << (i * total // n)
+    n = bin(mask).count("1")
+    words = (ctypes.c_uint32 * ((total + 31) // 32))(*[(mask >> (32 * i)) & 0xFFFFFFFF for i in range((total + 31) // 32)])
+    hip = ctypes.CDLL("libamdhip64.so")
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), len(words), words)
+    if rc != 0:
+        raise RuntimeError("hipExtStreamCreateWithCUMask failed (%d)" % rc)
+    from . import _lib
+    _lib.check(_lib.lib().eda_fps_set_cu_reserve(max(0, total - n)), "eda_fps_set_cu_reserve")
+    return torch.cuda.ExternalStream(handle.value, device=device)
+
+
 class PipelinedTrainStep:
     def __init__(self, model, first_batch, loss_fn, backward_fn, update_fn, *, stream=None, all_reduce=None,
                  split_update=False, prefetch="sa1", text_prefetch=True, after_loss=None, sa1_samples=2048,
@@ -102,7 +133,7 @@ class PipelinedTrainStep:
         assert all_reduce is None or not post_stages, "all_reduce and post_stages are alternatives"
         dev = first_batch["point_clouds"].device
         self.main = stream or torch.cuda.current_stream()
-        self.side = torch.cuda.Stream()
+        self.side = _side_stream(dev)
         mode = dict(capture_error_mode="thread_local")
 
         # ---- side stream, eager once: creates this stream's FPS workspace outside the capture (its sticky give-up flag
