@@ -395,6 +395,9 @@ def main():
                     help="use the N>1 graph structure (two graphs, eager all-reduce slot) even at N=1")
     ap.add_argument("--kernel-steps", type=int, default=3,
                     help="eager steps (after the timed region) used for the per-kernel event timings in graph mode")
+    ap.add_argument("--text-encoder-mode", choices=["train", "eval"], default="train",
+                    help="train (default, the reference: main_utils.py:459 puts the WHOLE model in train mode, so the frozen RoBERTa "
+                         "runs with its dropout layers active) or eval (no dropout inside the frozen encoder: what rounds 1-5 timed)")
     ap.add_argument("--graph", type=int, default=1,
                     help="1 = capture the whole training step in a HIP graph and replay it (default); "
                          "0 = eager launches")
@@ -486,7 +489,8 @@ def main():
 
     torch.manual_seed(0)                       # same init on every rank (DDP broadcast equivalent)
     model = BeaUTyDETR(num_queries=args.queries, butd=not args.no_butd).to(device).train()
-    model.text_encoder.eval()                  # frozen (bdetr.py:78-80)
+    if args.text_encoder_mode == "eval":       # (the reference: model.train() on everything, main_utils.py:459 -- the frozen
+        model.text_encoder.eval()              #  encoder's dropout layers are active while it trains; "eval": rounds 1-5's line)
     model.overlap_text_encoder = args.overlap
     no_drop = os.environ.get("EDA_BENCH_NO_DROPOUT", "")          # debugging aid: "1" (all), "modules", "attention"
     if no_drop:
@@ -1139,6 +1143,8 @@ def main():
                                   "hipGraph replay of the whole step" if world == 1 and not args.split_graphs else
                                   "two hipGraphs (fwd+bwd | clip+AdamW) with the RCCL all-reduce between them"),
                        "text_encoder": "RoBERTa-base random-init frozen, " + (
+                           "in train mode like the rest of the model (main_utils.py:459: its dropout layers are active), "
+                           if args.text_encoder_mode == "train" else "in eval mode (no dropout inside it), ") + (
                            "forward on own kernels (eda_amd/roberta_fast.py)" if fast_roberta else "stock Hugging Face forward (hipBLASLt / AOTriton)") + (
                            "; runs for the NEXT step's tokens on the second stream" if (args.graph and args.text_stream and not args.overlap
                                                                                       and args.fps_prefetch and args.text_prefetch) else ""),

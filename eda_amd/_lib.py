@@ -81,6 +81,8 @@ SIGNATURES = {
     "eda_add_n_f32": (_i, [_p, _i, _sz, _p, _p]),
     "eda_gemm_set_dma": (_i, [_i]),
     "eda_mha_fwd_hd64_f32": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _l, _p, _i, _i, _i, _i, _f, _p, _p]),
+    "eda_mha_fwd_hd64_drop_f32": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _l, _p, _i, _i, _i, _i, _f, _f, _p, _u, _p, _p]),
+    "eda_dropout_f32": (_i, [_p, _l, _f, _p, _u, _p, _p]),
     "eda_mha_fwd": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _l, _p, _i, _i, _i, _i, _i, _f, _f,
                         _p, _u, _p, _p, _i, _p]),
     "eda_mha_fwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),

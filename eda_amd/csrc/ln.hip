@@ -233,6 +233,27 @@ __global__ __launch_bounds__(1024) void ln_reduce_grouped_kernel(const long long
   }
 }
 
+// out[i] = keep(i) ? x[i] / (1 - p) : 0 with the library's counter-based mask (the hash of ln_drop over the flat element index):
+// the frozen text encoder's embedding dropout (transformers RobertaEmbeddings: dropout(LayerNorm(.)), active because the reference
+// trains with the whole model in train mode, main_utils.py:459)
+__global__ __launch_bounds__(256) void dropout_flat_kernel(const float *__restrict__ x, long n, float p,
+                                                           const unsigned long long *__restrict__ seed_ptr, unsigned salt,
+                                                           float *__restrict__ out) {
+  const LnDrop d = ln_drop(p, seed_ptr, salt);
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 4 <= n) {
+    float4 v = *reinterpret_cast<const float4 *>(x + i);
+    v.x = ln_hash32(d.seed ^ (unsigned)i) >= d.thresh ? v.x * d.inv_keep : 0.f;
+    v.y = ln_hash32(d.seed ^ (unsigned)(i + 1)) >= d.thresh ? v.y * d.inv_keep : 0.f;
+    v.z = ln_hash32(d.seed ^ (unsigned)(i + 2)) >= d.thresh ? v.z * d.inv_keep : 0.f;
+    v.w = ln_hash32(d.seed ^ (unsigned)(i + 3)) >= d.thresh ? v.w * d.inv_keep : 0.f;
+    *reinterpret_cast<float4 *>(out + i) = v;
+  } else {
+    for (long j = i; j < n; ++j) out[j] = ln_hash32(d.seed ^ (unsigned)j) >= d.thresh ? x[j] * d.inv_keep : 0.f;
+  }
+}
+
 }  // namespace
 
 // (EXTRA = the variant with the second output / second gradient input: a template flag, because a
@@ -420,6 +441,19 @@ extern "C" int eda_l2norm_rows_bwd_f32(const float *dy, const float *y, const fl
   long blocks = (R + 3) / 4;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dy, y, norm, R, C, eps, dx);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}
+
+// x, out: n floats, 16-byte aligned (out may be x); 0 < p < 1; the mask of element i is the hash of (counter, salt, i)
+extern "C" int eda_dropout_f32(const float *x, long n, float p_drop, const unsigned long long *seed_ptr, unsigned salt, float *out,
+                               void *stream_) {
+  EDA_CHECK_ARG(n >= 0 && p_drop > 0.f && p_drop < 1.f, "0 < p < 1");
+  if (n == 0) return 0;
+  EDA_CHECK_ARG(x && out && seed_ptr, "null pointer");
+  EDA_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0, "16-byte aligned buffers");
+  hipLaunchKernelGGL(dropout_flat_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, (hipStream_t)stream_, x, n, p_drop,
+                     seed_ptr, salt, out);
   EDA_CHECK_LAUNCH();
   return 0;
 }

@@ -42,7 +42,15 @@ struct Hd64Args {
   const unsigned char *mask;          // (B, Lk) 1 = ignore, or null
   int B, H, Lq, Lk;
   float scale;
+  float p_drop;                       // dropout on the probabilities (transformers RobertaSelfAttention, train mode)
+  const unsigned long long *seed_ptr;
+  unsigned salt;
 };
+
+__device__ __forceinline__ unsigned hd64_hash32(unsigned x) {       // (the mask hash of eda_mha_* / csrc/mha2.hip)
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
 
 // the lane's 16 contraction values of one 64-float row: dims 16g .. 16g+15 (MFMA k-step s of lane group g <-> dim 16g + s)
 __device__ __forceinline__ void load_row16(float (&r)[16], const float *row, int g) {
@@ -53,6 +61,7 @@ __device__ __forceinline__ void load_row16(float (&r)[16], const float *row, int
   }
 }
 
+template <bool DROP>
 __global__ __launch_bounds__(256) void mha_hd64_fwd_kernel(const Hd64Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int Lk = a.Lk;
@@ -84,6 +93,14 @@ __global__ __launch_bounds__(256) void mha_hd64_fwd_kernel(const Hd64Args a) {
   }
   __syncthreads();
 
+  unsigned dseed = 0u, dthresh = 0u;
+  float inv_keep = 1.f;
+  if (DROP) {                                   // 16-bit thresholds, two probabilities per hash: as csrc/mha2.hip
+    dseed = hd64_hash32((unsigned)(*a.seed_ptr) * 0x9E3779B1u + a.salt);
+    dthresh = (unsigned)((double)a.p_drop * 65536.0 + 0.5);
+    inv_keep = 1.f / (1.f - a.p_drop);
+  }
+  const unsigned rowbase = ((unsigned)bh * (unsigned)a.Lq + (unsigned)qi) * (unsigned)Lk;
   float m = -INFINITY, lsum = 0.f;
   f32x4 o[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
   const int nsub = Lk16 >> 4;
@@ -127,6 +144,18 @@ __global__ __launch_bounds__(256) void mha_hd64_fwd_kernel(const Hd64Args a) {
     m = m_new;
 #pragma unroll
     for (int n = 0; n < 4; ++n) o[n] *= alpha;
+    if (DROP) {                                 // (the softmax sum keeps every probability; only P v sees the mask)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        if (jj < nj) {
+#pragma unroll
+          for (int r2 = 0; r2 < 4; r2 += 2) {
+            const unsigned hh = hd64_hash32(dseed ^ (rowbase + (unsigned)(16 * (j0 + jj) + 4 * g + r2)));
+            st[jj][r2] = (hh & 0xffffu) >= dthresh ? st[jj][r2] : 0.f;
+            st[jj][r2 + 1] = (hh >> 16) >= dthresh ? st[jj][r2 + 1] : 0.f;
+          }
+        }
+    }
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
       if (jj < nj) {
@@ -144,7 +173,7 @@ __global__ __launch_bounds__(256) void mha_hd64_fwd_kernel(const Hd64Args a) {
   }
   lsum = grp_sum(lsum);
   if (qvalid) {
-    const float inv = 1.f / lsum;              // every key masked -> NaN, like the reference
+    const float inv = inv_keep / lsum;         // every key masked -> NaN, like the reference
     float *orow = a.o + (long)b * a.o_sb + (long)qi * a.o_sl + h * HD64;
 #pragma unroll
     for (int n = 0; n < 4; ++n)
@@ -157,14 +186,16 @@ bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
 
-extern "C" int eda_mha_fwd_hd64_f32(const float *q, const float *k, const float *v, long q_sb, long q_sl, long k_sb,
-                                    long k_sl, long v_sb, long v_sl, const unsigned char *key_padding_mask, int B, int H,
-                                    int Lq, int Lk, float scale, float *out, void *stream_) {
+extern "C" int eda_mha_fwd_hd64_drop_f32(const float *q, const float *k, const float *v, long q_sb, long q_sl, long k_sb,
+                                         long k_sl, long v_sb, long v_sl, const unsigned char *key_padding_mask, int B, int H,
+                                         int Lq, int Lk, float scale, float p_drop, const unsigned long long *seed_ptr,
+                                         unsigned salt, float *out, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EDA_CHECK_ARG(B >= 0 && H > 0 && Lq >= 0 && Lk >= 0, "bad dimension");
   if (B == 0 || Lq == 0) return 0;
   EDA_CHECK_ARG(Lk >= 1 && Lk <= MAXLK, "1 <= Lk <= 256 (K and V of a (sentence, head) are kept in LDS whole)");
   EDA_CHECK_ARG(q && k && v && out, "null pointer");
+  EDA_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed_ptr), "0 <= p < 1, and a counter when p > 0");
   EDA_CHECK_ARG(mult4(q_sb) && mult4(q_sl) && mult4(k_sb) && mult4(k_sl) && mult4(v_sb) && mult4(v_sl) && al16(q) &&
                     al16(k) && al16(v) && al16(out), "rows must be 16-byte aligned");
   EDA_CHECK_ARG((long)B * H <= 65535, "B*H too large");
@@ -172,13 +203,22 @@ extern "C" int eda_mha_fwd_hd64_f32(const float *q, const float *k, const float 
   a.q = q; a.k = k; a.v = v; a.q_sb = q_sb; a.q_sl = q_sl; a.k_sb = k_sb; a.k_sl = k_sl; a.v_sb = v_sb; a.v_sl = v_sl;
   a.o = out; a.o_sb = (long)Lq * H * HD64; a.o_sl = (long)H * HD64; a.mask = key_padding_mask;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale;
+  a.p_drop = p_drop; a.seed_ptr = seed_ptr; a.salt = salt;
   const size_t lds = sizeof(float) * 2 * (size_t)Lk * LDK + (size_t)((Lk + 15) & ~15);
+  auto kern = p_drop > 0.f ? mha_hd64_fwd_kernel<true> : mha_hd64_fwd_kernel<false>;
   {           // dynamic LDS above 64 KB needs the opt-in; the attribute is per DEVICE and cheap: set on every launch
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mha_hd64_fwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * 2 * MAXLK * LDK + 256));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(sizeof(float) * 2 * MAXLK * LDK + 256));
     if (e != hipSuccess) { eda_set_error("eda_mha_fwd_hd64_f32: %s", hipGetErrorString(e)); return (int)e; }
   }
-  hipLaunchKernelGGL(mha_hd64_fwd_kernel, dim3((unsigned)(B * H), (unsigned)((Lq + 63) / 64)), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(B * H), (unsigned)((Lq + 63) / 64)), dim3(256), lds, stream, a);
   EDA_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int eda_mha_fwd_hd64_f32(const float *q, const float *k, const float *v, long q_sb, long q_sl, long k_sb,
+                                    long k_sl, long v_sb, long v_sl, const unsigned char *key_padding_mask, int B, int H,
+                                    int Lq, int Lk, float scale, float *out, void *stream_) {
+  return eda_mha_fwd_hd64_drop_f32(q, k, v, q_sb, q_sl, k_sb, k_sl, v_sb, v_sl, key_padding_mask, B, H, Lq, Lk, scale, 0.f, nullptr,
+                                   0u, out, stream_);
 }

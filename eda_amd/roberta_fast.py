@@ -13,6 +13,13 @@ carry its parameter names); what changes on the GPU is how the forward is comput
 i.e. 7 launches per layer, none of them a library GEMM, an AOTriton attention or a TunableOp-selected kernel (what the
 stock module ran: 85 hipBLASLt + 12 Triton `attn_fwd` launches per step).  Numerics: fp32 throughout (exact-f32 MFMA);
 tests/test_roberta_fast_gpu.py compares with the Hugging Face forward of the same weights.
+
+Train mode.  The reference trains with `model.train()` on the WHOLE model (main_utils.py:459): its frozen encoder therefore runs
+with its dropout layers active (embeddings, attention probabilities, the two hidden dropouts of every layer: 0.1 each in
+roberta-base).  When the Hugging Face module is in train mode this forward does the same inside the same launches (the residual
+LayerNorm kernel's dropout, eda_mha_fwd_hd64_drop_f32, one eda_dropout_f32 after the embedding LayerNorm) with the library's
+counter-based masks -- a counter of its own, bumped once per call, so that the encoder may run on a second stream underneath the
+step and stay reproducible.  (Masks cannot equal torch's Philox stream bit for bit; the statistics are tested.)
 """
 import torch
 
@@ -20,8 +27,8 @@ from . import _lib, gemm
 from .ext import _timed
 
 
-def _ln_residual(x2, y2, y_bias, gamma, beta, eps, out=None):
-    """LayerNorm(x2 + y2 + y_bias) over the last dim of (R, C) fp32 matrices (csrc/ln.hip, dropout off)."""
+def _ln_residual(x2, y2, y_bias, gamma, beta, eps, out=None, p=0.0, seed=None, salt=0):
+    """LayerNorm(x2 + dropout_p(y2 + y_bias)) over the last dim of (R, C) fp32 matrices (csrc/ln.hip)."""
     R, C = x2.shape
     if out is None:
         out = torch.empty_like(x2)
@@ -29,14 +36,14 @@ def _ln_residual(x2, y2, y_bias, gamma, beta, eps, out=None):
     with torch.cuda.device(x2.device), _timed("add_dropout_ln_fwd", (R, C)):
         rc = _lib.lib().eda_add_dropout_ln_fwd_f32(
             x2.data_ptr(), y2.data_ptr(), y_bias.data_ptr() if y_bias is not None else None, gamma.data_ptr(),
-            beta.data_ptr(), R, C, float(eps), 0.0, None, 0, out.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
-            None, None, torch.cuda.current_stream().cuda_stream)
+            beta.data_ptr(), R, C, float(eps), float(p), seed.data_ptr() if p > 0 else None, int(salt) & 0xFFFFFFFF, out.data_ptr(),
+            stats[0].data_ptr(), stats[1].data_ptr(), None, None, torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "eda_add_dropout_ln_fwd_f32")
     return out
 
 
-def attention_hd64(q, k, v, key_padding_mask, num_heads, scale):
-    """softmax(q k^T * scale + mask) v for head_dim 64, q (B,Lq,D), k / v (B,Lk,D) column views with unit last stride;
+def attention_hd64(q, k, v, key_padding_mask, num_heads, scale, p=0.0, seed=None, salt=0):
+    """dropout_p(softmax(q k^T * scale + mask)) v for head_dim 64, q (B,Lq,D), k / v (B,Lk,D) column views with unit last stride;
     key_padding_mask (B,Lk) bool, True = ignore.  Forward only."""
     B, Lq, D = q.shape
     Lk = k.shape[1]
@@ -44,11 +51,11 @@ def attention_hd64(q, k, v, key_padding_mask, num_heads, scale):
     out = torch.empty((B, Lq, D), dtype=torch.float32, device=q.device)
     m8 = key_padding_mask.contiguous().view(torch.uint8) if key_padding_mask is not None else None
     with torch.cuda.device(q.device), _timed("mha_fwd_hd64", (B, num_heads, Lq, Lk)):
-        rc = _lib.lib().eda_mha_fwd_hd64_f32(
+        rc = _lib.lib().eda_mha_fwd_hd64_drop_f32(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0),
-            v.stride(1), m8.data_ptr() if m8 is not None else None, B, num_heads, Lq, Lk, float(scale), out.data_ptr(),
-            torch.cuda.current_stream().cuda_stream)
-    _lib.check(rc, "eda_mha_fwd_hd64_f32")
+            v.stride(1), m8.data_ptr() if m8 is not None else None, B, num_heads, Lq, Lk, float(scale), float(p),
+            seed.data_ptr() if p > 0 else None, int(salt) & 0xFFFFFFFF, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "eda_mha_fwd_hd64_drop_f32")
     return out
 
 
@@ -71,6 +78,9 @@ class FrozenRobertaFast:
         self.pad = int(hf_model.embeddings.padding_idx)
         self._versions = self._param_versions()
         self.layers = []
+        self.counter = None                   # train mode: this encoder's own dropout counter (device int64), bumped per call
+        from .fused_ln import new_salt_base
+        self._salt = new_salt_base()
         import os
         # the encoder is FROZEN: its weights are split once into bf16 x 3 planes and every linear layer runs on the bf16
         # matrix pipe at fp32 accuracy (csrc/gemm_frozen.hip; EDA_FROZEN_B3=0: the fp32-MFMA row products of csrc/gemm.hip)
@@ -101,34 +111,54 @@ class FrozenRobertaFast:
         if L > 256:
             raise NotImplementedError("FrozenRobertaFast: utterances of up to 256 tokens (csrc/mha_hd64.hip keeps K/V in LDS)")
         emb = m.embeddings
+        train = bool(m.training)
+        ph = float(self.cfg.hidden_dropout_prob) if train else 0.0
+        pa = float(self.cfg.attention_probs_dropout_prob) if train else 0.0
+        cnt, sb = None, self._salt
+        if ph > 0 or pa > 0:
+            if self.counter is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("roberta_fast: run one eager train-mode forward before capturing (dropout counter)")
+                from .attention import _initial_dropout_counter
+                self.counter = torch.full((1,), _initial_dropout_counter() ^ 0x5EED, dtype=torch.int64, device=input_ids.device)
+            cnt = self.counter
+            cnt.add_(1)                       # (capturable: every replay draws new masks)
         nonpad = input_ids.ne(self.pad)
         position_ids = torch.cumsum(nonpad.long(), dim=1) * nonpad.long() + self.pad    # create_position_ids_from_input_ids
         x = emb.word_embeddings.weight[input_ids].view(B * L, d)
         y = (emb.position_embeddings.weight[position_ids] + emb.token_type_embeddings.weight[0]).view(B * L, d)
         h = _ln_residual(x, y, None, emb.LayerNorm.weight, emb.LayerNorm.bias, self.eps)
+        if ph > 0:                                                              # RobertaEmbeddings: dropout(LayerNorm(.))
+            with torch.cuda.device(h.device):
+                rc = _lib.lib().eda_dropout_f32(h.data_ptr(), h.numel(), ph, cnt.data_ptr(), (sb + 1) & 0xFFFFFFFF, h.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "eda_dropout_f32")
         kpm = attention_mask.eq(0)                                              # True = padding key
         scale = 64 ** -0.5
-        for ent in self.layers:
+        for li, ent in enumerate(self.layers):
             lyr = ent["lyr"]
             pl = ent["planes"]
             ao = lyr.attention.output
+            s0 = sb + 8 + 4 * li              # salts of this layer's three dropout sites
             if pl is not None:
                 W = ent["w"]
                 qkv = _frozen_or_fp32(h, pl[0], W[0], ent["bqkv"], 0).view(B, L, 3 * d)
-                ctx = attention_hd64(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], kpm, self.heads, scale)
+                ctx = attention_hd64(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], kpm, self.heads, scale, pa, cnt, s0)
                 y = _frozen_or_fp32(ctx.view(B * L, d), pl[1], W[1], None, 0)   # (bias added by the LayerNorm kernel)
-                h = _ln_residual(h, y, ao.dense.bias, ao.LayerNorm.weight, ao.LayerNorm.bias, self.eps)
+                h = _ln_residual(h, y, ao.dense.bias, ao.LayerNorm.weight, ao.LayerNorm.bias, self.eps, p=ph, seed=cnt, salt=s0 + 1)
                 t = _frozen_or_fp32(h, pl[2], W[2], lyr.intermediate.dense.bias, 2)
                 y = _frozen_or_fp32(t, pl[3], W[3], None, 0)
-                h = _ln_residual(h, y, lyr.output.dense.bias, lyr.output.LayerNorm.weight, lyr.output.LayerNorm.bias, self.eps)
+                h = _ln_residual(h, y, lyr.output.dense.bias, lyr.output.LayerNorm.weight, lyr.output.LayerNorm.bias, self.eps,
+                                 p=ph, seed=cnt, salt=s0 + 2)
                 continue
             qkv = gemm.linear_fwd(h, ent["wqkv"], ent["bqkv"]).view(B, L, 3 * d)
-            ctx = attention_hd64(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], kpm, self.heads, scale)
+            ctx = attention_hd64(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], kpm, self.heads, scale, pa, cnt, s0)
             y = gemm.linear_fwd(ctx.view(B * L, d), ao.dense.weight)            # (bias added by the LayerNorm kernel)
-            h = _ln_residual(h, y, ao.dense.bias, ao.LayerNorm.weight, ao.LayerNorm.bias, self.eps)
+            h = _ln_residual(h, y, ao.dense.bias, ao.LayerNorm.weight, ao.LayerNorm.bias, self.eps, p=ph, seed=cnt, salt=s0 + 1)
             t = _gelu_linear(h, lyr.intermediate.dense.weight, lyr.intermediate.dense.bias)
             y = gemm.linear_fwd(t, lyr.output.dense.weight)
-            h = _ln_residual(h, y, lyr.output.dense.bias, lyr.output.LayerNorm.weight, lyr.output.LayerNorm.bias, self.eps)
+            h = _ln_residual(h, y, lyr.output.dense.bias, lyr.output.LayerNorm.weight, lyr.output.LayerNorm.bias, self.eps,
+                             p=ph, seed=cnt, salt=s0 + 2)
         return h.view(B, L, d)
 
 
@@ -171,5 +201,4 @@ def supported(hf_model, input_ids):
     cfg = getattr(hf_model, "config", None)
     return (input_ids.is_cuda and cfg is not None and getattr(cfg, "hidden_act", None) == "gelu"
             and hasattr(hf_model, "encoder") and hasattr(hf_model, "embeddings")
-            and cfg.hidden_size == 64 * cfg.num_attention_heads and input_ids.shape[1] <= 256
-            and not hf_model.training)
+            and cfg.hidden_size == 64 * cfg.num_attention_heads and input_ids.shape[1] <= 256)

@@ -204,6 +204,16 @@ int eda_mha_bwd_f32(const float *q, const float *k, const float *v, long q_sb, l
 int eda_mha_fwd_hd64_f32(const float *q, const float *k, const float *v, long q_sb, long q_sl, long k_sb, long k_sl,
                          long v_sb, long v_sl, const unsigned char *key_padding_mask, int B, int H, int Lq, int Lk,
                          float scale, float *out, void *stream);
+/* The same with dropout on the probabilities (RobertaSelfAttention.dropout) and eda_dropout_f32 for RobertaEmbeddings.dropout:
+ * the reference trains with the WHOLE model in train mode (main_utils.py:459 model.train()), so its frozen text encoder runs
+ * with its dropout layers active.  Masks: the library's counter-based hash (seed_ptr = the device-side counter, one salt per
+ * call site), as in eda_mha_fwd_f32 / eda_add_dropout_ln_fwd_f32.  p_drop = 0: the entry above. */
+int eda_mha_fwd_hd64_drop_f32(const float *q, const float *k, const float *v, long q_sb, long q_sl, long k_sb, long k_sl,
+                              long v_sb, long v_sl, const unsigned char *key_padding_mask, int B, int H, int Lq, int Lk,
+                              float scale, float p_drop, const unsigned long long *seed_ptr, unsigned salt, float *out,
+                              void *stream);
+int eda_dropout_f32(const float *x, long n, float p_drop, const unsigned long long *seed_ptr, unsigned salt, float *out,
+                    void *stream);
 
 /* ws: scratch of eda_mha_bwd_workspace_bytes() (0 = none needed: ws may be NULL), required when non-zero:
  * the split ranges' tickets and dense partials ("eda_mha_bwd and the split ranges" below).      */
