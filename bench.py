@@ -1169,9 +1169,10 @@ def main():
             "in_step": in_step,
             "native_ms_per_step": round(native_ms, 3),
             "fps": fps_info,
-            "kernel_timing": ("HIP events on the launch stream, %d eager runs of the same step after the "
-                              "graph-replayed timed region" % args.kernel_steps) if args.graph else
-                             "HIP events on the launch stream inside the timed region",
+            "kernel_timing": (("HIP events on the launch stream, %d eager runs of the same step after the "
+                               "graph-replayed timed region" % args.kernel_steps) if args.graph else
+                              "HIP events on the launch stream inside the timed region") +
+                             "; per op and shape the median bracket (mean below five calls)",
             "kernels": kernels[:40],
             "gemm_family_ms_per_step": round(sum(k["ms"] * k["calls_per_step"] for k in kernels
                                                  if k["op"].startswith(("gemm_", "sa_fused", "wgrad"))), 3),

@@ -289,10 +289,22 @@ def usable(end_points, set_criterion, assign):
         return False
     if any(n not in ("boxes", "labels", "contrastive_align") for n in set_criterion.losses):
         return False
+    maps = [end_points.get(k) for k in _KEYS]
+    if any(m is None or m.dtype != torch.float32 or m.dim() != 3 or m.stride(2) != 1 or m.shape != maps[0].shape for m in maps):
+        return False
+    if maps[0].shape[2] < t.shape[-1]:                      # (the kernels read map columns [0, classes) and [0, tokens))
+        return False
+    for k in ("center_label", "size_gts"):
+        v = end_points.get(k)
+        if v is None or v.dtype != torch.float32 or v.dim() != 3 or v.stride(2) != 1 or v.shape[2] < 3:
+            return False
+    if end_points["sem_cls_label"].dtype != torch.int64:
+        return False
     if "contrastive_align" in set_criterion.losses:
         if "proj_tokens" not in end_points:
             return False
-        if not _lib.lib().eda_sem_align_supported(int(t.shape[1]), int(end_points["proj_tokens"].shape[1])):
+        L = int(end_points["proj_tokens"].shape[1])
+        if L > maps[0].shape[2] or not _lib.lib().eda_sem_align_supported(int(t.shape[1]), L):
             return False
     return True
 

@@ -24,6 +24,7 @@ for name, what in [("default", "headline: fp32, B = 8 x 50 000 points, 256 queri
                    ("130_tokens", "130-token utterances (configs[4] shape, fp32)"),
                    ("hungarian_loss", "the REAL loss (Hungarian matching + `SetCriterion` + seed objectness) inside the graph (`--loss hungarian`; ~32 launches, `csrc/loss.hip`)"),
                    ("hungarian_loss_torch_form", "the same loss in its element-wise torch form (`EDA_FUSED_LOSS=0`: 690 launches; rounds 1-5)"),
+                   ("text_encoder_eval", "the frozen text encoder in eval mode (`--text-encoder-mode eval`: no dropout inside it; what rounds 1-5 timed -- the reference trains with it in train mode)"),
                    ("attn_bf16", "configs[2]: bf16-MFMA attention contractions (`--attn-dtype bf16`; separate line, never the headline)"),
                    ("attn_f16_130_tokens", "configs[4] on one GPU: fp16 attention + 130 tokens"),
                    ("split_graphs", "the N > 1 graph structure on one GPU (`--split-graphs`)"),
