@@ -153,6 +153,10 @@ def load_checkpoint(model, path, optimizer=None, scheduler=None, map_location="c
         if p0 is not None and p0.is_cuda:
             from . import attention
             attention.set_dropout_counter(p0.device, ckpt["eda_dropout_counter"])
+            te = getattr(model, "text_encoder", None)
+            if te is not None and ckpt.get("eda_text_dropout_counter") is not None:
+                from . import roberta_fast
+                roberta_fast.set_dropout_counter(te, ckpt["eda_text_dropout_counter"])
     return int(ckpt.get("epoch", 0)), list(res.missing_keys), list(res.unexpected_keys)
 
 
@@ -176,6 +180,10 @@ def save_checkpoint(model, path, optimizer=None, scheduler=None, epoch=0, config
         # continues the mask stream instead of replaying it
         from . import attention
         state["eda_dropout_counter"] = attention.get_dropout_counter(p0.device)
+        te = getattr(model, "text_encoder", None)
+        if te is not None:                       # (the frozen encoder's own counter: it may run on a second stream)
+            from . import roberta_fast
+            state["eda_text_dropout_counter"] = roberta_fast.get_dropout_counter(te)
     os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
     torch.save(state, path)
     return state

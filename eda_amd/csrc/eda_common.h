@@ -130,6 +130,31 @@ __device__ __forceinline__ unsigned eda_row_min_u32(unsigned v) {
   v = min(v, (unsigned)eda_dpp<EDA_DPP_ROW_ROR(8)>((int)v));
   return v;
 }
+// fp32 sum / max over the 64 lanes, every lane gets the result: four DPP steps inside the 16-lane rows, two gfx950 lane swaps
+// across them -- six short VALU instructions instead of the six ds_bpermute round trips of a __shfl_xor butterfly (a dependent
+// chain of LDS-crossbar latencies: what the row statistics of the LayerNorm kernels waited for).
+typedef unsigned eda_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float eda_wave_sum_f32(float v) {
+  v += __int_as_float(eda_dpp<EDA_DPP_QUAD_XOR1>(__float_as_int(v)));
+  v += __int_as_float(eda_dpp<EDA_DPP_QUAD_XOR2>(__float_as_int(v)));
+  v += __int_as_float(eda_dpp<EDA_DPP_ROW_ROR(4)>(__float_as_int(v)));
+  v += __int_as_float(eda_dpp<EDA_DPP_ROW_ROR(8)>(__float_as_int(v)));
+  eda_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r.x) + __uint_as_float(r.y);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float eda_wave_max_f32(float v) {
+  v = fmaxf(v, __int_as_float(eda_dpp<EDA_DPP_QUAD_XOR1>(__float_as_int(v))));
+  v = fmaxf(v, __int_as_float(eda_dpp<EDA_DPP_QUAD_XOR2>(__float_as_int(v))));
+  v = fmaxf(v, __int_as_float(eda_dpp<EDA_DPP_ROW_ROR(4)>(__float_as_int(v))));
+  v = fmaxf(v, __int_as_float(eda_dpp<EDA_DPP_ROW_ROR(8)>(__float_as_int(v))));
+  eda_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+}
+
 // Wave-wide all-reduce; the result is wave-uniform (SGPR).
 __device__ __forceinline__ int eda_wave_max_i32(int v) {
   v = eda_row_max_i32(v);

@@ -18,11 +18,7 @@ __device__ __forceinline__ unsigned ln_hash32(unsigned x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
-__device__ __forceinline__ float ln_wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+__device__ __forceinline__ float ln_wave_sum(float v) { return eda_wave_sum_f32(v); }
 
 struct LnDrop {
   bool on; unsigned seed, thresh; float inv_keep;
@@ -358,11 +354,7 @@ extern "C" int eda_ln_reduce_grouped_f32(const long long *desc, int nsites, int 
 namespace {
 constexpr int L2_MAXC = 1024;
 
-__device__ __forceinline__ float l2_wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+__device__ __forceinline__ float l2_wave_sum(float v) { return eda_wave_sum_f32(v); }
 
 __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float *__restrict__ x, long R, int C, float eps,
                                                          float *__restrict__ y, float *__restrict__ norm) {

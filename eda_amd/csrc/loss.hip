@@ -193,16 +193,8 @@ extern "C" int eda_box_loss_bwd_f32(const float *g_l1, const float *g_giou, cons
 // NOT repeated per head: scene b of the targets serves rows pb with pb % B == b.
 namespace {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return eda_wave_sum_f32(v); }
+__device__ __forceinline__ float wave_max(float v) { return eda_wave_max_f32(v); }
 
 // tq[pb][q] = the target slot g < ntargets whose assignment is q, else -1 (one workgroup per pb)
 __global__ __launch_bounds__(256) void match_slots_kernel(const int *__restrict__ assign, const int *__restrict__ ntargets,

@@ -502,11 +502,7 @@ __global__ __launch_bounds__(CL_THREADS) void bn_relu_bwd_stats_vec_kernel(
 constexpr int SM_THREADS = 1024;
 constexpr int SM_WAVES = SM_THREADS / 64;
 
-__device__ __forceinline__ float wave_sum64(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+__device__ __forceinline__ float wave_sum64(float v) { return eda_wave_sum_f32(v); }
 
 // Element dropout fused behind the ReLU (the heads' Conv-BN-ReLU-Dropout): the same counter-based
 // hash as csrc/ln.hip (step counter x call-site salt, element index), regenerated in the backward.

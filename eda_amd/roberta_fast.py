@@ -192,9 +192,32 @@ def encode(hf_model, input_ids, attention_mask):
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("roberta_fast: the packed weights must be built before a HIP graph is captured "
                                "(run one eager encode_text_frozen first)")
+        prev = fast
         fast = FrozenRobertaFast(hf_model)
+        if prev is not None and prev.m is hf_model:           # repacked after an in-place weight update: the mask stream goes on
+            fast.counter, fast._salt = prev.counter, prev._salt
         object.__setattr__(hf_model, "_eda_fast", fast)       # (not a sub-module / parameter: a plain attribute)
     return fast(input_ids, attention_mask)
+
+
+def get_dropout_counter(hf_model):
+    """Value of the train-mode dropout counter of this encoder's fast forward (host int; synchronises), or None before its
+    first train-mode call.  eda_amd/checkpoint.py stores it next to the library's other counter."""
+    fast = hf_model.__dict__.get("_eda_fast")
+    return None if fast is None or fast.counter is None else int(fast.counter.item())
+
+
+def set_dropout_counter(hf_model, value):
+    """Continue a saved mask stream (in place when the counter exists: graphs that captured it keep working)."""
+    fast = hf_model.__dict__.get("_eda_fast")
+    if fast is None or fast.m is not hf_model:
+        fast = FrozenRobertaFast(hf_model)
+        object.__setattr__(hf_model, "_eda_fast", fast)
+    dev = next(hf_model.parameters()).device
+    if fast.counter is None:
+        fast.counter = torch.full((1,), int(value), dtype=torch.int64, device=dev)
+    else:
+        fast.counter.fill_(int(value))
 
 
 def supported(hf_model, input_ids):

@@ -79,6 +79,7 @@ def test_hoisted_decoder_kv_projections_equal_per_layer_projections(monkeypatch)
     model.train().to(dev)
     inputs = MF.full_model_inputs(7, max_len=16)
     inputs = {k: ({kk: vv.to(dev) for kk, vv in v.items()} if isinstance(v, dict) else v.to(dev)) for k, v in inputs.items()}
+    from eda_amd import roberta_fast
     bn_state = {k: v.clone() for k, v in model.state_dict().items()}
     counter = attention.get_dropout_counter(torch.device(dev))
     res = {}
@@ -86,6 +87,7 @@ def test_hoisted_decoder_kv_projections_equal_per_layer_projections(monkeypatch)
         monkeypatch.setenv("EDA_HOIST_KV", hoist)
         model.load_state_dict(bn_state)                      # (running statistics move in train mode)
         attention.set_dropout_counter(torch.device(dev), counter)
+        roberta_fast.set_dropout_counter(model.text_encoder, 777)      # (the frozen encoder's own mask stream, train mode)
         torch.manual_seed(11)                                # (anything that draws from torch's generator)
         model.zero_grad(set_to_none=True)
         ep = model(inputs)

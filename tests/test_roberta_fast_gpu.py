@@ -98,6 +98,14 @@ def test_train_mode_runs_the_encoders_dropout_layers():
     d_mean = float((mean - ref)[keep].abs().mean())
     d_one = float((a - ref)[keep].abs().mean())
     assert d_one > 1e-3 and d_mean < 0.6 * d_one, (d_one, d_mean)
+    # an in-place weight update makes the packed copy stale: the repacked forward continues the same mask stream
+    c0 = roberta_fast.get_dropout_counter(mt)
+    with torch.no_grad():
+        mt.embeddings.LayerNorm.bias.add_(0.0)
+    roberta_fast.encode(mt, ids, am)
+    assert mt.__dict__["_eda_fast"] is not fast and roberta_fast.get_dropout_counter(mt) == c0 + 1
+    roberta_fast.set_dropout_counter(mt, c0 - 24 - 1)      # (checkpoint resume: eda_amd/checkpoint.py)
+    assert torch.equal(roberta_fast.encode(mt, ids, am), a)
 
 
 def test_dropout_primitives():
