@@ -514,6 +514,11 @@ def main():
         bt = make_inputs(rank + k_ * world, args.per_gpu, device, args.points, args.tokens)
         if args.loss == "hungarian":
             tg = make_targets(rank + k_ * world, args.per_gpu, device, bt)
+            if dist_on:
+                # the loss's normaliser is the GLOBAL batch's box count (losses.py:630-636): formed here, when the batch arrives,
+                # so that the captured step holds no collective (a loader would do the same one batch ahead)
+                from eda_amd import losses as _L
+                tg["num_boxes_global"] = _L.global_box_count(tg["box_label_mask"])
             target_keys = sorted(tg)
             bt.update(tg)
         batches.append(bt)

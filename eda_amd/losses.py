@@ -212,6 +212,19 @@ def count_boxes(ntargets):
     return num_boxes
 
 
+def global_box_count(box_label_mask):
+    """The loss's normaliser -- real target boxes of the GLOBAL batch (losses.py:630-636: sum over the scenes, all-reduced over
+    the ranks) -- from a batch's `box_label_mask` alone, as a (1,) float32 tensor.  It depends on the targets only, so a data
+    loader can form it when the batch arrives and hand it over as end_points["num_boxes_global"]: compute_hungarian_loss then runs
+    NO collective, which is what lets the loss live inside a captured HIP graph at N > 1 (a collective captured in the step is
+    queried by RCCL's watchdog thread while the stream captures: the process aborts, bench.py --force-dist --loss hungarian did
+    in 2 of 3 runs).  Same number as the reference's in-loss all-reduce."""
+    nb = (box_label_mask > 0).sum().to(torch.float32).reshape(1)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(nb)
+    return nb
+
+
 class SetCriterion(nn.Module):
     """Position-aligned cross entropy, box L1 + GIoU and semantic-alignment contrastive losses
     (losses.py:339-647) on padded targets."""
@@ -343,7 +356,8 @@ def compute_hungarian_loss(end_points, num_decoder_layers, set_criterion, query_
     same keys into end_points.  The reference runs matcher + criterion once per head; here the P
     heads are stacked into the batch dimension -- one (P*B, Q, G) cost, ONE assignment launch,
     one pass of each loss -- and the per-head values are read off the per-scene sums.
-    `assign`: optional {prefix: (B,G) assignment} (tests on CPU).  On CUDA tensors the same arithmetic runs as a handful
+    `assign`: optional {prefix: (B,G) assignment} (tests on CPU).  end_points["num_boxes_global"] (optional, (1,) float:
+    global_box_count of this batch) replaces the in-loss all-reduce of the box count.  On CUDA tensors the same arithmetic runs as a handful
     of fused launches (losses_fused.py / csrc/loss.hip) unless EDA_FUSED_LOSS=0."""
     from . import losses_fused
     if losses_fused.usable(end_points, set_criterion, assign):
@@ -367,7 +381,9 @@ def compute_hungarian_loss(end_points, num_decoder_layers, set_criterion, query_
         out["proj_queries"] = stack("proj_queries")
         out["tokenized"] = {"attention_mask": rep(end_points["tokenized"]["attention_mask"])}
     a_in = None if assign is None else torch.cat([assign[p] for p in prefixes], dim=0)
-    losses, a = set_criterion.forward_padded(out, tgt, rep(nt), rep(valid), a_in, num_boxes=count_boxes(nt),
+    nb = end_points.get("num_boxes_global")          # (the caller's: global_box_count() outside the step) or counted here
+    losses, a = set_criterion.forward_padded(out, tgt, rep(nt), rep(valid), a_in,
+                                             num_boxes=count_boxes(nt) if nb is None else nb.to(torch.float32).reshape(1),
                                              per_scene=True)
     tot = {"loss_ce": 0, "loss_bbox": 0, "loss_giou": 0, "loss_sem_align": 0}
     for k, v in losses.items():

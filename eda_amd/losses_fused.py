@@ -317,7 +317,10 @@ def compute_hungarian_loss(end_points, num_decoder_layers, set_criterion, query_
     nt, valid_u8, tgt_boxes, tgt_labels, mp, nb = compact_targets(
         end_points["box_label_mask"], end_points["center_label"], end_points["size_gts"], end_points["sem_cls_label"],
         [end_points[k] for k in _KEYS])
-    if dist.is_available() and dist.is_initialized():
+    given = end_points.get("num_boxes_global")
+    if given is not None:                                     # losses.global_box_count(): formed outside the (captured) step
+        nb = given.to(torch.float32).reshape(1)
+    elif dist.is_available() and dist.is_initialized():
         dist.all_reduce(nb)                                   # losses.py:630-636: boxes of the global batch
     maps = dict(zip(_KEYS, mp))
     B, G = tgt_boxes.shape[:2]

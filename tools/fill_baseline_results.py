@@ -24,6 +24,8 @@ for name, what in [("default", "headline: fp32, B = 8 x 50 000 points, 256 queri
                    ("130_tokens", "130-token utterances (configs[4] shape, fp32)"),
                    ("hungarian_loss", "the REAL loss (Hungarian matching + `SetCriterion` + seed objectness) inside the graph (`--loss hungarian`; ~32 launches, `csrc/loss.hip`)"),
                    ("hungarian_loss_torch_form", "the same loss in its element-wise torch form (`EDA_FUSED_LOSS=0`: 690 launches; rounds 1-5)"),
+                   ("force_dist_hungarian", "the N > 1 step structure + the real loss (`--force-dist --loss hungarian`): the loss's global box count is formed when the batch arrives (`losses.global_box_count`), the captured step holds no collective"),
+                   ("force_dist_sync_bn_native_hungarian", "the reference's whole training configuration on one rank: SyncBatchNorm (peer memory) + DDP step structure + real loss (`--force-dist --sync-bn native --loss hungarian`)"),
                    ("text_encoder_eval", "the frozen text encoder in eval mode (`--text-encoder-mode eval`: no dropout inside it; what rounds 1-5 timed -- the reference trains with it in train mode)"),
                    ("attn_bf16", "configs[2]: bf16-MFMA attention contractions (`--attn-dtype bf16`; separate line, never the headline)"),
                    ("attn_f16_130_tokens", "configs[4] on one GPU: fp16 attention + 130 tokens"),

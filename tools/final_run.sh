@@ -43,6 +43,8 @@ EDA_GEMM_B3ROWS=0 python bench.py --in-step-steps 0 > $O/bench_b3rows_off.json 2
 EDA_MHA2_BWD_MERGE=0 EDA_MHA2_BWD_DBUF=0 python bench.py --in-step-steps 0 > $O/bench_mha_bwd_r05_form.json 2> $O/bench_mha_bwd_r05_form.err
 EDA_FROZEN_B3=0 python bench.py --in-step-steps 0 > $O/bench_frozen_b3_off.json 2> $O/bench_frozen_b3_off.err
 EDA_MHA4=1 python bench.py --in-step-steps 0 > $O/bench_mha4_on.json 2> $O/bench_mha4_on.err
+python bench.py --force-dist --loss hungarian --in-step-steps 0 > $O/bench_force_dist_hungarian.json 2> $O/bench_force_dist_hungarian.err
+python bench.py --force-dist --sync-bn native --loss hungarian --in-step-steps 0 > $O/bench_force_dist_sync_bn_native_hungarian.json 2> $O/bench_force_dist_sync_bn_native_hungarian.err
 python bench.py --text-encoder-mode eval --in-step-steps 0 > $O/bench_text_encoder_eval.json 2> $O/bench_text_encoder_eval.err
 EDA_FUSED_LOSS=0 python bench.py --loss hungarian --in-step-steps 0 > $O/bench_hungarian_loss_torch_form.json 2> $O/bench_hungarian_loss_torch_form.err
 python tools/loss_census.py > $O/loss_census.txt 2>&1
