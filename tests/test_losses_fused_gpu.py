@@ -48,6 +48,9 @@ GRAD_KEYS = [k for k in LF.GRAD_KEYS if k != "seeds_obj_cls_logits"]
     ("sr3d", 3, 32, 20, (2, 0, 5)),
     ("scanrefer", 8, 256, 130, (3, 1, 2, 8, 1, 1, 4, 2)),
     ("scanrefer", 2, 64, 256, (1, 6)),
+    ("sr3d", 1, 4, 21, (3,)),                       # one scene, four queries, an odd token count
+    ("scanrefer", 5, 68, 33, (4, 4, 0, 0, 1)),      # query count not a multiple of 64 / of the chunk size
+    ("sr3d", 2, 128, 255, (9, 2)),                  # LDS nearly full: the column sums meet a few waves at a time
 ])
 def test_fused_loss_equals_torch_form(dataset, B, Q, L, counts, monkeypatch):
     from eda_amd import losses_fused
