@@ -625,8 +625,18 @@ def main():
         record_loss(loss)
         return loss
 
+    # clip + AdamW as two launches on the flat buffers (csrc/optim.hip; torch's optimizer object keeps the state);
+    # EDA_FLAT_ADAMW=0: FlatParams.clip_grad_norm_ + torch's fused AdamW (~12 launches; rounds 1-6)
+    flat_opt = None
+    if os.environ.get("EDA_FLAT_ADAMW", "1") != "0":
+        from eda_amd.parallel import FlatClipAdamW
+        flat_opt = FlatClipAdamW(flat, opt)
+
     def update():
-        flat.clip_grad_norm_(0.1, pre_scale=1.0 / world)      # main_utils.py:483-486 (on the mean over ranks)
+        if flat_opt is not None:
+            flat_opt.step(0.1, 1.0 / world)                   # main_utils.py:483-486 (on the mean over ranks) + :277-305
+            return
+        flat.clip_grad_norm_(0.1, pre_scale=1.0 / world)
         opt.step()
 
     def core_step():
@@ -1158,6 +1168,9 @@ def main():
                                         " of the NEXT step's batch on the second stream during the "
                                         "current step (once per step; --fps-prefetch 0 puts it back on the critical path)")
                        if (args.graph and args.text_stream and not args.overlap and args.fps_prefetch) else "inside the step",
+                       "optimizer": ("clip_grad_norm_(0.1) + AdamW(3 lr groups, weight_decay 5e-4) as two launches on the flat buffers "
+                                     "(csrc/optim.hip; torch.optim.AdamW keeps the state)") if flat_opt is not None else
+                                    "FlatParams.clip_grad_norm_ + torch.optim.AdamW(fused, capturable)",
                        "attention_dtype": args.attn_dtype,
                        "deterministic": bool(args.deterministic),
                        "own_gemms": "every pointwise layer of the model AND of the frozen text encoder (csrc/gemm.hip)" if fast_roberta

@@ -103,6 +103,9 @@ SIGNATURES = {
     "eda_pos_align_chunk": (_i, [_i, _i]),
     "eda_pos_align_fwd_f32": (_i, [_p, _p, _p, _p, _l, _l, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p]),
     "eda_scale_by_scene_f32": (_i, [_p, _p, _p, _i, _l, _l, _i, _p, _p]),
+    "eda_grad_sumsq_workspace_bytes": (_sz, []),
+    "eda_grad_sumsq_f32": (_i, [_p, _l, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
+    "eda_adamw_flat_f32": (_i, [_p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _p]),
     "eda_compact_targets": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p]),
     "eda_loss_combine_fwd_f32": (_i, [_p, _p, _p, _p, _f, _f, _i, _i, _p, _p, _p, _p]),
     "eda_loss_combine_bwd_f32": (_i, [_p, _p, _f, _f, _p, _p, _p, _i, _p]),

@@ -304,6 +304,80 @@ class FlatParams:
         return norm
 
 
+class FlatClipAdamW:
+    """clip_grad_norm_ + torch.optim.AdamW.step() of a FlatParams model as TWO launches (csrc/optim.hip) instead of ~12: the
+    norm of the flat gradient (+ the step counters, + the learning rates read from a pinned host array), then one pass that
+    applies the clip coefficient, the decoupled weight decay, both moments and the bias corrections.  `optimizer` is a
+    torch.optim.AdamW over flat.groups (amsgrad / maximize off) and stays the OWNER of the state: its state_dict()
+    (step, exp_avg, exp_avg_sq per group) is what checkpoints carry (eda_amd/checkpoint.py) and stepping it with
+    optimizer.step() instead gives the same numbers to fp32 rounding (tests/test_flat_adamw_gpu.py).  Learning rates are read
+    from optimizer.param_groups at every step() -- a host write, so a scheduler works across replays of a captured graph:
+    call sync_lrs() before each replay."""
+
+    def __init__(self, flat, optimizer):
+        import ctypes
+        from . import _lib
+        self.flat, self.opt = flat, optimizer
+        groups = optimizer.param_groups
+        assert 1 <= len(groups) <= 4 and all(len(g["params"]) == 1 for g in groups), "one flat parameter per group, at most 4 groups"
+        assert not any(g.get("amsgrad") or g.get("maximize") for g in groups), "amsgrad / maximize are not implemented"
+        dev = flat.flat_param.device
+        base = flat.flat_param.data_ptr()
+        self.lo, self.hi = [], []
+        for g in groups:
+            p = g["params"][0]
+            off = (p.data_ptr() - base) // 4
+            assert p.is_contiguous() and 0 <= off and off + p.numel() <= flat.flat_param.numel() and off % 4 == 0
+            self.lo.append(off)
+            self.hi.append(off + p.numel())
+            st = optimizer.state[p]
+            if "step" not in st:                                   # torch's own lazy initialisation, capturable layout
+                st["step"] = torch.zeros((), dtype=torch.float32, device=dev)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            assert st["step"].is_cuda and st["step"].dtype == torch.float32, "AdamW(capturable=True) keeps its step on the device"
+        n = len(groups)
+        self.n = n
+        self.ws = torch.zeros(_lib.lib().eda_grad_sumsq_workspace_bytes(), dtype=torch.uint8, device=dev)
+        self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.lr_host = torch.zeros(4, dtype=torch.float32).pin_memory()
+        self.lr_dev = torch.zeros(12, dtype=torch.float32, device=dev)      # rates | bias corrections (csrc/optim.hip)
+        self._c, self._lib = ctypes, _lib
+        self.sync_lrs()
+
+    def sync_lrs(self):
+        """Current learning rates of the groups into the pinned array the next step (or graph replay) reads."""
+        for k, g in enumerate(self.opt.param_groups):
+            self.lr_host[k] = float(g["lr"])
+
+    def step(self, max_norm=0.0, pre_scale=1.0):
+        """Returns |grad|_2 * pre_scale as a device tensor (what clip_grad_norm_ returns)."""
+        c, L = self._c, self._lib
+        self.sync_lrs()
+        fl, groups = self.flat, self.opt.param_groups
+        sts = [self.opt.state[g["params"][0]] for g in groups]
+        P = c.c_void_p * self.n
+        F = c.c_float * self.n
+        LG = c.c_long * self.n
+        steps = P(*[s["step"].data_ptr() for s in sts])
+        n = fl.flat_grad.numel()
+        stream = torch.cuda.current_stream().cuda_stream
+        with torch.cuda.device(fl.flat_grad.device):
+            D = c.c_double * self.n
+            b1, b2 = D(*[g["betas"][0] for g in groups]), D(*[g["betas"][1] for g in groups])      # (doubles: 1 - beta is formed in double)
+            rc = L.lib().eda_grad_sumsq_f32(fl.flat_grad.data_ptr(), n, self.ws.data_ptr(), self.norm.data_ptr(), self.n, steps, b1, b2,
+                                            self.lr_host.data_ptr(), self.lr_dev.data_ptr(), stream)
+            L.check(rc, "eda_grad_sumsq_f32")
+            rc = L.lib().eda_adamw_flat_f32(
+                fl.flat_param.data_ptr(), fl.flat_grad.data_ptr(), n, self.n, LG(*self.lo), LG(*self.hi),
+                P(*[s["exp_avg"].data_ptr() for s in sts]), P(*[s["exp_avg_sq"].data_ptr() for s in sts]), steps,
+                self.lr_dev.data_ptr(), b1, b2,
+                F(*[g["eps"] for g in groups]), F(*[g["weight_decay"] for g in groups]), self.norm.data_ptr(), float(max_norm),
+                float(pre_scale), stream)
+            L.check(rc, "eda_adamw_flat_f32")
+        return self.norm * pre_scale if pre_scale != 1.0 else self.norm
+
+
 def reserve_cus_for_collectives(cus=32):
     """N > 1: keep `cus` CUs out of the furthest point sampler's co-residency plan (include/eda_hip.h:
     eda_fps_set_cu_reserve) -- RCCL's channel workgroups spin on their peers like the sampler's workgroups spin on each

@@ -721,6 +721,22 @@ int eda_sem_align_fwd_f32(const float *logits, const long *tq, const float *cons
  * scene; positives = the topk (<= 8) seeds of each real target's instance nearest its centre in box-normalised distance (equal
  * distances: lowest seed index -- the reference's torch.topk leaves that choice to the library).  loss (B) = per-scene shares of
  * the reference's scalar; grad0 (B, K) = d sum(loss) / d logits. */
+/* ---- The tail of a training step on flat buffers (csrc/optim.hip) -------------------------------------------------------------
+ * main_utils.py:483-486 clips the global gradient norm (torch.nn.utils.clip_grad_norm_, 0.1) and :277-305 updates three
+ * learning-rate groups with torch.optim.AdamW: on one flat parameter / gradient buffer (eda_amd/parallel.py FlatParams) that is
+ * two launches.  eda_grad_sumsq_f32: |grad|_2 (bit-reproducible: fixed-order partials), the groups' step counters + 1, the
+ * learning rates copied from a pinned host array (a scheduler changes them between replays of a captured graph).
+ * eda_adamw_flat_f32: clip coefficient (not written back to grad), decoupled weight decay, moments, bias corrections: the
+ * arithmetic of torch's fused AdamW (amsgrad off).  Group ranges are multiples of 4 floats; state tensors are the caller's
+ * (torch.optim.AdamW's own state_dict layout: step as one device float, exp_avg, exp_avg_sq). */
+size_t eda_grad_sumsq_workspace_bytes(void);
+int eda_grad_sumsq_f32(const float *grad, long n, void *ws /* zero before the first call */, float *norm_out, int nseg,
+                       float *const *steps, const double *beta1, const double *beta2, const float *lr_host,
+                       float *lr_dev /* 12 floats: rates | bias corrections */, void *stream);
+int eda_adamw_flat_f32(float *param, const float *grad, long n, int nseg, const long *lo, const long *hi, float *const *exp_avg,
+                       float *const *exp_avg_sq, float *const *steps, const float *lr_dev, const double *beta1, const double *beta2,
+                       const float *eps, const float *weight_decay, const float *norm, float max_norm, float pre_scale, void *stream);
+
 /* compute_hungarian_loss's two ends (models/losses.py:650-738).  eda_compact_targets: the padded targets with the valid slots first
  * (the reference's per-scene boolean indexing, :660-690) for up to 8 tensors of 4-byte words + counts, valid mask, box count.
  * eda_loss_combine_*: per-head values, totals and loss = w_obj * objectness + inv * (w . [ce, bbox, giou, sem]) (:716-738) and its
