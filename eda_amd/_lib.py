@@ -103,6 +103,7 @@ SIGNATURES = {
     "eda_pos_align_chunk": (_i, [_i, _i]),
     "eda_pos_align_fwd_f32": (_i, [_p, _p, _p, _p, _l, _l, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p]),
     "eda_scale_by_scene_f32": (_i, [_p, _p, _p, _i, _l, _l, _i, _p, _p]),
+    "eda_center_query_pos_f32": (_i, [_p, _p, _p, _l, _p, _p, _p]),
     "eda_grad_sumsq_workspace_bytes": (_sz, []),
     "eda_grad_sumsq_f32": (_i, [_p, _l, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
     "eda_adamw_flat_f32": (_i, [_p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _p]),

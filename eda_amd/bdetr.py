@@ -265,7 +265,7 @@ class BeaUTyDETR(nn.Module):
         from .posembed_batched import PosEmbedBatch
         pb = None
         if self.training and self.self_position_embedding == "loc_learned" and self.num_decoder_layers > 1:
-            probe = torch.cat([base_xyz, base_size], -1)
+            probe = hb.last_query_pos if (hb is not None and hb.last_query_pos is not None) else torch.cat([base_xyz, base_size], -1)
             if all(PosEmbedBatch.usable(getattr(L, "self_posembed", None), probe) for L in self.decoder):
                 pb = PosEmbedBatch()
         for i in range(self.num_decoder_layers):
@@ -275,7 +275,9 @@ class BeaUTyDETR(nn.Module):
             elif self.self_position_embedding == "xyz_learned":
                 query_pos = base_xyz
             elif self.self_position_embedding == "loc_learned":
-                query_pos = torch.cat([base_xyz, base_size], -1)
+                # (the batched heads form it in the launch that adds the centre residual)
+                query_pos = (hb.last_query_pos if (hb is not None and hb.last_query_pos is not None)
+                             else torch.cat([base_xyz, base_size], -1))
             else:
                 raise NotImplementedError
             query = self.decoder[i](query, vis, text_feats, query_pos, None, text_padding_mask,

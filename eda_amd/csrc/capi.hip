@@ -187,6 +187,36 @@ extern "C" int eda_device_copy_f32(const float *src, float *dst, size_t n, void 
   return 0;
 }
 
+// ---- a prediction head's box update (models/modules.py ClsAgnosticPredictHead: center = base_xyz + residual; the next decoder
+// layer's position input is cat([center, size]) of the detached values, models/bdetr.py:300-308) as one launch --------------
+namespace {
+__global__ __launch_bounds__(256) void center_query_pos_kernel(const float *__restrict__ base, const float *__restrict__ res,
+                                                               const float *__restrict__ size, long rows, float *__restrict__ center,
+                                                               float *__restrict__ qpos) {
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v = base[3 * r + c] + res[3 * r + c];
+    center[3 * r + c] = v;
+    qpos[6 * r + c] = v;
+    qpos[6 * r + 3 + c] = size[3 * r + c];
+  }
+}
+}  // namespace
+
+// base, res, size, center: (rows, 3) dense; qpos: (rows, 6) = [center | size]
+extern "C" int eda_center_query_pos_f32(const float *base, const float *res, const float *size, long rows, float *center, float *qpos,
+                                        void *stream_) {
+  EDA_CHECK_ARG(rows >= 0, "bad dimension");
+  if (rows == 0) return 0;
+  EDA_CHECK_ARG(base && res && size && center && qpos, "null pointer");
+  hipLaunchKernelGGL(center_query_pos_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, base, res, size,
+                     rows, center, qpos);
+  EDA_CHECK_LAUNCH();
+  return 0;
+}
+
 // ---- transposed copies of many small matrices in one launch --------------------------------------------
 // The input gradient of a linear layer, dX = dY W with W (N, K) row-major, contracts over W's ROW index; the
 // row-GEMM kernels read a weight fastest along the contraction (gemm.hip: "NT" form, 16-byte fragments).  Instead

@@ -194,6 +194,7 @@ class HeadsBatch:
 
     def __init__(self):
         self.recs, self.meta = [], []
+        self.last_query_pos = None          # cat([center, size]) of the head added last (values; None: not formed)
 
     @staticmethod
     def usable(heads, rows):
@@ -228,10 +229,25 @@ class HeadsBatch:
         self.recs.append(r)
         self.meta.append((head, base_xyz, end_points, prefix, B, Q))
         o = dict(zip(names, r.outs))
-        center = base_xyz + o["center_residual_head"].view(B, Q, 3)
+        res, size = o["center_residual_head"], o["size_pred_head"]
+        self.last_query_pos = None
+        if (not base_xyz.requires_grad and base_xyz.is_contiguous() and res.is_contiguous() and size.is_contiguous()
+                and base_xyz.dtype == res.dtype == size.dtype == torch.float32):
+            # center = base_xyz + residual AND the next decoder layer's position input cat([center, size]) (bdetr.py:300-308;
+            # both are values only here: the differentiable outputs are formed in finalize()) in one launch
+            from . import _lib
+            center = torch.empty((B, Q, 3), dtype=torch.float32, device=res.device)
+            qpos = torch.empty((B, Q, 6), dtype=torch.float32, device=res.device)
+            with torch.cuda.device(res.device):
+                rc = _lib.lib().eda_center_query_pos_f32(base_xyz.data_ptr(), res.data_ptr(), size.data_ptr(), B * Q, center.data_ptr(),
+                                                         qpos.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "eda_center_query_pos_f32")
+            self.last_query_pos = qpos
+        else:
+            center = base_xyz + res.view(B, Q, 3)
         # (kept for finalize(): the recorded output of the centre stack, unless base_xyz itself is differentiable)
         r.center = center.view(B * Q, 3) if not base_xyz.requires_grad else None
-        return center, o["size_pred_head"].view(B, Q, 3)
+        return center, size.view(B, Q, 3)
 
     def finalize(self):
         if not self.recs:

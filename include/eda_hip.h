@@ -721,6 +721,11 @@ int eda_sem_align_fwd_f32(const float *logits, const long *tq, const float *cons
  * scene; positives = the topk (<= 8) seeds of each real target's instance nearest its centre in box-normalised distance (equal
  * distances: lowest seed index -- the reference's torch.topk leaves that choice to the library).  loss (B) = per-scene shares of
  * the reference's scalar; grad0 (B, K) = d sum(loss) / d logits. */
+/* A prediction head's box update, models/modules.py (center = base_xyz + center_residual) and the next decoder layer's position
+ * input cat([center, size]) of models/bdetr.py:300-308, as one launch: center (rows, 3), qpos (rows, 6). */
+int eda_center_query_pos_f32(const float *base, const float *res, const float *size, long rows, float *center, float *qpos,
+                             void *stream);
+
 /* ---- The tail of a training step on flat buffers (csrc/optim.hip) -------------------------------------------------------------
  * main_utils.py:483-486 clips the global gradient norm (torch.nn.utils.clip_grad_norm_, 0.1) and :277-305 updates three
  * learning-rate groups with torch.optim.AdamW: on one flat parameter / gradient buffer (eda_amd/parallel.py FlatParams) that is
