@@ -12,7 +12,9 @@ import glob
 import re
 import sys
 
-NATIVE = re.compile(r"^(add_dropout_ln|add_n_kernel|ball_query|bf16x3_split|bn_|colsum|copy_kernel|det_scatter|fps_|gather_points|gemm_|gq_|"
+NATIVE = re.compile(r"^(adamw_flat|add_dropout_ln|add_n_kernel|ball_query|bf16x3_split|bn_|box_loss|center_query_pos|colsum|compact_targets|"
+                    r"copy_kernel|det_scatter|dropout_flat|fps_|gather_points|gemm_|gq_|grad_sumsq|loss_combine|match_|pos_align|"
+                    r"scale_by_scene|seed_objectness|sem_align|"
                     r"group_|l2norm_|linear_frozen|ln_reduce|lsa_|mha|peer_|rows_scatter|sa_|three_|tiny_out|transpose_batch|wcolsum|"
                     r"weight_transpose|wgrad|zero_kernel)")
 
