@@ -120,6 +120,12 @@ def algorithmic_flops(name):
         return f if op == "sa_fused_fwd" else 2.0 * f      # dX + dW (the first layer's dX only where it is needed)
     if op == "wgrad_grouped" and len(d) >= 4:
         return 2.0e6 * d[3]                  # (targets, jobs, tiles, 10^6 multiply-adds of all dW = dY^T X)
+    if op == "gemm_frozen_b3":               # the frozen text encoder's wide layers (rows, K, N)
+        r, k, n = d
+        return 2.0 * r * k * n
+    if op == "mha_fwd_hd64":                 # the frozen text encoder's attention, head_dim 64
+        b, h, lq, lk = d
+        return 4.0 * b * h * lq * lk * 64
     return 0.0
 
 
@@ -863,6 +869,12 @@ def main():
                             "tflops": round(flops / (ms * 1e-3) / 1e12, 2) if flops and ms > 0 else None})
         kernels.sort(key=lambda k: -k["ms"] * k["calls_per_step"])
         native_ms = sum(k["ms"] * k["calls_per_step"] for k in kernels)
+        # matrix work of ONE step (algorithmic FLOPs of every product-shaped native call, both streams) against the step's time:
+        # how much of the fp32 matrix pipe the whole step keeps busy, whatever the launch structure
+        mat = {"main": 0.0, "side": 0.0}
+        for name, (calls, _ms) in summ.items():
+            tag = timer.tags.get(name, "main") if pipelined_sched else "main"
+            mat["side" if tag == "side" else "main"] += algorithmic_flops(name) * calls / ksteps
         # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) of
         # THIS build of the kernels (tools/measure_traffic.py stamps them with the source hash); null otherwise
         pmc_traffic, traffic_how = load_pmc_traffic()
@@ -1186,6 +1198,14 @@ def main():
             "roofline_gemm": roofline_gemm,
             "in_step": in_step,
             "native_ms_per_step": round(native_ms, 3),
+            "step_matrix": {"gflop_per_step": round((mat["main"] + mat["side"]) / 1e9, 1), "gflop_main_stream": round(mat["main"] / 1e9, 1),
+                            "gflop_second_stream": round(mat["side"] / 1e9, 1),
+                            "tflops_over_the_step": round((mat["main"] + mat["side"]) / (ms_per_step * 1e-3) / 1e12, 2),
+                            "frac_of_nominal_fp32_mfma": round((mat["main"] + mat["side"]) / (ms_per_step * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                            "frac_of_measured_issue_rate": round((mat["main"] + mat["side"]) / (ms_per_step * 1e-3) / 1e12 / MFMA_F32_MEASURED_TFLOPS, 4),
+                            "note": "algorithmic FLOPs of every product-shaped native call of one step (attention, row products, SA "
+                                    "stacks, weight gradients, the frozen text encoder) over the step's wall time: the share of the fp32 "
+                                    "matrix pipe the WHOLE step keeps busy (its bf16 x 3 kernels are counted at their fp32 FLOPs)"},
             "fps": fps_info,
             "kernel_timing": (("HIP events on the launch stream, %d eager runs of the same step after the "
                                "graph-replayed timed region" % args.kernel_steps) if args.graph else

@@ -219,12 +219,16 @@ class _FusedMHA(Function):
 
 def _qproj_fused_ok(d, num_heads, Lk, *tensors):
     """The fused [q-projection | attention core] launch (include/eda_hip.h eda_mha_qproj_fwd) takes this site.
-    Measured (tools/time_qproj_site.py, graph replay, B = 8): 256 queries x 80 / 132 keys 15.3 / 17.0 us against 18.5 /
-    19.4 us for the two launches (one workgroup of 64 queries x 1 head per CU, one round); 1024 queries: 62 / 71 us against
-    36 / 42 us (four rounds of 106 KB workgroups) -- so the default takes the launch only while it is ONE round of the
-    chip (EDA_MHA_QPROJ=1 forces it, =0 switches it off)."""
+    Measured alone (tools/time_qproj_site.py, graph replay, B = 8): 256 queries x 80 / 132 keys 15.4 / 17.0 us against 17.1 /
+    18.1 us for the two launches (one workgroup of 64 queries x 1 head per CU, one round); 1024 queries: 62 / 71 us against
+    36 / 42 us (four rounds of 106 KB workgroups).  Measured IN THE STEP, EDA_MHA_QPROJ=auto (the launch on the twelve one-round
+    sites: rounds 4-6's default) against =0, four evidence runs: 459.7 / 461.1, 461.4 / 462.5, 463.6 / 467.2, 460.0 / 460.3
+    scenes/s -- off is never behind and at most a few tenths of a percent ahead (run-to-run spread on one box: ~1.5 scenes/s), so
+    the 1-2 us it saves alone do not arrive in the step.  Why not was NOT investigated.  The default is OFF since the end of
+    round 6 (one kernel variant less on the default path); =auto takes it while it is one round of the chip, =1 forces it for
+    every supported shape (the 1024-query sites included: 17.49 against 17.30 ms per step)."""
     import os
-    mode = os.environ.get("EDA_MHA_QPROJ", "auto")
+    mode = os.environ.get("EDA_MHA_QPROJ", "0")
     if mode == "0" or d % num_heads or not all(t.is_cuda and t.dtype == torch.float32 for t in tensors):
         return False
     if not _lib.lib().eda_mha_qproj_supported(num_heads, d // num_heads, int(Lk)):

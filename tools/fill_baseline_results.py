@@ -41,6 +41,8 @@ for name, what in [("default", "headline: fp32, B = 8 x 50 000 points, 256 queri
                    ("splitk_off", "split contraction of the row products off (`EDA_GEMM_SPLITK=0`)"),
                    ("kc96_off", "96-wide chunks off (`EDA_GEMM_KC96=0`)"),
                    ("mha3_ksplit_off", "key-split and bf16 x 3 attention forward off (`EDA_MHA3=0 EDA_MHA2_KSPLIT=0`)"),
+                   ("qproj_off", "`EDA_MHA_QPROJ=0` in the evidence run itself, whose build still had `auto` as its default: the configuration that is HEAD's default (the headline line above is HEAD, timed after the switch on another box)"),
+                   ("qproj_auto", "the q-projection inside the attention launch of the short-key sites (`EDA_MHA_QPROJ=auto`: rounds 4-6's default, off since the end of round 6)"),
                    ("frozen_b3_off", "the frozen text encoder's wide layers on fp32-MFMA products instead of pre-split bf16 x 3 planes (`EDA_FROZEN_B3=0`)"),
                    ("mha_bwd_r05_form", "attention backward as in round 5: every split range summed by a second launch, single-buffered short-key variants (`EDA_MHA2_BWD_MERGE=0 EDA_MHA2_BWD_DBUF=0`)"),
                    ("mha4_on", "text -> point cross-attention forward on the keys-per-wave kernel (`EDA_MHA4=1`; not the default)"),

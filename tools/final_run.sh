@@ -33,7 +33,7 @@ EDA_TIMING_SKIP_SIDE=fps,text python bench.py --in-step-steps 0 > $O/bench_main_
 EDA_MHA3=0 EDA_MHA2_KSPLIT=0 python bench.py --in-step-steps 0 > $O/bench_mha3_ksplit_off.json 2> $O/bench_mha3_ksplit_off.err
 python tools/dbg_pipeline_gemm.py 12 > $O/dbg_pipeline_gemm.txt 2>&1
 python tools/bench_sa_eval.py > $O/sa_eval.txt 2>&1
-EDA_MHA_QPROJ=0 python bench.py --in-step-steps 0 > $O/bench_qproj_off.json 2> $O/bench_qproj_off.err
+EDA_MHA_QPROJ=auto python bench.py --in-step-steps 0 > $O/bench_qproj_auto.json 2> $O/bench_qproj_auto.err
 EDA_WGRAD_BF16X3=0 python bench.py --in-step-steps 0 > $O/bench_wgrad_fp32_mfma.json 2> $O/bench_wgrad_fp32_mfma.err
 EDA_BATCHED_HEADS=0 python bench.py --in-step-steps 0 > $O/bench_heads_per_head.json 2> $O/bench_heads_per_head.err
 EDA_RESIDUAL_LINK=0 python bench.py --in-step-steps 0 > $O/bench_residual_link_off.json 2> $O/bench_residual_link_off.err

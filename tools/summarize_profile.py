@@ -14,14 +14,16 @@ NATIVE = [
     ("native: BN+ReLU(+pool) fwd/bwd", r"^bn_"),
     ("native: residual+dropout+LayerNorm", r"^add_dropout_ln|^ln_reduce"),
     ("native: weight/bias gradients (grouped wgrad fp32 / bf16 x 3, wgrad_x, colsum, the heads' 3-channel layers) and the SA layers' one-launch backward (sa_layer_bwd: weight + input gradient)", r"^wgrad_|^colsum_|^wcolsum_|^weight_transpose|^transpose_batch|^tiny_out_|^sa_layer_bwd|^sa_gather_layer_bwd|^rows_scatter_add"),
-    ("native: small fused kernels (ordered / n-ary adds, l2norm of the contrastive projections, device assignment, peer exchange)", r"^add_n_kernel|^l2norm_|^lsa_|^peer_|^det_scatter|^copy_kernel|^sa_eval"),
+    ("native: small fused kernels (ordered / n-ary adds, l2norm of the contrastive projections, device assignment, peer exchange)", r"^add_n_kernel|^l2norm_|^lsa_|^peer_|^det_scatter|^copy_kernel|^sa_eval|^center_query_pos"),
     ("native: ball query (grid build + query)", r"^gq_|^ball_query"),
     ("native: gather/group/3-NN", r"^group_|^gather_|^three_"),
+    ("native: clip + AdamW on the flat buffers (optim.hip)", r"^grad_sumsq_kernel|^adamw_flat_kernel"),
+    ("native: the training loss (loss.hip; --loss hungarian only) and the frozen text encoder's dropout", r"^compact_targets|^match_|^box_loss|^pos_align|^sem_align|^seed_objectness|^loss_combine|^scale_by_scene|^dropout_flat"),
     ("native: zero-fill", r"^zero_kernel"),
 ]
 TORCH = [
     ("library GEMM (hipBLASLt, fp32: the batched query x token products of the contrastive losses; the text encoder too with EDA_FAST_ROBERTA=0)", r"^Cijk_|gemm|Gemm"),
-    ("optimizer / foreach", r"multi_tensor_apply"),
+    ("torch foreach (gradient gather, batch rotation; rounds 1-5: also the optimizer)", r"multi_tensor_apply"),
     ("torch reduce", r"reduce_kernel"),
     ("torch layernorm / softmax / attention (RoBERTa)", r"layer_norm|softmax|attn_fwd|LayerNorm"),
     ("torch copy/cat", r"copy|Copy|CatArray"),
